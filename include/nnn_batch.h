@@ -1,0 +1,102 @@
+// SPDX-License-Identifier: BSD-3-Clause
+/*
+ * nnn_batch.h -- batched entry points of the MI355X process_frame backend.
+ *
+ * The reference has no batched API: its only "N independent states in lock-step" call sites are
+ * the per-channel loops `for ch { states[ch].process_frame(out[ch], in[ch]) }` at
+ * src/signal.rs:102-104 and src/nnnoiseless.rs:318-320.  nnn_batch_process_* replaces exactly
+ * that loop: n_streams independent DenoiseState's (src/denoise.rs:37-42) advanced by n_frames
+ * calls of DenoiseState::process_frame (src/denoise.rs:95-116) each.
+ *
+ * Plain C ABI: pointers and sizes only.  All functions return 0 on success, non-zero on error
+ * (nnn_last_error() has the text); nothing falls back to a CPU path.
+ */
+#ifndef NNN_BATCH_H
+#define NNN_BATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nnn_batch nnn_batch;
+#ifndef RNNOISE_H
+typedef struct RNNModel RNNModel;
+#endif
+
+#define NNN_FRAME_SIZE 480 /* DenoiseState::FRAME_SIZE, src/denoise.rs:46 */
+
+/* RnnModel::from_bytes (src/rnn.rs:75-77, validation :116-232): NULL where the reference returns None. */
+RNNModel *nnn_model_from_bytes(const uint8_t *bytes, size_t len);
+/* RnnModel::default (src/rnn.rs:235-240): the built-in weights.rnn. */
+RNNModel *nnn_model_default(void);
+void nnn_model_free(RNNModel *m);
+/* shape[0..5] = input_dense in/out, vad/noise/denoise GRU neurons, gains out; shape[6..11] = activations */
+void nnn_model_shape(const RNNModel *m, int32_t shape[12]);
+
+/* n_streams x DenoiseState::with_model(model) (src/denoise.rs:72-74); model NULL = DenoiseState::new().
+ * The model is copied to the device; it need not outlive the batch.  device = HIP device ordinal. */
+nnn_batch *nnn_batch_create(const RNNModel *model, int n_streams, int device);
+void nnn_batch_destroy(nnn_batch *b);
+int nnn_batch_num_streams(const nnn_batch *b);
+/* Back to freshly-created state (all zeros, src/features.rs:58-74). */
+int nnn_batch_reset(nnn_batch *b);
+
+/*
+ * n_frames x process_frame for every stream, buffers resident in device memory.
+ *   sample i of frame t of stream s:  d_in [s * stream_stride + t * frame_stride + i]   (floats)
+ *                                     d_out[s * stream_stride + t * frame_stride + i]   (may alias d_in)
+ *   VAD probability (return value of process_frame): d_vad[t * n_streams + s]           (NULL to skip)
+ * hip_stream: a hipStream_t to enqueue on (NULL = the batch's own stream).  Asynchronous.
+ */
+int nnn_batch_process_device(nnn_batch *b, const float *d_in, float *d_out, float *d_vad, int n_frames,
+                             size_t stream_stride, size_t frame_stride, void *hip_stream);
+/* Same with host buffers (copies over PCIe, synchronous). */
+int nnn_batch_process_host(nnn_batch *b, const float *in, float *out, float *vad, int n_frames,
+                           size_t stream_stride, size_t frame_stride);
+int nnn_batch_synchronize(nnn_batch *b);
+
+/* Parity taps: intermediate quantities of the most recent frame, copied to the host as
+ * [n_streams][len] (float32 or int32, see nnn_tap_info).  Test/diagnostic interface. */
+enum nnn_tap {
+    NNN_TAP_FILTERED = 0, /* [480] f32  high-passed input (features.rs:97-104)           */
+    NNN_TAP_XLP,          /* [864] f32  pitch_buf after pitch_downsample (pitch.rs:448)   */
+    NNN_TAP_AC,           /* [5]   f32  windowed autocorrelation                          */
+    NNN_TAP_LPC2,         /* [5]   f32  FIR taps                                          */
+    NNN_TAP_XCORR1,       /* [147] f32  coarse cross-correlation                          */
+    NNN_TAP_BEST1,        /* [2]   i32  best / second best coarse lag                     */
+    NNN_TAP_XCORR2C,      /* [10]  f32  fine cross-correlation at 2*best-2..+2, 2*second-2..+2 */
+    NNN_TAP_PITCH_SEARCH, /* [1]   i32                                                    */
+    NNN_TAP_PITCH,        /* [1]   i32  pitch period after remove_doubling                */
+    NNN_TAP_PITCH_GAIN,   /* [1]   f32                                                    */
+    NNN_TAP_X,            /* [962] f32  (re,im) x 481, signal spectrum before filtering   */
+    NNN_TAP_P,            /* [962] f32  pitch-lagged spectrum                             */
+    NNN_TAP_EX, NNN_TAP_EP, NNN_TAP_EXP, /* [22] f32                                      */
+    NNN_TAP_FEATURES,     /* [42]  f32                                                    */
+    NNN_TAP_SILENCE,      /* [1]   i32                                                    */
+    NNN_TAP_G_RAW,        /* [22]  f32  RNN gains                                         */
+    NNN_TAP_G,            /* [22]  f32  smoothed gains                                    */
+    NNN_TAP_VAD,          /* [1]   f32                                                    */
+    NNN_TAP_COUNT
+};
+int nnn_tap_info(int tap, int *len, int *is_int);
+int nnn_batch_read_tap(nnn_batch *b, int tap, void *host_dst, size_t dst_bytes);
+
+/* Per-kernel timing with HIP events on the launch stream (off by default: it adds two event
+ * records per launch).  Times accumulate until read; reading resets them. */
+int nnn_batch_set_profiling(nnn_batch *b, int on);
+int nnn_batch_num_kernels(void);
+const char *nnn_batch_kernel_name(int k);
+int nnn_batch_read_kernel_times(nnn_batch *b, double *total_ms, int64_t *launches, int n);
+
+/* 1 = replay each frame step from a captured hipGraph (default), 0 = eager launches. */
+int nnn_batch_set_graph(nnn_batch *b, int on);
+
+const char *nnn_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNN_BATCH_H */

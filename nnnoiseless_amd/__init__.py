@@ -1,0 +1,159 @@
+"""nnnoiseless_amd -- MI355X-native batched backend for nnnoiseless' DenoiseState::process_frame.
+
+Host-side mirror of the reference's public interface for this path (jneem/nnnoiseless v0.5.1):
+
+  RnnModel      from_bytes / from_static_bytes / default          (src/rnn.rs:72-94, 235-240)
+  DenoiseState  FRAME_SIZE, new / from_model / with_model, process_frame(output, input) -> vad
+                                                                    (src/denoise.rs:44-116)
+  BatchDenoiser n independent DenoiseStates advanced in lock-step (the per-channel loop of
+                src/signal.rs:102-104 and src/nnnoiseless.rs:318-320 as one call)
+
+All arithmetic runs in hand-written HIP kernels (csrc/nnn_kernels.hip) behind the C ABI of
+include/nnn_batch.h and include/rnnoise.h.  There is no CPU fallback: importing works anywhere,
+but creating a state without the built library or without a GPU raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .build import LIB_PATH, build_library
+
+FRAME_SIZE = 480
+FREQ_SIZE = 481
+NB_BANDS = 22
+NB_FEATURES = 42
+
+_lib = None
+
+
+def library():
+    """The hipcc-built gfx950 library (loaded on first use)."""
+    global _lib
+    if _lib is None:
+        _lib = _ffi.Library(LIB_PATH)
+    return _lib
+
+
+class RnnModel:
+    """Model parameters (reference: src/rnn.rs:54-62).  Constructors return None on malformed input
+    exactly where the reference returns None."""
+
+    def __init__(self, handle, lib):
+        self._h, self._lib = handle, lib
+
+    @classmethod
+    def from_bytes(cls, data, lib=None):
+        lib = lib or library()
+        data = bytes(data)
+        h = lib.L.nnn_model_from_bytes(data, len(data))
+        return cls(h, lib) if h else None
+
+    from_static_bytes = from_bytes
+
+    @classmethod
+    def default(cls, lib=None):
+        lib = lib or library()
+        return cls(lib.L.nnn_model_default(), lib)
+
+    def shape(self):
+        s = (C.c_int32 * 12)()
+        self._lib.L.nnn_model_shape(self._h, s)
+        return list(s)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.L.nnn_model_free(self._h)
+            self._h = None
+
+
+class BatchDenoiser:
+    """n_streams DenoiseStates in lock-step on one GPU."""
+
+    def __init__(self, n_streams, model=None, device=0, lib=None):
+        self._lib = lib or library()
+        self._model = model
+        self.n_streams = int(n_streams)
+        self._h = self._lib.L.nnn_batch_create(model._h if model is not None else None, self.n_streams, device)
+        if not self._h:
+            raise RuntimeError("nnnoiseless_amd: " + self._lib.error())
+
+    def process(self, x):
+        """x: float32 [n_streams, n_frames, 480] on the host -> (out same shape, vad [n_frames, n_streams])."""
+        x = _ffi.as_f32(x)
+        S, T, F = x.shape
+        assert S == self.n_streams and F == FRAME_SIZE
+        out = np.empty_like(x)
+        vad = np.empty((T, S), np.float32)
+        self._lib.check(self._lib.L.nnn_batch_process_host(self._h, _ffi.ptr(x), _ffi.ptr(out), _ffi.ptr(vad), T,
+                                                           T * FRAME_SIZE, FRAME_SIZE))
+        return out, vad
+
+    def process_device(self, d_in, d_out, d_vad, n_frames, stream_stride, frame_stride, hip_stream=0):
+        """Raw device pointers (ints); asynchronous on hip_stream (0 = the batch's own stream)."""
+        self._lib.check(self._lib.L.nnn_batch_process_device(self._h, d_in, d_out, d_vad, n_frames, stream_stride,
+                                                             frame_stride, hip_stream))
+
+    def synchronize(self):
+        self._lib.check(self._lib.L.nnn_batch_synchronize(self._h))
+
+    def reset(self):
+        self._lib.check(self._lib.L.nnn_batch_reset(self._h))
+
+    def tap(self, name):
+        """Intermediate quantity of the most recent frame as [n_streams, len] (parity checks)."""
+        t = _ffi.TAPS.index(name)
+        ln, isint = C.c_int(), C.c_int()
+        self._lib.check(self._lib.L.nnn_tap_info(t, C.byref(ln), C.byref(isint)))
+        a = np.empty((self.n_streams, ln.value), np.int32 if isint.value else np.float32)
+        self._lib.check(self._lib.L.nnn_batch_read_tap(self._h, t, _ffi.ptr(a), a.nbytes))
+        return a
+
+    def set_profiling(self, on):
+        self._lib.check(self._lib.L.nnn_batch_set_profiling(self._h, int(on)))
+
+    def set_graph(self, on):
+        self._lib.check(self._lib.L.nnn_batch_set_graph(self._h, int(on)))
+
+    def kernel_times(self):
+        """{kernel: (total_ms, launches)} accumulated while profiling; resets the counters."""
+        n = self._lib.L.nnn_batch_num_kernels()
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        self._lib.check(self._lib.L.nnn_batch_read_kernel_times(self._h, ms, cnt, n))
+        return {self._lib.L.nnn_batch_kernel_name(k).decode(): (ms[k], cnt[k]) for k in range(n)}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.L.nnn_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class DenoiseState:
+    """One stream (reference: src/denoise.rs:36-116); a batch of one on the GPU."""
+
+    FRAME_SIZE = FRAME_SIZE
+
+    def __init__(self, model=None, device=0, lib=None):
+        self._b = BatchDenoiser(1, model, device, lib)
+
+    @classmethod
+    def new(cls, **kw):
+        return cls(None, **kw)
+
+    @classmethod
+    def from_model(cls, model, **kw):
+        return cls(model, **kw)
+
+    with_model = from_model
+
+    def process_frame(self, output, input):
+        """Writes 480 samples into `output`, returns the VAD probability (src/denoise.rs:95-116)."""
+        input = _ffi.as_f32(input)
+        if input.shape != (FRAME_SIZE,) or output.shape != (FRAME_SIZE,):
+            raise ValueError("process_frame needs slices of length DenoiseState.FRAME_SIZE")  # src/features.rs:98
+        out, vad = self._b.process(input.reshape(1, 1, FRAME_SIZE))
+        output[:] = out[0, 0]
+        return float(vad[0, 0])

@@ -1,0 +1,78 @@
+"""ctypes binding of the C ABI in include/nnn_batch.h and include/rnnoise.h."""
+import ctypes as C
+import os
+
+import numpy as np
+
+FRAME_SIZE = 480
+
+TAPS = ["filtered", "xlp", "ac", "lpc2", "xcorr1", "best1", "xcorr2c", "pitch_search", "pitch", "pitch_gain",
+        "X", "P", "ex", "ep", "exp", "features", "silence", "g_raw", "g", "vad"]
+
+# every symbol the two headers declare (tests check that the built library exports all of them)
+BATCH_SYMBOLS = [
+    "nnn_model_from_bytes", "nnn_model_default", "nnn_model_free", "nnn_model_shape",
+    "nnn_batch_create", "nnn_batch_destroy", "nnn_batch_num_streams", "nnn_batch_reset",
+    "nnn_batch_process_device", "nnn_batch_process_host", "nnn_batch_synchronize",
+    "nnn_tap_info", "nnn_batch_read_tap", "nnn_batch_set_profiling", "nnn_batch_num_kernels",
+    "nnn_batch_kernel_name", "nnn_batch_read_kernel_times", "nnn_batch_set_graph", "nnn_last_error",
+]
+RNNOISE_SYMBOLS = [
+    "rnnoise_get_frame_size", "rnnoise_get_size", "rnnoise_init", "rnnoise_create", "rnnoise_destroy",
+    "rnnoise_process_frame", "rnnoise_model_from_file", "rnnoise_model_free",
+]
+
+
+class Library:
+    """A loaded build of the backend.  The package default is the hipcc-built gfx950 library."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"nnnoiseless_amd: HIP library not found at {path}. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); there is no CPU fallback.")
+        self.path = path
+        L = self.L = C.CDLL(path)
+        vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+        L.nnn_model_from_bytes.restype = vp
+        L.nnn_model_from_bytes.argtypes = [C.c_char_p, sz]
+        L.nnn_model_default.restype = vp
+        L.nnn_model_free.argtypes = [vp]
+        L.nnn_model_shape.argtypes = [vp, C.POINTER(C.c_int32)]
+        L.nnn_batch_create.restype = vp
+        L.nnn_batch_create.argtypes = [vp, i32, i32]
+        L.nnn_batch_destroy.argtypes = [vp]
+        L.nnn_batch_num_streams.argtypes = [vp]
+        L.nnn_batch_reset.argtypes = [vp]
+        L.nnn_batch_process_device.argtypes = [vp, vp, vp, vp, i32, sz, sz, vp]
+        L.nnn_batch_process_host.argtypes = [vp, vp, vp, vp, i32, sz, sz]
+        L.nnn_batch_synchronize.argtypes = [vp]
+        L.nnn_tap_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
+        L.nnn_batch_read_tap.argtypes = [vp, i32, vp, sz]
+        L.nnn_batch_set_profiling.argtypes = [vp, i32]
+        L.nnn_batch_kernel_name.restype = C.c_char_p
+        L.nnn_batch_kernel_name.argtypes = [i32]
+        L.nnn_batch_read_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
+        L.nnn_batch_set_graph.argtypes = [vp, i32]
+        L.nnn_last_error.restype = C.c_char_p
+        L.rnnoise_create.restype = vp
+        L.rnnoise_create.argtypes = [vp]
+        L.rnnoise_destroy.argtypes = [vp]
+        L.rnnoise_process_frame.restype = C.c_float
+        L.rnnoise_process_frame.argtypes = [vp, vp, vp]
+        L.rnnoise_model_free.argtypes = [vp]
+
+    def error(self):
+        return self.L.nnn_last_error().decode()
+
+    def check(self, rc):
+        if rc != 0:
+            raise RuntimeError("nnnoiseless_amd: " + self.error())
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def as_f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)

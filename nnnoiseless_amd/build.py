@@ -1,0 +1,34 @@
+"""Build the gfx950 library in-tree with hipcc (no cmake, no JIT cache: the .so must travel)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libnnnoiseless_mi355x.so")
+WEIGHTS = os.path.join(HERE, "data", "weights.rnn")
+SOURCES = ["nnn_batch.hip", "nnn_model.cpp", "rnnoise_capi.cpp"]
+DEPS = SOURCES + ["nnn_kernels.hip", "nnn_layout.h", "nnn_model.h"]
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, d) for d in DEPS] + [WEIGHTS, os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> nnnoiseless_amd/lib/libnnnoiseless_mi355x.so"""
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-Wno-unused-value", f'-DNNN_WEIGHTS_PATH="{WEIGHTS}"', "-x", "hip"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH

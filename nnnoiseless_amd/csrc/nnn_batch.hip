@@ -1,0 +1,517 @@
+// nnn_batch.hip -- host side of the batched process_frame backend: the state slab in HBM, the
+// per-frame kernel pipeline (eager or as a replayed hipGraph), parity taps, per-kernel timing.
+// C ABI declared in include/nnn_batch.h.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/nnn_batch.h"
+#include "nnn_kernels.hip"
+#include "nnn_model.h"
+
+using namespace nnn;
+
+static thread_local std::string g_err;
+extern "C" const char *nnn_last_error(void) { return g_err.c_str(); }
+static int fail(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+enum KernelId { K_HP, K_DECIM, K_LPC, K_FIR, K_XCORR, K_BEST1, K_REFINE, K_BEST2, K_DOUBLING, K_FFT_FWD, K_FEATURES, K_RNN, K_SYNTH, K_ADVANCE, K_COUNT };
+static const char *kKernelNames[K_COUNT] = {"k_hp", "k_decim", "k_lpc", "k_fir", "k_xcorr", "k_best1", "k_refine", "k_best2",
+                                            "k_doubling", "k_fft_fwd", "k_features", "k_rnn", "k_synth", "k_advance"};
+
+struct nnn_batch {
+    Buffers b;
+    ModelDims md;
+    int device = 0;
+    int S = 0, S_pad = 0, NT = 0;
+    uint64_t frame_count = 0;
+    std::vector<void *> allocs;     // everything hipMalloc'ed
+    std::vector<std::pair<void *, size_t>> state_bufs;  // zeroed by reset
+    StepParams *sp = nullptr;       // device
+    hipStream_t stream = nullptr;
+    size_t rnn_lds = 0;
+    bool use_graph = true;
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t graph_stream = nullptr;  // stream the graph was captured on
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;     // pairs per launch while profiling
+    std::vector<int> ev_kernel;
+    double k_ms[K_COUNT] = {0};
+    int64_t k_launches[K_COUNT] = {0};
+};
+
+template <class T> static hipError_t dalloc(nnn_batch *h, T **p, size_t count, bool is_state)
+{
+    size_t bytes = count * sizeof(T);
+    hipError_t e = hipMalloc((void **)p, bytes ? bytes : 4);
+    if (e != hipSuccess) return e;
+    h->allocs.push_back(*p);
+    e = hipMemset(*p, 0, bytes);
+    if (is_state) h->state_bufs.push_back({(void *)*p, bytes});
+    return e;
+}
+template <class T> static hipError_t upload(nnn_batch *h, const T **p, const std::vector<T> &v)
+{
+    T *d = nullptr;
+    hipError_t e = dalloc(h, &d, v.size(), false);
+    if (e != hipSuccess) return e;
+    *p = d;
+    return hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+// Tables.  Window and DCT follow the reference exactly (f64 math, f32 storage; src/lib.rs:107-127);
+// the tanh table is tanh(0.04 i) to six decimals with upstream's three off-by-one entries
+// (src/util.rs:3-27).
+static void make_tables(std::vector<float> &window, std::vector<float> &dct, std::vector<float2> &tw,
+                        std::vector<float> &tansig, std::vector<float> &bin_frac, std::vector<int> &bin_band, float &wnorm)
+{
+    const double pi = 3.14159265358979323846;
+    window.resize(WINDOW);
+    for (int i = 0; i < FRAME; i++) {
+        double s = sin(0.5 * pi * ((double)i + 0.5) / (double)FRAME);
+        float w = (float)sin(0.5 * pi * s * s);
+        window[i] = w;
+        window[WINDOW - 1 - i] = w;
+    }
+    float acc = 0.0f;
+    for (int i = 0; i < WINDOW; i++) acc += window[i] * window[i];
+    wnorm = 1.0f / acc;
+    dct.resize(NB * NB);
+    for (int i = 0; i < NB; i++)
+        for (int j = 0; j < NB; j++) {
+            float v = (float)cos(((double)i + 0.5) * (double)j * pi / (double)NB);
+            if (j == 0) v *= sqrtf(0.5f);
+            dct[i * NB + j] = v;
+        }
+    tw.resize(WINDOW);
+    for (int k = 0; k < WINDOW; k++) {
+        tw[k].x = (float)cos(-2.0 * pi * k / (double)WINDOW);
+        tw[k].y = (float)sin(-2.0 * pi * k / (double)WINDOW);
+    }
+    tansig.resize(201);
+    for (int i = 0; i <= 200; i++) tansig[i] = (float)(floor(tanh(0.04 * (double)i) * 1e6 + 0.5) / 1e6);
+    tansig[70] = 0.992631f;
+    tansig[170] = 0.999997f;
+    tansig[190] = 1.000000f;
+    static const int E[NB] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100};
+    bin_frac.assign(400, 0.0f);
+    bin_band.assign(400, 0);
+    for (int i = 0; i < NB - 1; i++) {
+        int band_size = (E[i + 1] - E[i]) << 2;
+        for (int j = 0; j < band_size; j++) {
+            bin_frac[(E[i] << 2) + j] = (float)j / (float)band_size;  // src/lib.rs:73
+            bin_band[(E[i] << 2) + j] = i;
+        }
+    }
+}
+
+extern "C" void nnn_batch_destroy(nnn_batch *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    for (hipEvent_t e : h->ev) hipEventDestroy(e);
+    for (void *p : h->allocs) hipFree(p);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int device)
+{
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("no HIP device %d (found %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    h->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->S = n_streams;
+    h->S_pad = (n_streams + TILE - 1) / TILE * TILE;
+    h->NT = h->S_pad / TILE;
+    const size_t Sp = (size_t)h->S_pad;
+
+    RNNModel *own = nullptr;
+    if (!model) {
+        size_t len;
+        const uint8_t *w = nnn_builtin_weights(&len);
+        own = nnn_model_parse(w, len);
+        if (!own) return fail("built-in weights failed to parse");
+        model = own;
+    }
+    std::vector<float> wf;
+    nnn_model_expand(*model, wf, h->md);
+    delete own;
+    const ModelDims &md = h->md;
+    const int nmax = md.nv > md.nn ? (md.nv > md.ndn ? md.nv : md.ndn) : (md.nn > md.ndn ? md.nn : md.ndn);
+    h->rnn_lds = (256 + (size_t)(md.nd + md.nv + md.nn + md.ndn + nmax) * TILE) * sizeof(float);
+    if (h->rnn_lds > 160 * 1024) return fail("model too large for the RNN kernel's LDS exchange (%zu bytes)", h->rnn_lds);
+
+    Buffers &b = h->b;
+    memset(&b, 0, sizeof(b));
+    b.S = h->S; b.S_pad = h->S_pad; b.NT = h->NT;
+    // persistent state
+    HIPCHK(dalloc(h, &b.hist, Sp * RING, true));
+    HIPCHK(dalloc(h, &b.hp_mem, Sp * 2, true));
+    HIPCHK(dalloc(h, &b.ceps_mem, Sp * CEPS_MEM * NB, true));
+    HIPCHK(dalloc(h, &b.mem_id, Sp, true));
+    HIPCHK(dalloc(h, &b.synth_mem, Sp * FRAME, true));
+    HIPCHK(dalloc(h, &b.lastg, Sp * NB, true));
+    HIPCHK(dalloc(h, &b.last_period, Sp, true));
+    HIPCHK(dalloc(h, &b.last_gain, Sp, true));
+    HIPCHK(dalloc(h, &b.gru_v, Sp * md.nv, true));
+    HIPCHK(dalloc(h, &b.gru_n, Sp * md.nn, true));
+    HIPCHK(dalloc(h, &b.gru_dn, Sp * md.ndn, true));
+    // scratch
+    HIPCHK(dalloc(h, &b.xlp_raw, Sp * XLP, false));
+    HIPCHK(dalloc(h, &b.lpc, Sp * 10, false));
+    HIPCHK(dalloc(h, &b.xlp_ti, Sp * XLP, false));
+    HIPCHK(dalloc(h, &b.xlp_sm, Sp * XLP, false));
+    HIPCHK(dalloc(h, &b.xc1, Sp * NLAG1, false));
+    HIPCHK(dalloc(h, &b.best1, Sp * 2, false));
+    HIPCHK(dalloc(h, &b.xc2, Sp * 10, false));
+    HIPCHK(dalloc(h, &b.psearch, Sp, false));
+    HIPCHK(dalloc(h, &b.xx_yy, Sp * 386, false));
+    HIPCHK(dalloc(h, &b.pitch, Sp, false));
+    HIPCHK(dalloc(h, &b.pgain, Sp, false));
+    HIPCHK(dalloc(h, &b.X, Sp * FREQ, false));
+    HIPCHK(dalloc(h, &b.P, Sp * FREQ, false));
+    HIPCHK(dalloc(h, &b.ex, Sp * NB, false));
+    HIPCHK(dalloc(h, &b.ep, Sp * NB, false));
+    HIPCHK(dalloc(h, &b.exp_, Sp * NB, false));
+    HIPCHK(dalloc(h, &b.feat, Sp * NFEAT, false));
+    HIPCHK(dalloc(h, &b.silence, Sp, false));
+    HIPCHK(dalloc(h, &b.g_raw, Sp * NB, false));
+    HIPCHK(dalloc(h, &b.g, Sp * NB, false));
+    HIPCHK(dalloc(h, &b.vad, Sp, false));
+    HIPCHK(dalloc(h, &h->sp, 1, false));
+    // tables
+    std::vector<float> window, dct, tansig, bin_frac;
+    std::vector<float2> tw;
+    std::vector<int> bin_band;
+    make_tables(window, dct, tw, tansig, bin_frac, bin_band, b.wnorm);
+    HIPCHK(upload(h, &b.window, window));
+    HIPCHK(upload(h, &b.dct, dct));
+    HIPCHK(upload(h, &b.tw960, tw));
+    HIPCHK(upload(h, &b.tansig, tansig));
+    HIPCHK(upload(h, &b.bin_frac, bin_frac));
+    HIPCHK(upload(h, &b.bin_band, bin_band));
+    HIPCHK(upload(h, &b.weights, wf));
+    if (h->rnn_lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->rnn_lds));
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+extern "C" nnn_batch *nnn_batch_create(const RNNModel *model, int n_streams, int device)
+{
+    if (n_streams <= 0) {
+        fail("n_streams must be positive");
+        return nullptr;
+    }
+    nnn_batch *h = new nnn_batch();
+    if (create_impl(h, model, n_streams, device) != 0) {
+        std::string keep = g_err;
+        nnn_batch_destroy(h);
+        g_err = keep;
+        return nullptr;
+    }
+    return h;
+}
+
+extern "C" int nnn_batch_num_streams(const nnn_batch *h) { return h ? h->S : 0; }
+
+extern "C" int nnn_batch_synchronize(nnn_batch *h)
+{
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int nnn_batch_reset(nnn_batch *h)
+{
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (auto &sb : h->state_bufs) HIPCHK(hipMemset(sb.first, 0, sb.second));
+    HIPCHK(hipDeviceSynchronize());
+    h->frame_count = 0;
+    return 0;
+}
+
+// ---- one frame of the pipeline -----------------------------------------------------------------
+struct Launcher {
+    nnn_batch *h;
+    hipStream_t st;
+    bool prof;
+    template <class K, class... A> void go(int id, K kern, dim3 grid, dim3 block, size_t lds, A... args)
+    {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (prof) {
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            hipEventRecord(e0, st);
+        }
+        hipLaunchKernelGGL(kern, grid, block, lds, st, args...);
+        if (prof) {
+            hipEventRecord(e1, st);
+            h->ev.push_back(e0);
+            h->ev.push_back(e1);
+            h->ev_kernel.push_back(id);
+        }
+    }
+};
+
+static void enqueue_frame(nnn_batch *h, hipStream_t st, bool prof)
+{
+    Launcher L{h, st, prof};
+    const Buffers &b = h->b;
+    const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad;
+    L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, (const StepParams *)h->sp);
+    L.go(K_DECIM, k_decim, dim3(NT, XLP / 32), dim3(256), 0, b, (const StepParams *)h->sp);
+    L.go(K_LPC, k_lpc, dim3(NT), dim3(64), 0, b);
+    L.go(K_FIR, k_fir, dim3(NT, XLP / 32), dim3(64), 0, b);
+    L.go(K_XCORR, k_xcorr, dim3(NT, (NLAG1 + 7) / 8), dim3(64), 0, b);
+    L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
+    L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
+    L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
+    L.go(K_DOUBLING, k_doubling, dim3(Sp / 4), dim3(256), 0, b);
+    L.go(K_FFT_FWD, k_fft_fwd, dim3(Sp), dim3(64), 0, b, (const StepParams *)h->sp);
+    L.go(K_FEATURES, k_features, dim3(NT), dim3(64), 0, b);
+    L.go(K_RNN, k_rnn, dim3(NT), dim3(64 * RNN_WAVES), h->rnn_lds, b, h->md);
+    L.go(K_SYNTH, k_synth, dim3(Sp), dim3(64), 0, b, (const StepParams *)h->sp);
+    L.go(K_ADVANCE, k_advance, dim3(1), dim3(1), 0, h->sp);
+}
+
+static int drain_profile(nnn_batch *h)
+{
+    for (size_t i = 0; i < h->ev_kernel.size(); i++) {
+        float ms = 0.0f;
+        HIPCHK(hipEventSynchronize(h->ev[2 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+        h->k_ms[h->ev_kernel[i]] += ms;
+        h->k_launches[h->ev_kernel[i]] += 1;
+        hipEventDestroy(h->ev[2 * i]);
+        hipEventDestroy(h->ev[2 * i + 1]);
+    }
+    h->ev.clear();
+    h->ev_kernel.clear();
+    return 0;
+}
+
+extern "C" int nnn_batch_process_device(nnn_batch *h, const float *d_in, float *d_out, float *d_vad, int n_frames,
+                                        size_t stream_stride, size_t frame_stride, void *hip_stream)
+{
+    if (!h) return fail("null batch");
+    if (n_frames <= 0) return 0;
+    if (!d_in || !d_out) return fail("null buffer");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    StepParams v;
+    v.in = d_in; v.out = d_out; v.vad = d_vad;
+    v.stream_stride = stream_stride; v.frame_stride = frame_stride;
+    v.slot = (int)(h->frame_count & 3);
+    v.n_streams = h->S;
+    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, h->sp, v);
+    const bool graph = h->use_graph && !h->profiling;
+    if (graph && (!h->graph_exec || h->graph_stream != st)) {
+        if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            enqueue_frame(h, st, false);
+            if (hipStreamEndCapture(st, &g) == hipSuccess && g &&
+                hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                h->graph_stream = st;
+            } else {
+                h->graph_exec = nullptr;
+            }
+            if (g) hipGraphDestroy(g);
+        }
+        if (!h->graph_exec) h->use_graph = false;  // capture unsupported here: stay eager
+        (void)hipGetLastError();
+    }
+    for (int t = 0; t < n_frames; t++) {
+        if (graph && h->graph_exec) HIPCHK(hipGraphLaunch(h->graph_exec, st));
+        else enqueue_frame(h, st, h->profiling);
+    }
+    h->frame_count += (uint64_t)n_frames;
+    HIPCHK(hipGetLastError());
+    if (h->profiling) {
+        HIPCHK(hipStreamSynchronize(st));
+        return drain_profile(h);
+    }
+    return 0;
+}
+
+extern "C" int nnn_batch_process_host(nnn_batch *h, const float *in, float *out, float *vad, int n_frames,
+                                      size_t stream_stride, size_t frame_stride)
+{
+    if (!h) return fail("null batch");
+    if (n_frames <= 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    // the host buffer may be strided; ship the bounding span
+    size_t span = (size_t)(h->S - 1) * stream_stride + (size_t)(n_frames - 1) * frame_stride + FRAME;
+    float *d = nullptr, *dv = nullptr;
+    HIPCHK(hipMalloc((void **)&d, span * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d, in, span * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && vad) e = hipMalloc((void **)&dv, (size_t)n_frames * h->S * sizeof(float));
+    int rc = 0;
+    if (e != hipSuccess) rc = fail("host staging failed: %s", hipGetErrorString(e));
+    if (!rc) rc = nnn_batch_process_device(h, d, d, dv, n_frames, stream_stride, frame_stride, h->stream);
+    if (!rc) {
+        // `out` may alias `in` and may be strided: bring the span back and copy only real frames
+        std::vector<float> tmp(span);
+        e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipMemcpy(tmp.data(), d, span * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            for (int s = 0; s < h->S; s++)
+                for (int t = 0; t < n_frames; t++) {
+                    size_t o = (size_t)s * stream_stride + (size_t)t * frame_stride;
+                    memcpy(out + o, tmp.data() + o, FRAME * sizeof(float));
+                }
+        if (e == hipSuccess && vad) e = hipMemcpy(vad, dv, (size_t)n_frames * h->S * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail("copy back failed: %s", hipGetErrorString(e));
+    }
+    hipFree(d);
+    if (dv) hipFree(dv);
+    return rc;
+}
+
+// ---- taps ---------------------------------------------------------------------------------------
+struct TapDesc { int len; int is_int; int layout; /* 0 TI, 1 SM float, 2 SM float2, 3 hist ring */ int sub_ofs; int sub_len; };
+static bool tap_desc(const nnn_batch *h, int tap, TapDesc &d, const void **ptr)
+{
+    const Buffers *b = h ? &h->b : nullptr;
+#define TP(field) (b ? (const void *)b->field : nullptr)
+    switch (tap) {
+    case NNN_TAP_FILTERED: d = {FRAME, 0, 3, 0, FRAME}; *ptr = TP(hist); return true;
+    case NNN_TAP_XLP: d = {XLP, 0, 0, 0, XLP}; *ptr = TP(xlp_ti); return true;
+    case NNN_TAP_AC: d = {5, 0, 0, 0, 10}; *ptr = TP(lpc); return true;
+    case NNN_TAP_LPC2: d = {5, 0, 0, 5, 10}; *ptr = TP(lpc); return true;
+    case NNN_TAP_XCORR1: d = {NLAG1, 0, 0, 0, NLAG1}; *ptr = TP(xc1); return true;
+    case NNN_TAP_BEST1: d = {2, 1, 0, 0, 2}; *ptr = TP(best1); return true;
+    case NNN_TAP_XCORR2C: d = {10, 0, 0, 0, 10}; *ptr = TP(xc2); return true;
+    case NNN_TAP_PITCH_SEARCH: d = {1, 1, 0, 0, 1}; *ptr = TP(psearch); return true;
+    case NNN_TAP_PITCH: d = {1, 1, 0, 0, 1}; *ptr = TP(pitch); return true;
+    case NNN_TAP_PITCH_GAIN: d = {1, 0, 0, 0, 1}; *ptr = TP(pgain); return true;
+    case NNN_TAP_X: d = {2 * FREQ, 0, 2, 0, 2 * FREQ}; *ptr = TP(X); return true;
+    case NNN_TAP_P: d = {2 * FREQ, 0, 2, 0, 2 * FREQ}; *ptr = TP(P); return true;
+    case NNN_TAP_EX: d = {NB, 0, 0, 0, NB}; *ptr = TP(ex); return true;
+    case NNN_TAP_EP: d = {NB, 0, 0, 0, NB}; *ptr = TP(ep); return true;
+    case NNN_TAP_EXP: d = {NB, 0, 0, 0, NB}; *ptr = TP(exp_); return true;
+    case NNN_TAP_FEATURES: d = {NFEAT, 0, 0, 0, NFEAT}; *ptr = TP(feat); return true;
+    case NNN_TAP_SILENCE: d = {1, 1, 0, 0, 1}; *ptr = TP(silence); return true;
+    case NNN_TAP_G_RAW: d = {NB, 0, 0, 0, NB}; *ptr = TP(g_raw); return true;
+    case NNN_TAP_G: d = {NB, 0, 0, 0, NB}; *ptr = TP(g); return true;
+    case NNN_TAP_VAD: d = {1, 0, 0, 0, 1}; *ptr = TP(vad); return true;
+    default: return false;
+    }
+#undef TP
+}
+
+extern "C" int nnn_tap_info(int tap, int *len, int *is_int)
+{
+    TapDesc d;
+    const void *p;
+    if (!tap_desc(nullptr, tap, d, &p)) return fail("unknown tap %d", tap);
+    if (len) *len = d.len;
+    if (is_int) *is_int = d.is_int;
+    return 0;
+}
+
+extern "C" int nnn_batch_read_tap(nnn_batch *h, int tap, void *host_dst, size_t dst_bytes)
+{
+    if (!h) return fail("null batch");
+    TapDesc d;
+    const void *p;
+    if (!tap_desc(h, tap, d, &p)) return fail("unknown tap %d", tap);
+    if (dst_bytes < (size_t)h->S * d.len * 4) return fail("tap buffer too small");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipDeviceSynchronize());
+    uint32_t *dst = (uint32_t *)host_dst;
+    const size_t Sp = (size_t)h->S_pad;
+    if (d.layout == 0) {
+        std::vector<uint32_t> tmp(Sp * d.sub_len);
+        HIPCHK(hipMemcpy(tmp.data(), p, tmp.size() * 4, hipMemcpyDeviceToHost));
+        for (int s = 0; s < h->S; s++)
+            for (int i = 0; i < d.len; i++)
+                dst[(size_t)s * d.len + i] = tmp[((size_t)(s / TILE) * d.sub_len + d.sub_ofs + i) * TILE + s % TILE];
+    } else if (d.layout == 2) {
+        std::vector<uint32_t> tmp(Sp * d.len);
+        HIPCHK(hipMemcpy(tmp.data(), p, tmp.size() * 4, hipMemcpyDeviceToHost));
+        memcpy(dst, tmp.data(), (size_t)h->S * d.len * 4);
+    } else {  // newest frame in the history ring
+        std::vector<uint32_t> tmp(Sp * RING);
+        HIPCHK(hipMemcpy(tmp.data(), p, tmp.size() * 4, hipMemcpyDeviceToHost));
+        int slot = (int)((h->frame_count + 3) & 3);  // slot of the most recent frame
+        for (int s = 0; s < h->S; s++) memcpy(dst + (size_t)s * FRAME, tmp.data() + (size_t)s * RING + slot * FRAME, FRAME * 4);
+    }
+    return 0;
+}
+
+// ---- profiling / graph switches ---------------------------------------------------------------
+extern "C" int nnn_batch_set_profiling(nnn_batch *h, int on)
+{
+    if (!h) return fail("null batch");
+    h->profiling = on != 0;
+    return 0;
+}
+extern "C" int nnn_batch_num_kernels(void) { return K_COUNT; }
+extern "C" const char *nnn_batch_kernel_name(int k) { return (k >= 0 && k < K_COUNT) ? kKernelNames[k] : ""; }
+extern "C" int nnn_batch_read_kernel_times(nnn_batch *h, double *total_ms, int64_t *launches, int n)
+{
+    if (!h) return fail("null batch");
+    for (int k = 0; k < n && k < K_COUNT; k++) {
+        total_ms[k] = h->k_ms[k];
+        launches[k] = h->k_launches[k];
+        h->k_ms[k] = 0;
+        h->k_launches[k] = 0;
+    }
+    return 0;
+}
+extern "C" int nnn_batch_set_graph(nnn_batch *h, int on)
+{
+    if (!h) return fail("null batch");
+    h->use_graph = on != 0;
+    return 0;
+}
+
+// ---- model entry points -------------------------------------------------------------------------
+extern "C" RNNModel *nnn_model_from_bytes(const uint8_t *bytes, size_t len)
+{
+    RNNModel *m = nnn_model_parse(bytes, len);
+    if (!m) fail("malformed .rnn model");
+    return m;
+}
+extern "C" RNNModel *nnn_model_default(void)
+{
+    size_t len;
+    const uint8_t *w = nnn_builtin_weights(&len);
+    return nnn_model_parse(w, len);
+}
+extern "C" void nnn_model_free(RNNModel *m) { delete m; }
+extern "C" void nnn_model_shape(const RNNModel *m, int32_t s[12])
+{
+    s[0] = m->input_dense.nb_inputs; s[1] = m->input_dense.nb_neurons; s[2] = m->vad_gru.nb_neurons;
+    s[3] = m->noise_gru.nb_neurons; s[4] = m->denoise_gru.nb_neurons; s[5] = m->denoise_output.nb_neurons;
+    s[6] = m->input_dense.activation; s[7] = m->vad_gru.activation; s[8] = m->noise_gru.activation;
+    s[9] = m->denoise_gru.activation; s[10] = m->denoise_output.activation; s[11] = m->vad_output.activation;
+}

@@ -1,0 +1,1053 @@
+// nnn_kernels.hip -- CDNA4 (gfx950) kernels for the batched nnnoiseless process_frame path.
+//
+// Compiled with -ffp-contract=off: everything upstream of the integer pitch index must round
+// exactly like the scalar reference (which never fuses a*b+c); fmaf() is written explicitly
+// where fusing is allowed (FFT, RNN mat-vecs, band sums: tolerance-only quantities).
+//
+// Mapping rule: a stage whose result feeds the pitch index runs lane = stream on
+// the tile-interleaved (TI) layout, so every lane executes the reference's scalar recurrence in the
+// reference's summation order at full lane utilisation, with extra parallelism (lag chunks, sample
+// chunks, neuron blocks) spread over waves.  Stages with data-dependent addressing or a 960-point
+// transform run wave = stream on the stream-major (SM) layout with the stream's data staged in LDS.
+//
+// Reference citations are into jneem/nnnoiseless v0.5.1.
+#pragma once
+#include "nnn_layout.h"
+
+namespace nnn {
+
+#define NNN_TI(ptr, len, tile, lane) ((ptr) + ((size_t)(tile) * (len)) * TILE + (lane))
+
+// Bark-ish band edges in units of 4 bins (ref: src/lib.rs:55-58) and SECOND_CHECK (ref: src/pitch.rs:489)
+__constant__ int kEband[NB] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100};
+__constant__ int kSecondCheck[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};
+
+// ---------------------------------------------------------------------------------------------
+// K1  hp_filter: high-pass biquad (f64 arithmetic, f32 state) + append to the history ring.
+//     ref: src/features.rs:97-104, src/util.rs:95-107.  lane = stream; the 480-step recurrence is
+//     inherently serial per stream.  Input and history are stream-major, so 64x32 tiles are
+//     transposed through LDS to keep every global access coalesced.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp)
+{
+    const float *in = sp->in;
+    const size_t stream_stride = sp->stream_stride;
+    const int slot = sp->slot;
+    __shared__ float tl[64][33];
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    float *hp = NNN_TI(b.hp_mem, 2, tile, lane);
+    float m0 = hp[0], m1 = hp[TILE];
+    const double a0 = (double)-1.99599f, a1 = (double)0.99600f, b0 = (double)-2.0f, b1 = (double)1.0f;
+    const int sub = lane >> 5, col = lane & 31;
+    for (int c = 0; c < FRAME / 32; c++) {
+        for (int r = 0; r < 32; r++) {
+            int row = r * 2 + sub, s = tile * TILE + row;
+            tl[row][col] = (s < b.S) ? in[(size_t)s * stream_stride + c * 32 + col] : 0.0f;
+        }
+        __syncthreads();
+        for (int j = 0; j < 32; j++) {
+            double x64 = (double)tl[lane][j];
+            double y64 = x64 + (double)m0;
+            m0 = (float)((double)m1 + (b0 * x64 - a0 * y64));
+            m1 = (float)(b1 * x64 - a1 * y64);
+            tl[lane][j] = (float)y64;
+        }
+        __syncthreads();
+        for (int r = 0; r < 32; r++) {
+            int row = r * 2 + sub, s = tile * TILE + row;
+            b.hist[(size_t)s * RING + slot * FRAME + c * 32 + col] = tl[row][col];
+        }
+        __syncthreads();
+    }
+    hp[0] = m0;
+    hp[TILE] = m1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2  decimate: 2:1 decimation with [.25 .5 .25], ref: src/pitch.rs:455-458.  Elementwise, so any
+//     mapping is exact; a block takes 32 outputs of one 64-stream tile, reads the SM history ring
+//     coalesced, transposes through LDS and writes TI rows.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_decim(Buffers b, const StepParams *sp)
+{
+    const int slot = sp->slot;
+    __shared__ float tl[64][67];
+    const int tid = threadIdx.x, tile = blockIdx.x, c = blockIdx.y;
+    const int rb = ring_base(slot);
+    for (int idx = tid; idx < 64 * 66; idx += 256) {
+        int row = idx / 66, col = idx - row * 66;
+        int li = 64 * c - 1 + col;
+        float v = 0.0f;
+        if (li >= 0 && li < HIST) {
+            int ph = rb + li;
+            if (ph >= RING) ph -= RING;
+            v = b.hist[(size_t)(tile * TILE + row) * RING + ph];
+        }
+        tl[row][col] = v;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    float *o = NNN_TI(b.xlp_raw, XLP, tile, lane);
+    for (int k = wave; k < 32; k += 4) {
+        int i = 32 * c + k;
+        float a = tl[lane][2 * k], m = tl[lane][2 * k + 1], n = tl[lane][2 * k + 2];
+        float v = (i == 0) ? (n / 2.0f + m) / 2.0f : ((a + n) / 2.0f + m) / 2.0f;
+        o[(size_t)i * TILE] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3  lpc: 5-lag autocorrelation (strictly sequential per lag), lag window, order-4 Levinson,
+//     bandwidth expansion and the extra zero.  ref: src/pitch.rs:433-446, 460-480, 257-292.
+//     lane = stream; the five chains share one sliding window in registers.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_lpc(Buffers b)
+{
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    const float *x = NNN_TI(b.xlp_raw, XLP, tile, lane);
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f, c4 = 0.0f;
+    float x0 = x[0], x1 = x[TILE], x2 = x[2 * TILE], x3 = x[3 * TILE];
+    const int fast_n = XLP - 4;
+#pragma unroll 4
+    for (int j = 0; j < fast_n; j++) {
+        float x4 = x[(size_t)(j + 4) * TILE];
+        c0 += x0 * x0;
+        c1 += x0 * x1;
+        c2 += x0 * x2;
+        c3 += x0 * x3;
+        c4 += x0 * x4;
+        x0 = x1; x1 = x2; x2 = x3; x3 = x4;
+    }
+    // tails: d_k = sum_{i=k+860}^{863} x[i] x[i-k]; x0..x3 now hold x[860..863]
+    float ac[5];
+    {
+        float d0 = 0.0f; d0 += x0 * x0; d0 += x1 * x1; d0 += x2 * x2; d0 += x3 * x3;
+        float d1 = 0.0f; d1 += x1 * x0; d1 += x2 * x1; d1 += x3 * x2;
+        float d2 = 0.0f; d2 += x2 * x0; d2 += x3 * x1;
+        float d3 = 0.0f; d3 += x3 * x0;
+        ac[0] = c0 + d0; ac[1] = c1 + d1; ac[2] = c2 + d2; ac[3] = c3 + d3; ac[4] = c4 + 0.0f;
+    }
+    ac[0] *= 1.0001f;
+#pragma unroll
+    for (int i = 1; i < 5; i++) ac[i] -= ac[i] * (0.008f * (float)i) * (0.008f * (float)i);
+
+    float lpc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (ac[0] != 0.0f) {
+        float error = ac[0];
+        bool done = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (!done) {
+                float rr = 0.0f;
+#pragma unroll
+                for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
+                rr += ac[i + 1];
+                float r = -rr / error;
+                lpc[i] = r;
+#pragma unroll
+                for (int j = 0; j < (i + 1) / 2; j++) {
+                    float t1 = lpc[j], t2 = lpc[i - 1 - j];
+                    lpc[j] = t1 + r * t2;
+                    lpc[i - 1 - j] = t2 + r * t1;
+                }
+                error = error - r * r * error;
+                if (error < 0.001f * ac[0]) done = true;
+            }
+        }
+    }
+    float tmp = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { tmp *= 0.9f; lpc[i] *= tmp; }
+    float l2[5];
+    l2[0] = lpc[0] + 0.8f;
+    l2[1] = lpc[1] + 0.8f * lpc[0];
+    l2[2] = lpc[2] + 0.8f * lpc[1];
+    l2[3] = lpc[3] + 0.8f * lpc[2];
+    l2[4] = 0.8f * lpc[3];
+    float *o = NNN_TI(b.lpc, 10, tile, lane);
+#pragma unroll
+    for (int i = 0; i < 5; i++) { o[(size_t)i * TILE] = ac[i]; o[(size_t)(5 + i) * TILE] = l2[i]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4  fir5: pitch_buf = FIR5(decimated history), zero initial memory each frame.
+//     ref: src/pitch.rs:407-429.  Elementwise in i; writes the TI copy (scans, coarse xcorr) and
+//     the SM copy (wave = stream inner products) of pitch_buf.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_fir(Buffers b)
+{
+    __shared__ float tl[64][33];
+    const int lane = threadIdx.x, tile = blockIdx.x, c = blockIdx.y;
+    const float *x = NNN_TI(b.xlp_raw, XLP, tile, lane);
+    const float *l = NNN_TI(b.lpc, 10, tile, lane);
+    const float n0 = l[5 * TILE], n1 = l[6 * TILE], n2 = l[7 * TILE], n3 = l[8 * TILE], n4 = l[9 * TILE];
+    const int i0 = 32 * c;
+    float m0 = i0 >= 1 ? x[(size_t)(i0 - 1) * TILE] : 0.0f;
+    float m1 = i0 >= 2 ? x[(size_t)(i0 - 2) * TILE] : 0.0f;
+    float m2 = i0 >= 3 ? x[(size_t)(i0 - 3) * TILE] : 0.0f;
+    float m3 = i0 >= 4 ? x[(size_t)(i0 - 4) * TILE] : 0.0f;
+    float m4 = i0 >= 5 ? x[(size_t)(i0 - 5) * TILE] : 0.0f;
+    float *o = NNN_TI(b.xlp_ti, XLP, tile, lane);
+    for (int k = 0; k < 32; k++) {
+        float xi = x[(size_t)(i0 + k) * TILE];
+        float out = xi + n0 * m0 + n1 * m1 + n2 * m2 + n3 * m3 + n4 * m4;
+        m4 = m3; m3 = m2; m2 = m1; m1 = m0; m0 = xi;
+        o[(size_t)(i0 + k) * TILE] = out;
+        tl[lane][k] = out;
+    }
+    __syncthreads();
+    const int sub = lane >> 5, col = lane & 31;
+    for (int r = 0; r < 32; r++) {
+        int row = r * 2 + sub;
+        b.xlp_sm[(size_t)(tile * TILE + row) * XLP + i0 + col] = tl[row][col];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5  xcorr_coarse: 147 lags x 240 taps on the 4x-decimated signal, every lag a strictly
+//     sequential sum in j (ref: src/pitch.rs:296-363, call site :82).  lane = stream, one wave per
+//     (tile, chunk of 8 lags); 8 accumulators + an 8-deep sliding window of y in registers, so a
+//     step costs 2 coalesced row loads for 8 multiply-adds.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_xcorr(Buffers b)
+{
+    const int lane = threadIdx.x, tile = blockIdx.x, L0 = blockIdx.y * 8;
+    const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
+#define X4(j) p[(size_t)(384 + 2 * (j)) * TILE]
+#define Y4(m) p[(size_t)(2 * (m)) * TILE]
+    float acc[8], y[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { acc[q] = 0.0f; y[q] = Y4(L0 + q); }
+    for (int j = 0; j < 240; j += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float xv = X4(j + k);
+            int mn = L0 + j + k + 8;                 // next y entering the window
+            float yn = Y4(mn < 432 ? mn : 431);      // stays inside pitch_buf; lags >= 147 are discarded
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc[q] += xv * y[(k + q) & 7];
+            y[k & 7] = yn;
+        }
+    }
+#undef X4
+#undef Y4
+    float *o = NNN_TI(b.xc1, NLAG1, tile, lane);
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+        if (L0 + q < NLAG1) o[(size_t)(L0 + q) * TILE] = acc[q];
+}
+
+// running best / second-best update of find_best_pitch, ref: src/pitch.rs:383-400
+struct BestPitch {
+    float best_num, second_num, best_den, second_den;
+    int best, second;
+    __device__ void init() { best_num = -1.0f; second_num = -1.0f; best_den = 0.0f; second_den = 0.0f; best = 0; second = 1; }
+    __device__ void update(int i, float corr, float y_sq_norm) {
+        if (corr > 0.0f) {
+            float num = corr * corr;
+            if (num * second_den > second_num * y_sq_norm) {
+                if (num * best_den > best_num * y_sq_norm) {
+                    second_num = best_num; second_den = best_den; second = best;
+                    best_num = num; best_den = y_sq_norm; best = i;
+                } else {
+                    second_num = num; second_den = y_sq_norm; second = i;
+                }
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// K6  best1: find_best_pitch over the coarse lags (running energy with its >= 1 clamp is a serial
+//     scan).  ref: src/pitch.rs:372-405, call site :83-84.  lane = stream.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_best1(Buffers b)
+{
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
+    const float *xc = NNN_TI(b.xc1, NLAG1, tile, lane);
+    float ysq = 1.0f;
+    for (int j = 0; j < 240; j++) { float v = p[(size_t)(2 * j) * TILE]; ysq += v * v; }
+    BestPitch bp;
+    bp.init();
+    for (int i = 0; i < NLAG1; i++) {
+        bp.update(i, xc[(size_t)i * TILE], ysq);
+        float a = p[(size_t)(2 * (i + 240)) * TILE], c = p[(size_t)(2 * i) * TILE];
+        ysq += a * a - c * c;
+        ysq = fmaxf(ysq, 1.0f);
+    }
+    int *o = (int *)NNN_TI(b.best1, 2, tile, lane);
+    o[0] = bp.best;
+    o[TILE] = bp.second;
+}
+
+// 4-way interleaved inner product partial (ref: src/pitch.rs:225-244): lane (e, q) accumulates
+// xs[4m+q]*ys[4m+q]; the caller combines ((s0+s1)+s2)+s3.
+__device__ __forceinline__ float ip480_partial(const float *xs, const float *ys, int q)
+{
+    float s = 0.0f;
+    for (int m = 0; m < 120; m++) s += xs[4 * m + q] * ys[4 * m + q];
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7a refine: fine cross-correlation at the <= 10 lags within +-2 of 2*best / 2*second
+//     (ref: src/pitch.rs:88-96).  Lags are data dependent, so wave = stream with pitch_buf in LDS;
+//     lane (candidate, partial) keeps the reference's 4 interleaved partial sums.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_refine(Buffers b)
+{
+    __shared__ float sh[4][XLP];
+    __shared__ float part[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + wave, tile = s >> 6, sl = s & 63;
+    for (int i = lane; i < XLP; i += 64) sh[wave][i] = b.xlp_sm[(size_t)s * XLP + i];
+    const int *b1 = NNN_TI(b.best1, 2, tile, sl);
+    const int best = b1[0], second = b1[TILE];
+    __syncthreads();
+    const int c = lane >> 2, q = lane & 3;
+    int lag = (c < 5) ? 2 * best - 2 + c : 2 * second - 2 + (c - 5);
+    const bool valid = c < 10 && lag >= 0 && lag < NLAG2;
+    part[wave][lane] = valid ? ip480_partial(&sh[wave][384], &sh[wave][lag], q) : 0.0f;
+    __syncthreads();
+    if (q == 0 && c < 10) {
+        float v = 0.0f;
+        if (valid) {
+            v = part[wave][lane] + part[wave][lane + 1] + part[wave][lane + 2] + part[wave][lane + 3];
+            v = fmaxf(v, -1.0f);
+        }
+        NNN_TI(b.xc2, 10, tile, sl)[(size_t)c * TILE] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7b best2: find_best_pitch over the 294 fine lags + pseudo-interpolation (ref: src/pitch.rs:97-114)
+//     and, for remove_doubling, xx and the 384-step running energy yy_lookup (ref: :133-142).
+//     All serial scans -> lane = stream.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float xc2_at(const float *xc2, int i, int best, int second)
+{
+    // xcorr[i] of the reference: zero unless i is within 2 of 2*best or 2*second
+    if (i < 0 || i >= NLAG2) return 0.0f;
+    int d1 = i - (2 * best - 2), d2 = i - (2 * second - 2);
+    if (d1 >= 0 && d1 <= 4) return xc2[(size_t)d1 * TILE];
+    if (d2 >= 0 && d2 <= 4) return xc2[(size_t)(5 + d2) * TILE];
+    return 0.0f;
+}
+
+__global__ void __launch_bounds__(64) k_best2(Buffers b)
+{
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
+    const float *xc2 = NNN_TI(b.xc2, 10, tile, lane);
+    const int *b1 = NNN_TI(b.best1, 2, tile, lane);
+    const int best1 = b1[0], second1 = b1[TILE];
+    float ysq = 1.0f;
+    for (int j = 0; j < 480; j++) { float v = p[(size_t)j * TILE]; ysq += v * v; }
+    BestPitch bp;
+    bp.init();
+    for (int i = 0; i < NLAG2; i++) {
+        bp.update(i, xc2_at(xc2, i, best1, second1), ysq);
+        float a = p[(size_t)(i + 480) * TILE], c = p[(size_t)i * TILE];
+        ysq += a * a - c * c;
+        ysq = fmaxf(ysq, 1.0f);
+    }
+    int offset = 0;
+    if (bp.best > 0 && bp.best < NLAG2 - 1) {
+        float a = xc2_at(xc2, bp.best - 1, best1, second1);
+        float bb = xc2_at(xc2, bp.best, best1, second1);
+        float c = xc2_at(xc2, bp.best + 1, best1, second1);
+        if (c - a > 0.7f * (bb - a)) offset = 1;
+        else if (a - c > 0.7f * (bb - c)) offset = -1;
+    }
+    NNN_TI(b.psearch, 1, tile, lane)[0] = 2 * bp.best - offset;
+
+    // xx = inner_prod(x[384..], x[384..], 480) with the 4 interleaved partial sums
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (int m = 0; m < 120; m++) {
+        float v0 = p[(size_t)(384 + 4 * m) * TILE], v1 = p[(size_t)(385 + 4 * m) * TILE];
+        float v2 = p[(size_t)(386 + 4 * m) * TILE], v3 = p[(size_t)(387 + 4 * m) * TILE];
+        s0 += v0 * v0; s1 += v1 * v1; s2 += v2 * v2; s3 += v3 * v3;
+    }
+    const float xx = s0 + s1 + s2 + s3;
+    float *yo = NNN_TI(b.xx_yy, 386, tile, lane);
+    yo[0] = xx;
+    yo[TILE] = xx;  // yy_lookup[0]
+    float yy = xx;
+    for (int i = 1; i <= 384; i++) {
+        float a = p[(size_t)(384 - i) * TILE], c = p[(size_t)(384 + 480 - i) * TILE];
+        yy += a * a - c * c;
+        yo[(size_t)(1 + i) * TILE] = fmaxf(yy, 0.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7c doubling: remove_doubling (ref: src/pitch.rs:118-221).  The 29 candidate periods depend only
+//     on t0, so all their inner products are computed up front, lane (candidate, partial); the
+//     k = 2..15 decision loop then runs on scalars.  wave = stream, pitch_buf in LDS.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1.0f + xx * yy); }
+
+__global__ void __launch_bounds__(256) k_doubling(Buffers b)
+{
+    __shared__ float sh[4][XLP];
+    __shared__ float part[4][64];
+    __shared__ float ipv[4][32], yyc[4][32];
+    __shared__ int cand[4][32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + wave, tile = s >> 6, sl = s & 63;
+    for (int i = lane; i < XLP; i += 64) sh[wave][i] = b.xlp_sm[(size_t)s * XLP + i];
+    const int ps = NNN_TI(b.psearch, 1, tile, sl)[0];
+    const int last_period = NNN_TI(b.last_period, 1, tile, sl)[0];
+    const float last_gain = NNN_TI(b.last_gain, 1, tile, sl)[0];
+    const float *xy_tab = NNN_TI(b.xx_yy, 386, tile, sl);
+    const float xx = xy_tab[0];
+    const int min_period = PITCH_MIN / 2, max_period = PITCH_MAX / 2;
+    int t0 = (PITCH_MAX - ps) / 2;
+    if (t0 > max_period - 1) t0 = max_period - 1;
+    const int prev_period = last_period / 2;
+    if (lane < 29) {
+        int t;
+        if (lane == 0) t = t0;
+        else {
+            int k = 2 + (lane - 1) / 2;
+            int t1 = (2 * t0 + k) / (2 * k);
+            if ((lane - 1) & 1) {
+                const int sc = kSecondCheck[k];
+                t = (k == 2) ? ((t1 + t0 > max_period) ? t0 : t0 + t1) : (2 * sc * t0 + k) / (2 * k);
+            } else t = t1;
+        }
+        cand[wave][lane] = t;
+        yyc[wave][lane] = xy_tab[(size_t)(1 + t) * TILE];
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; pass++) {
+        int e = pass * 16 + (lane >> 2), q = lane & 3;
+        float v = 0.0f;
+        if (e < 29) v = ip480_partial(&sh[wave][max_period], &sh[wave][max_period - cand[wave][e]], q);
+        part[wave][lane] = v;
+        __syncthreads();
+        if ((lane & 3) == 0 && e < 29)
+            ipv[wave][e] = part[wave][lane] + part[wave][lane + 1] + part[wave][lane + 2] + part[wave][lane + 3];
+        __syncthreads();
+    }
+    // decision loop on scalars (every lane computes the same thing)
+    int t = t0;
+    float xy = ipv[wave][0], yy = yyc[wave][0];
+    float best_xy = xy, best_yy = yy;
+    const float g0 = pitch_gain(xy, xx, yy);
+    float g = g0;
+    for (int k = 2; k <= 15; k++) {
+        int t1 = cand[wave][1 + 2 * (k - 2)];
+        if (t1 < min_period) break;
+        int e1 = 1 + 2 * (k - 2), e2 = e1 + 1;
+        xy = (ipv[wave][e1] + ipv[wave][e2]) / 2.0f;
+        yy = (yyc[wave][e1] + yyc[wave][e2]) / 2.0f;
+        float g1 = pitch_gain(xy, xx, yy);
+        int d = t1 - prev_period;
+        if (d < 0) d = -d;
+        float cont;
+        if (d <= 1) cont = last_gain;
+        else if (d <= 2 && 5 * k * k < t0) cont = last_gain / 2.0f;
+        else cont = 0.0f;
+        float thresh;
+        if (t1 < 3 * min_period) thresh = fmaxf(0.85f * g0 - cont, 0.4f);
+        else if (t1 < 2 * min_period) thresh = fmaxf(0.9f * g0 - cont, 0.5f);
+        else thresh = fmaxf(0.7f * g0 - cont, 0.3f);
+        if (g1 > thresh) { best_xy = xy; best_yy = yy; t = t1; g = g1; }
+    }
+    best_xy = fmaxf(best_xy, 0.0f);
+    float pg = (best_yy <= best_xy) ? 1.0f : best_xy / (best_yy + 1.0f);
+    // final +-1 refinement: three inner products around t
+    {
+        int e = lane >> 2, q = lane & 3;
+        float v = 0.0f;
+        if (e < 3) v = ip480_partial(&sh[wave][max_period], &sh[wave][max_period - (t + e - 1)], q);
+        part[wave][lane] = v;
+    }
+    __syncthreads();
+    float xc[3];
+#pragma unroll
+    for (int e = 0; e < 3; e++)
+        xc[e] = part[wave][4 * e] + part[wave][4 * e + 1] + part[wave][4 * e + 2] + part[wave][4 * e + 3];
+    int offset = 0;
+    if (xc[2] - xc[0] > 0.7f * (xc[1] - xc[0])) offset = 1;
+    else if (xc[0] - xc[2] > 0.7f * (xc[1] - xc[2])) offset = -1;
+    pg = fminf(pg, g);
+    int res = 2 * t + offset;
+    if (res < PITCH_MIN) res = PITCH_MIN;
+    if (lane == 0) {
+        NNN_TI(b.pitch, 1, tile, sl)[0] = res;
+        NNN_TI(b.pgain, 1, tile, sl)[0] = pg;
+        NNN_TI(b.last_period, 1, tile, sl)[0] = res;
+        NNN_TI(b.last_gain, 1, tile, sl)[0] = pg;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 960-point complex FFT in LDS, Stockham autosort, radices 8 x 8 x 5 x 3, one wave per transform.
+// (The reference's FFT is third-party: easyfft 0.4.2 -> realfft 3.5.0 -> rustfft 6.4.1; call sites
+// src/features.rs:264,290; un-normalised in both directions.)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cmulf(float2 a, float2 w)
+{
+    return make_float2(fmaf(a.x, w.x, -a.y * w.y), fmaf(a.x, w.y, a.y * w.x));
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 c) { return make_float2(a.x + c.x, a.y + c.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 c) { return make_float2(a.x - c.x, a.y - c.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+
+__device__ __forceinline__ void bfly2(float2 &a, float2 &c) { float2 t = csub(a, c); a = cadd(a, c); c = t; }
+
+__device__ __forceinline__ void dft8(float2 *v)
+{
+    const float h = 0.70710678118654752440f;
+    // three radix-2 stages, decimation in time on bit-reversed order handled by index pattern
+    float2 a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7];
+    bfly2(a0, a4); bfly2(a1, a5); bfly2(a2, a6); bfly2(a3, a7);
+    a5 = make_float2((a5.x + a5.y) * h, (a5.y - a5.x) * h);   // * exp(-i pi/4)
+    a6 = mul_mi(a6);                                          // * exp(-i pi/2)
+    a7 = make_float2((a7.y - a7.x) * h, (-a7.x - a7.y) * h);  // * exp(-3i pi/4)
+    bfly2(a0, a2); bfly2(a1, a3); bfly2(a4, a6); bfly2(a5, a7);
+    a3 = mul_mi(a3); a7 = mul_mi(a7);
+    bfly2(a0, a1); bfly2(a2, a3); bfly2(a4, a5); bfly2(a6, a7);
+    v[0] = a0; v[4] = a1; v[2] = a2; v[6] = a3; v[1] = a4; v[5] = a5; v[3] = a6; v[7] = a7;
+}
+
+__device__ __forceinline__ void dft3(float2 *v)
+{
+    const float s = 0.86602540378443864676f;  // sin(2 pi / 3)
+    float2 t1 = cadd(v[1], v[2]);
+    float2 t2 = csub(v[1], v[2]);
+    float2 m = make_float2(v[0].x - 0.5f * t1.x, v[0].y - 0.5f * t1.y);
+    float2 js = make_float2(s * t2.y, -s * t2.x);  // -i * s * t2
+    v[0] = cadd(v[0], t1);
+    v[1] = cadd(m, js);
+    v[2] = csub(m, js);
+}
+
+__device__ __forceinline__ void dft5(float2 *v)
+{
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;  // cos(2pi/5), cos(4pi/5)
+    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;   // sin(2pi/5), sin(4pi/5)
+    float2 a1 = cadd(v[1], v[4]), b1 = csub(v[1], v[4]);
+    float2 a2 = cadd(v[2], v[3]), b2 = csub(v[2], v[3]);
+    float2 x0 = v[0];
+    float2 m1 = make_float2(x0.x + c1 * a1.x + c2 * a2.x, x0.y + c1 * a1.y + c2 * a2.y);
+    float2 m2 = make_float2(x0.x + c2 * a1.x + c1 * a2.x, x0.y + c2 * a1.y + c1 * a2.y);
+    // -i * (s1 b1 + s2 b2)  and  -i * (s2 b1 - s1 b2)
+    float2 n1 = make_float2(s1 * b1.y + s2 * b2.y, -(s1 * b1.x + s2 * b2.x));
+    float2 n2 = make_float2(s2 * b1.y - s1 * b2.y, -(s2 * b1.x - s1 * b2.x));
+    v[0] = make_float2(x0.x + a1.x + a2.x, x0.y + a1.y + a2.y);
+    v[1] = cadd(m1, n1);
+    v[4] = csub(m1, n1);
+    v[2] = cadd(m2, n2);
+    v[3] = csub(m2, n2);
+}
+
+template <int R> __device__ __forceinline__ void dftR(float2 *v)
+{
+    if (R == 8) dft8(v);
+    else if (R == 5) dft5(v);
+    else dft3(v);
+}
+
+// one Stockham pass: N = 960, radix R, Ns = product of the radices already applied
+template <int R, int NS>
+__device__ __forceinline__ void fft_pass(const float2 *src, float2 *dst, const float2 *tw, int lane)
+{
+    constexpr int NB_ = 960 / R;
+    for (int j = lane; j < NB_; j += 64) {
+        float2 v[R];
+        const int k = j % NS;
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = src[j + r * NB_];
+        if (NS > 1) {
+            const int step = 960 / (NS * R);
+#pragma unroll
+            for (int r = 1; r < R; r++) v[r] = cmulf(v[r], tw[(r * k * step) % 960]);
+        }
+        dftR<R>(v);
+        const int base = (j / NS) * NS * R + k;
+#pragma unroll
+        for (int r = 0; r < R; r++) dst[base + r * NS] = v[r];
+    }
+}
+
+// forward FFT of the 960 points in A (B is scratch); the result lands in A.  Barriers included.
+__device__ __forceinline__ void fft960(float2 *A, float2 *B, const float2 *tw, int lane)
+{
+    fft_pass<8, 1>(A, B, tw, lane);
+    __syncthreads();
+    fft_pass<8, 8>(B, A, tw, lane);
+    __syncthreads();
+    fft_pass<5, 64>(A, B, tw, lane);
+    __syncthreads();
+    fft_pass<3, 320>(B, A, tw, lane);
+    __syncthreads();
+}
+
+// band sums in the reference's accumulation order (ref: src/lib.rs:65-82): out[b] first receives
+// the frac-weighted terms of interval b-1, then the (1-frac)-weighted terms of interval b.
+__device__ __forceinline__ float band_sum(const float *v, int bnd, const float *bin_frac)
+{
+    const int e_lo = bnd >= 1 ? kEband[bnd - 1] : 0, e_mid = kEband[bnd], e_hi = bnd < NB - 1 ? kEband[bnd + 1] : 0;
+    float acc = 0.0f;
+    if (bnd >= 1)
+        for (int k = 4 * e_lo; k < 4 * e_mid; k++) acc += bin_frac[k] * v[k];
+    if (bnd < NB - 1)
+        for (int k = 4 * e_mid; k < 4 * e_hi; k++) acc += (1.0f - bin_frac[k]) * v[k];
+    if (bnd == 0 || bnd == NB - 1) acc *= 2.0f;
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8  fft_fwd: transform_input for lag 0 and lag = pitch in ONE complex transform (z = x + i p),
+//     then un-mix, normalise and band energies/correlation.  ref: src/features.rs:281-298,
+//     src/lib.rs:65-82, 150-155.  One wave per stream, 960 complex points in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_fft_fwd(Buffers b, const StepParams *sp)
+{
+    const int slot = sp->slot;
+    __shared__ float2 A[WINDOW], B[WINDOW];
+    const int lane = threadIdx.x, s = blockIdx.x, tile = s >> 6, sl = s & 63;
+    const int rb = ring_base(slot);
+    const int pitch = NNN_TI(b.pitch, 1, tile, sl)[0];
+    const float *h = b.hist + (size_t)s * RING;
+    for (int n = lane; n < WINDOW; n += 64) {
+        float w = b.window[n];
+        int ix = (rb + (HIST - WINDOW) + n) % RING;
+        int ip = (rb + (HIST - WINDOW) - pitch + n) % RING;
+        A[n] = make_float2(h[ix] * w, h[ip] * w);
+    }
+    __syncthreads();
+    fft960(A, B, b.tw960, lane);
+    // un-mix: X = (Z[k] + conj Z[N-k]) / 2, P = (Z[k] - conj Z[N-k]) / (2i); then * wnorm
+    float *vxx = (float *)B, *vpp = vxx + 400, *vxp = vpp + 400;
+    const float wn = b.wnorm;
+    for (int k = lane; k < FREQ; k += 64) {
+        float2 zk = A[k], zn = A[(WINDOW - k) % WINDOW];
+        float2 X = make_float2(0.5f * (zk.x + zn.x) * wn, 0.5f * (zk.y - zn.y) * wn);
+        float2 P = make_float2(0.5f * (zk.y + zn.y) * wn, -0.5f * (zk.x - zn.x) * wn);
+        b.X[(size_t)s * FREQ + k] = X;
+        b.P[(size_t)s * FREQ + k] = P;
+        if (k < 400) {
+            vxx[k] = X.x * X.x + X.y * X.y;
+            vpp[k] = P.x * P.x + P.y * P.y;
+            vxp[k] = X.x * P.x + X.y * P.y;
+        }
+    }
+    __syncthreads();
+    for (int t = lane; t < 3 * NB; t += 64) {
+        const int q = t / NB, bnd = t - q * NB;
+        const float *v = q == 0 ? vxx : (q == 1 ? vpp : vxp);
+        float *dst = q == 0 ? b.ex : (q == 1 ? b.ep : b.exp_);
+        NNN_TI(dst, NB, tile, sl)[(size_t)bnd * TILE] = band_sum(v, bnd, b.bin_frac);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K9  features: the 42 RNN inputs from band energies, pitch and the cepstral history.
+//     ref: src/features.rs:135-219, src/lib.rs:139-148.  lane = stream.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dct_out(const float *x, const float *dct, int i)
+{
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NB; j++) sum += x[j] * dct[j * NB + i];
+    return (float)((double)sum * 0.30151134457776363 /* sqrt(2/22) */);
+}
+
+__global__ void __launch_bounds__(64) k_features(Buffers b)
+{
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    float ex[NB], ly[NB], tmp[NB];
+    const float *exg = NNN_TI(b.ex, NB, tile, lane), *epg = NNN_TI(b.ep, NB, tile, lane);
+    float *xpg = NNN_TI(b.exp_, NB, tile, lane);
+    float *f = NNN_TI(b.feat, NFEAT, tile, lane);
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        ex[i] = exg[(size_t)i * TILE];
+        float v = xpg[(size_t)i * TILE] / sqrtf(0.001f + ex[i] * epg[(size_t)i * TILE]);
+        tmp[i] = v;
+        xpg[(size_t)i * TILE] = v;
+    }
+    const int pitch = NNN_TI(b.pitch, 1, tile, lane)[0];
+    float fpc[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) fpc[i] = dct_out(tmp, b.dct, i);
+    fpc[0] -= 1.3f;
+    fpc[1] -= 0.9f;
+    const float fpitch = 0.01f * ((float)pitch - 300.0f);
+    float log_max = -2.0f, follow = -2.0f, e = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        float l = fmaxf(fmaxf(log10f(1e-2f + ex[i]), log_max - 7.0f), follow - 1.5f);
+        ly[i] = l;
+        log_max = fmaxf(log_max, l);
+        follow = fmaxf(follow - 1.5f, l);
+        e += ex[i];
+    }
+    const bool silent = e < 0.04f;
+    NNN_TI(b.silence, 1, tile, lane)[0] = silent ? 1 : 0;
+    if (silent) {
+        for (int i = 0; i < NFEAT; i++) f[(size_t)i * TILE] = 0.0f;
+        return;
+    }
+    float c[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) c[i] = dct_out(ly, b.dct, i);
+    c[0] -= 12.0f;
+    c[1] -= 4.0f;
+    int *midp = NNN_TI(b.mem_id, 1, tile, lane);
+    int mem_id = midp[0];
+    const int c0 = mem_id, c1 = mem_id < 1 ? CEPS_MEM + mem_id - 1 : mem_id - 1;
+    const int c2 = mem_id < 2 ? CEPS_MEM + mem_id - 2 : mem_id - 2;
+    float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, lane);
+#pragma unroll
+    for (int i = 0; i < NB; i++) cm[(size_t)(c0 * NB + i) * TILE] = c[i];
+    mem_id += 1;
+    if (mem_id == CEPS_MEM) mem_id = 0;
+    midp[0] = mem_id;
+#pragma unroll
+    for (int i = 0; i < NB; i++) f[(size_t)i * TILE] = c[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        float v0 = c[i], v1 = cm[(size_t)(c1 * NB + i) * TILE], v2 = cm[(size_t)(c2 * NB + i) * TILE];
+        f[(size_t)i * TILE] = v0 + v1 + v2;
+        f[(size_t)(NB + i) * TILE] = v0 - v2;
+        f[(size_t)(NB + 6 + i) * TILE] = v0 - 2.0f * v1 + v2;
+        f[(size_t)(NB + 12 + i) * TILE] = fpc[i];
+    }
+    f[(size_t)40 * TILE] = fpitch;
+    // spectral variability: mean over i of min_{j != i} |c_i - c_j|^2 ; dist(i,j) == dist(j,i) exactly
+    float mind[CEPS_MEM];
+#pragma unroll
+    for (int i = 0; i < CEPS_MEM; i++) mind[i] = 1e15f;
+#pragma unroll
+    for (int i = 0; i < CEPS_MEM; i++) {
+        float ri[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) ri[k] = cm[(size_t)(i * NB + k) * TILE];
+#pragma unroll
+        for (int j = i + 1; j < CEPS_MEM; j++) {
+            float dist = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                float d = ri[k] - cm[(size_t)(j * NB + k) * TILE];
+                dist += d * d;
+            }
+            mind[i] = fminf(mind[i], dist);
+            mind[j] = fminf(mind[j], dist);
+        }
+    }
+    float sv = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CEPS_MEM; i++) sv += mind[i];
+    f[(size_t)41 * TILE] = sv / (float)CEPS_MEM - 2.1f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K10 rnn: dense + 3 GRUs + 2 dense, i8-origin weights, activations via the 201-entry tanh table.
+//     ref: src/rnn.rs:251-272, 292-327, 343-379, 402-410; src/util.rs:29-53.
+//     lane = stream (one 64-stream tile per block); the weight of (input k, neuron n) is the same
+//     for all lanes, so it is a scalar (SGPR) operand: one v_fmac per 64 stream-MACs.  Neurons are
+//     split over the block's 8 waves in register blocks of OB; layer outputs are exchanged in LDS.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tansig_approx(float x, const float *tab)
+{
+    if (!(x < 8.0f)) return 1.0f;
+    if (!(x > -8.0f)) return -1.0f;
+    float sign = 1.0f;
+    if (x < 0.0f) { x = -x; sign = -1.0f; }
+    float fi = floorf(0.5f + 25.0f * x);
+    x -= 0.04f * fi;
+    float y = tab[(int)fi];
+    float dy = 1.0f - y * y;
+    y = y + x * dy * (1.0f - y * x);
+    return sign * y;
+}
+__device__ __forceinline__ float sigmoid_approx(float x, const float *tab) { return 0.5f + 0.5f * tansig_approx(0.5f * x, tab); }
+__device__ __forceinline__ float activate(int act, float x, const float *tab)
+{
+    if (act == 0) return tansig_approx(x, tab);
+    if (act == 1) return sigmoid_approx(x, tab);
+    return fmaxf(x, 0.0f);
+}
+
+constexpr int RNN_WAVES = 8;
+constexpr int OB = 4;                                  // neurons per register block
+constexpr int RNN_MAXBLK = (MAXN + RNN_WAVES * OB - 1) / (RNN_WAVES * OB);
+
+struct InSeg { const float *p; int n; };               // input column (row stride TILE) of n values
+
+// acc[c] += sum_k W[k][col0 + o0 + c] * in_k
+__device__ __forceinline__ void matvec_block(float *acc, const float *W, int wstride, const int *oc,
+                                             const float *in, int n_in)
+{
+    for (int k = 0; k < n_in; k++) {
+        float v = in[(size_t)k * TILE];
+        const float *row = W + (size_t)k * wstride;
+#pragma unroll
+        for (int c = 0; c < OB; c++) acc[c] = fmaf(row[oc[c]], v, acc[c]);
+    }
+}
+
+// One GRU layer (ref: src/rnn.rs:292-327).  Each wave owns neuron blocks {o0, o0+32, ...}: phase 1
+// computes its z and r (z stays in registers, r*state goes to LDS because every neuron's candidate
+// needs all of it), phase 2 its candidate and the new state.
+template <int NSEG>
+__device__ __forceinline__ void gru_layer(const float *W, int wofs, int rofs, int bofs, int n, int act,
+                                          float *st, float *NEW, float *R, const InSeg *seg, int wave,
+                                          int lane, bool live, const float *tab)
+{
+    const float scale = 1.0f / 256.0f;
+    const int str = 3 * n;
+    float zreg[RNN_MAXBLK][OB];
+#pragma unroll
+    for (int blk = 0; blk < RNN_MAXBLK; blk++) {
+        const int o0 = (blk * RNN_WAVES + wave) * OB;
+        if (o0 < n) {
+            int oc[OB], ocr[OB];
+            float az[OB], ar[OB];
+#pragma unroll
+            for (int c = 0; c < OB; c++) {
+                oc[c] = min(o0 + c, n - 1);
+                ocr[c] = n + oc[c];
+                az[c] = W[bofs + oc[c]];
+                ar[c] = W[bofs + ocr[c]];
+            }
+            int row0 = 0;
+#pragma unroll
+            for (int sg = 0; sg < NSEG; sg++) {
+                matvec_block(az, W + wofs + (size_t)row0 * str, str, oc, seg[sg].p, seg[sg].n);
+                matvec_block(ar, W + wofs + (size_t)row0 * str, str, ocr, seg[sg].p, seg[sg].n);
+                row0 += seg[sg].n;
+            }
+            matvec_block(az, W + rofs, str, oc, st, n);
+            matvec_block(ar, W + rofs, str, ocr, st, n);
+#pragma unroll
+            for (int c = 0; c < OB; c++) {
+                zreg[blk][c] = sigmoid_approx(scale * az[c], tab);
+                if (o0 + c < n) R[(o0 + c) * TILE + lane] = st[(size_t)(o0 + c) * TILE] * sigmoid_approx(scale * ar[c], tab);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int blk = 0; blk < RNN_MAXBLK; blk++) {
+        const int o0 = (blk * RNN_WAVES + wave) * OB;
+        if (o0 < n) {
+            int och[OB];
+            float ah[OB];
+#pragma unroll
+            for (int c = 0; c < OB; c++) {
+                och[c] = 2 * n + min(o0 + c, n - 1);
+                ah[c] = W[bofs + och[c]];
+            }
+            int row0 = 0;
+#pragma unroll
+            for (int sg = 0; sg < NSEG; sg++) {
+                matvec_block(ah, W + wofs + (size_t)row0 * str, str, och, seg[sg].p, seg[sg].n);
+                row0 += seg[sg].n;
+            }
+            matvec_block(ah, W + rofs, str, och, R + lane, n);
+#pragma unroll
+            for (int c = 0; c < OB; c++) {
+                if (o0 + c < n) {
+                    float hh = activate(act, scale * ah[c], tab);
+                    float z = zreg[blk][c], sold = st[(size_t)(o0 + c) * TILE];
+                    float snew = z * sold + (1.0f - z) * hh;
+                    NEW[(o0 + c) * TILE + lane] = snew;
+                    if (live) st[(size_t)(o0 + c) * TILE] = snew;   // silent frames leave the state alone
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void dense_layer(const float *W, int wofs, int bofs, int n_out, const float *in,
+                                            int n_in, int o0, float *acc)
+{
+    int oc[OB];
+#pragma unroll
+    for (int c = 0; c < OB; c++) {
+        oc[c] = min(o0 + c, n_out - 1);
+        acc[c] = W[bofs + oc[c]];
+    }
+    matvec_block(acc, W + wofs, n_out, oc, in, n_in);
+}
+
+__global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, ModelDims md)
+{
+    HIP_DYNAMIC_SHARED(float, lds)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, tile = blockIdx.x;
+    const int nd = md.nd, nv = md.nv, nn = md.nn, ndn = md.ndn;
+    const int nmax = max(max(nv, nn), ndn);
+    // LDS carve-up (rows of 64 floats): tanh table, D, V, N, DN, R
+    float *tab = lds;
+    float *D = lds + 256;
+    float *V = D + nd * TILE, *N = V + nv * TILE, *DN = N + nn * TILE, *R = DN + ndn * TILE;
+    (void)nmax;
+    for (int i = threadIdx.x; i < 201; i += 64 * RNN_WAVES) tab[i] = b.tansig[i];
+    const float *W = b.weights;
+    const float *feat = NNN_TI(b.feat, NFEAT, tile, lane);
+    const bool live = NNN_TI(b.silence, 1, tile, lane)[0] == 0;
+    float *sv = NNN_TI(b.gru_v, nv, tile, lane), *sn = NNN_TI(b.gru_n, nn, tile, lane), *sdn = NNN_TI(b.gru_dn, ndn, tile, lane);
+    const float scale = 1.0f / 256.0f;
+    __syncthreads();
+
+    // ---- input dense: feat[42] -> D[nd]   (ref: src/rnn.rs:353-355)
+    for (int o0 = wave * OB; o0 < nd; o0 += RNN_WAVES * OB) {
+        float acc[OB];
+        dense_layer(W, md.w_d, md.b_d, nd, feat, NFEAT, o0, acc);
+#pragma unroll
+        for (int c = 0; c < OB; c++)
+            if (o0 + c < nd) D[(o0 + c) * TILE + lane] = activate(md.act_d, acc[c] * scale, tab);
+    }
+    __syncthreads();
+    {   // vad GRU: input D                      (ref: src/rnn.rs:356-358)
+        InSeg seg[1] = {{D + lane, nd}};
+        gru_layer<1>(W, md.w_v, md.r_v, md.b_v, nv, md.act_v, sv, V, R, seg, wave, lane, live, tab);
+    }
+    {   // noise GRU: input [D | V | feat]       (ref: src/rnn.rs:361-366)
+        InSeg seg[3] = {{D + lane, nd}, {V + lane, nv}, {feat, NFEAT}};
+        gru_layer<3>(W, md.w_n, md.r_n, md.b_n, nn, md.act_n, sn, N, R, seg, wave, lane, live, tab);
+    }
+    {   // denoise GRU: input [V | N | feat]     (ref: src/rnn.rs:368-377)
+        InSeg seg[3] = {{V + lane, nv}, {N + lane, nn}, {feat, NFEAT}};
+        gru_layer<3>(W, md.w_dn, md.r_dn, md.b_dn, ndn, md.act_dn, sdn, DN, R, seg, wave, lane, live, tab);
+    }
+    // ---- outputs: gains (ref: src/rnn.rs:378), smoothing g = max(g, 0.6 lastg) (ref: src/denoise.rs:106-109)
+    float *graw = NNN_TI(b.g_raw, NB, tile, lane), *gs = NNN_TI(b.g, NB, tile, lane), *lastg = NNN_TI(b.lastg, NB, tile, lane);
+    for (int o0 = wave * OB; o0 < NB; o0 += RNN_WAVES * OB) {
+        float acc[OB];
+        dense_layer(W, md.w_o, md.b_o, NB, DN + lane, ndn, o0, acc);
+#pragma unroll
+        for (int c = 0; c < OB; c++) {
+            int o = o0 + c;
+            if (o < NB) {
+                float gr = live ? activate(md.act_o, acc[c] * scale, tab) : 0.0f;
+                graw[(size_t)o * TILE] = gr;
+                float g = 0.0f;
+                if (live) {
+                    g = fmaxf(gr, 0.6f * lastg[(size_t)o * TILE]);
+                    lastg[(size_t)o * TILE] = g;
+                }
+                gs[(size_t)o * TILE] = g;
+            }
+        }
+    }
+    if (wave == RNN_WAVES - 1) {   // vad output, 1 x nv (ref: src/rnn.rs:359)
+        float acc = W[md.b_vo];
+        for (int k = 0; k < nv; k++) acc = fmaf(W[md.w_vo + k], V[k * TILE + lane], acc);
+        NNN_TI(b.vad, 1, tile, lane)[0] = live ? activate(md.act_vo, acc * scale, tab) : 0.0f;
+    }
+}
+
+// interpolated band gain at bin k (ref: src/lib.rs:84-97): zero for k >= 400
+__device__ __forceinline__ float interp_gain(const float *g, int k, const float *bin_frac, const int *bin_band)
+{
+    if (k >= 400) return 0.0f;
+    int i = bin_band[k];
+    float frac = bin_frac[k];
+    return (1.0f - frac) * g[i] + frac * g[i + 1];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K11 synth: pitch filter, band renormalisation, gains, inverse FFT, window, overlap-add.
+//     ref: src/features.rs:223-275, src/denoise.rs:103-114.  One wave per stream.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
+{
+    float *out = sp->out;
+    const size_t out_stride = sp->stream_stride;
+    float *vad_out = sp->vad;
+    __shared__ float2 A[WINDOW], B[WINDOW];
+    __shared__ float r[NB], r2[NB], gg[NB];
+    const int lane = threadIdx.x, s = blockIdx.x, tile = s >> 6, sl = s & 63;
+    const bool live = NNN_TI(b.silence, 1, tile, sl)[0] == 0;
+    const float2 *Xg = b.X + (size_t)s * FREQ, *Pg = b.P + (size_t)s * FREQ;
+    float *ebuf = (float *)B;  // 400 floats of scratch for band energies
+    float exb = 0.0f;
+    if (live) {
+        if (lane < NB) {
+            float ex = NNN_TI(b.ex, NB, tile, sl)[(size_t)lane * TILE], ep = NNN_TI(b.ep, NB, tile, sl)[(size_t)lane * TILE];
+            float xp = NNN_TI(b.exp_, NB, tile, sl)[(size_t)lane * TILE], g = NNN_TI(b.g_raw, NB, tile, sl)[(size_t)lane * TILE];
+            float v;
+            if (xp > g) v = 1.0f;
+            else {
+                float exp_sq = xp * xp, g_sq = g * g;
+                v = exp_sq * (1.0f - g_sq) / (0.001f + g_sq * (1.0f - exp_sq));
+            }
+            v = sqrtf(fminf(fmaxf(v, 0.0f), 1.0f));
+            v *= sqrtf(ex / (1e-8f + ep));
+            r[lane] = v;
+            gg[lane] = NNN_TI(b.g, NB, tile, sl)[(size_t)lane * TILE];
+            exb = ex;
+        }
+        __syncthreads();
+        for (int k = lane; k < FREQ; k += 64) {
+            float2 X = Xg[k], P = Pg[k];
+            float rf = interp_gain(r, k, b.bin_frac, b.bin_band);
+            X.x = X.x + P.x * rf;
+            X.y = X.y + P.y * rf;
+            A[k] = X;
+            if (k < 400) ebuf[k] = X.x * X.x + X.y * X.y;
+        }
+        __syncthreads();
+        if (lane < NB) r2[lane] = sqrtf(exb / (1e-8f + band_sum(ebuf, lane, b.bin_frac)));
+        __syncthreads();
+    }
+    // Hermitian extension, re/im swapped so that the forward transform computes the inverse
+    float2 xs[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        int k = lane + 64 * u;
+        float2 X = make_float2(0.0f, 0.0f);
+        if (k < FREQ) {
+            if (live) {
+                X = A[k];
+                float rf = interp_gain(r2, k, b.bin_frac, b.bin_band);
+                X.x *= rf; X.y *= rf;
+                float gf = interp_gain(gg, k, b.bin_frac, b.bin_band);
+                X.x *= gf; X.y *= gf;
+            } else X = Xg[k];
+        }
+        xs[u] = X;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        int k = lane + 64 * u;
+        if (k < FREQ) {
+            A[k] = make_float2(xs[u].y, xs[u].x);
+            if (k > 0 && k < FRAME) A[WINDOW - k] = make_float2(-xs[u].y, xs[u].x);
+        }
+    }
+    __syncthreads();
+    fft960(A, B, b.tw960, lane);
+    if (lane == 0 && vad_out && s < b.S) vad_out[s] = NNN_TI(b.vad, 1, tile, sl)[0];
+    float *sm = b.synth_mem + (size_t)s * FRAME;
+    for (int n = lane; n < FRAME; n += 64) {
+        float v0 = A[n].y / 2.0f * b.window[n];
+        float v1 = A[n + FRAME].y / 2.0f * b.window[n + FRAME];
+        if (s < b.S) out[(size_t)s * out_stride + n] = v0 + sm[n];
+        sm[n] = v1;
+    }
+}
+
+// Launch-parameter bookkeeping (one thread each): set at the start of a process call, stepped
+// after every frame so the captured graph of one frame can be replayed unchanged.
+__global__ void k_set_params(StepParams *sp, StepParams v) { *sp = v; }
+__global__ void k_advance(StepParams *sp)
+{
+    sp->in += sp->frame_stride;
+    sp->out += sp->frame_stride;
+    if (sp->vad) sp->vad += sp->n_streams;
+    sp->slot = (sp->slot + 1) & 3;
+}
+
+}  // namespace nnn

@@ -1,0 +1,100 @@
+// nnn_layout.h -- sizes, HBM layouts and the kernel argument block of the batched
+// process_frame path (reference: jneem/nnnoiseless src/denoise.rs:95-116).
+//
+// Two canonical layouts (S_pad = streams rounded up to a multiple of 64):
+//   SM ("stream-major")     a[s * LEN + i]                      one stream contiguous; used by the
+//                            wave-per-stream kernels (FFT, data-dependent-lag inner products)
+//   TI ("tile-interleaved")  a[((s / 64) * LEN + i) * 64 + s % 64]   64 streams of one tile side by
+//                            side; lane = stream kernels read/write one 256-byte row per wave
+//                            instruction (fully coalesced) and every lane runs the reference's scalar
+//                            recurrence in the reference's order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace nnn {
+
+constexpr int FRAME = 480;        // src/lib.rs:38
+constexpr int WINDOW = 960;       // src/lib.rs:39
+constexpr int FREQ = 481;         // src/lib.rs:41
+constexpr int NB = 22;            // src/lib.rs:49
+constexpr int NFEAT = 42;         // src/lib.rs:53
+constexpr int CEPS_MEM = 8;       // src/lib.rs:50
+constexpr int HIST = 1728;        // PITCH_BUF_SIZE, src/lib.rs:46
+constexpr int RING = 1920;        // history ring: 4 frame slots instead of the reference's memmove
+constexpr int XLP = 864;          // HIST / 2
+constexpr int PITCH_MIN = 60, PITCH_MAX = 768;
+constexpr int NLAG1 = 147;        // coarse lags  (PITCH_MAX - 3*PITCH_MIN) / 4
+constexpr int NLAG2 = 294;        // fine lags
+constexpr int TILE = 64;
+constexpr int MAXN = 127;         // layer sizes are non-negative i8 (src/rnn.rs:128-134)
+
+struct ModelDims {
+    int nd, nv, nn, ndn;                       // input_dense, vad_gru, noise_gru, denoise_gru neurons
+    int act_d, act_v, act_n, act_dn, act_o, act_vo;
+    // offsets (floats) into the expanded f32 weight buffer, all matrices input-major like the file
+    int w_d, b_d;
+    int w_v, r_v, b_v;
+    int w_n, r_n, b_n;
+    int w_dn, r_dn, b_dn;
+    int w_o, b_o;
+    int w_vo, b_vo;
+};
+
+struct Buffers {
+    // ---- persistent per-stream state (src/denoise.rs:37-42, features.rs:18-46, pitch.rs:4-17, rnn.rs:65-70)
+    float *hist;         // SM [RING]   high-passed input history, ring of 4 frames
+    float *hp_mem;       // TI [2]      biquad state
+    float *ceps_mem;     // TI [8*22]
+    int *mem_id;         // TI [1]
+    float *synth_mem;    // SM [480]
+    float *lastg;        // TI [22]
+    int *last_period;    // TI [1]
+    float *last_gain;    // TI [1]
+    float *gru_v, *gru_n, *gru_dn;  // TI [nv], [nn], [ndn]
+    // ---- per-frame scratch (doubles as the parity taps)
+    float *xlp_raw;      // TI [864]    decimated history before the LPC FIR
+    float *lpc;          // TI [10]     ac[5], lpc2[5]
+    float *xlp_ti;       // TI [864]    pitch_buf
+    float *xlp_sm;       // SM [864]    pitch_buf
+    float *xc1;          // TI [147]
+    int *best1;          // TI [2]
+    float *xc2;          // TI [10]     fine xcorr at 2*best-2..+2, 2*second-2..+2
+    int *psearch;        // TI [1]
+    float *xx_yy;        // TI [386]    [0] = xx, [1 + i] = yy_lookup[i]
+    int *pitch;          // TI [1]
+    float *pgain;        // TI [1]
+    float2 *X, *P;       // SM [481]
+    float *ex, *ep, *exp_;  // TI [22]
+    float *feat;         // TI [42]
+    int *silence;        // TI [1]
+    float *g_raw, *g;    // TI [22]
+    float *vad;          // TI [1]
+    // ---- read-only tables
+    const float *window;     // [960]
+    const float *dct;        // [22*22]
+    const float2 *tw960;     // [960]  exp(-2 pi i k / 960)
+    const float *tansig;     // [201]
+    const float *bin_frac;   // [400]  j / band_size
+    const int *bin_band;     // [400]
+    const float *weights;    // expanded f32
+    float wnorm;
+    int S, S_pad, NT;
+};
+
+// Per-frame launch parameters, resident in device memory so that one captured hipGraph can be
+// replayed for every frame: k_advance steps it at the end of each frame.
+struct StepParams {
+    const float *in;   // frame t of stream s at in[s * stream_stride + i]
+    float *out;
+    float *vad;        // [n_streams] for this frame, may be null
+    unsigned long long stream_stride, frame_stride;
+    int slot;          // history ring slot that receives this frame (frame index mod 4)
+    int n_streams;
+};
+
+// ring position of logical input_mem[0] when the newest frame sits in slot `slot`
+__host__ __device__ inline int ring_base(int slot) { return (FRAME * slot + 672) % RING; }
+
+}  // namespace nnn

@@ -1,0 +1,28 @@
+"""Builds the TEST-ONLY SIMT-interpreter build of the product sources (g++, no GPU, no hipcc).
+
+The same nnnoiseless_amd/csrc/*.hip files are compiled against tests/hostsim/hip/hip_runtime.h, a
+stand-in runtime that runs each workgroup's threads as fibers on the CPU.  Used by the `not gpu`
+tests to check kernel logic against the oracle where no MI355X is present.  Never used by the package.
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "nnnoiseless_amd", "csrc")
+OUT = os.path.join(HERE, "_build", "libnnn_hostsim.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(CSRC, s) for s in ("nnn_batch.hip", "nnn_model.cpp", "rnnoise_capi.cpp")]
+    srcs.append(os.path.join(HERE, "hostsim.cpp"))
+    deps = srcs + [os.path.join(CSRC, d) for d in ("nnn_kernels.hip", "nnn_layout.h", "nnn_model.h")]
+    deps.append(os.path.join(HERE, "hip", "hip_runtime.h"))
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    weights = os.path.join(ROOT, "nnnoiseless_amd", "data", "weights.rnn")
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+           "-I", HERE, f'-DNNN_WEIGHTS_PATH="{weights}"', "-x", "c++"] + srcs + ["-o", OUT]
+    subprocess.check_call(cmd)
+    return OUT
