@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- 480-sample frames/sec of the batched process_frame path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch: every stream of this rank's shard advances by
+`--frames-per-step` frames (default 1 = one 10 ms tick of live audio for all streams).  The workload
+is BASELINE.json configs[1]: 4096 concurrent mono streams per GPU, built-in model, synthetic 48 kHz
+sine + noise, inputs resident in HBM before the timed region.  Streams are
+independent, so ranks shard them with no data-path collective (weak scaling: 4096 streams per GPU);
+the only collective is the aggregation of the result.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel: algorithmic bytes per launch / its average duration measured live
+                with HIP events on the launch stream (a second, event-instrumented pass over the same
+                workload: the timed pass replays a hipGraph, which cannot carry per-kernel events)
+  cpu_baseline  the CPU oracle (scalar C port of the reference, f32 FFT) on the host's cores, bounded
+                sample; the genuine Rust reference cannot be built here (no cargo), hence kind "port"
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_PEAK_TFLOPS = 157.3
+BYTES_PER_FRAME_FUSED = 16948  # I/O + resident-state touch of one process_frame
+FLOPS_PER_FRAME = 0.42e6
+
+# Algorithmic HBM bytes per stream-frame of each kernel (its own inputs + outputs, each counted once;
+# derivation in DESIGN.md "Kernels")
+KERNEL_BYTES = {
+    "k_hp": 1920 + 1920 + 16,
+    "k_decim": 6912 + 3456,
+    "k_lpc": 3456 + 40,
+    "k_fir": 3456 + 20 + 2 * 3456,
+    "k_xcorr": 3456 + 588,
+    "k_best1": 1548 + 588 + 8,
+    "k_refine": 3456 + 8 + 40,
+    "k_best2": 3456 + 40 + 8 + 4 + 1544,
+    "k_doubling": 3456 + 116 + 24,
+    "k_fft_fwd": 6912 + 4 + 7696 + 264,
+    "k_features": 264 + 88 + 704 + 88 + 168 + 16,
+    "k_rnn": 168 + 2 * 672 + 2 * 88 + 180,
+    "k_synth": 7696 + 440 + 3840 + 1920 + 4,
+    "k_advance": 0,
+}
+
+
+def cpu_baseline(budget_s=12.0):
+    """Time the CPU oracle (f32-FFT build) on all host cores over a bounded sample of the same workload."""
+    from oracle import oracle as O
+    from nnnoiseless_amd.synthetic import make_streams_fast
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    model = O.Model(open(os.path.join(ROOT, "nnnoiseless_amd", "data", "weights.rnn"), "rb").read(), f32_fft=True)
+    frames = 100
+    x = make_streams_fast(cores, frames, seed=99)
+    t0 = time.perf_counter()
+    O.run_streams(model, x[:1], n_threads=1, want=("out",))
+    per_frame = (time.perf_counter() - t0) / frames
+    per_thread = max(1, min(64, int(budget_s / (per_frame * frames))))
+    x = make_streams_fast(cores * per_thread, frames, seed=99)
+    t0 = time.perf_counter()
+    used = O.run_streams(model, x, n_threads=cores, want=("out",))["threads"]
+    dt = time.perf_counter() - t0
+    total = x.shape[0] * frames
+    return {"value": total / dt, "unit": "frames/s", "cores": used, "kind": "port",
+            "sample": f"{x.shape[0]} synthetic streams x {frames} frames, {used} threads, "
+                      f"oracle/nnn_oracle.c -O3 f32 FFT; single-thread {1.0 / per_frame:.0f} frames/s",
+            "note": "genuine Rust reference not buildable here (no cargo/rustc)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--streams", type=int, default=4096, help="concurrent streams PER GPU")
+    ap.add_argument("--frames-per-step", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams_fast
+    from nnnoiseless_amd.shard import aggregate
+
+    S, fps, K, W = args.streams, args.frames_per_step, args.steps, args.warmup
+    total_frames = (K + W) * fps
+    # distinct audio for every step while it fits ~6 GB per GPU, else cycle through a pool of frames
+    pool = total_frames
+    while S * pool * 480 * 4 > 6e9 and pool > 8:
+        pool //= 2
+    x_host = make_streams_fast(S, pool, seed=rank)
+    x = torch.from_numpy(x_host).to(dev)              # [S][pool][480], resident in HBM
+    y = torch.empty_like(x)
+    vad = torch.empty((pool, S), dtype=torch.float32, device=dev)
+    del x_host
+    bd = nn.BatchDenoiser(S, device=local_rank)
+    bd.set_graph(not args.no_graph)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        f0 = (i * fps) % pool
+        n = min(fps, pool - f0)  # a step never wraps inside the pool unless fps does not divide it
+        bd.process_device(x.data_ptr() + f0 * 480 * 4, y.data_ptr() + f0 * 480 * 4, vad.data_ptr() + f0 * S * 4,
+                          n, pool * 480, 480, stream)
+        if n < fps:
+            bd.process_device(x.data_ptr(), y.data_ptr(), vad.data_ptr(), fps - n, pool * 480, 480, stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(W):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    frames_done, elapsed_max = aggregate(dist if world > 1 else None, S * fps * K, elapsed, dev)
+    ms_per_step = elapsed_max * 1e3 / K
+    value = frames_done / elapsed_max
+    finite = bool(torch.isfinite(y).all().item())
+
+    roofline = None
+    kern = {}
+    if rank == 0 and not args.no_roofline:
+        # second pass over the same workload with HIP events around every launch (eager launches)
+        bd.set_profiling(True)
+        kp = min(K, 50)
+        t1 = time.perf_counter()
+        for i in range(W + K, W + K + kp):
+            step(i)
+        torch.cuda.synchronize()
+        prof_ms_per_step = (time.perf_counter() - t1) * 1e3 / kp
+        times = bd.kernel_times()
+        bd.set_profiling(False)
+        kern = {k: {"avg_us": 1e3 * ms / max(n, 1), "launches": n} for k, (ms, n) in times.items()}
+        dom = max(times, key=lambda k: times[k][0])
+        avg_s = times[dom][0] / times[dom][1] * 1e-3
+        achieved = KERNEL_BYTES[dom] * S / avg_s / 1e9
+        sum_us = sum(v["avg_us"] for v in kern.values())
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "avg_kernel_us": avg_s * 1e6, "bytes_per_launch": KERNEL_BYTES[dom] * S,
+                    "sum_kernel_us_per_frame": sum_us, "profiled_ms_per_step": prof_ms_per_step,
+                    "pipeline_fused_bytes_GBs": value / args.gpus * BYTES_PER_FRAME_FUSED / 1e9,
+                    "pipeline_hbm_frac": value / args.gpus * BYTES_PER_FRAME_FUSED / 1e9 / HBM_PEAK_GBS,
+                    "pipeline_fp32_frac": value / args.gpus * FLOPS_PER_FRAME / 1e12 / FP32_PEAK_TFLOPS,
+                    "note": "path is FP32-VALU/latency bound (23-100 FLOP/B, SURVEY 8d); HBM fraction reported as north_star asks"}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        line = {
+            "metric": "480-sample frames/sec (whole node) at N concurrent streams", "value": value, "unit": "frames/s",
+            "n_gpus": args.gpus, "steps": K, "warmup": W, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{S} concurrent mono streams per GPU, built-in weights.rnn, synthetic 48 kHz sine+noise "
+                                   f"(BASELINE.json configs[1]), {fps} frame(s) per stream per step",
+                       "streams_per_gpu": S, "streams_total": S * world, "frames_per_step": fps,
+                       "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": f"streams sharded x{world}"},
+            "outputs_finite": finite,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,21 @@
+"""Stream sharding across ranks: streams are independent, so each rank owns a
+contiguous block and the only collective is the throughput aggregation (sum of frames, max of time)."""
+
+
+def shard_range(n_streams, rank, world):
+    """Contiguous, balanced block [lo, hi) of `n_streams` for `rank` of `world`."""
+    base, rem = divmod(n_streams, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def aggregate(dist, frames_done, elapsed_s, device=None):
+    """(total frames over all ranks, max elapsed over ranks).  `dist` = torch.distributed or None."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return frames_done, elapsed_s
+    import torch
+    f = torch.tensor([float(frames_done)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
+    dist.all_reduce(f, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(f.item()), float(t.item())

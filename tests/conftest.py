@@ -1,0 +1,67 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "hostsim")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+WEIGHTS = os.path.join(ROOT, "nnnoiseless_amd", "data", "weights.rnn")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_metric(out_f32, ref_i16):
+    """The reference's own acceptance metric, src/lib.rs:184-194: outputs cast `as i16`
+    (truncate toward zero, saturating), sum (ref-out)^2 / sum out^2."""
+    o16 = np.clip(np.trunc(out_f32), -32768, 32767).astype(np.int16)
+    xx = float((o16.astype(np.float64) ** 2).sum())
+    diff = float(((ref_i16.astype(np.float64) - o16.astype(np.float64)) ** 2).sum())
+    return diff / xx
+
+
+@pytest.fixture(scope="session")
+def weights_bytes():
+    return open(WEIGHTS, "rb").read()
+
+
+@pytest.fixture(scope="session")
+def golden_io():
+    inp = np.fromfile(os.path.join(GOLDEN, "testing.raw"), dtype="<i2").astype(np.float32)
+    ref = np.fromfile(os.path.join(GOLDEN, "reference_output.raw"), dtype="<i2")
+    nfr = len(inp) // 480  # chunks_exact: the 44 trailing samples are dropped (src/lib.rs:204)
+    return inp[: nfr * 480].reshape(nfr, 480), ref
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def hostsim_lib():
+    """The product sources under the TEST-ONLY SIMT interpreter (tests/hostsim)."""
+    import build_hostsim
+    from nnnoiseless_amd import _ffi
+    return _ffi.Library(build_hostsim.build())
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    import nnnoiseless_amd
+    return nnnoiseless_amd.library()
+
+
+def rel_rms(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    den = float((b ** 2).sum())
+    return (float(((a - b) ** 2).sum()) / den) ** 0.5 if den > 0 else float(np.abs(a - b).max())

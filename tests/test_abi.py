@@ -1,0 +1,104 @@
+"""The C-ABI library: it builds for gfx950, loads, exports every symbol the headers declare, and its
+GPU-free entry points (model container) behave like the reference's.  No kernel runs here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from nnnoiseless_amd.build import build_library
+    import nnnoiseless_amd
+    build_library()
+    return nnnoiseless_amd.library()
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b((?:nnn|rnnoise)_[a-z0-9_]+)\s*\(", src))
+
+
+def test_exports_every_declared_symbol(lib):
+    from nnnoiseless_amd import _ffi
+    declared = _declared("nnn_batch.h") | _declared("rnnoise.h")
+    assert declared == set(_ffi.BATCH_SYMBOLS) | set(_ffi.RNNOISE_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib.L, sym), sym
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.path]).decode()
+    for sym in declared:
+        assert re.search(rf"\bT {sym}\b", out), sym
+
+
+def test_library_holds_gfx950_code(lib):
+    blob = open(lib.path, "rb").read()
+    assert b"gfx950" in blob and b"k_fft_fwd" in blob
+
+
+def test_frame_size_and_state_size(lib):
+    assert lib.L.rnnoise_get_frame_size() == 480      # src/capi.rs:16-19
+    assert lib.L.rnnoise_get_size() > 0
+
+
+def test_model_container_rules(lib, weights_bytes):
+    import nnnoiseless_amd as nn
+    assert nn.RnnModel.default().shape() == [42, 24, 24, 48, 96, 22, 0, 2, 2, 2, 1, 1]
+    assert nn.RnnModel.from_bytes(weights_bytes).shape()[:6] == [42, 24, 24, 48, 96, 22]
+    sh = open(os.path.join(GOLDEN, "sh.rnn"), "rb").read()
+    assert nn.RnnModel.from_bytes(sh).shape()[6:] == [0, 0, 2, 0, 1, 1]
+    # where the reference returns None (src/rnn.rs:196-222)
+    for bad in (weights_bytes[:-1], weights_bytes + b"\0", b"", bytes([41]) + weights_bytes[1:],
+                weights_bytes[:2] + b"\x03" + weights_bytes[3:], bytes([0x80]) + weights_bytes[1:]):
+        assert nn.RnnModel.from_bytes(bad) is None
+
+
+def test_model_from_file_closes_and_parses(lib, tmp_path, weights_bytes):
+    """rnnoise_model_from_file takes ownership of the FILE* (src/capi.rs:93-94)."""
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    lib.L.rnnoise_model_from_file.restype = C.c_void_p
+    lib.L.rnnoise_model_from_file.argtypes = [C.c_void_p]
+    good = tmp_path / "m.rnn"
+    good.write_bytes(weights_bytes)
+    m = lib.L.rnnoise_model_from_file(libc.fopen(str(good).encode(), b"rb"))
+    assert m
+    lib.L.rnnoise_model_free(m)
+    bad = tmp_path / "bad.rnn"
+    bad.write_bytes(weights_bytes[:1000])
+    assert not lib.L.rnnoise_model_from_file(libc.fopen(str(bad).encode(), b"rb"))
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    """Without a usable HIP device the product fails loudly instead of computing on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import nnnoiseless_amd as nn
+    with pytest.raises(RuntimeError):
+        nn.BatchDenoiser(4)
+    lib.L.rnnoise_create.restype = C.c_void_p
+    assert not lib.L.rnnoise_create(None)
+
+
+def test_product_never_touches_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "nnnoiseless_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower() and "hostsim" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_reference_demo_compiles_against_our_header(tmp_path):
+    """The reference's C demo (test_data/rnnoise_demo.c) builds unmodified against include/rnnoise.h.
+    Only where the reference tree is mounted (build container)."""
+    demo = "/root/reference/test_data/rnnoise_demo.c"
+    if not os.path.exists(demo):
+        pytest.skip("reference tree not present")
+    subprocess.check_call(["gcc", "-c", "-I", os.path.join(ROOT, "include"), demo, "-o", str(tmp_path / "demo.o")])

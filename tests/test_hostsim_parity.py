@@ -1,0 +1,94 @@
+"""Kernel LOGIC against the oracle where there is no GPU: the unmodified product sources run under the
+test-only SIMT interpreter (tests/hostsim).  Same assertions as the GPU parity tests, small sizes."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_metric, rel_rms
+
+INT_TAPS = {"best1": "best1", "pitch_search": "pitch_search", "pitch": "pitch_idx", "silence": "silence"}
+EXACT_TAPS = {"filtered": "filtered", "xlp": "xlp", "ac": "ac", "lpc2": "lpc2", "xcorr1": "xcorr1", "pitch_gain": "pitch_gain"}
+TOL_TAPS = {"X": "X", "P": "P", "ex": "ex", "ep": "ep", "exp": "exp_", "features": "features", "g_raw": "g_raw", "g": "g", "vad": "vad"}
+
+
+def test_every_stage_against_oracle_taps(hostsim_lib, oracle_mod, weights_bytes, golden_io):
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T = 66, 5  # two tiles, the second one mostly padding
+    x = make_streams(0, S, T)
+    x[0] = golden_io[0][:T]
+    om = oracle_mod.Model(weights_bytes)
+    states = [oracle_mod.State(om) for _ in range(S)]
+    bd = nn.BatchDenoiser(S, lib=hostsim_lib)
+    for t in range(T):
+        out, vad = bd.process(x[:, t:t + 1])
+        taps = {k: bd.tap(k) for k in list(INT_TAPS) + list(EXACT_TAPS) + list(TOL_TAPS)}
+        for s in range(S):
+            o, v = states[s].process_frame(x[s, t])
+            ot = states[s].taps()
+            for k, ok in INT_TAPS.items():
+                assert np.array_equal(taps[k][s], np.atleast_1d(ot[ok])), (k, s, t)
+            for k, ok in EXACT_TAPS.items():   # everything upstream of the pitch index: bit-identical
+                assert np.array_equal(taps[k][s].view(np.uint32), np.atleast_1d(ot[ok]).astype(np.float32).view(np.uint32)), (k, s, t)
+            for k, ok in TOL_TAPS.items():
+                ref = np.atleast_1d(ot[ok]).astype(np.float64)
+                err = np.abs(taps[k][s] - ref).max()
+                assert err <= 2e-5 * max(np.abs(ref).max(), 1.0), (k, s, t, err)
+            assert np.abs(out[s, 0] - o).max() <= 2e-5 * max(np.abs(o).max(), 1.0)
+            assert abs(vad[0, s] - v) < 1e-5
+
+
+def test_golden_vectors_through_the_kernels(hostsim_lib, golden_io):
+    import nnnoiseless_amd as nn
+    frames, ref = golden_io
+    bd = nn.BatchDenoiser(1, lib=hostsim_lib)
+    out, vad = bd.process(frames[None])                      # 100 frames in one call
+    assert golden_metric(out[0, 1:].reshape(-1), ref) < 1e-5
+    kat = json.load(open(os.path.join(GOLDEN, "pitch_kat.json")))
+    assert bd.tap("pitch")[0, 0] == kat["testing_raw"][-1]
+
+
+def test_chunking_and_reset_are_bit_identical(hostsim_lib):
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(20, 5, 6)
+    bd = nn.BatchDenoiser(5, lib=hostsim_lib)
+    a, va = bd.process(x)
+    bd.reset()
+    parts = [bd.process(x[:, t:t + 2]) for t in range(0, 6, 2)]
+    b = np.concatenate([p[0] for p in parts], axis=1)
+    vb = np.concatenate([p[1] for p in parts], axis=0)
+    assert np.array_equal(a, b) and np.array_equal(va, vb)
+
+
+def test_custom_model(hostsim_lib, oracle_mod):
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    sh = open(os.path.join(GOLDEN, "sh.rnn"), "rb").read()
+    x = make_streams(0, 4, 6)
+    ref = oracle_mod.run_streams(oracle_mod.Model(sh), x)
+    bd = nn.BatchDenoiser(4, model=nn.RnnModel.from_bytes(sh, lib=hostsim_lib), lib=hostsim_lib)
+    out, vad = bd.process(x)
+    assert np.array_equal(bd.tap("pitch")[:, 0], ref["pitch"][:, -1])
+    assert rel_rms(out, ref["out"]) < 1e-5
+    assert np.abs(vad.T - ref["vad"]).max() < 1e-4
+
+
+def test_rnnoise_c_abi_flow(hostsim_lib, golden_io):
+    """The call sequence of the reference's rnnoise_demo.c (create, in-place process_frame, destroy)."""
+    frames, ref = golden_io
+    L = hostsim_lib.L
+    st = L.rnnoise_create(None)
+    assert st
+    outs = []
+    for f in frames[:12]:
+        buf = np.array(f, np.float32)
+        vad = L.rnnoise_process_frame(st, buf.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p))  # out aliases in
+        assert 0.0 <= vad <= 1.0
+        outs.append(buf)
+    L.rnnoise_destroy(st)
+    got = np.concatenate(outs[1:])
+    assert golden_metric(got, ref[: got.size]) < 1e-4
