@@ -34,9 +34,9 @@ static int fail(const char *fmt, ...)
         if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));  \
     } while (0)
 
-enum KernelId { K_HP, K_DECIM, K_LPC, K_FIR, K_XCORR, K_BEST1, K_REFINE, K_BEST2, K_DOUBLING, K_FFT_FWD, K_FEATURES, K_RNN, K_SYNTH, K_ADVANCE, K_COUNT };
+enum KernelId { K_HP, K_DECIM, K_LPC, K_FIR, K_XCORR, K_BEST1, K_REFINE, K_BEST2, K_YY, K_DOUBLING, K_FFT_X, K_FFT_P, K_FEATURES, K_RNN, K_SYNTH, K_ADVANCE, K_COUNT };
 static const char *kKernelNames[K_COUNT] = {"k_hp", "k_decim", "k_lpc", "k_fir", "k_xcorr", "k_best1", "k_refine", "k_best2",
-                                            "k_doubling", "k_fft_fwd", "k_features", "k_rnn", "k_synth", "k_advance"};
+                                            "k_yy", "k_doubling", "k_fft_x", "k_fft_p", "k_features", "k_rnn", "k_synth", "k_advance"};
 
 struct nnn_batch {
     Buffers b;
@@ -52,6 +52,9 @@ struct nnn_batch {
     bool use_graph = true;
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t graph_stream = nullptr;  // stream the graph was captured on
+    hipStream_t side[2] = {nullptr, nullptr};        // branches of the per-frame DAG
+    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
+    bool use_branches = true;
     bool profiling = false;
     std::vector<hipEvent_t> ev;     // pairs per launch while profiling
     std::vector<int> ev_kernel;
@@ -130,6 +133,11 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    for (int i = 0; i < 2; i++) {
+        if (h->side[i]) hipStreamDestroy(h->side[i]);
+        if (h->ev_fork[i]) hipEventDestroy(h->ev_fork[i]);
+        if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
+    }
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -144,6 +152,11 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     HIPCHK(hipSetDevice(device));
     h->device = device;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_fork[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    }
     h->S = n_streams;
     h->S_pad = (n_streams + TILE - 1) / TILE * TILE;
     h->NT = h->S_pad / TILE;
@@ -279,24 +292,43 @@ struct Launcher {
     }
 };
 
+// Per-frame DAG.  Critical path: hp -> decim -> lpc -> fir -> xcorr -> best1 -> refine -> best2 -> doubling
+// -> fft_p -> features -> rnn -> synth.  Two branches run beside it: fft_x (needs only the filtered
+// history) and yy (needs only pitch_buf).  With `branches` off (profiling) everything is serial on `st`.
 static void enqueue_frame(nnn_batch *h, hipStream_t st, bool prof)
 {
-    Launcher L{h, st, prof};
     const Buffers &b = h->b;
     const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad;
-    L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, (const StepParams *)h->sp);
-    L.go(K_DECIM, k_decim, dim3(NT, XLP / 32), dim3(256), 0, b, (const StepParams *)h->sp);
+    const StepParams *sp = h->sp;
+    const bool br = h->use_branches && !prof;
+    Launcher L{h, st, prof}, L0{h, br ? h->side[0] : st, prof}, L1{h, br ? h->side[1] : st, prof};
+    L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp);
+    if (br) {
+        hipEventRecord(h->ev_fork[0], st);
+        hipStreamWaitEvent(h->side[0], h->ev_fork[0], 0);
+    }
+    L0.go(K_FFT_X, k_fft_x, dim3(Sp), dim3(64), 0, b, sp);
+    if (br) hipEventRecord(h->ev_join[0], h->side[0]);
+    L.go(K_DECIM, k_decim, dim3(NT, XLP / 32), dim3(256), 0, b, sp);
     L.go(K_LPC, k_lpc, dim3(NT), dim3(64), 0, b);
     L.go(K_FIR, k_fir, dim3(NT, XLP / 32), dim3(64), 0, b);
+    if (br) {
+        hipEventRecord(h->ev_fork[1], st);
+        hipStreamWaitEvent(h->side[1], h->ev_fork[1], 0);
+    }
+    L1.go(K_YY, k_yy, dim3(NT), dim3(64), 0, b);
+    if (br) hipEventRecord(h->ev_join[1], h->side[1]);
     L.go(K_XCORR, k_xcorr, dim3(NT, (NLAG1 + 7) / 8), dim3(64), 0, b);
     L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
     L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
     L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
+    if (br) hipStreamWaitEvent(st, h->ev_join[1], 0);
     L.go(K_DOUBLING, k_doubling, dim3(Sp / 4), dim3(256), 0, b);
-    L.go(K_FFT_FWD, k_fft_fwd, dim3(Sp), dim3(64), 0, b, (const StepParams *)h->sp);
+    if (br) hipStreamWaitEvent(st, h->ev_join[0], 0);
+    L.go(K_FFT_P, k_fft_p, dim3(Sp), dim3(64), 0, b, sp);
     L.go(K_FEATURES, k_features, dim3(NT), dim3(64), 0, b);
-    L.go(K_RNN, k_rnn, dim3(NT), dim3(64 * RNN_WAVES), h->rnn_lds, b, h->md);
-    L.go(K_SYNTH, k_synth, dim3(Sp), dim3(64), 0, b, (const StepParams *)h->sp);
+    L.go(K_RNN, k_rnn, dim3(NT), dim3(64 * RNN_WAVES), h->rnn_lds, b, h->md, b.weights);
+    L.go(K_SYNTH, k_synth, dim3(Sp), dim3(64), 0, b, sp);
     L.go(K_ADVANCE, k_advance, dim3(1), dim3(1), 0, h->sp);
 }
 

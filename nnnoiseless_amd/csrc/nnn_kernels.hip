@@ -39,20 +39,39 @@ __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp)
     float m0 = hp[0], m1 = hp[TILE];
     const double a0 = (double)-1.99599f, a1 = (double)0.99600f, b0 = (double)-2.0f, b1 = (double)1.0f;
     const int sub = lane >> 5, col = lane & 31;
+    // row pointers of the two streams this lane moves per transposed access (nullptr = padding stream)
+    float stage[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        int s = tile * TILE + r * 2 + sub;
+        stage[r] = (s < b.S) ? in[(size_t)s * stream_stride + col] : 0.0f;
+    }
     for (int c = 0; c < FRAME / 32; c++) {
-        for (int r = 0; r < 32; r++) {
-            int row = r * 2 + sub, s = tile * TILE + row;
-            tl[row][col] = (s < b.S) ? in[(size_t)s * stream_stride + c * 32 + col] : 0.0f;
-        }
+#pragma unroll
+        for (int r = 0; r < 32; r++) tl[r * 2 + sub][col] = stage[r];
         __syncthreads();
+        if (c + 1 < FRAME / 32) {   // next chunk's loads stay in flight during the serial recurrence
+#pragma unroll
+            for (int r = 0; r < 32; r++) {
+                int s = tile * TILE + r * 2 + sub;
+                stage[r] = (s < b.S) ? in[(size_t)s * stream_stride + (c + 1) * 32 + col] : 0.0f;
+            }
+        }
+        float xs[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) xs[j] = tl[lane][j];
+#pragma unroll
         for (int j = 0; j < 32; j++) {
-            double x64 = (double)tl[lane][j];
+            double x64 = (double)xs[j];
             double y64 = x64 + (double)m0;
             m0 = (float)((double)m1 + (b0 * x64 - a0 * y64));
             m1 = (float)(b1 * x64 - a1 * y64);
-            tl[lane][j] = (float)y64;
+            xs[j] = (float)y64;
         }
+#pragma unroll
+        for (int j = 0; j < 32; j++) tl[lane][j] = xs[j];
         __syncthreads();
+#pragma unroll
         for (int r = 0; r < 32; r++) {
             int row = r * 2 + sub, s = tile * TILE + row;
             b.hist[(size_t)s * RING + slot * FRAME + c * 32 + col] = tl[row][col];
@@ -107,16 +126,29 @@ __global__ void __launch_bounds__(64) k_lpc(Buffers b)
     const float *x = NNN_TI(b.xlp_raw, XLP, tile, lane);
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f, c4 = 0.0f;
     float x0 = x[0], x1 = x[TILE], x2 = x[2 * TILE], x3 = x[3 * TILE];
-    const int fast_n = XLP - 4;
-#pragma unroll 4
-    for (int j = 0; j < fast_n; j++) {
-        float x4 = x[(size_t)(j + 4) * TILE];
-        c0 += x0 * x0;
-        c1 += x0 * x1;
-        c2 += x0 * x2;
-        c3 += x0 * x3;
-        c4 += x0 * x4;
-        x0 = x1; x1 = x2; x2 = x3; x3 = x4;
+    const int fast_n = XLP - 4;   // 860 = 43 blocks of 20 rows; a block's loads are issued together
+    constexpr int BL = 20;
+    float nxt[BL];
+#pragma unroll
+    for (int i = 0; i < BL; i++) nxt[i] = x[(size_t)(4 + i) * TILE];
+    for (int j0 = 0; j0 < fast_n; j0 += BL) {
+        float cur[BL];
+#pragma unroll
+        for (int i = 0; i < BL; i++) cur[i] = nxt[i];
+        if (j0 + BL < fast_n) {
+#pragma unroll
+            for (int i = 0; i < BL; i++) nxt[i] = x[(size_t)(j0 + BL + 4 + i) * TILE];
+        }
+#pragma unroll
+        for (int i = 0; i < BL; i++) {
+            float x4 = cur[i];
+            c0 += x0 * x0;
+            c1 += x0 * x1;
+            c2 += x0 * x2;
+            c3 += x0 * x3;
+            c4 += x0 * x4;
+            x0 = x1; x1 = x2; x2 = x3; x3 = x4;
+        }
     }
     // tails: d_k = sum_{i=k+860}^{863} x[i] x[i-k]; x0..x3 now hold x[860..863]
     float ac[5];
@@ -267,14 +299,29 @@ __global__ void __launch_bounds__(64) k_best1(Buffers b)
     const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
     const float *xc = NNN_TI(b.xc1, NLAG1, tile, lane);
     float ysq = 1.0f;
-    for (int j = 0; j < 240; j++) { float v = p[(size_t)(2 * j) * TILE]; ysq += v * v; }
+    for (int j0 = 0; j0 < 240; j0 += 24) {
+        float v[24];
+#pragma unroll
+        for (int i = 0; i < 24; i++) v[i] = p[(size_t)(2 * (j0 + i)) * TILE];
+#pragma unroll
+        for (int i = 0; i < 24; i++) ysq += v[i] * v[i];
+    }
     BestPitch bp;
     bp.init();
-    for (int i = 0; i < NLAG1; i++) {
-        bp.update(i, xc[(size_t)i * TILE], ysq);
-        float a = p[(size_t)(2 * (i + 240)) * TILE], c = p[(size_t)(2 * i) * TILE];
-        ysq += a * a - c * c;
-        ysq = fmaxf(ysq, 1.0f);
+    for (int i0 = 0; i0 < NLAG1; i0 += 21) {   // 147 = 7 x 21
+        float c[21], a[21], d[21];
+#pragma unroll
+        for (int i = 0; i < 21; i++) {
+            c[i] = xc[(size_t)(i0 + i) * TILE];
+            a[i] = p[(size_t)(2 * (i0 + i + 240)) * TILE];
+            d[i] = p[(size_t)(2 * (i0 + i)) * TILE];
+        }
+#pragma unroll
+        for (int i = 0; i < 21; i++) {
+            bp.update(i0 + i, c[i], ysq);
+            ysq += a[i] * a[i] - d[i] * d[i];
+            ysq = fmaxf(ysq, 1.0f);
+        }
     }
     int *o = (int *)NNN_TI(b.best1, 2, tile, lane);
     o[0] = bp.best;
@@ -325,15 +372,22 @@ __global__ void __launch_bounds__(256) k_refine(Buffers b)
 //     and, for remove_doubling, xx and the 384-step running energy yy_lookup (ref: :133-142).
 //     All serial scans -> lane = stream.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float xc2_at(const float *xc2, int i, int best, int second)
-{
-    // xcorr[i] of the reference: zero unless i is within 2 of 2*best or 2*second
-    if (i < 0 || i >= NLAG2) return 0.0f;
-    int d1 = i - (2 * best - 2), d2 = i - (2 * second - 2);
-    if (d1 >= 0 && d1 <= 4) return xc2[(size_t)d1 * TILE];
-    if (d2 >= 0 && d2 <= 4) return xc2[(size_t)(5 + d2) * TILE];
-    return 0.0f;
-}
+struct Xc2 {   // xcorr[] of the fine search: zero except within 2 of 2*best / 2*second (ref: src/pitch.rs:88-96)
+    float v[10];
+    int lo1, lo2;
+    __device__ __forceinline__ float at(int i) const
+    {
+        float r = 0.0f;
+        if (i >= 0 && i < NLAG2) {
+            const int d1 = i - lo1, d2 = i - lo2;
+#pragma unroll
+            for (int u = 4; u >= 0; u--) if (d2 == u) r = v[5 + u];
+#pragma unroll
+            for (int u = 4; u >= 0; u--) if (d1 == u) r = v[u];   // first window wins where they overlap (same value)
+        }
+        return r;
+    }
+};
 
 __global__ void __launch_bounds__(64) k_best2(Buffers b)
 {
@@ -341,43 +395,80 @@ __global__ void __launch_bounds__(64) k_best2(Buffers b)
     const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
     const float *xc2 = NNN_TI(b.xc2, 10, tile, lane);
     const int *b1 = NNN_TI(b.best1, 2, tile, lane);
-    const int best1 = b1[0], second1 = b1[TILE];
+    Xc2 xc;
+    xc.lo1 = 2 * b1[0] - 2;
+    xc.lo2 = 2 * b1[TILE] - 2;
+#pragma unroll
+    for (int u = 0; u < 10; u++) xc.v[u] = xc2[(size_t)u * TILE];
     float ysq = 1.0f;
-    for (int j = 0; j < 480; j++) { float v = p[(size_t)j * TILE]; ysq += v * v; }
+    for (int j0 = 0; j0 < 480; j0 += 24) {
+        float v[24];
+#pragma unroll
+        for (int i = 0; i < 24; i++) v[i] = p[(size_t)(j0 + i) * TILE];
+#pragma unroll
+        for (int i = 0; i < 24; i++) ysq += v[i] * v[i];
+    }
     BestPitch bp;
     bp.init();
-    for (int i = 0; i < NLAG2; i++) {
-        bp.update(i, xc2_at(xc2, i, best1, second1), ysq);
-        float a = p[(size_t)(i + 480) * TILE], c = p[(size_t)i * TILE];
-        ysq += a * a - c * c;
-        ysq = fmaxf(ysq, 1.0f);
+    for (int i0 = 0; i0 < NLAG2; i0 += 21) {   // 294 = 14 x 21
+        float a[21], d[21];
+#pragma unroll
+        for (int i = 0; i < 21; i++) {
+            a[i] = p[(size_t)(i0 + i + 480) * TILE];
+            d[i] = p[(size_t)(i0 + i) * TILE];
+        }
+#pragma unroll
+        for (int i = 0; i < 21; i++) {
+            bp.update(i0 + i, xc.at(i0 + i), ysq);
+            ysq += a[i] * a[i] - d[i] * d[i];
+            ysq = fmaxf(ysq, 1.0f);
+        }
     }
     int offset = 0;
     if (bp.best > 0 && bp.best < NLAG2 - 1) {
-        float a = xc2_at(xc2, bp.best - 1, best1, second1);
-        float bb = xc2_at(xc2, bp.best, best1, second1);
-        float c = xc2_at(xc2, bp.best + 1, best1, second1);
+        float a = xc.at(bp.best - 1), bb = xc.at(bp.best), c = xc.at(bp.best + 1);
         if (c - a > 0.7f * (bb - a)) offset = 1;
         else if (a - c > 0.7f * (bb - c)) offset = -1;
     }
     NNN_TI(b.psearch, 1, tile, lane)[0] = 2 * bp.best - offset;
+}
 
-    // xx = inner_prod(x[384..], x[384..], 480) with the 4 interleaved partial sums
+// ---------------------------------------------------------------------------------------------
+// K7y yy: xx = |x|^2 over the analysis frame (4 interleaved partial sums) and the 384-step running
+//     energy yy_lookup of remove_doubling (ref: src/pitch.rs:133-142).  Depends only on pitch_buf, so
+//     it runs beside the pitch search.  lane = stream.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_yy(Buffers b)
+{
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    for (int m = 0; m < 120; m++) {
-        float v0 = p[(size_t)(384 + 4 * m) * TILE], v1 = p[(size_t)(385 + 4 * m) * TILE];
-        float v2 = p[(size_t)(386 + 4 * m) * TILE], v3 = p[(size_t)(387 + 4 * m) * TILE];
-        s0 += v0 * v0; s1 += v1 * v1; s2 += v2 * v2; s3 += v3 * v3;
+    for (int j0 = 0; j0 < 480; j0 += 24) {
+        float v[24];
+#pragma unroll
+        for (int i = 0; i < 24; i++) v[i] = p[(size_t)(384 + j0 + i) * TILE];
+#pragma unroll
+        for (int i = 0; i < 24; i += 4) {
+            s0 += v[i] * v[i]; s1 += v[i + 1] * v[i + 1]; s2 += v[i + 2] * v[i + 2]; s3 += v[i + 3] * v[i + 3];
+        }
     }
     const float xx = s0 + s1 + s2 + s3;
     float *yo = NNN_TI(b.xx_yy, 386, tile, lane);
     yo[0] = xx;
     yo[TILE] = xx;  // yy_lookup[0]
     float yy = xx;
-    for (int i = 1; i <= 384; i++) {
-        float a = p[(size_t)(384 - i) * TILE], c = p[(size_t)(384 + 480 - i) * TILE];
-        yy += a * a - c * c;
-        yo[(size_t)(1 + i) * TILE] = fmaxf(yy, 0.0f);
+    for (int i0 = 1; i0 <= 384; i0 += 24) {
+        float a[24], c[24];
+#pragma unroll
+        for (int i = 0; i < 24; i++) {
+            a[i] = p[(size_t)(384 - (i0 + i)) * TILE];
+            c[i] = p[(size_t)(384 + 480 - (i0 + i)) * TILE];
+        }
+#pragma unroll
+        for (int i = 0; i < 24; i++) {
+            yy += a[i] * a[i] - c[i] * c[i];
+            yo[(size_t)(1 + i0 + i) * TILE] = fmaxf(yy, 0.0f);
+        }
     }
 }
 
@@ -485,10 +576,13 @@ __global__ void __launch_bounds__(256) k_doubling(Buffers b)
 }
 
 // ---------------------------------------------------------------------------------------------
-// 960-point complex FFT in LDS, Stockham autosort, radices 8 x 8 x 5 x 3, one wave per transform.
-// (The reference's FFT is third-party: easyfft 0.4.2 -> realfft 3.5.0 -> rustfft 6.4.1; call sites
-// src/features.rs:264,290; un-normalised in both directions.)
+// Real 960-point transforms as 480-point complex FFTs in LDS (Stockham autosort, radices 8 x 6 x 10,
+// one wave per transform) plus the split/merge step.  The reference's FFT is third-party
+// (easyfft 0.4.2 -> realfft 3.5.0 -> rustfft 6.4.1; call sites src/features.rs:264,290),
+// un-normalised in both directions.
 // ---------------------------------------------------------------------------------------------
+constexpr int NFFT = 480;
+
 __device__ __forceinline__ float2 cmulf(float2 a, float2 w)
 {
     return make_float2(fmaf(a.x, w.x, -a.y * w.y), fmaf(a.x, w.y, a.y * w.x));
@@ -502,7 +596,6 @@ __device__ __forceinline__ void bfly2(float2 &a, float2 &c) { float2 t = csub(a,
 __device__ __forceinline__ void dft8(float2 *v)
 {
     const float h = 0.70710678118654752440f;
-    // three radix-2 stages, decimation in time on bit-reversed order handled by index pattern
     float2 a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7];
     bfly2(a0, a4); bfly2(a1, a5); bfly2(a2, a6); bfly2(a3, a7);
     a5 = make_float2((a5.x + a5.y) * h, (a5.y - a5.x) * h);   // * exp(-i pi/4)
@@ -514,56 +607,81 @@ __device__ __forceinline__ void dft8(float2 *v)
     v[0] = a0; v[4] = a1; v[2] = a2; v[6] = a3; v[1] = a4; v[5] = a5; v[3] = a6; v[7] = a7;
 }
 
-__device__ __forceinline__ void dft3(float2 *v)
+__device__ __forceinline__ void dft3(float2 &v0, float2 &v1, float2 &v2)
 {
     const float s = 0.86602540378443864676f;  // sin(2 pi / 3)
-    float2 t1 = cadd(v[1], v[2]);
-    float2 t2 = csub(v[1], v[2]);
-    float2 m = make_float2(v[0].x - 0.5f * t1.x, v[0].y - 0.5f * t1.y);
+    float2 t1 = cadd(v1, v2);
+    float2 t2 = csub(v1, v2);
+    float2 m = make_float2(v0.x - 0.5f * t1.x, v0.y - 0.5f * t1.y);
     float2 js = make_float2(s * t2.y, -s * t2.x);  // -i * s * t2
-    v[0] = cadd(v[0], t1);
-    v[1] = cadd(m, js);
-    v[2] = csub(m, js);
+    v0 = cadd(v0, t1);
+    v1 = cadd(m, js);
+    v2 = csub(m, js);
 }
 
-__device__ __forceinline__ void dft5(float2 *v)
+__device__ __forceinline__ void dft5(float2 &v0, float2 &v1, float2 &v2, float2 &v3, float2 &v4)
 {
     const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;  // cos(2pi/5), cos(4pi/5)
     const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;   // sin(2pi/5), sin(4pi/5)
-    float2 a1 = cadd(v[1], v[4]), b1 = csub(v[1], v[4]);
-    float2 a2 = cadd(v[2], v[3]), b2 = csub(v[2], v[3]);
-    float2 x0 = v[0];
+    float2 a1 = cadd(v1, v4), b1 = csub(v1, v4);
+    float2 a2 = cadd(v2, v3), b2 = csub(v2, v3);
+    float2 x0 = v0;
     float2 m1 = make_float2(x0.x + c1 * a1.x + c2 * a2.x, x0.y + c1 * a1.y + c2 * a2.y);
     float2 m2 = make_float2(x0.x + c2 * a1.x + c1 * a2.x, x0.y + c2 * a1.y + c1 * a2.y);
-    // -i * (s1 b1 + s2 b2)  and  -i * (s2 b1 - s1 b2)
-    float2 n1 = make_float2(s1 * b1.y + s2 * b2.y, -(s1 * b1.x + s2 * b2.x));
-    float2 n2 = make_float2(s2 * b1.y - s1 * b2.y, -(s2 * b1.x - s1 * b2.x));
-    v[0] = make_float2(x0.x + a1.x + a2.x, x0.y + a1.y + a2.y);
-    v[1] = cadd(m1, n1);
-    v[4] = csub(m1, n1);
-    v[2] = cadd(m2, n2);
-    v[3] = csub(m2, n2);
+    float2 n1 = make_float2(s1 * b1.y + s2 * b2.y, -(s1 * b1.x + s2 * b2.x));  // -i (s1 b1 + s2 b2)
+    float2 n2 = make_float2(s2 * b1.y - s1 * b2.y, -(s2 * b1.x - s1 * b2.x));  // -i (s2 b1 - s1 b2)
+    v0 = make_float2(x0.x + a1.x + a2.x, x0.y + a1.y + a2.y);
+    v1 = cadd(m1, n1);
+    v4 = csub(m1, n1);
+    v2 = cadd(m2, n2);
+    v3 = csub(m2, n2);
+}
+
+// 6 = 2 x 3 and 10 = 2 x 5 by the prime-factor map (no inner twiddles):
+// input n = (N2 n1 + 2 n2) mod N, output k = (N2 k1 + c k2) mod N with c = 4 (N = 6) or 6 (N = 10).
+__device__ __forceinline__ void dft6(float2 *v)
+{
+    float2 a0 = v[0], a1 = v[2], a2 = v[4], b0 = v[3], b1 = v[5], b2 = v[1];
+    dft3(a0, a1, a2);
+    dft3(b0, b1, b2);
+    v[0] = cadd(a0, b0); v[3] = csub(a0, b0);
+    v[4] = cadd(a1, b1); v[1] = csub(a1, b1);
+    v[2] = cadd(a2, b2); v[5] = csub(a2, b2);
+}
+
+__device__ __forceinline__ void dft10(float2 *v)
+{
+    float2 a0 = v[0], a1 = v[2], a2 = v[4], a3 = v[6], a4 = v[8];
+    float2 b0 = v[5], b1 = v[7], b2 = v[9], b3 = v[1], b4 = v[3];
+    dft5(a0, a1, a2, a3, a4);
+    dft5(b0, b1, b2, b3, b4);
+    v[0] = cadd(a0, b0); v[5] = csub(a0, b0);
+    v[6] = cadd(a1, b1); v[1] = csub(a1, b1);
+    v[2] = cadd(a2, b2); v[7] = csub(a2, b2);
+    v[8] = cadd(a3, b3); v[3] = csub(a3, b3);
+    v[4] = cadd(a4, b4); v[9] = csub(a4, b4);
 }
 
 template <int R> __device__ __forceinline__ void dftR(float2 *v)
 {
     if (R == 8) dft8(v);
-    else if (R == 5) dft5(v);
-    else dft3(v);
+    else if (R == 6) dft6(v);
+    else dft10(v);
 }
 
-// one Stockham pass: N = 960, radix R, Ns = product of the radices already applied
+// one Stockham pass of the 480-point transform: radix R, NS = product of the radices already applied;
+// tw = exp(-2 pi i k / 960), k < 960
 template <int R, int NS>
 __device__ __forceinline__ void fft_pass(const float2 *src, float2 *dst, const float2 *tw, int lane)
 {
-    constexpr int NB_ = 960 / R;
-    for (int j = lane; j < NB_; j += 64) {
+    constexpr int NBF = NFFT / R;
+    for (int j = lane; j < NBF; j += 64) {
         float2 v[R];
         const int k = j % NS;
 #pragma unroll
-        for (int r = 0; r < R; r++) v[r] = src[j + r * NB_];
+        for (int r = 0; r < R; r++) v[r] = src[j + r * NBF];
         if (NS > 1) {
-            const int step = 960 / (NS * R);
+            constexpr int step = 960 / (NS * R);
 #pragma unroll
             for (int r = 1; r < R; r++) v[r] = cmulf(v[r], tw[(r * k * step) % 960]);
         }
@@ -574,17 +692,25 @@ __device__ __forceinline__ void fft_pass(const float2 *src, float2 *dst, const f
     }
 }
 
-// forward FFT of the 960 points in A (B is scratch); the result lands in A.  Barriers included.
-__device__ __forceinline__ void fft960(float2 *A, float2 *B, const float2 *tw, int lane)
+// forward 480-point FFT: input in A, result in B (A is clobbered).  Ends with a barrier.
+__device__ __forceinline__ void fft480(float2 *A, float2 *B, const float2 *tw, int lane)
 {
     fft_pass<8, 1>(A, B, tw, lane);
     __syncthreads();
-    fft_pass<8, 8>(B, A, tw, lane);
+    fft_pass<6, 8>(B, A, tw, lane);
     __syncthreads();
-    fft_pass<5, 64>(A, B, tw, lane);
+    fft_pass<10, 48>(A, B, tw, lane);
     __syncthreads();
-    fft_pass<3, 320>(B, A, tw, lane);
-    __syncthreads();
+}
+
+// bin k (0..480) of the real 960-point spectrum from Z = FFT480(x[2n] + i x[2n+1])
+__device__ __forceinline__ float2 rfft_bin(const float2 *Z, const float2 *tw, int k)
+{
+    float2 zk = Z[k % NFFT], zn = Z[(NFFT - k) % NFFT];
+    float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+    float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));   // (zk - conj zn) / (2i)
+    float2 wo = cmulf(o, tw[k]);
+    return cadd(e, wo);
 }
 
 // band sums in the reference's accumulation order (ref: src/lib.rs:65-82): out[b] first receives
@@ -602,48 +728,59 @@ __device__ __forceinline__ float band_sum(const float *v, int bnd, const float *
 }
 
 // ---------------------------------------------------------------------------------------------
-// K8  fft_fwd: transform_input for lag 0 and lag = pitch in ONE complex transform (z = x + i p),
-//     then un-mix, normalise and band energies/correlation.  ref: src/features.rs:281-298,
-//     src/lib.rs:65-82, 150-155.  One wave per stream, 960 complex points in LDS.
+// K8x / K8p  fft_x, fft_p: transform_input (window, real FFT, normalise, band energy) at lag 0 and at
+//     lag = pitch.  ref: src/features.rs:281-298, src/lib.rs:65-82, 150-155.  One wave per stream.
+//     fft_x depends only on the filtered history, so it runs beside the whole pitch search;
+//     fft_p also forms the band correlation of X and P (ref: src/features.rs:135).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_fft_fwd(Buffers b, const StepParams *sp)
+template <bool LAGGED>
+__device__ __forceinline__ void transform_input(Buffers b, const StepParams *sp, float2 *A, float2 *B)
 {
-    const int slot = sp->slot;
-    __shared__ float2 A[WINDOW], B[WINDOW];
     const int lane = threadIdx.x, s = blockIdx.x, tile = s >> 6, sl = s & 63;
-    const int rb = ring_base(slot);
-    const int pitch = NNN_TI(b.pitch, 1, tile, sl)[0];
+    const int rb = ring_base(sp->slot);
+    const int lag = LAGGED ? NNN_TI(b.pitch, 1, tile, sl)[0] : 0;
     const float *h = b.hist + (size_t)s * RING;
-    for (int n = lane; n < WINDOW; n += 64) {
-        float w = b.window[n];
-        int ix = (rb + (HIST - WINDOW) + n) % RING;
-        int ip = (rb + (HIST - WINDOW) - pitch + n) % RING;
-        A[n] = make_float2(h[ix] * w, h[ip] * w);
+    const int start = rb + (HIST - WINDOW) - lag;   // > 0
+    for (int n = lane; n < NFFT; n += 64) {
+        int i0 = (start + 2 * n) % RING, i1 = (start + 2 * n + 1) % RING;
+        A[n] = make_float2(h[i0] * b.window[2 * n], h[i1] * b.window[2 * n + 1]);
     }
     __syncthreads();
-    fft960(A, B, b.tw960, lane);
-    // un-mix: X = (Z[k] + conj Z[N-k]) / 2, P = (Z[k] - conj Z[N-k]) / (2i); then * wnorm
-    float *vxx = (float *)B, *vpp = vxx + 400, *vxp = vpp + 400;
+    fft480(A, B, b.tw960, lane);
+    float *vv = (float *)A, *vc = vv + 400;   // per-bin |.|^2 and Re(X conj P)
     const float wn = b.wnorm;
+    float2 *dst = (LAGGED ? b.P : b.X) + (size_t)s * FREQ;
     for (int k = lane; k < FREQ; k += 64) {
-        float2 zk = A[k], zn = A[(WINDOW - k) % WINDOW];
-        float2 X = make_float2(0.5f * (zk.x + zn.x) * wn, 0.5f * (zk.y - zn.y) * wn);
-        float2 P = make_float2(0.5f * (zk.y + zn.y) * wn, -0.5f * (zk.x - zn.x) * wn);
-        b.X[(size_t)s * FREQ + k] = X;
-        b.P[(size_t)s * FREQ + k] = P;
+        float2 Y = rfft_bin(B, b.tw960, k);
+        Y.x *= wn;
+        Y.y *= wn;
+        dst[k] = Y;
         if (k < 400) {
-            vxx[k] = X.x * X.x + X.y * X.y;
-            vpp[k] = P.x * P.x + P.y * P.y;
-            vxp[k] = X.x * P.x + X.y * P.y;
+            vv[k] = Y.x * Y.x + Y.y * Y.y;
+            if (LAGGED) {
+                float2 X = b.X[(size_t)s * FREQ + k];
+                vc[k] = X.x * Y.x + X.y * Y.y;
+            }
         }
     }
     __syncthreads();
-    for (int t = lane; t < 3 * NB; t += 64) {
+    for (int t = lane; t < (LAGGED ? 2 : 1) * NB; t += 64) {
         const int q = t / NB, bnd = t - q * NB;
-        const float *v = q == 0 ? vxx : (q == 1 ? vpp : vxp);
-        float *dst = q == 0 ? b.ex : (q == 1 ? b.ep : b.exp_);
-        NNN_TI(dst, NB, tile, sl)[(size_t)bnd * TILE] = band_sum(v, bnd, b.bin_frac);
+        float *out = LAGGED ? (q == 0 ? b.ep : b.exp_) : b.ex;
+        NNN_TI(out, NB, tile, sl)[(size_t)bnd * TILE] = band_sum(q == 0 ? vv : vc, bnd, b.bin_frac);
     }
+}
+
+__global__ void __launch_bounds__(64) k_fft_x(Buffers b, const StepParams *sp)
+{
+    __shared__ float2 A[NFFT], B[NFFT];
+    transform_input<false>(b, sp, A, B);
+}
+
+__global__ void __launch_bounds__(64) k_fft_p(Buffers b, const StepParams *sp)
+{
+    __shared__ float2 A[NFFT], B[NFFT];
+    transform_input<true>(b, sp, A, B);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -879,7 +1016,7 @@ __device__ __forceinline__ void dense_layer(const float *W, int wofs, int bofs, 
     matvec_block(acc, W + wofs, n_out, oc, in, n_in);
 }
 
-__global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, ModelDims md)
+__global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, ModelDims md, const float *__restrict__ W)
 {
     HIP_DYNAMIC_SHARED(float, lds)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -892,7 +1029,6 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, ModelDims md)
     float *V = D + nd * TILE, *N = V + nv * TILE, *DN = N + nn * TILE, *R = DN + ndn * TILE;
     (void)nmax;
     for (int i = threadIdx.x; i < 201; i += 64 * RNN_WAVES) tab[i] = b.tansig[i];
-    const float *W = b.weights;
     const float *feat = NNN_TI(b.feat, NFEAT, tile, lane);
     const bool live = NNN_TI(b.silence, 1, tile, lane)[0] == 0;
     float *sv = NNN_TI(b.gru_v, nv, tile, lane), *sn = NNN_TI(b.gru_n, nn, tile, lane), *sdn = NNN_TI(b.gru_dn, ndn, tile, lane);
@@ -965,12 +1101,12 @@ __global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
     float *out = sp->out;
     const size_t out_stride = sp->stream_stride;
     float *vad_out = sp->vad;
-    __shared__ float2 A[WINDOW], B[WINDOW];
+    __shared__ float2 A[FREQ + 3], B[FREQ + 3], C[NFFT];
     __shared__ float r[NB], r2[NB], gg[NB];
     const int lane = threadIdx.x, s = blockIdx.x, tile = s >> 6, sl = s & 63;
     const bool live = NNN_TI(b.silence, 1, tile, sl)[0] == 0;
     const float2 *Xg = b.X + (size_t)s * FREQ, *Pg = b.P + (size_t)s * FREQ;
-    float *ebuf = (float *)B;  // 400 floats of scratch for band energies
+    float *ebuf = (float *)C;  // 400 floats of scratch for band energies
     float exb = 0.0f;
     if (live) {
         if (lane < NB) {
@@ -1001,41 +1137,45 @@ __global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
         if (lane < NB) r2[lane] = sqrtf(exb / (1e-8f + band_sum(ebuf, lane, b.bin_frac)));
         __syncthreads();
     }
-    // Hermitian extension, re/im swapped so that the forward transform computes the inverse
-    float2 xs[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        int k = lane + 64 * u;
-        float2 X = make_float2(0.0f, 0.0f);
-        if (k < FREQ) {
-            if (live) {
-                X = A[k];
-                float rf = interp_gain(r2, k, b.bin_frac, b.bin_band);
-                X.x *= rf; X.y *= rf;
-                float gf = interp_gain(gg, k, b.bin_frac, b.bin_band);
-                X.x *= gf; X.y *= gf;
-            } else X = Xg[k];
-        }
-        xs[u] = X;
+    // filtered spectrum -> B[0..480]
+    for (int k = lane; k < FREQ; k += 64) {
+        float2 X;
+        if (live) {
+            X = A[k];
+            float rf = interp_gain(r2, k, b.bin_frac, b.bin_band);
+            X.x *= rf; X.y *= rf;
+            float gf = interp_gain(gg, k, b.bin_frac, b.bin_band);
+            X.x *= gf; X.y *= gf;
+        } else X = Xg[k];
+        B[k] = X;
     }
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        int k = lane + 64 * u;
-        if (k < FREQ) {
-            A[k] = make_float2(xs[u].y, xs[u].x);
-            if (k > 0 && k < FRAME) A[WINDOW - k] = make_float2(-xs[u].y, xs[u].x);
-        }
+    // complex-to-real 960-point inverse as a 480-point complex inverse: Zin[k] = (X[k] + conj X[480-k])
+    // + i e^{+2 pi i k/960} (X[k] - conj X[480-k]); stored re/im-swapped so the forward FFT inverts.
+    for (int k = lane; k < NFFT; k += 64) {
+        float2 a = B[k], c = B[NFFT - k];
+        float2 e2 = make_float2(a.x + c.x, a.y - c.y);
+        float2 d = make_float2(a.x - c.x, a.y + c.y);
+        float2 w = b.tw960[k];
+        w.y = -w.y;
+        float2 o2 = cmulf(d, w);
+        float2 z = make_float2(e2.x - o2.y, e2.y + o2.x);
+        A[k] = make_float2(z.y, z.x);
     }
     __syncthreads();
-    fft960(A, B, b.tw960, lane);
+    fft480(A, C, b.tw960, lane);   // time samples: x[2n] = C[n].y, x[2n+1] = C[n].x
     if (lane == 0 && vad_out && s < b.S) vad_out[s] = NNN_TI(b.vad, 1, tile, sl)[0];
     float *sm = b.synth_mem + (size_t)s * FRAME;
-    for (int n = lane; n < FRAME; n += 64) {
-        float v0 = A[n].y / 2.0f * b.window[n];
-        float v1 = A[n + FRAME].y / 2.0f * b.window[n + FRAME];
-        if (s < b.S) out[(size_t)s * out_stride + n] = v0 + sm[n];
-        sm[n] = v1;
+    for (int n = lane; n < FRAME / 2; n += 64) {
+        float2 lo = C[n], hi = C[n + FRAME / 2];
+        float v0 = lo.y / 2.0f * b.window[2 * n], v1 = lo.x / 2.0f * b.window[2 * n + 1];
+        float u0 = hi.y / 2.0f * b.window[FRAME + 2 * n], u1 = hi.x / 2.0f * b.window[FRAME + 2 * n + 1];
+        if (s < b.S) {
+            out[(size_t)s * out_stride + 2 * n] = v0 + sm[2 * n];
+            out[(size_t)s * out_stride + 2 * n + 1] = v1 + sm[2 * n + 1];
+        }
+        sm[2 * n] = u0;
+        sm[2 * n + 1] = u1;
     }
 }
 

@@ -109,6 +109,8 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 enum { hipStreamNonBlocking = 1 };
 hipError_t hipEventCreate(hipEvent_t *e);
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

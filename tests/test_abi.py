@@ -38,7 +38,7 @@ def test_exports_every_declared_symbol(lib):
 
 def test_library_holds_gfx950_code(lib):
     blob = open(lib.path, "rb").read()
-    assert b"gfx950" in blob and b"k_fft_fwd" in blob
+    assert b"gfx950" in blob and b"k_fft_x" in blob
 
 
 def test_frame_size_and_state_size(lib):
