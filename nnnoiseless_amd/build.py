@@ -8,7 +8,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libnnnoiseless_mi355x.so")
 WEIGHTS = os.path.join(HERE, "data", "weights.rnn")
 SOURCES = ["nnn_batch.hip", "nnn_model.cpp", "rnnoise_capi.cpp"]
-DEPS = SOURCES + ["nnn_kernels.hip", "nnn_layout.h", "nnn_model.h"]
+DEPS = SOURCES + ["nnn_kernels.hip", "nnn_layout.h", "nnn_model.h", "nnn_mfma.h"]
 
 
 def _stale():
@@ -26,7 +26,7 @@ def build_library(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Wno-unused-value", f'-DNNN_WEIGHTS_PATH="{WEIGHTS}"', "-x", "hip"]
+           "-Wno-unused-value", "-I", CSRC, f'-DNNN_WEIGHTS_PATH="{WEIGHTS}"', "-x", "hip"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))

@@ -41,6 +41,9 @@ static const char *kKernelNames[K_COUNT] = {"k_hp", "k_decim", "k_lpc", "k_fir",
 struct nnn_batch {
     Buffers b;
     ModelDims md;
+    RnnPlan plan;
+    const uint4 *wq = nullptr;     // packed bf16 weights (device)
+    const float *fpar = nullptr;   // biases + vad output layer (device)
     int device = 0;
     int S = 0, S_pad = 0, NT = 0;
     uint64_t frame_count = 0;
@@ -170,13 +173,12 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
         if (!own) return fail("built-in weights failed to parse");
         model = own;
     }
-    std::vector<float> wf;
-    nnn_model_expand(*model, wf, h->md);
+    std::vector<uint16_t> wq;
+    std::vector<float> fpar;
+    h->rnn_lds = nnn_model_pack(*model, wq, fpar, h->plan, h->md);
     delete own;
     const ModelDims &md = h->md;
-    const int nmax = md.nv > md.nn ? (md.nv > md.ndn ? md.nv : md.ndn) : (md.nn > md.ndn ? md.nn : md.ndn);
-    h->rnn_lds = (256 + (size_t)(md.nd + md.nv + md.nn + md.ndn + nmax) * TILE) * sizeof(float);
-    if (h->rnn_lds > 160 * 1024) return fail("model too large for the RNN kernel's LDS exchange (%zu bytes)", h->rnn_lds);
+    if (h->rnn_lds > 160 * 1024) return fail("model too large for the RNN kernel's LDS operand matrices (%zu bytes)", h->rnn_lds);
 
     Buffers &b = h->b;
     memset(&b, 0, sizeof(b));
@@ -227,7 +229,12 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     HIPCHK(upload(h, &b.tansig, tansig));
     HIPCHK(upload(h, &b.bin_frac, bin_frac));
     HIPCHK(upload(h, &b.bin_band, bin_band));
-    HIPCHK(upload(h, &b.weights, wf));
+    {
+        const uint16_t *dq = nullptr;
+        HIPCHK(upload(h, &dq, wq));
+        h->wq = (const uint4 *)dq;
+        HIPCHK(upload(h, &h->fpar, fpar));
+    }
     if (h->rnn_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->rnn_lds));
     HIPCHK(hipDeviceSynchronize());
@@ -327,7 +334,7 @@ static void enqueue_frame(nnn_batch *h, hipStream_t st, bool prof)
     if (br) hipStreamWaitEvent(st, h->ev_join[0], 0);
     L.go(K_FFT_P, k_fft_p, dim3(Sp), dim3(64), 0, b, sp);
     L.go(K_FEATURES, k_features, dim3(NT), dim3(64), 0, b);
-    L.go(K_RNN, k_rnn, dim3(NT), dim3(64 * RNN_WAVES), h->rnn_lds, b, h->md, b.weights);
+    L.go(K_RNN, k_rnn, dim3(NT), dim3(64 * RNN_WAVES), h->rnn_lds, b, h->plan, h->wq, h->fpar);
     L.go(K_SYNTH, k_synth, dim3(Sp), dim3(64), 0, b, sp);
     L.go(K_ADVANCE, k_advance, dim3(1), dim3(1), 0, h->sp);
 }

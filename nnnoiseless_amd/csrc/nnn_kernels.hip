@@ -13,6 +13,7 @@
 // Reference citations are into jneem/nnnoiseless v0.5.1.
 #pragma once
 #include "nnn_layout.h"
+#include <nnn_mfma.h>
 
 namespace nnn {
 
@@ -913,173 +914,224 @@ __device__ __forceinline__ float activate(int act, float x, const float *tab)
 }
 
 constexpr int RNN_WAVES = 8;
-constexpr int OB = 4;                                  // neurons per register block
-constexpr int RNN_MAXBLK = (MAXN + RNN_WAVES * OB - 1) / (RNN_WAVES * OB);
 
-struct InSeg { const float *p; int n; };               // input column (row stride TILE) of n values
-
-// acc[c] += sum_k W[k][col0 + o0 + c] * in_k
-__device__ __forceinline__ void matvec_block(float *acc, const float *W, int wstride, const int *oc,
-                                             const float *in, int n_in)
+__device__ __forceinline__ unsigned short bf16_rn(float x)   // round to nearest even
 {
-    for (int k = 0; k < n_in; k++) {
-        float v = in[(size_t)k * TILE];
-        const float *row = W + (size_t)k * wstride;
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+// x = hi + mid + lo exactly (8 + 8 + 8 significand bits), one bf16 plane each
+__device__ __forceinline__ void store_split(unsigned short *P, int plane_stride, int idx, float x)
+{
+    unsigned short h = bf16_rn(x);
+    float r1 = x - bf16_f32(h);
+    unsigned short m = bf16_rn(r1);
+    float r2 = r1 - bf16_f32(m);
+    P[idx] = h;
+    P[idx + plane_stride] = m;
+    P[idx + 2 * plane_stride] = bf16_rn(r2);
+}
+__device__ __forceinline__ float load_split(const unsigned short *P, int plane_stride, int idx)
+{
+    return (bf16_f32(P[idx]) + bf16_f32(P[idx + plane_stride])) + bf16_f32(P[idx + 2 * plane_stride]);
+}
+
+// acc[G0 + g][mb] += A[16 (mb0 + mb) .. +15][kbase ..] * B(gate G0 + g), g < NG, mb < MB, over all k-steps and
+// the three activation planes.  Bnb points at this neuron block's fragments ([gate][k-step][lane]).
+template <int NG, int MB, int G0>
+__device__ __forceinline__ void gemm_acc(f32x4 (&acc)[3][4], const unsigned short *A, int plane_stride, int row_w, int mb0,
+                                         const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane)
+{
+    const int arow = lane & 15, akg = 8 * (lane >> 4);
+    for (int ks = 0; ks < g.ksteps; ks++) {
+        uint4 bfr[NG];
 #pragma unroll
-        for (int c = 0; c < OB; c++) acc[c] = fmaf(row[oc[c]], v, acc[c]);
+        for (int gi = 0; gi < NG; gi++) bfr[gi] = Bnb[((G0 + gi) * g.ksteps + ks) * 64 + lane];
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) {
+            const unsigned short *ap = A + (size_t)((mb0 + mb) * 16 + arow) * row_w + g.kbase + ks * 32 + akg;
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                const uint4 af = *(const uint4 *)(ap + (size_t)pl * plane_stride);
+#pragma unroll
+                for (int gi = 0; gi < NG; gi++) acc[G0 + gi][mb] = mfma_16x16x32_bf16(af, bfr[gi], acc[G0 + gi][mb]);
+            }
+        }
     }
 }
 
-// One GRU layer (ref: src/rnn.rs:292-327).  Each wave owns neuron blocks {o0, o0+32, ...}: phase 1
-// computes its z and r (z stays in registers, r*state goes to LDS because every neuron's candidate
-// needs all of it), phase 2 its candidate and the new state.
-template <int NSEG>
-__device__ __forceinline__ void gru_layer(const float *W, int wofs, int rofs, int bofs, int n, int act,
-                                          float *st, float *NEW, float *R, const InSeg *seg, int wave,
-                                          int lane, bool live, const float *tab)
+struct RnnLds {
+    const float *tab;
+    const int *live;
+    unsigned short *IN, *REC;
+    int in_ps, rec_ps;   // plane strides (elements)
+};
+
+// One GRU layer (ref: src/rnn.rs:292-327) as three GEMM groups on the matrix cores.  A wave owns one
+// (neuron block, MB stream blocks) unit: z, r and the input part of the candidate accumulate together,
+// r * state goes back through LDS (every candidate needs all of it), then the recurrent part of the
+// candidate and the state update.  z and the old state stay in registers in the C-fragment layout.
+template <int MB>
+__device__ __forceinline__ void gru_layer(const LayerDesc &L, const RnnPlan &pl, const RnnLds &lds, float *state,
+                                          const uint4 *__restrict__ Wq, const float *__restrict__ fpar, int wave, int lane)
 {
     const float scale = 1.0f / 256.0f;
-    const int str = 3 * n;
-    float zreg[RNN_MAXBLK][OB];
-#pragma unroll
-    for (int blk = 0; blk < RNN_MAXBLK; blk++) {
-        const int o0 = (blk * RNN_WAVES + wave) * OB;
-        if (o0 < n) {
-            int oc[OB], ocr[OB];
-            float az[OB], ar[OB];
-#pragma unroll
-            for (int c = 0; c < OB; c++) {
-                oc[c] = min(o0 + c, n - 1);
-                ocr[c] = n + oc[c];
-                az[c] = W[bofs + oc[c]];
-                ar[c] = W[bofs + ocr[c]];
-            }
-            int row0 = 0;
-#pragma unroll
-            for (int sg = 0; sg < NSEG; sg++) {
-                matvec_block(az, W + wofs + (size_t)row0 * str, str, oc, seg[sg].p, seg[sg].n);
-                matvec_block(ar, W + wofs + (size_t)row0 * str, str, ocr, seg[sg].p, seg[sg].n);
-                row0 += seg[sg].n;
-            }
-            matvec_block(az, W + rofs, str, oc, st, n);
-            matvec_block(ar, W + rofs, str, ocr, st, n);
-#pragma unroll
-            for (int c = 0; c < OB; c++) {
-                zreg[blk][c] = sigmoid_approx(scale * az[c], tab);
-                if (o0 + c < n) R[(o0 + c) * TILE + lane] = st[(size_t)(o0 + c) * TILE] * sigmoid_approx(scale * ar[c], tab);
-            }
-        }
+    const int groups = 4 / MB, units = L.nb * groups;
+    const bool mine = wave < units;
+    const int nbi = wave / groups, mb0 = (wave % groups) * MB;
+    const int neuron = nbi * 16 + (lane & 15);
+    const bool nvalid = mine && neuron < L.n;
+    // old state -> recurrent operand planes (columns >= n stay zero)
+    for (int e = threadIdx.x; e < TILE * L.n; e += 64 * RNN_WAVES) {
+        int row = e / L.n, col = e - row * L.n;
+        store_split(lds.REC, lds.rec_ps, row * pl.rec_w + col, state[e]);
     }
     __syncthreads();
+    f32x4 acc[3][4];
+    float sold[4][4], zz[4][4], rs[4][4];
+    if (mine) {
 #pragma unroll
-    for (int blk = 0; blk < RNN_MAXBLK; blk++) {
-        const int o0 = (blk * RNN_WAVES + wave) * OB;
-        if (o0 < n) {
-            int och[OB];
-            float ah[OB];
+        for (int g = 0; g < 3; g++) {
+            const float bv = (neuron < L.n) ? fpar[L.bias + g * L.n + neuron] : 0.0f;
 #pragma unroll
-            for (int c = 0; c < OB; c++) {
-                och[c] = 2 * n + min(o0 + c, n - 1);
-                ah[c] = W[bofs + och[c]];
+            for (int mb = 0; mb < MB; mb++) acc[g][mb] = f32x4{bv, bv, bv, bv};
+        }
+        gemm_acc<3, MB, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, Wq + L.in.wofs + (size_t)nbi * 3 * L.in.ksteps * 64, lane);
+        gemm_acc<2, MB, 0>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Wq + L.rec.wofs + (size_t)nbi * 3 * L.rec.ksteps * 64, lane);
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int row = (mb0 + mb) * 16 + 4 * (lane >> 4) + q;
+                const float so = nvalid ? state[(size_t)row * L.n + neuron] : 0.0f;
+                sold[mb][q] = so;
+                zz[mb][q] = sigmoid_approx(scale * acc[0][mb][q], lds.tab);
+                rs[mb][q] = so * sigmoid_approx(scale * acc[1][mb][q], lds.tab);
             }
-            int row0 = 0;
+    }
+    __syncthreads();   // every wave is done reading the old state planes
+    if (nvalid) {
 #pragma unroll
-            for (int sg = 0; sg < NSEG; sg++) {
-                matvec_block(ah, W + wofs + (size_t)row0 * str, str, och, seg[sg].p, seg[sg].n);
-                row0 += seg[sg].n;
+        for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int row = (mb0 + mb) * 16 + 4 * (lane >> 4) + q;
+                store_split(lds.REC, lds.rec_ps, row * pl.rec_w + neuron, rs[mb][q]);
             }
-            matvec_block(ah, W + rofs, str, och, R + lane, n);
+    }
+    __syncthreads();
+    if (mine) {
+        gemm_acc<1, MB, 2>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Wq + L.rec.wofs + (size_t)nbi * 3 * L.rec.ksteps * 64, lane);
+        if (nvalid) {
 #pragma unroll
-            for (int c = 0; c < OB; c++) {
-                if (o0 + c < n) {
-                    float hh = activate(act, scale * ah[c], tab);
-                    float z = zreg[blk][c], sold = st[(size_t)(o0 + c) * TILE];
-                    float snew = z * sold + (1.0f - z) * hh;
-                    NEW[(o0 + c) * TILE + lane] = snew;
-                    if (live) st[(size_t)(o0 + c) * TILE] = snew;   // silent frames leave the state alone
+            for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int row = (mb0 + mb) * 16 + 4 * (lane >> 4) + q;
+                    const float hh = activate(L.act, scale * acc[2][mb][q], lds.tab);
+                    const float z = zz[mb][q];
+                    const float snew = z * sold[mb][q] + (1.0f - z) * hh;
+                    store_split(lds.IN, lds.in_ps, row * pl.in_w + L.out_col + neuron, snew);
+                    if (lds.live[row]) state[(size_t)row * L.n + neuron] = snew;   // silent frames leave the state alone
                 }
-            }
         }
     }
     __syncthreads();
 }
 
-__device__ __forceinline__ void dense_layer(const float *W, int wofs, int bofs, int n_out, const float *in,
-                                            int n_in, int o0, float *acc)
+// dense layer on the matrix cores: returns act(W x + b) for this wave's (neuron block, stream block) unit
+__device__ __forceinline__ bool dense_unit(const LayerDesc &L, const RnnPlan &pl, const RnnLds &lds, const uint4 *__restrict__ Wq,
+                                           const float *__restrict__ fpar, int wave, int lane, f32x4 &out, int &neuron, int &mb0)
 {
-    int oc[OB];
+    const int units = L.nb * 4;
+    const int nbi = wave / 4;
+    mb0 = wave % 4;
+    neuron = nbi * 16 + (lane & 15);
+    if (wave >= units) return false;
+    f32x4 acc[3][4];
+    const float bv = (neuron < L.n) ? fpar[L.bias + neuron] : 0.0f;
+    acc[0][0] = f32x4{bv, bv, bv, bv};
+    gemm_acc<1, 1, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, Wq + L.in.wofs + (size_t)nbi * L.in.ksteps * 64, lane);
 #pragma unroll
-    for (int c = 0; c < OB; c++) {
-        oc[c] = min(o0 + c, n_out - 1);
-        acc[c] = W[bofs + oc[c]];
-    }
-    matvec_block(acc, W + wofs, n_out, oc, in, n_in);
+    for (int q = 0; q < 4; q++) out[q] = activate(L.act, acc[0][0][q] * (1.0f / 256.0f), lds.tab);
+    return neuron < L.n;
 }
 
-__global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, ModelDims md, const float *__restrict__ W)
+// ---------------------------------------------------------------------------------------------
+// K10 rnn: one 64-stream tile per block, 8 waves.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, const uint4 *__restrict__ Wq,
+                                                          const float *__restrict__ fpar)
 {
-    HIP_DYNAMIC_SHARED(float, lds)
+    HIP_DYNAMIC_SHARED(float, lds_raw)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63, tile = blockIdx.x;
-    const int nd = md.nd, nv = md.nv, nn = md.nn, ndn = md.ndn;
-    const int nmax = max(max(nv, nn), ndn);
-    // LDS carve-up (rows of 64 floats): tanh table, D, V, N, DN, R
-    float *tab = lds;
-    float *D = lds + 256;
-    float *V = D + nd * TILE, *N = V + nv * TILE, *DN = N + nn * TILE, *R = DN + ndn * TILE;
-    (void)nmax;
-    for (int i = threadIdx.x; i < 201; i += 64 * RNN_WAVES) tab[i] = b.tansig[i];
-    const float *feat = NNN_TI(b.feat, NFEAT, tile, lane);
-    const bool live = NNN_TI(b.silence, 1, tile, lane)[0] == 0;
-    float *sv = NNN_TI(b.gru_v, nv, tile, lane), *sn = NNN_TI(b.gru_n, nn, tile, lane), *sdn = NNN_TI(b.gru_dn, ndn, tile, lane);
-    const float scale = 1.0f / 256.0f;
-    __syncthreads();
-
-    // ---- input dense: feat[42] -> D[nd]   (ref: src/rnn.rs:353-355)
-    for (int o0 = wave * OB; o0 < nd; o0 += RNN_WAVES * OB) {
-        float acc[OB];
-        dense_layer(W, md.w_d, md.b_d, nd, feat, NFEAT, o0, acc);
-#pragma unroll
-        for (int c = 0; c < OB; c++)
-            if (o0 + c < nd) D[(o0 + c) * TILE + lane] = activate(md.act_d, acc[c] * scale, tab);
+    const int lane = threadIdx.x & 63, tile = blockIdx.x, tid = threadIdx.x;
+    float *tab = lds_raw;
+    int *live = (int *)(lds_raw + 256);
+    unsigned short *IN = (unsigned short *)(lds_raw + 256 + 64);
+    const int in_ps = TILE * pl.in_w, rec_ps = TILE * pl.rec_w;
+    unsigned short *REC = IN + 3 * in_ps;
+    RnnLds lds{tab, live, IN, REC, in_ps, rec_ps};
+    // zero both operand matrices (padding columns must read as 0), load table, flags, features
+    {
+        uint4 *z = (uint4 *)IN;
+        const int n16 = 3 * (in_ps + rec_ps) / 8;
+        for (int i = tid; i < n16; i += 64 * RNN_WAVES) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = tid; i < 201; i += 64 * RNN_WAVES) tab[i] = b.tansig[i];
+        if (tid < TILE) live[tid] = NNN_TI(b.silence, 1, tile, tid)[0] == 0;
     }
     __syncthreads();
-    {   // vad GRU: input D                      (ref: src/rnn.rs:356-358)
-        InSeg seg[1] = {{D + lane, nd}};
-        gru_layer<1>(W, md.w_v, md.r_v, md.b_v, nv, md.act_v, sv, V, R, seg, wave, lane, live, tab);
-    }
-    {   // noise GRU: input [D | V | feat]       (ref: src/rnn.rs:361-366)
-        InSeg seg[3] = {{D + lane, nd}, {V + lane, nv}, {feat, NFEAT}};
-        gru_layer<3>(W, md.w_n, md.r_n, md.b_n, nn, md.act_n, sn, N, R, seg, wave, lane, live, tab);
-    }
-    {   // denoise GRU: input [V | N | feat]     (ref: src/rnn.rs:368-377)
-        InSeg seg[3] = {{V + lane, nv}, {N + lane, nn}, {feat, NFEAT}};
-        gru_layer<3>(W, md.w_dn, md.r_dn, md.b_dn, ndn, md.act_dn, sdn, DN, R, seg, wave, lane, live, tab);
-    }
-    // ---- outputs: gains (ref: src/rnn.rs:378), smoothing g = max(g, 0.6 lastg) (ref: src/denoise.rs:106-109)
-    float *graw = NNN_TI(b.g_raw, NB, tile, lane), *gs = NNN_TI(b.g, NB, tile, lane), *lastg = NNN_TI(b.lastg, NB, tile, lane);
-    for (int o0 = wave * OB; o0 < NB; o0 += RNN_WAVES * OB) {
-        float acc[OB];
-        dense_layer(W, md.w_o, md.b_o, NB, DN + lane, ndn, o0, acc);
+    for (int k = wave; k < NFEAT; k += RNN_WAVES)
+        store_split(IN, in_ps, lane * pl.in_w + pl.cF + k, NNN_TI(b.feat, NFEAT, tile, lane)[(size_t)k * TILE]);
+    __syncthreads();
+    {   // input dense (ref: src/rnn.rs:353-355)
+        f32x4 o;
+        int neuron, mb0;
+        if (dense_unit(pl.dense, pl, lds, Wq, fpar, wave, lane, o, neuron, mb0)) {
 #pragma unroll
-        for (int c = 0; c < OB; c++) {
-            int o = o0 + c;
-            if (o < NB) {
-                float gr = live ? activate(md.act_o, acc[c] * scale, tab) : 0.0f;
-                graw[(size_t)o * TILE] = gr;
-                float g = 0.0f;
-                if (live) {
-                    g = fmaxf(gr, 0.6f * lastg[(size_t)o * TILE]);
-                    lastg[(size_t)o * TILE] = g;
-                }
-                gs[(size_t)o * TILE] = g;
-            }
+            for (int q = 0; q < 4; q++) store_split(IN, in_ps, (mb0 * 16 + 4 * (lane >> 4) + q) * pl.in_w + pl.dense.out_col + neuron, o[q]);
         }
     }
-    if (wave == RNN_WAVES - 1) {   // vad output, 1 x nv (ref: src/rnn.rs:359)
-        float acc = W[md.b_vo];
-        for (int k = 0; k < nv; k++) acc = fmaf(W[md.w_vo + k], V[k * TILE + lane], acc);
-        NNN_TI(b.vad, 1, tile, lane)[0] = live ? activate(md.act_vo, acc * scale, tab) : 0.0f;
+    __syncthreads();
+    float *sv = b.gru_v + (size_t)tile * TILE * pl.vad.n, *sn = b.gru_n + (size_t)tile * TILE * pl.noise.n,
+          *sdn = b.gru_dn + (size_t)tile * TILE * pl.dn.n;
+#define NNN_GRU(L, st)                                                        \
+    switch ((L).mb) {                                                         \
+    case 4: gru_layer<4>(L, pl, lds, st, Wq, fpar, wave, lane); break;        \
+    case 2: gru_layer<2>(L, pl, lds, st, Wq, fpar, wave, lane); break;        \
+    default: gru_layer<1>(L, pl, lds, st, Wq, fpar, wave, lane); break;       \
+    }
+    NNN_GRU(pl.vad, sv)                                                        // ref: src/rnn.rs:356-358
+    if (wave == RNN_WAVES - 1) {   // vad output, 1 x nv, lane = stream (ref: src/rnn.rs:359)
+        float acc = fpar[pl.vo_b];
+        for (int k = 0; k < pl.vad.n; k++) acc = fmaf(fpar[pl.vo_w + k], load_split(IN, in_ps, lane * pl.in_w + pl.cV + k), acc);
+        NNN_TI(b.vad, 1, tile, lane)[0] = live[lane] ? activate(pl.act_vo, acc * (1.0f / 256.0f), tab) : 0.0f;
+    }
+    NNN_GRU(pl.noise, sn)                                                      // ref: src/rnn.rs:361-366
+    NNN_GRU(pl.dn, sdn)                                                        // ref: src/rnn.rs:368-377
+#undef NNN_GRU
+    {   // gains (ref: src/rnn.rs:378) and smoothing g = max(g, 0.6 lastg) (ref: src/denoise.rs:106-109)
+        f32x4 o;
+        int band, mb0;
+        if (dense_unit(pl.out, pl, lds, Wq, fpar, wave, lane, o, band, mb0)) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int row = mb0 * 16 + 4 * (lane >> 4) + q;
+                const bool lv = live[row] != 0;
+                const float gr = lv ? o[q] : 0.0f;
+                NNN_TI(b.g_raw, NB, tile, row)[(size_t)band * TILE] = gr;
+                float g = 0.0f;
+                if (lv) {
+                    float *lg = NNN_TI(b.lastg, NB, tile, row) + (size_t)band * TILE;
+                    g = fmaxf(gr, 0.6f * *lg);
+                    *lg = g;
+                }
+                NNN_TI(b.g, NB, tile, row)[(size_t)band * TILE] = g;
+            }
+        }
     }
 }
 

@@ -42,6 +42,31 @@ struct ModelDims {
     int w_vo, b_vo;
 };
 
+// RNN as batched GEMMs on the matrix cores (k_rnn).  Activations of a 64-stream tile live in LDS as
+// [stream][column] matrices in three bf16 planes (x = hi + mid + lo exactly), weights are small integers
+// (exact in bf16) pre-packed on the host in MFMA B-fragment order [neuron block][gate][k-step][lane][8].
+struct GemmDesc {
+    int wofs;     // uint4 index of neuron block 0 in the packed weight buffer
+    int ksteps;   // k-steps of 32 columns
+    int kbase;    // first LDS column
+    int ngates;   // gates packed per neuron block (3 for a GRU, 1 for a dense layer)
+};
+struct LayerDesc {
+    GemmDesc in, rec;
+    int n;            // neurons
+    int nb;           // neuron blocks of 16
+    int mb;           // stream blocks (of 16) per wave work unit: 1, 2 or 4
+    int act;
+    int bias;         // float index into the f32 parameter buffer ([gate][n])
+    int out_col;      // LDS column of the input matrix that receives this layer's output
+};
+struct RnnPlan {
+    int in_w, rec_w;  // row strides (bf16 elements) of the input and recurrent LDS matrices
+    int cF, cV;       // LDS columns of the features and of the vad-GRU state
+    LayerDesc dense, vad, noise, dn, out;
+    int vo_w, vo_b, act_vo;   // vad output layer (1 x nv), f32 parameters
+};
+
 struct Buffers {
     // ---- persistent per-stream state (src/denoise.rs:37-42, features.rs:18-46, pitch.rs:4-17, rnn.rs:65-70)
     float *hist;         // SM [RING]   high-passed input history, ring of 4 frames
@@ -52,7 +77,7 @@ struct Buffers {
     float *lastg;        // TI [22]
     int *last_period;    // TI [1]
     float *last_gain;    // TI [1]
-    float *gru_v, *gru_n, *gru_dn;  // TI [nv], [nn], [ndn]
+    float *gru_v, *gru_n, *gru_dn;  // SM [nv], [nn], [ndn]
     // ---- per-frame scratch (doubles as the parity taps)
     float *xlp_raw;      // TI [864]    decimated history before the LPC FIR
     float *lpc;          // TI [10]     ac[5], lpc2[5]
@@ -78,7 +103,6 @@ struct Buffers {
     const float *tansig;     // [201]
     const float *bin_frac;   // [400]  j / band_size
     const int *bin_band;     // [400]
-    const float *weights;    // expanded f32
     float wnorm;
     int S, S_pad, NT;
 };

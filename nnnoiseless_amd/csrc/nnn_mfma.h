@@ -1,0 +1,18 @@
+// nnn_mfma.h -- the one CDNA4 matrix instruction the RNN kernel uses.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// v_mfma_f32_16x16x32_bf16: D(16x16 f32) = A(16x32 bf16) * B(32x16 bf16) + C, one wave.
+// Fragments: lane l holds A[l & 15][8 (l >> 4) .. +7], B[8 (l >> 4) .. +7][l & 15] as 8 packed bf16,
+// and C/D[4 (l >> 4) + q][l & 15] in element q.
+__device__ __forceinline__ f32x4 mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+}  // namespace nnn

@@ -4,6 +4,8 @@
 
 #include <string.h>
 
+#include <algorithm>
+
 // The built-in model is the reference's src/weights.rnn (BSD-3-Clause, (c) Mozilla / Xiph / J. Neeman),
 // shipped as data in nnnoiseless_amd/data/weights.rnn and linked in verbatim
 // (reference: include_bytes!("weights.rnn"), src/rnn.rs:237).
@@ -87,38 +89,116 @@ RNNModel *nnn_model_parse(const uint8_t *bytes, size_t len)
     return m;
 }
 
-void nnn_model_expand(const RNNModel &m, std::vector<float> &w, nnn::ModelDims &md)
+namespace {
+inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
+inline uint16_t bf16_of_int(int v)  // |v| <= 128: exact
 {
-    w.clear();
-    auto push = [&](size_t ofs, size_t n) {
-        int at = (int)w.size();
-        for (size_t i = 0; i < n; i++) w.push_back((float)m.blob[ofs + i]);
-        while (w.size() % 4) w.push_back(0.0f);  // keep every array 16-byte aligned for wide scalar loads
+    float f = (float)v;
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (uint16_t)(u >> 16);
+}
+
+// Appends one GEMM operand in fragment order [neuron block][gate][k-step][lane][8]:
+// element = W[colmap(k)][gate * n + neuron], k = kbase + 32 ks + 8 (lane >> 4) + e, neuron = 16 nb + (lane & 15).
+template <class ColMap>
+nnn::GemmDesc pack_gemm(std::vector<uint16_t> &wq, const int8_t *W, int row_stride, int n, int ngates, int ksteps, int kbase,
+                        ColMap colmap)
+{
+    nnn::GemmDesc g;
+    g.wofs = (int)(wq.size() / 8);
+    g.ksteps = ksteps;
+    g.kbase = kbase;
+    g.ngates = ngates;
+    const int nb = pad_to(n, 16) / 16;
+    for (int b = 0; b < nb; b++)
+        for (int gate = 0; gate < ngates; gate++)
+            for (int ks = 0; ks < ksteps; ks++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int e = 0; e < 8; e++) {
+                        int k = kbase + 32 * ks + 8 * (lane >> 4) + e, neuron = 16 * b + (lane & 15);
+                        int row = colmap(k);
+                        int v = (row >= 0 && neuron < n) ? W[(size_t)row * row_stride + gate * n + neuron] : 0;
+                        wq.push_back(bf16_of_int(v));
+                    }
+    return g;
+}
+}  // namespace
+
+size_t nnn_model_pack(const RNNModel &m, std::vector<uint16_t> &wq, std::vector<float> &fpar, nnn::RnnPlan &plan,
+                      nnn::ModelDims &md)
+{
+    using nnn::LayerDesc;
+    wq.clear();
+    fpar.clear();
+    const int nd = m.input_dense.nb_neurons, nv = m.vad_gru.nb_neurons, nn = m.noise_gru.nb_neurons,
+              ndn = m.denoise_gru.nb_neurons;
+    md.nd = nd; md.nv = nv; md.nn = nn; md.ndn = ndn;
+    md.act_d = m.input_dense.activation; md.act_v = m.vad_gru.activation; md.act_n = m.noise_gru.activation;
+    md.act_dn = m.denoise_gru.activation; md.act_o = m.denoise_output.activation; md.act_vo = m.vad_output.activation;
+    const int8_t *blob = m.blob.data();
+    // LDS columns of the input matrix: [ noise state | vad state | features (48) | dense out ]
+    const int cN = 0, cV = pad_to(nn, 8), cF = cV + pad_to(nv, 8), cD = cF + 48;
+    const int NF = 42;
+    auto ks_of = [](int cols) { return (cols + 31) / 32; };
+    auto fbias = [&](size_t ofs, int count) {
+        int at = (int)fpar.size();
+        for (int i = 0; i < count; i++) fpar.push_back((float)blob[ofs + i]);
         return at;
     };
-    md.nd = m.input_dense.nb_neurons;
-    md.nv = m.vad_gru.nb_neurons;
-    md.nn = m.noise_gru.nb_neurons;
-    md.ndn = m.denoise_gru.nb_neurons;
-    md.act_d = m.input_dense.activation;
-    md.act_v = m.vad_gru.activation;
-    md.act_n = m.noise_gru.activation;
-    md.act_dn = m.denoise_gru.activation;
-    md.act_o = m.denoise_output.activation;
-    md.act_vo = m.vad_output.activation;
-    md.w_d = push(m.input_dense.weights, (size_t)42 * md.nd);
-    md.b_d = push(m.input_dense.bias, md.nd);
-    auto gru = [&](const NnnGru &g, int &wo, int &ro, int &bo) {
-        size_t n = g.nb_neurons;
-        wo = push(g.weights, 3 * n * g.nb_inputs);
-        ro = push(g.rec, 3 * n * n);
-        bo = push(g.bias, 3 * n);
+    auto finish = [&](LayerDesc &L, int n, int act, int bias, int out_col) {
+        L.n = n;
+        L.nb = pad_to(n, 16) / 16;
+        L.mb = L.nb >= 5 ? 4 : (L.nb >= 3 ? 2 : 1);
+        L.act = act;
+        L.bias = bias;
+        L.out_col = out_col;
     };
-    gru(m.vad_gru, md.w_v, md.r_v, md.b_v);
-    gru(m.noise_gru, md.w_n, md.r_n, md.b_n);
-    gru(m.denoise_gru, md.w_dn, md.r_dn, md.b_dn);
-    md.w_o = push(m.denoise_output.weights, (size_t)md.ndn * 22);
-    md.b_o = push(m.denoise_output.bias, 22);
-    md.w_vo = push(m.vad_output.weights, md.nv);
-    md.b_vo = push(m.vad_output.bias, 1);
+    // input dense: features -> D                                  (ref: src/rnn.rs:353-355)
+    plan.dense.in = pack_gemm(wq, blob + m.input_dense.weights, nd, nd, 1, 2, cF,
+                              [&](int k) { return (k >= cF && k < cF + NF) ? k - cF : -1; });
+    plan.dense.rec = nnn::GemmDesc{0, 0, 0, 0};
+    finish(plan.dense, nd, m.input_dense.activation, fbias(m.input_dense.bias, nd), cD);
+    // vad GRU: input D                                             (ref: src/rnn.rs:356-358)
+    plan.vad.in = pack_gemm(wq, blob + m.vad_gru.weights, 3 * nv, nv, 3, ks_of(nd), cD,
+                            [&](int k) { return (k >= cD && k < cD + nd) ? k - cD : -1; });
+    plan.vad.rec = pack_gemm(wq, blob + m.vad_gru.rec, 3 * nv, nv, 3, ks_of(nv), 0, [&](int k) { return k < nv ? k : -1; });
+    finish(plan.vad, nv, m.vad_gru.activation, fbias(m.vad_gru.bias, 3 * nv), cV);
+    // noise GRU: reference input order [D | V | F]                 (ref: src/rnn.rs:361-366)
+    plan.noise.in = pack_gemm(wq, blob + m.noise_gru.weights, 3 * nn, nn, 3, ks_of(cD + nd - cV), cV, [&](int k) {
+        if (k >= cV && k < cV + nv) return nd + (k - cV);
+        if (k >= cF && k < cF + NF) return nd + nv + (k - cF);
+        if (k >= cD && k < cD + nd) return k - cD;
+        return -1;
+    });
+    plan.noise.rec = pack_gemm(wq, blob + m.noise_gru.rec, 3 * nn, nn, 3, ks_of(nn), 0, [&](int k) { return k < nn ? k : -1; });
+    finish(plan.noise, nn, m.noise_gru.activation, fbias(m.noise_gru.bias, 3 * nn), cN);
+    // denoise GRU: reference input order [V | N | F]               (ref: src/rnn.rs:368-377)
+    plan.dn.in = pack_gemm(wq, blob + m.denoise_gru.weights, 3 * ndn, ndn, 3, ks_of(cF + NF), 0, [&](int k) {
+        if (k < nn) return nv + k;
+        if (k >= cV && k < cV + nv) return k - cV;
+        if (k >= cF && k < cF + NF) return nv + nn + (k - cF);
+        return -1;
+    });
+    plan.dn.rec = pack_gemm(wq, blob + m.denoise_gru.rec, 3 * ndn, ndn, 3, ks_of(ndn), 0, [&](int k) { return k < ndn ? k : -1; });
+    finish(plan.dn, ndn, m.denoise_gru.activation, fbias(m.denoise_gru.bias, 3 * ndn), 0);
+    // gains: denoise state (written to columns 0..ndn) -> 22       (ref: src/rnn.rs:378)
+    plan.out.in = pack_gemm(wq, blob + m.denoise_output.weights, 22, 22, 1, ks_of(ndn), 0, [&](int k) { return k < ndn ? k : -1; });
+    plan.out.rec = nnn::GemmDesc{0, 0, 0, 0};
+    finish(plan.out, 22, m.denoise_output.activation, fbias(m.denoise_output.bias, 22), 0);
+    // vad output, 1 x nv, stays on the vector ALU                  (ref: src/rnn.rs:359)
+    plan.vo_w = fbias(m.vad_output.weights, nv);
+    plan.vo_b = fbias(m.vad_output.bias, 1);
+    plan.act_vo = m.vad_output.activation;
+    plan.cF = cF;
+    plan.cV = cV;
+    int width = 0;
+    auto need = [&](const nnn::GemmDesc &g) { width = std::max(width, g.kbase + 32 * g.ksteps); };
+    need(plan.dense.in); need(plan.vad.in); need(plan.noise.in); need(plan.dn.in); need(plan.out.in);
+    width = std::max(width, pad_to(ndn, 8));
+    plan.in_w = pad_to(width, 8) + 8;   // +16 bytes per row keeps 16-byte fragment reads off one bank group
+    plan.rec_w = 32 * ks_of(std::max(nv, std::max(nn, ndn))) + 8;
+    (void)cN;
+    // dynamic LDS: tanh table (256 floats) + live flags (64 ints) + 3 planes of both matrices
+    return 256 * 4 + 64 * 4 + (size_t)3 * 64 * (plan.in_w + plan.rec_w) * 2;
 }

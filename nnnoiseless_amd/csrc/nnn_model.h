@@ -27,5 +27,7 @@ struct RNNModel {
 RNNModel *nnn_model_parse(const uint8_t *bytes, size_t len);
 const uint8_t *nnn_builtin_weights(size_t *len);
 
-// Expand the i8 weights to f32 in file order (exact: |w| <= 128) and fill the kernel's offsets.
-void nnn_model_expand(const RNNModel &m, std::vector<float> &w, nnn::ModelDims &md);
+// Pack the i8 weights for the MFMA RNN kernel: bf16 (exact: |w| <= 128) in B-fragment order, biases
+// and the vad output layer as f32, plus the LDS column plan.  Returns the dynamic LDS bytes the kernel needs.
+size_t nnn_model_pack(const RNNModel &m, std::vector<uint16_t> &wq, std::vector<float> &fpar, nnn::RnnPlan &plan,
+                      nnn::ModelDims &md);

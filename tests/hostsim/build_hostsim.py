@@ -17,12 +17,12 @@ def build(force=False):
     srcs = [os.path.join(CSRC, s) for s in ("nnn_batch.hip", "nnn_model.cpp", "rnnoise_capi.cpp")]
     srcs.append(os.path.join(HERE, "hostsim.cpp"))
     deps = srcs + [os.path.join(CSRC, d) for d in ("nnn_kernels.hip", "nnn_layout.h", "nnn_model.h")]
-    deps.append(os.path.join(HERE, "hip", "hip_runtime.h"))
+    deps += [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "nnn_mfma.h"), os.path.join(HERE, "hostsim.cpp")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     weights = os.path.join(ROOT, "nnnoiseless_amd", "data", "weights.rnn")
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",
-           "-I", HERE, f'-DNNN_WEIGHTS_PATH="{weights}"', "-x", "c++"] + srcs + ["-o", OUT]
+           "-I", HERE, "-I", CSRC, f'-DNNN_WEIGHTS_PATH="{weights}"', "-x", "c++"] + srcs + ["-o", OUT]
     subprocess.check_call(cmd)
     return OUT

@@ -36,6 +36,8 @@ struct dim3 {
 struct uint3_ { unsigned x, y, z; };
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
+struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r = {x, y, z, w}; return r; }
 static inline float2 make_float2(float x, float y) { float2 r = {x, y}; return r; }
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r = {x, y, z, w}; return r; }
 
@@ -55,6 +57,9 @@ extern char dyn_lds[160 * 1024];
 void yield_barrier();
 unsigned long long yield_shfl_u64(unsigned long long v, int src_lane_or_mask, int mode, int width);
 void run_grid(dim3 grid, dim3 block, const std::function<void()> &body);
+// every live lane of the calling wave deposits (in, out); fn runs once with all of them
+typedef void (*WaveFn)(const void *const *ins, void *const *outs, int nlanes);
+void wave_collective(const void *in, void *out, WaveFn fn);
 }  // namespace hostsim
 
 #define threadIdx (hostsim::g.threadIdx)
@@ -85,6 +90,8 @@ template <class T> static inline T max(T a, T b) { return a < b ? b : a; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline int hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return 0; }
 
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float __fmul_rn(float a, float b) { return a * b; }
 static inline float __fadd_rn(float a, float b) { return a + b; }
 

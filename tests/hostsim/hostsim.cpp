@@ -17,7 +17,7 @@ Sim g;
 char dyn_lds[160 * 1024];
 
 namespace {
-enum State { RUNNABLE, AT_BARRIER, AT_SHFL, DONE };
+enum State { RUNNABLE, AT_BARRIER, AT_SHFL, AT_COLL, DONE };
 struct Fiber {
     ucontext_t ctx;
     char *stack = nullptr;
@@ -25,6 +25,9 @@ struct Fiber {
     unsigned long long xchg = 0;  // shuffle payload
     int shfl_arg = 0, shfl_mode = 0, shfl_width = 64;
     unsigned long long shfl_result = 0;
+    const void *coll_in = nullptr;
+    void *coll_out = nullptr;
+    WaveFn coll_fn = nullptr;
 };
 const size_t kStack = 512 * 1024;
 std::vector<Fiber> fibers;
@@ -64,6 +67,32 @@ unsigned long long yield_shfl_u64(unsigned long long v, int a, int mode, int wid
     swapcontext(&f.ctx, &sched_ctx);
     set_tid(me);
     return fibers[me].shfl_result;
+}
+
+void wave_collective(const void *in, void *out, WaveFn fn) {
+    int me = cur;
+    Fiber &f = fibers[me];
+    f.coll_in = in;
+    f.coll_out = out;
+    f.coll_fn = fn;
+    f.st = AT_COLL;
+    swapcontext(&f.ctx, &sched_ctx);
+    set_tid(me);
+}
+
+static void resolve_coll(int w0, int w1) {
+    const void *ins[64];
+    void *outs[64];
+    WaveFn fn = nullptr;
+    for (int t = w0; t < w0 + 64; t++) {
+        bool on = t < w1 && fibers[t].st == AT_COLL;
+        ins[t - w0] = on ? fibers[t].coll_in : nullptr;
+        outs[t - w0] = on ? fibers[t].coll_out : nullptr;
+        if (on) fn = fibers[t].coll_fn;
+    }
+    if (fn) fn(ins, outs, 64);
+    for (int t = w0; t < w1; t++)
+        if (fibers[t].st == AT_COLL) fibers[t].st = RUNNABLE;
 }
 
 static void resolve_shfl(int wave_begin, int wave_end) {
@@ -126,6 +155,12 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()> &body) {
                             else if (fibers[t].st != DONE) all = false;
                         }
                         if (any && all) { resolve_shfl(w0, w1); ran = true; }
+                        bool anyc = false, allc = true;
+                        for (int t = w0; t < w1; t++) {
+                            if (fibers[t].st == AT_COLL) anyc = true;
+                            else if (fibers[t].st != DONE) allc = false;
+                        }
+                        if (anyc && allc) { resolve_coll(w0, w1); ran = true; }
                     }
                     // release the barrier when every live thread waits on it
                     bool anyb = false, allb = true, alldone = true;

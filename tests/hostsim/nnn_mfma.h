@@ -1,0 +1,54 @@
+// tests/hostsim/nnn_mfma.h -- TEST-ONLY shadow of nnnoiseless_amd/csrc/nnn_mfma.h for the SIMT
+// interpreter: the 64 fibers of a wave rendezvous and the tile product is computed in plain C++
+// with the fragment layout documented for v_mfma_f32_16x16x32_bf16.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nnn {
+
+struct f32x4 {
+    float x, y, z, w;
+    float &operator[](int i) { return (&x)[i]; }
+    const float &operator[](int i) const { return (&x)[i]; }
+};
+
+namespace detail {
+struct MfmaIn { uint4 a, b; f32x4 c; };
+static inline float bf16_to_f32(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline void mfma_tile(const void *const *ins, void *const *outs, int nl)
+{
+    static float A[16][32], B[32][16], C[16][16];
+    for (int l = 0; l < nl; l++) {
+        if (!ins[l]) continue;
+        const MfmaIn *in = (const MfmaIn *)ins[l];
+        unsigned short ha[8], hb[8];
+        memcpy(ha, &in->a, 16);
+        memcpy(hb, &in->b, 16);
+        for (int e = 0; e < 8; e++) {
+            A[l & 15][8 * (l >> 4) + e] = bf16_to_f32(ha[e]);
+            B[8 * (l >> 4) + e][l & 15] = bf16_to_f32(hb[e]);
+        }
+        for (int q = 0; q < 4; q++) C[4 * (l >> 4) + q][l & 15] = in->c[q];
+    }
+    for (int l = 0; l < nl; l++) {
+        if (!outs[l]) continue;
+        f32x4 *d = (f32x4 *)outs[l];
+        for (int q = 0; q < 4; q++) {
+            int i = 4 * (l >> 4) + q, j = l & 15;
+            float acc = C[i][j];
+            for (int k = 0; k < 32; k++) acc = fmaf(A[i][k], B[k][j], acc);
+            (*d)[q] = acc;
+        }
+    }
+}
+}  // namespace detail
+
+static inline f32x4 mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c)
+{
+    detail::MfmaIn in = {a, b, c};
+    f32x4 d;
+    hostsim::wave_collective(&in, &d, detail::mfma_tile);
+    return d;
+}
+
+}  // namespace nnn
