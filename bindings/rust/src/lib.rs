@@ -1,0 +1,152 @@
+//! Drop-in façade with the reference's API (`DenoiseState`, `RnnModel`, jneem/nnnoiseless src/denoise.rs,
+//! src/rnn.rs) over the MI355X backend's C ABI (include/nnn_batch.h).  Written against the FFI only;
+//! it was not compiled in the build image, which has no Rust toolchain.
+use std::os::raw::{c_float, c_int, c_void};
+
+#[repr(C)]
+pub struct RawModel {
+    _p: [u8; 0],
+}
+#[repr(C)]
+pub struct RawBatch {
+    _p: [u8; 0],
+}
+
+extern "C" {
+    fn nnn_model_from_bytes(bytes: *const u8, len: usize) -> *mut RawModel;
+    fn nnn_model_default() -> *mut RawModel;
+    fn nnn_model_free(m: *mut RawModel);
+    fn nnn_batch_create(model: *const RawModel, n_streams: c_int, device: c_int) -> *mut RawBatch;
+    fn nnn_batch_destroy(b: *mut RawBatch);
+    fn nnn_batch_reset(b: *mut RawBatch) -> c_int;
+    fn nnn_batch_process_host(
+        b: *mut RawBatch,
+        input: *const c_float,
+        output: *mut c_float,
+        vad: *mut c_float,
+        n_frames: c_int,
+        stream_stride: usize,
+        frame_stride: usize,
+    ) -> c_int;
+    fn nnn_batch_process_device(
+        b: *mut RawBatch,
+        d_in: *const c_float,
+        d_out: *mut c_float,
+        d_vad: *mut c_float,
+        n_frames: c_int,
+        stream_stride: usize,
+        frame_stride: usize,
+        hip_stream: *mut c_void,
+    ) -> c_int;
+}
+
+/// Model parameters; `from_bytes` returns `None` exactly where the reference does (src/rnn.rs:196-222).
+pub struct RnnModel(*mut RawModel);
+unsafe impl Send for RnnModel {}
+unsafe impl Sync for RnnModel {}
+
+impl RnnModel {
+    pub fn from_bytes(bytes: &[u8]) -> Option<RnnModel> {
+        let p = unsafe { nnn_model_from_bytes(bytes.as_ptr(), bytes.len()) };
+        if p.is_null() {
+            None
+        } else {
+            Some(RnnModel(p))
+        }
+    }
+    pub fn from_static_bytes(bytes: &'static [u8]) -> Option<RnnModel> {
+        Self::from_bytes(bytes)
+    }
+}
+impl Default for RnnModel {
+    fn default() -> RnnModel {
+        RnnModel(unsafe { nnn_model_default() })
+    }
+}
+impl Drop for RnnModel {
+    fn drop(&mut self) {
+        unsafe { nnn_model_free(self.0) }
+    }
+}
+
+/// `n` independent denoisers advanced in lock-step (the loop of src/signal.rs:102-104 as one call).
+pub struct BatchDenoiser {
+    raw: *mut RawBatch,
+    n: usize,
+}
+unsafe impl Send for BatchDenoiser {}
+
+impl BatchDenoiser {
+    pub fn new(n_streams: usize, model: Option<&RnnModel>, device: i32) -> Option<BatchDenoiser> {
+        let m = model.map_or(std::ptr::null(), |m| m.0 as *const RawModel);
+        let raw = unsafe { nnn_batch_create(m, n_streams as c_int, device) };
+        if raw.is_null() {
+            None
+        } else {
+            Some(BatchDenoiser { raw, n: n_streams })
+        }
+    }
+    /// `input`/`output`: `[n_streams][n_frames][480]`; `vad`: `[n_frames][n_streams]`.
+    pub fn process(&mut self, output: &mut [f32], input: &[f32], vad: &mut [f32], n_frames: usize) {
+        assert_eq!(input.len(), self.n * n_frames * DenoiseState::FRAME_SIZE);
+        assert_eq!(output.len(), input.len());
+        assert_eq!(vad.len(), self.n * n_frames);
+        let rc = unsafe {
+            nnn_batch_process_host(
+                self.raw,
+                input.as_ptr(),
+                output.as_mut_ptr(),
+                vad.as_mut_ptr(),
+                n_frames as c_int,
+                n_frames * DenoiseState::FRAME_SIZE,
+                DenoiseState::FRAME_SIZE,
+            )
+        };
+        assert_eq!(rc, 0, "nnnoiseless-mi355x: backend error");
+    }
+    /// Device-resident buffers (see include/nnn_batch.h); asynchronous.
+    pub unsafe fn process_device(
+        &mut self,
+        d_out: *mut f32,
+        d_in: *const f32,
+        d_vad: *mut f32,
+        n_frames: usize,
+        stream_stride: usize,
+        frame_stride: usize,
+        hip_stream: *mut c_void,
+    ) {
+        let rc = nnn_batch_process_device(self.raw, d_in, d_out, d_vad, n_frames as c_int, stream_stride, frame_stride, hip_stream);
+        assert_eq!(rc, 0, "nnnoiseless-mi355x: backend error");
+    }
+    pub fn reset(&mut self) {
+        unsafe { nnn_batch_reset(self.raw) };
+    }
+}
+impl Drop for BatchDenoiser {
+    fn drop(&mut self) {
+        unsafe { nnn_batch_destroy(self.raw) }
+    }
+}
+
+/// Same surface as `nnnoiseless::DenoiseState` (src/denoise.rs:36-116).
+pub struct DenoiseState(BatchDenoiser);
+
+impl DenoiseState {
+    pub const FRAME_SIZE: usize = 480;
+    pub fn new() -> Box<DenoiseState> {
+        Box::new(DenoiseState(BatchDenoiser::new(1, None, 0).expect("no MI355X backend")))
+    }
+    pub fn from_model(model: RnnModel) -> Box<DenoiseState> {
+        Self::with_model(&model)
+    }
+    pub fn with_model(model: &RnnModel) -> Box<DenoiseState> {
+        // the backend copies the model to the device, so no borrow needs to outlive this call
+        Box::new(DenoiseState(BatchDenoiser::new(1, Some(model), 0).expect("no MI355X backend")))
+    }
+    pub fn process_frame(&mut self, output: &mut [f32], input: &[f32]) -> f32 {
+        assert!(input.len() == Self::FRAME_SIZE); // src/features.rs:98
+        let mut vad = [0.0f32];
+        self.0.process(&mut output[..Self::FRAME_SIZE], input, &mut vad, 1);
+        vad[0]
+    }
+}

@@ -1,0 +1,94 @@
+// SPDX-License-Identifier: BSD-3-Clause
+// nnnoiseless.hpp -- C++ host-side mirror of the reference's public interface for the process_frame path
+// (Rust is not available in the build image, so the host side above the C ABI is C++; the Rust façade a
+// maintainer would compile is in bindings/rust/).  Same names, argument meaning and error behaviour:
+//
+//   reference (Rust)                                         here (C++)
+//   RnnModel::from_bytes(&[u8]) -> Option<RnnModel>          RnnModel::from_bytes(ptr, len) -> std::optional<RnnModel>   src/rnn.rs:75-77
+//   RnnModel::default()                                      RnnModel::default_model()                                  src/rnn.rs:235-240
+//   DenoiseState::FRAME_SIZE                                 DenoiseState::FRAME_SIZE                                   src/denoise.rs:46
+//   DenoiseState::new() / from_model / with_model            DenoiseState::create() / from_model / with_model           src/denoise.rs:53-74
+//   process_frame(&mut self, &mut [f32], &[f32]) -> f32      process_frame(float* out, const float* in) -> float        src/denoise.rs:95-116
+//   for ch { states[ch].process_frame(..) }                  BatchDenoiser::process(...)                                src/signal.rs:102-104
+//
+// Everything runs in the HIP kernels behind include/nnn_batch.h; failures throw std::runtime_error.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+
+#include "nnn_batch.h"
+
+namespace nnnoiseless {
+
+class RnnModel {
+  public:
+    static std::optional<RnnModel> from_bytes(const uint8_t *bytes, size_t len)
+    {
+        RNNModel *m = nnn_model_from_bytes(bytes, len);
+        if (!m) return std::nullopt;
+        return RnnModel(m);
+    }
+    static RnnModel default_model() { return RnnModel(nnn_model_default()); }
+    const RNNModel *raw() const { return m_.get(); }
+
+  private:
+    explicit RnnModel(RNNModel *m) : m_(m, nnn_model_free) {}
+    std::shared_ptr<RNNModel> m_;  // Clone in the reference; sharing is equivalent for an immutable model
+};
+
+// n independent DenoiseStates advanced in lock-step on one GPU
+class BatchDenoiser {
+  public:
+    BatchDenoiser(int n_streams, const RnnModel *model = nullptr, int device = 0)
+        : b_(nnn_batch_create(model ? model->raw() : nullptr, n_streams, device), nnn_batch_destroy)
+    {
+        if (!b_) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+    }
+    int num_streams() const { return nnn_batch_num_streams(b_.get()); }
+    // host buffers: sample i of frame t of stream s at [s * stream_stride + t * frame_stride + i]; vad[t * n_streams + s]
+    void process(const float *in, float *out, float *vad, int n_frames, size_t stream_stride, size_t frame_stride)
+    {
+        check(nnn_batch_process_host(b_.get(), in, out, vad, n_frames, stream_stride, frame_stride));
+    }
+    // device buffers, asynchronous on `hip_stream` (nullptr = the batch's own stream)
+    void process_device(const float *d_in, float *d_out, float *d_vad, int n_frames, size_t stream_stride, size_t frame_stride,
+                        void *hip_stream = nullptr)
+    {
+        check(nnn_batch_process_device(b_.get(), d_in, d_out, d_vad, n_frames, stream_stride, frame_stride, hip_stream));
+    }
+    void synchronize() { check(nnn_batch_synchronize(b_.get())); }
+    void reset() { check(nnn_batch_reset(b_.get())); }
+    nnn_batch *raw() { return b_.get(); }
+
+  private:
+    static void check(int rc)
+    {
+        if (rc) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+    }
+    std::shared_ptr<nnn_batch> b_;
+};
+
+class DenoiseState {
+  public:
+    static constexpr size_t FRAME_SIZE = NNN_FRAME_SIZE;
+    static DenoiseState create(int device = 0) { return DenoiseState(nullptr, device); }                    // DenoiseState::new()
+    static DenoiseState from_model(const RnnModel &m, int device = 0) { return DenoiseState(&m, device); }
+    static DenoiseState with_model(const RnnModel &m, int device = 0) { return DenoiseState(&m, device); }
+    // `out` may alias `in`; returns the VAD probability
+    float process_frame(float *out, const float *in)
+    {
+        float vad = 0.f;
+        b_.process(in, out, &vad, 1, FRAME_SIZE, FRAME_SIZE);
+        return vad;
+    }
+
+  private:
+    DenoiseState(const RnnModel *m, int device) : b_(1, m, device) {}
+    BatchDenoiser b_;
+};
+
+}  // namespace nnnoiseless
