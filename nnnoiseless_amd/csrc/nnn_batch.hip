@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -58,6 +59,7 @@ struct nnn_batch {
     hipStream_t side[2] = {nullptr, nullptr};        // branches of the per-frame DAG
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
     bool use_branches = true;
+    int xcorr_chunk = 0;            // lags per k_xcorr wave: 4, 8 or 16 (0 = by batch size); env NNN_XCORR_CHUNK
     bool profiling = false;
     std::vector<hipEvent_t> ev;     // pairs per launch while profiling
     std::vector<int> ev_kernel;
@@ -160,6 +162,10 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
     }
+    if (const char *e = getenv("NNN_XCORR_CHUNK")) {
+        int v = atoi(e);
+        if (v == 4 || v == 8 || v == 16) h->xcorr_chunk = v;
+    }
     h->S = n_streams;
     h->S_pad = (n_streams + TILE - 1) / TILE * TILE;
     h->NT = h->S_pad / TILE;
@@ -203,6 +209,7 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     HIPCHK(dalloc(h, &b.xc1, Sp * NLAG1, false));
     HIPCHK(dalloc(h, &b.best1, Sp * 2, false));
     HIPCHK(dalloc(h, &b.xc2, Sp * 10, false));
+    HIPCHK(dalloc(h, &b.ysq2, Sp * NLAG2, false));
     HIPCHK(dalloc(h, &b.psearch, Sp, false));
     HIPCHK(dalloc(h, &b.xx_yy, Sp * 386, false));
     HIPCHK(dalloc(h, &b.pitch, Sp, false));
@@ -229,6 +236,25 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     HIPCHK(upload(h, &b.tansig, tansig));
     HIPCHK(upload(h, &b.bin_frac, bin_frac));
     HIPCHK(upload(h, &b.bin_band, bin_band));
+    {   // band-sum segmentation: every band interval cut into segments of <= 8 bins (54 segments)
+        static const int E[NB] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100};
+        std::vector<int> seg(192, 0);
+        int ns = 0;
+        for (int i = 0; i < NB - 1; i++) {
+            int k = E[i] << 2, end = E[i + 1] << 2;
+            seg[128 + i] = ns;
+            while (k < end) {
+                int c = end - k < 8 ? end - k : 8;
+                seg[ns] = k;
+                seg[64 + ns] = c;
+                ns++;
+                k += c;
+            }
+            seg[160 + i] = ns - seg[128 + i];
+        }
+        if (ns > 64) return fail("band segmentation overflow");
+        HIPCHK(upload(h, &b.seg, seg));
+    }
     {
         const uint16_t *dq = nullptr;
         HIPCHK(upload(h, &dq, wq));
@@ -317,7 +343,7 @@ static void enqueue_frame(nnn_batch *h, hipStream_t st, bool prof)
     L0.go(K_FFT_X, k_fft_x, dim3(Sp), dim3(64), 0, b, sp);
     if (br) hipEventRecord(h->ev_join[0], h->side[0]);
     L.go(K_DECIM, k_decim, dim3(NT, XLP / 32), dim3(256), 0, b, sp);
-    L.go(K_LPC, k_lpc, dim3(NT), dim3(64), 0, b);
+    L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b);
     L.go(K_FIR, k_fir, dim3(NT, XLP / 32), dim3(64), 0, b);
     if (br) {
         hipEventRecord(h->ev_fork[1], st);
@@ -325,7 +351,10 @@ static void enqueue_frame(nnn_batch *h, hipStream_t st, bool prof)
     }
     L1.go(K_YY, k_yy, dim3(NT), dim3(64), 0, b);
     if (br) hipEventRecord(h->ev_join[1], h->side[1]);
-    L.go(K_XCORR, k_xcorr, dim3(NT, (NLAG1 + 7) / 8), dim3(64), 0, b);
+    const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
+    if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4), dim3(64), 0, b);
+    else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8), dim3(64), 0, b);
+    else L.go(K_XCORR, k_xcorr<16>, dim3(NT, (NLAG1 + 15) / 16), dim3(64), 0, b);
     L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
     L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
     L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);

@@ -119,47 +119,45 @@ __global__ void __launch_bounds__(256) k_decim(Buffers b, const StepParams *sp)
 // ---------------------------------------------------------------------------------------------
 // K3  lpc: 5-lag autocorrelation (strictly sequential per lag), lag window, order-4 Levinson,
 //     bandwidth expansion and the extra zero.  ref: src/pitch.rs:433-446, 460-480, 257-292.
-//     lane = stream; the five chains share one sliding window in registers.
+//     lane = stream; the five strictly sequential chains run on five waves of the block.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_lpc(Buffers b)
+__global__ void __launch_bounds__(320) k_lpc(Buffers b)
 {
-    const int lane = threadIdx.x, tile = blockIdx.x;
+    __shared__ float acs[5][64];
+    const int lane = threadIdx.x & 63, tile = blockIdx.x;
+    const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // this wave's lag
     const float *x = NNN_TI(b.xlp_raw, XLP, tile, lane);
-    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f, c4 = 0.0f;
-    float x0 = x[0], x1 = x[TILE], x2 = x[2 * TILE], x3 = x[3 * TILE];
     const int fast_n = XLP - 4;   // 860 = 43 blocks of 20 rows; a block's loads are issued together
     constexpr int BL = 20;
-    float nxt[BL];
-#pragma unroll
-    for (int i = 0; i < BL; i++) nxt[i] = x[(size_t)(4 + i) * TILE];
-    for (int j0 = 0; j0 < fast_n; j0 += BL) {
-        float cur[BL];
-#pragma unroll
-        for (int i = 0; i < BL; i++) cur[i] = nxt[i];
-        if (j0 + BL < fast_n) {
-#pragma unroll
-            for (int i = 0; i < BL; i++) nxt[i] = x[(size_t)(j0 + BL + 4 + i) * TILE];
-        }
-#pragma unroll
-        for (int i = 0; i < BL; i++) {
-            float x4 = cur[i];
-            c0 += x0 * x0;
-            c1 += x0 * x1;
-            c2 += x0 * x2;
-            c3 += x0 * x3;
-            c4 += x0 * x4;
-            x0 = x1; x1 = x2; x2 = x3; x3 = x4;
-        }
-    }
-    // tails: d_k = sum_{i=k+860}^{863} x[i] x[i-k]; x0..x3 now hold x[860..863]
-    float ac[5];
     {
-        float d0 = 0.0f; d0 += x0 * x0; d0 += x1 * x1; d0 += x2 * x2; d0 += x3 * x3;
-        float d1 = 0.0f; d1 += x1 * x0; d1 += x2 * x1; d1 += x3 * x2;
-        float d2 = 0.0f; d2 += x2 * x0; d2 += x3 * x1;
-        float d3 = 0.0f; d3 += x3 * x0;
-        ac[0] = c0 + d0; ac[1] = c1 + d1; ac[2] = c2 + d2; ac[3] = c3 + d3; ac[4] = c4 + 0.0f;
+        float c = 0.0f;
+        float na[BL], nb[BL];
+#pragma unroll
+        for (int i = 0; i < BL; i++) { na[i] = x[(size_t)i * TILE]; nb[i] = x[(size_t)(i + k) * TILE]; }
+        for (int j0 = 0; j0 < fast_n; j0 += BL) {
+            float ca[BL], cb[BL];
+#pragma unroll
+            for (int i = 0; i < BL; i++) { ca[i] = na[i]; cb[i] = nb[i]; }
+            if (j0 + BL < fast_n) {
+#pragma unroll
+                for (int i = 0; i < BL; i++) {
+                    na[i] = x[(size_t)(j0 + BL + i) * TILE];
+                    nb[i] = x[(size_t)(j0 + BL + i + k) * TILE];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < BL; i++) c += ca[i] * cb[i];
+        }
+        // tail d_k = sum_{i = k+860}^{863} x[i] x[i-k], added after the main sum (ref: src/pitch.rs:439-445)
+        float d = 0.0f;
+        for (int i = k + fast_n; i < XLP; i++) d += x[(size_t)i * TILE] * x[(size_t)(i - k) * TILE];
+        acs[k][lane] = c + d;
     }
+    __syncthreads();
+    if (k != 0) return;
+    float ac[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) ac[i] = acs[i][lane];
     ac[0] *= 1.0001f;
 #pragma unroll
     for (int i = 1; i < 5; i++) ac[i] -= ac[i] * (0.008f * (float)i) * (0.008f * (float)i);
@@ -239,34 +237,40 @@ __global__ void __launch_bounds__(64) k_fir(Buffers b)
 // ---------------------------------------------------------------------------------------------
 // K5  xcorr_coarse: 147 lags x 240 taps on the 4x-decimated signal, every lag a strictly
 //     sequential sum in j (ref: src/pitch.rs:296-363, call site :82).  lane = stream, one wave per
-//     (tile, chunk of 8 lags); 8 accumulators + an 8-deep sliding window of y in registers, so a
-//     step costs 2 coalesced row loads for 8 multiply-adds.
+//     (tile, chunk of LC lags); LC accumulators + an LC-deep sliding window of y in registers, so a
+//     step costs 2 coalesced row loads for LC multiply-adds.  Small batches use short chunks (more waves,
+//     shorter serial chain), large batches long chunks (fewer L2 reads per multiply-add).
 // ---------------------------------------------------------------------------------------------
+template <int LC>
 __global__ void __launch_bounds__(64) k_xcorr(Buffers b)
 {
-    const int lane = threadIdx.x, tile = blockIdx.x, L0 = blockIdx.y * 8;
+    const int lane = threadIdx.x, tile = blockIdx.x, L0 = blockIdx.y * LC;
     const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
 #define X4(j) p[(size_t)(384 + 2 * (j)) * TILE]
 #define Y4(m) p[(size_t)(2 * (m)) * TILE]
-    float acc[8], y[8];
+    float acc[LC], y[LC];
 #pragma unroll
-    for (int q = 0; q < 8; q++) { acc[q] = 0.0f; y[q] = Y4(L0 + q); }
-    for (int j = 0; j < 240; j += 8) {
+    for (int q = 0; q < LC; q++) { acc[q] = 0.0f; y[q] = Y4(L0 + q); }
+    for (int j = 0; j < 240; j += LC) {
+        float xv[LC], yn[LC];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            float xv = X4(j + k);
-            int mn = L0 + j + k + 8;                 // next y entering the window
-            float yn = Y4(mn < 432 ? mn : 431);      // stays inside pitch_buf; lags >= 147 are discarded
+        for (int k = 0; k < LC; k++) {               // this block's 2 LC row loads are issued together
+            xv[k] = X4(j + k);
+            int mn = L0 + j + k + LC;                // next y entering the window
+            yn[k] = Y4(mn < 432 ? mn : 431);         // stays inside pitch_buf; lags >= 147 are discarded
+        }
 #pragma unroll
-            for (int q = 0; q < 8; q++) acc[q] += xv * y[(k + q) & 7];
-            y[k & 7] = yn;
+        for (int k = 0; k < LC; k++) {
+#pragma unroll
+            for (int q = 0; q < LC; q++) acc[q] += xv[k] * y[(k + q) % LC];
+            y[k % LC] = yn[k];
         }
     }
 #undef X4
 #undef Y4
     float *o = NNN_TI(b.xc1, NLAG1, tile, lane);
 #pragma unroll
-    for (int q = 0; q < 8; q++)
+    for (int q = 0; q < LC; q++)
         if (L0 + q < NLAG1) o[(size_t)(L0 + q) * TILE] = acc[q];
 }
 
@@ -396,6 +400,7 @@ __global__ void __launch_bounds__(64) k_best2(Buffers b)
     const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
     const float *xc2 = NNN_TI(b.xc2, 10, tile, lane);
     const int *b1 = NNN_TI(b.best1, 2, tile, lane);
+    float *yq = NNN_TI(b.ysq2, NLAG2, tile, lane);
     Xc2 xc;
     xc.lo1 = 2 * b1[0] - 2;
     xc.lo2 = 2 * b1[TILE] - 2;
@@ -409,8 +414,9 @@ __global__ void __launch_bounds__(64) k_best2(Buffers b)
 #pragma unroll
         for (int i = 0; i < 24; i++) ysq += v[i] * v[i];
     }
-    BestPitch bp;
-    bp.init();
+    // Serial part: the running energy y_sq_norm for every lag (ref: src/pitch.rs:401-402), kept per step.
+    // xcorr is zero outside two 5-lag windows, so only <= 10 lags can update the best pitch; they are
+    // replayed below in increasing lag order with the energy each of them saw.
     for (int i0 = 0; i0 < NLAG2; i0 += 21) {   // 294 = 14 x 21
         float a[21], d[21];
 #pragma unroll
@@ -420,10 +426,19 @@ __global__ void __launch_bounds__(64) k_best2(Buffers b)
         }
 #pragma unroll
         for (int i = 0; i < 21; i++) {
-            bp.update(i0 + i, xc.at(i0 + i), ysq);
+            yq[(size_t)(i0 + i) * TILE] = ysq;
             ysq += a[i] * a[i] - d[i] * d[i];
             ysq = fmaxf(ysq, 1.0f);
         }
+    }
+    BestPitch bp;
+    bp.init();
+    const int loA = min(xc.lo1, xc.lo2), loB = max(xc.lo1, xc.lo2);
+#pragma unroll
+    for (int u = 0; u < 10; u++) {
+        const int i = u < 5 ? loA + u : loB + (u - 5);
+        const bool on = i >= 0 && i < NLAG2 && (u < 5 || i > loA + 4);
+        if (on) bp.update(i, xc.at(i), yq[(size_t)i * TILE]);
     }
     int offset = 0;
     if (bp.best > 0 && bp.best < NLAG2 - 1) {
@@ -728,6 +743,55 @@ __device__ __forceinline__ float band_sum(const float *v, int bnd, const float *
     return acc;
 }
 
+// Parallel band sums for tolerance-only quantities (every band energy is downstream of an FFT):
+// the 21 band intervals are cut into 54 segments of <= 8 bins (table b.seg: k0, count, interval per
+// segment; first segment and segment count per interval); lane = segment forms the two triangularly
+// weighted partial sums of up to NQ quantities, then lane = band adds its partials.
+template <int NQ>
+__device__ __forceinline__ void band_sums_par(const Buffers &b, const float *const (&v)[NQ], float *part /* [2 * NQ][64] */,
+                                              float (&out)[NQ], int lane)
+{
+    const int *seg = b.seg;
+    if (lane < 54) {
+        const int k0 = seg[lane], cnt = seg[64 + lane];
+        float pa[NQ], pb[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { pa[q] = 0.0f; pb[q] = 0.0f; }
+        for (int k = k0; k < k0 + cnt; k++) {
+            const float fr = b.bin_frac[k];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const float x = v[q][k];
+                pa[q] = fmaf(1.0f - fr, x, pa[q]);
+                pb[q] = fmaf(fr, x, pb[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { part[(2 * q) * 64 + lane] = pa[q]; part[(2 * q + 1) * 64 + lane] = pb[q]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; q++) out[q] = 0.0f;
+    if (lane < NB) {
+        if (lane >= 1) {
+            const int s0 = seg[128 + lane - 1], ns = seg[160 + lane - 1];
+            for (int i = s0; i < s0 + ns; i++)
+#pragma unroll
+                for (int q = 0; q < NQ; q++) out[q] += part[(2 * q + 1) * 64 + i];
+        }
+        if (lane < NB - 1) {
+            const int s0 = seg[128 + lane], ns = seg[160 + lane];
+            for (int i = s0; i < s0 + ns; i++)
+#pragma unroll
+                for (int q = 0; q < NQ; q++) out[q] += part[(2 * q) * 64 + i];
+        }
+        if (lane == 0 || lane == NB - 1) {
+#pragma unroll
+            for (int q = 0; q < NQ; q++) out[q] *= 2.0f;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K8x / K8p  fft_x, fft_p: transform_input (window, real FFT, normalise, band energy) at lag 0 and at
 //     lag = pitch.  ref: src/features.rs:281-298, src/lib.rs:65-82, 150-155.  One wave per stream.
@@ -735,16 +799,20 @@ __device__ __forceinline__ float band_sum(const float *v, int bnd, const float *
 //     fft_p also forms the band correlation of X and P (ref: src/features.rs:135).
 // ---------------------------------------------------------------------------------------------
 template <bool LAGGED>
-__device__ __forceinline__ void transform_input(Buffers b, const StepParams *sp, float2 *A, float2 *B)
+__device__ __forceinline__ void transform_input(Buffers b, const StepParams *sp, float2 *A, float2 *B, float *part)
 {
     const int lane = threadIdx.x, s = blockIdx.x, tile = s >> 6, sl = s & 63;
     const int rb = ring_base(sp->slot);
     const int lag = LAGGED ? NNN_TI(b.pitch, 1, tile, sl)[0] : 0;
     const float *h = b.hist + (size_t)s * RING;
-    const int start = rb + (HIST - WINDOW) - lag;   // > 0
+    int start = rb + (HIST - WINDOW) - lag;   // in (0, 2 RING)
+    if (start >= RING) start -= RING;
     for (int n = lane; n < NFFT; n += 64) {
-        int i0 = (start + 2 * n) % RING, i1 = (start + 2 * n + 1) % RING;
-        A[n] = make_float2(h[i0] * b.window[2 * n], h[i1] * b.window[2 * n + 1]);
+        int i0 = start + 2 * n, i1 = i0 + 1;
+        if (i0 >= RING) i0 -= RING;
+        if (i1 >= RING) i1 -= RING;
+        const float2 w = ((const float2 *)b.window)[n];
+        A[n] = make_float2(h[i0] * w.x, h[i1] * w.y);
     }
     __syncthreads();
     fft480(A, B, b.tw960, lane);
@@ -765,23 +833,34 @@ __device__ __forceinline__ void transform_input(Buffers b, const StepParams *sp,
         }
     }
     __syncthreads();
-    for (int t = lane; t < (LAGGED ? 2 : 1) * NB; t += 64) {
-        const int q = t / NB, bnd = t - q * NB;
-        float *out = LAGGED ? (q == 0 ? b.ep : b.exp_) : b.ex;
-        NNN_TI(out, NB, tile, sl)[(size_t)bnd * TILE] = band_sum(q == 0 ? vv : vc, bnd, b.bin_frac);
+    if (LAGGED) {
+        const float *const v[2] = {vv, vc};
+        float o[2];
+        band_sums_par<2>(b, v, part, o, lane);
+        if (lane < NB) {
+            NNN_TI(b.ep, NB, tile, sl)[(size_t)lane * TILE] = o[0];
+            NNN_TI(b.exp_, NB, tile, sl)[(size_t)lane * TILE] = o[1];
+        }
+    } else {
+        const float *const v[1] = {vv};
+        float o[1];
+        band_sums_par<1>(b, v, part, o, lane);
+        if (lane < NB) NNN_TI(b.ex, NB, tile, sl)[(size_t)lane * TILE] = o[0];
     }
 }
 
 __global__ void __launch_bounds__(64) k_fft_x(Buffers b, const StepParams *sp)
 {
     __shared__ float2 A[NFFT], B[NFFT];
-    transform_input<false>(b, sp, A, B);
+    __shared__ float part[2 * 64];
+    transform_input<false>(b, sp, A, B, part);
 }
 
 __global__ void __launch_bounds__(64) k_fft_p(Buffers b, const StepParams *sp)
 {
     __shared__ float2 A[NFFT], B[NFFT];
-    transform_input<true>(b, sp, A, B);
+    __shared__ float part[4 * 64];
+    transform_input<true>(b, sp, A, B, part);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -946,10 +1025,17 @@ __device__ __forceinline__ void gemm_acc(f32x4 (&acc)[3][4], const unsigned shor
                                          const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane)
 {
     const int arow = lane & 15, akg = 8 * (lane >> 4);
+    uint4 bnext[NG];
+#pragma unroll
+    for (int gi = 0; gi < NG; gi++) bnext[gi] = Bnb[((G0 + gi) * g.ksteps) * 64 + lane];
     for (int ks = 0; ks < g.ksteps; ks++) {
         uint4 bfr[NG];
 #pragma unroll
-        for (int gi = 0; gi < NG; gi++) bfr[gi] = Bnb[((G0 + gi) * g.ksteps + ks) * 64 + lane];
+        for (int gi = 0; gi < NG; gi++) bfr[gi] = bnext[gi];
+        if (ks + 1 < g.ksteps) {   // next k-step's weight fragments travel while this one multiplies
+#pragma unroll
+            for (int gi = 0; gi < NG; gi++) bnext[gi] = Bnb[((G0 + gi) * g.ksteps + ks + 1) * 64 + lane];
+        }
 #pragma unroll
         for (int mb = 0; mb < MB; mb++) {
             const unsigned short *ap = A + (size_t)((mb0 + mb) * 16 + arow) * row_w + g.kbase + ks * 32 + akg;
@@ -985,9 +1071,22 @@ __device__ __forceinline__ void gru_layer(const LayerDesc &L, const RnnPlan &pl,
     const int neuron = nbi * 16 + (lane & 15);
     const bool nvalid = mine && neuron < L.n;
     // old state -> recurrent operand planes (columns >= n stay zero)
-    for (int e = threadIdx.x; e < TILE * L.n; e += 64 * RNN_WAVES) {
-        int row = e / L.n, col = e - row * L.n;
-        store_split(lds.REC, lds.rec_ps, row * pl.rec_w + col, state[e]);
+    {
+        constexpr int PRE = (TILE * MAXN + 64 * RNN_WAVES - 1) / (64 * RNN_WAVES);   // 16 loads in flight per thread
+        float pre[PRE];
+#pragma unroll
+        for (int i = 0; i < PRE; i++) {
+            const int e = threadIdx.x + i * 64 * RNN_WAVES;
+            pre[i] = e < TILE * L.n ? state[e] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < PRE; i++) {
+            const int e = threadIdx.x + i * 64 * RNN_WAVES;
+            if (e < TILE * L.n) {
+                int row = e / L.n, col = e - row * L.n;
+                store_split(lds.REC, lds.rec_ps, row * pl.rec_w + col, pre[i]);
+            }
+        }
     }
     __syncthreads();
     f32x4 acc[3][4];
@@ -1155,6 +1254,7 @@ __global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
     float *vad_out = sp->vad;
     __shared__ float2 A[FREQ + 3], B[FREQ + 3], C[NFFT];
     __shared__ float r[NB], r2[NB], gg[NB];
+    __shared__ float part[2 * 64];
     const int lane = threadIdx.x, s = blockIdx.x, tile = s >> 6, sl = s & 63;
     const bool live = NNN_TI(b.silence, 1, tile, sl)[0] == 0;
     const float2 *Xg = b.X + (size_t)s * FREQ, *Pg = b.P + (size_t)s * FREQ;
@@ -1186,7 +1286,12 @@ __global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
             if (k < 400) ebuf[k] = X.x * X.x + X.y * X.y;
         }
         __syncthreads();
-        if (lane < NB) r2[lane] = sqrtf(exb / (1e-8f + band_sum(ebuf, lane, b.bin_frac)));
+        {
+            const float *const v[1] = {ebuf};
+            float ne[1];
+            band_sums_par<1>(b, v, part, ne, lane);
+            if (lane < NB) r2[lane] = sqrtf(exb / (1e-8f + ne[0]));
+        }
         __syncthreads();
     }
     // filtered spectrum -> B[0..480]

@@ -86,6 +86,7 @@ struct Buffers {
     float *xc1;          // TI [147]
     int *best1;          // TI [2]
     float *xc2;          // TI [10]     fine xcorr at 2*best-2..+2, 2*second-2..+2
+    float *ysq2;         // TI [294]    running energy seen by every fine lag
     int *psearch;        // TI [1]
     float *xx_yy;        // TI [386]    [0] = xx, [1 + i] = yy_lookup[i]
     int *pitch;          // TI [1]
@@ -103,6 +104,7 @@ struct Buffers {
     const float *tansig;     // [201]
     const float *bin_frac;   // [400]  j / band_size
     const int *bin_band;     // [400]
+    const int *seg;          // [192] band-sum segments: k0[64], count[64], first segment[32], segments[32] per interval
     float wnorm;
     int S, S_pad, NT;
 };

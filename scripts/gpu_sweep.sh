@@ -1,11 +1,11 @@
 #!/bin/bash
-# Stream-count sweep + HBM counter passes (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 runs).
+# Stream-count sweep + counter passes (separate rocprofv3 runs per counter set).  Outputs under gpurun_out/.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-for S in 1024 4096 16384 32768 65536; do
+for S in ${SWEEP:-4096 16384 65536}; do
   timeout 600 python bench.py --streams $S --steps 60 --warmup 10 --no-cpu-baseline > $O/sweep_$S.json 2> $O/sweep_$S.err
   python - <<PY
 import json
@@ -15,7 +15,9 @@ print("S=$S value=%.3e ms/step=%.3f prof_ms=%.3f" % (d["value"], d["ms_per_step"
 PY
 done
 cd /tmp && export TMPDIR=/tmp
-for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/pmc_$C -o pmc -- python $R/bench.py --streams 4096 --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $O/pmc_$C.json 2> $O/pmc_$C.err
-  tail -1 $O/pmc_$C.err; ls $O/pmc_$C | head
+PS=${PMC_STREAMS:-16384}
+for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
+  tag=$(echo $C | cut -d' ' -f1)
+  timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/pmc_$tag -o pmc -- python $R/bench.py --streams $PS --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $O/pmc_$tag.json 2> $O/pmc_$tag.err
+  tail -1 $O/pmc_$tag.err | cut -c1-150
 done

@@ -92,3 +92,18 @@ def test_rnnoise_c_abi_flow(hostsim_lib, golden_io):
     L.rnnoise_destroy(st)
     got = np.concatenate(outs[1:])
     assert golden_metric(got, ref[: got.size]) < 1e-4
+
+
+@pytest.mark.parametrize("chunk", ["8", "16"])
+def test_xcorr_chunk_variants_bit_identical(hostsim_lib, monkeypatch, chunk):
+    """k_xcorr<8> and <16> (picked for large batches) give the same bits as <4>: the per-lag sums stay sequential."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(40, 3, 3)
+    base = nn.BatchDenoiser(3, lib=hostsim_lib)
+    base.process(x)
+    want = base.tap("xcorr1")
+    monkeypatch.setenv("NNN_XCORR_CHUNK", chunk)
+    other = nn.BatchDenoiser(3, lib=hostsim_lib)
+    other.process(x)
+    assert np.array_equal(other.tap("xcorr1").view(np.uint32), want.view(np.uint32))
