@@ -338,7 +338,13 @@ __global__ void __launch_bounds__(64) k_best1(Buffers b)
 __device__ __forceinline__ float ip480_partial(const float *xs, const float *ys, int q)
 {
     float s = 0.0f;
-    for (int m = 0; m < 120; m++) s += xs[4 * m + q] * ys[4 * m + q];
+    for (int m0 = 0; m0 < 120; m0 += 8) {
+        float xv[8], yv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { xv[i] = xs[4 * (m0 + i) + q]; yv[i] = ys[4 * (m0 + i) + q]; }
+#pragma unroll
+        for (int i = 0; i < 8; i++) s += xv[i] * yv[i];
+    }
     return s;
 }
 
@@ -685,38 +691,49 @@ template <int R> __device__ __forceinline__ void dftR(float2 *v)
     else dft10(v);
 }
 
-// one Stockham pass of the 480-point transform: radix R, NS = product of the radices already applied;
-// tw = exp(-2 pi i k / 960), k < 960
+// one Stockham pass of the 480-point transform, in place: every lane pulls its butterflies into registers,
+// the wave synchronises, then scatters the results (autosort order).  Radix R, NS = product of the radices
+// already applied; tw = exp(-2 pi i k / 960), k < 960.  One 3.8 KB buffer per transform keeps LDS small
+// enough for a full complement of waves per CU.
 template <int R, int NS>
-__device__ __forceinline__ void fft_pass(const float2 *src, float2 *dst, const float2 *tw, int lane)
+__device__ __forceinline__ void fft_pass(float2 *buf, const float2 *tw, int lane)
 {
-    constexpr int NBF = NFFT / R;
-    for (int j = lane; j < NBF; j += 64) {
-        float2 v[R];
-        const int k = j % NS;
+    constexpr int NBF = NFFT / R, IT = (NBF + 63) / 64;
+    float2 v[IT][R];
 #pragma unroll
-        for (int r = 0; r < R; r++) v[r] = src[j + r * NBF];
-        if (NS > 1) {
-            constexpr int step = 960 / (NS * R);
+    for (int it = 0; it < IT; it++) {
+        const int j = lane + 64 * it;
+        if (j < NBF) {
+            const int k = j % NS;
 #pragma unroll
-            for (int r = 1; r < R; r++) v[r] = cmulf(v[r], tw[(r * k * step) % 960]);
+            for (int r = 0; r < R; r++) v[it][r] = buf[j + r * NBF];
+            if (NS > 1) {
+                constexpr int step = 960 / (NS * R);
+#pragma unroll
+                for (int r = 1; r < R; r++) v[it][r] = cmulf(v[it][r], tw[(r * k * step) % 960]);
+            }
+            dftR<R>(v[it]);
         }
-        dftR<R>(v);
-        const int base = (j / NS) * NS * R + k;
-#pragma unroll
-        for (int r = 0; r < R; r++) dst[base + r * NS] = v[r];
     }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        const int j = lane + 64 * it;
+        if (j < NBF) {
+            const int base = (j / NS) * NS * R + (j % NS);
+#pragma unroll
+            for (int r = 0; r < R; r++) buf[base + r * NS] = v[it][r];
+        }
+    }
+    __syncthreads();
 }
 
-// forward 480-point FFT: input in A, result in B (A is clobbered).  Ends with a barrier.
-__device__ __forceinline__ void fft480(float2 *A, float2 *B, const float2 *tw, int lane)
+// forward 480-point FFT in place (natural order in, natural order out)
+__device__ __forceinline__ void fft480(float2 *buf, const float2 *tw, int lane)
 {
-    fft_pass<8, 1>(A, B, tw, lane);
-    __syncthreads();
-    fft_pass<6, 8>(B, A, tw, lane);
-    __syncthreads();
-    fft_pass<10, 48>(A, B, tw, lane);
-    __syncthreads();
+    fft_pass<8, 1>(buf, tw, lane);
+    fft_pass<6, 8>(buf, tw, lane);
+    fft_pass<10, 48>(buf, tw, lane);
 }
 
 // bin k (0..480) of the real 960-point spectrum from Z = FFT480(x[2n] + i x[2n+1])
@@ -799,36 +816,54 @@ __device__ __forceinline__ void band_sums_par(const Buffers &b, const float *con
 //     fft_p also forms the band correlation of X and P (ref: src/features.rs:135).
 // ---------------------------------------------------------------------------------------------
 template <bool LAGGED>
-__device__ __forceinline__ void transform_input(Buffers b, const StepParams *sp, float2 *A, float2 *B, float *part)
+__device__ __forceinline__ void transform_input(Buffers b, const StepParams *sp, float2 *Z, float *vv, float *vc, float *part)
 {
     const int lane = threadIdx.x, s = blockIdx.x, tile = s >> 6, sl = s & 63;
     const int rb = ring_base(sp->slot);
+    // loads that do not depend on the pitch go first
+    float2 Xr[7];
+    if (LAGGED) {
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            const int k = lane + 64 * u;
+            Xr[u] = k < 400 ? b.X[(size_t)s * FREQ + k] : make_float2(0.0f, 0.0f);
+        }
+    }
+    float2 w[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int n = lane + 64 * u;
+        w[u] = n < NFFT ? ((const float2 *)b.window)[n] : make_float2(0.0f, 0.0f);
+    }
     const int lag = LAGGED ? NNN_TI(b.pitch, 1, tile, sl)[0] : 0;
     const float *h = b.hist + (size_t)s * RING;
     int start = rb + (HIST - WINDOW) - lag;   // in (0, 2 RING)
     if (start >= RING) start -= RING;
-    for (int n = lane; n < NFFT; n += 64) {
-        int i0 = start + 2 * n, i1 = i0 + 1;
-        if (i0 >= RING) i0 -= RING;
-        if (i1 >= RING) i1 -= RING;
-        const float2 w = ((const float2 *)b.window)[n];
-        A[n] = make_float2(h[i0] * w.x, h[i1] * w.y);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int n = lane + 64 * u;
+        if (n < NFFT) {
+            int i0 = start + 2 * n, i1 = i0 + 1;
+            if (i0 >= RING) i0 -= RING;
+            if (i1 >= RING) i1 -= RING;
+            Z[n] = make_float2(h[i0] * w[u].x, h[i1] * w[u].y);
+        }
     }
     __syncthreads();
-    fft480(A, B, b.tw960, lane);
-    float *vv = (float *)A, *vc = vv + 400;   // per-bin |.|^2 and Re(X conj P)
+    fft480(Z, b.tw960, lane);
     const float wn = b.wnorm;
     float2 *dst = (LAGGED ? b.P : b.X) + (size_t)s * FREQ;
-    for (int k = lane; k < FREQ; k += 64) {
-        float2 Y = rfft_bin(B, b.tw960, k);
-        Y.x *= wn;
-        Y.y *= wn;
-        dst[k] = Y;
-        if (k < 400) {
-            vv[k] = Y.x * Y.x + Y.y * Y.y;
-            if (LAGGED) {
-                float2 X = b.X[(size_t)s * FREQ + k];
-                vc[k] = X.x * Y.x + X.y * Y.y;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = lane + 64 * u;
+        if (k < FREQ) {
+            float2 Y = rfft_bin(Z, b.tw960, k);
+            Y.x *= wn;
+            Y.y *= wn;
+            dst[k] = Y;
+            if (k < 400) {
+                vv[k] = Y.x * Y.x + Y.y * Y.y;
+                if (LAGGED) vc[k] = Xr[u < 7 ? u : 6].x * Y.x + Xr[u < 7 ? u : 6].y * Y.y;
             }
         }
     }
@@ -851,16 +886,18 @@ __device__ __forceinline__ void transform_input(Buffers b, const StepParams *sp,
 
 __global__ void __launch_bounds__(64) k_fft_x(Buffers b, const StepParams *sp)
 {
-    __shared__ float2 A[NFFT], B[NFFT];
+    __shared__ float2 Z[NFFT];
+    __shared__ float vv[400];
     __shared__ float part[2 * 64];
-    transform_input<false>(b, sp, A, B, part);
+    transform_input<false>(b, sp, Z, vv, nullptr, part);
 }
 
 __global__ void __launch_bounds__(64) k_fft_p(Buffers b, const StepParams *sp)
 {
-    __shared__ float2 A[NFFT], B[NFFT];
+    __shared__ float2 Z[NFFT];
+    __shared__ float vv[400], vc[400];
     __shared__ float part[4 * 64];
-    transform_input<true>(b, sp, A, B, part);
+    transform_input<true>(b, sp, Z, vv, vc, part);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1019,15 +1056,23 @@ __device__ __forceinline__ float load_split(const unsigned short *P, int plane_s
 }
 
 // acc[G0 + g][mb] += A[16 (mb0 + mb) .. +15][kbase ..] * B(gate G0 + g), g < NG, mb < MB, over all k-steps and
-// the three activation planes.  Bnb points at this neuron block's fragments ([gate][k-step][lane]).
+// the three activation planes.  Bnb points at this neuron block's fragments ([gate][k-step][lane]); the
+// fragments of k-step 0 are passed in (`first`) so that the caller can have them in flight early.
+template <int NG, int G0>
+__device__ __forceinline__ void load_first(uint4 (&first)[NG], const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane)
+{
+#pragma unroll
+    for (int gi = 0; gi < NG; gi++) first[gi] = Bnb[((G0 + gi) * g.ksteps) * 64 + lane];
+}
+
 template <int NG, int MB, int G0>
 __device__ __forceinline__ void gemm_acc(f32x4 (&acc)[3][4], const unsigned short *A, int plane_stride, int row_w, int mb0,
-                                         const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane)
+                                         const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane, const uint4 (&first)[NG])
 {
     const int arow = lane & 15, akg = 8 * (lane >> 4);
     uint4 bnext[NG];
 #pragma unroll
-    for (int gi = 0; gi < NG; gi++) bnext[gi] = Bnb[((G0 + gi) * g.ksteps) * 64 + lane];
+    for (int gi = 0; gi < NG; gi++) bnext[gi] = first[gi];
     for (int ks = 0; ks < g.ksteps; ks++) {
         uint4 bfr[NG];
 #pragma unroll
@@ -1060,32 +1105,42 @@ struct RnnLds {
 // (neuron block, MB stream blocks) unit: z, r and the input part of the candidate accumulate together,
 // r * state goes back through LDS (every candidate needs all of it), then the recurrent part of the
 // candidate and the state update.  z and the old state stay in registers in the C-fragment layout.
+constexpr int RNN_PRE = (TILE * MAXN + 64 * RNN_WAVES - 1) / (64 * RNN_WAVES);   // state values per thread (<= 16)
+
+__device__ __forceinline__ void preload_state(float (&pre)[RNN_PRE], const float *state, int n)
+{
+#pragma unroll
+    for (int i = 0; i < RNN_PRE; i++) {
+        const int e = threadIdx.x + i * 64 * RNN_WAVES;
+        pre[i] = e < TILE * n ? state[e] : 0.0f;
+    }
+}
+
 template <int MB>
 __device__ __forceinline__ void gru_layer(const LayerDesc &L, const RnnPlan &pl, const RnnLds &lds, float *state,
-                                          const uint4 *__restrict__ Wq, const float *__restrict__ fpar, int wave, int lane)
+                                          const float (&pre)[RNN_PRE], const uint4 *__restrict__ Wq,
+                                          const float *__restrict__ fpar, int wave, int lane)
 {
     const float scale = 1.0f / 256.0f;
     const int groups = 4 / MB, units = L.nb * groups;
     const bool mine = wave < units;
-    const int nbi = wave / groups, mb0 = (wave % groups) * MB;
+    const int nbi = mine ? wave / groups : 0, mb0 = (wave % groups) * MB;
     const int neuron = nbi * 16 + (lane & 15);
     const bool nvalid = mine && neuron < L.n;
-    // old state -> recurrent operand planes (columns >= n stay zero)
-    {
-        constexpr int PRE = (TILE * MAXN + 64 * RNN_WAVES - 1) / (64 * RNN_WAVES);   // 16 loads in flight per thread
-        float pre[PRE];
+    const uint4 *Bin = Wq + L.in.wofs + (size_t)nbi * 3 * L.in.ksteps * 64;
+    const uint4 *Brec = Wq + L.rec.wofs + (size_t)nbi * 3 * L.rec.ksteps * 64;
+    // weight fragments of every GEMM's first k-step start travelling now
+    uint4 f_in[3], f_zr[2], f_h[1];
+    load_first<3, 0>(f_in, L.in, Bin, lane);
+    load_first<2, 0>(f_zr, L.rec, Brec, lane);
+    load_first<1, 2>(f_h, L.rec, Brec, lane);
+    // old state (loaded at kernel start) -> recurrent operand planes (columns >= n stay zero)
 #pragma unroll
-        for (int i = 0; i < PRE; i++) {
-            const int e = threadIdx.x + i * 64 * RNN_WAVES;
-            pre[i] = e < TILE * L.n ? state[e] : 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < PRE; i++) {
-            const int e = threadIdx.x + i * 64 * RNN_WAVES;
-            if (e < TILE * L.n) {
-                int row = e / L.n, col = e - row * L.n;
-                store_split(lds.REC, lds.rec_ps, row * pl.rec_w + col, pre[i]);
-            }
+    for (int i = 0; i < RNN_PRE; i++) {
+        const int e = threadIdx.x + i * 64 * RNN_WAVES;
+        if (e < TILE * L.n) {
+            int row = e / L.n, col = e - row * L.n;
+            store_split(lds.REC, lds.rec_ps, row * pl.rec_w + col, pre[i]);
         }
     }
     __syncthreads();
@@ -1098,14 +1153,15 @@ __device__ __forceinline__ void gru_layer(const LayerDesc &L, const RnnPlan &pl,
 #pragma unroll
             for (int mb = 0; mb < MB; mb++) acc[g][mb] = f32x4{bv, bv, bv, bv};
         }
-        gemm_acc<3, MB, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, Wq + L.in.wofs + (size_t)nbi * 3 * L.in.ksteps * 64, lane);
-        gemm_acc<2, MB, 0>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Wq + L.rec.wofs + (size_t)nbi * 3 * L.rec.ksteps * 64, lane);
+        gemm_acc<3, MB, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, Bin, lane, f_in);
+        gemm_acc<2, MB, 0>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Brec, lane, f_zr);
 #pragma unroll
         for (int mb = 0; mb < MB; mb++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int row = (mb0 + mb) * 16 + 4 * (lane >> 4) + q;
-                const float so = nvalid ? state[(size_t)row * L.n + neuron] : 0.0f;
+                // the three planes hold the old state exactly
+                const float so = nvalid ? load_split(lds.REC, lds.rec_ps, row * pl.rec_w + neuron) : 0.0f;
                 sold[mb][q] = so;
                 zz[mb][q] = sigmoid_approx(scale * acc[0][mb][q], lds.tab);
                 rs[mb][q] = so * sigmoid_approx(scale * acc[1][mb][q], lds.tab);
@@ -1123,7 +1179,7 @@ __device__ __forceinline__ void gru_layer(const LayerDesc &L, const RnnPlan &pl,
     }
     __syncthreads();
     if (mine) {
-        gemm_acc<1, MB, 2>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Wq + L.rec.wofs + (size_t)nbi * 3 * L.rec.ksteps * 64, lane);
+        gemm_acc<1, MB, 2>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Brec, lane, f_h);
         if (nvalid) {
 #pragma unroll
             for (int mb = 0; mb < MB; mb++)
@@ -1142,8 +1198,15 @@ __device__ __forceinline__ void gru_layer(const LayerDesc &L, const RnnPlan &pl,
 }
 
 // dense layer on the matrix cores: returns act(W x + b) for this wave's (neuron block, stream block) unit
+__device__ __forceinline__ const uint4 *dense_frags(const LayerDesc &L, const uint4 *__restrict__ Wq, int wave)
+{
+    const int nbi = wave < L.nb * 4 ? wave / 4 : 0;
+    return Wq + L.in.wofs + (size_t)nbi * L.in.ksteps * 64;
+}
+
 __device__ __forceinline__ bool dense_unit(const LayerDesc &L, const RnnPlan &pl, const RnnLds &lds, const uint4 *__restrict__ Wq,
-                                           const float *__restrict__ fpar, int wave, int lane, f32x4 &out, int &neuron, int &mb0)
+                                           const float *__restrict__ fpar, int wave, int lane, const uint4 (&first)[1],
+                                           f32x4 &out, int &neuron, int &mb0)
 {
     const int units = L.nb * 4;
     const int nbi = wave / 4;
@@ -1153,7 +1216,7 @@ __device__ __forceinline__ bool dense_unit(const LayerDesc &L, const RnnPlan &pl
     f32x4 acc[3][4];
     const float bv = (neuron < L.n) ? fpar[L.bias + neuron] : 0.0f;
     acc[0][0] = f32x4{bv, bv, bv, bv};
-    gemm_acc<1, 1, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, Wq + L.in.wofs + (size_t)nbi * L.in.ksteps * 64, lane);
+    gemm_acc<1, 1, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, dense_frags(L, Wq, wave), lane, first);
 #pragma unroll
     for (int q = 0; q < 4; q++) out[q] = activate(L.act, acc[0][0][q] * (1.0f / 256.0f), lds.tab);
     return neuron < L.n;
@@ -1174,7 +1237,24 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     const int in_ps = TILE * pl.in_w, rec_ps = TILE * pl.rec_w;
     unsigned short *REC = IN + 3 * in_ps;
     RnnLds lds{tab, live, IN, REC, in_ps, rec_ps};
-    // zero both operand matrices (padding columns must read as 0), load table, flags, features
+    float *sv = b.gru_v + (size_t)tile * TILE * pl.vad.n, *sn = b.gru_n + (size_t)tile * TILE * pl.noise.n,
+          *sdn = b.gru_dn + (size_t)tile * TILE * pl.dn.n;
+    // Everything this block needs from HBM that does not depend on its own results starts travelling now:
+    // features, the three old GRU states, the first weight fragments of the two dense layers.
+    float fpre[(NFEAT + RNN_WAVES - 1) / RNN_WAVES];
+#pragma unroll
+    for (int i = 0; i < (NFEAT + RNN_WAVES - 1) / RNN_WAVES; i++) {
+        const int k = wave + i * RNN_WAVES;
+        fpre[i] = k < NFEAT ? NNN_TI(b.feat, NFEAT, tile, lane)[(size_t)k * TILE] : 0.0f;
+    }
+    float pre_v[RNN_PRE], pre_n[RNN_PRE], pre_d[RNN_PRE];
+    preload_state(pre_v, sv, pl.vad.n);
+    preload_state(pre_n, sn, pl.noise.n);
+    preload_state(pre_d, sdn, pl.dn.n);
+    uint4 f_dense[1], f_out[1];
+    load_first<1, 0>(f_dense, pl.dense.in, dense_frags(pl.dense, Wq, wave), lane);
+    load_first<1, 0>(f_out, pl.out.in, dense_frags(pl.out, Wq, wave), lane);
+    // zero both operand matrices (padding columns must read as 0), load table and flags
     {
         uint4 *z = (uint4 *)IN;
         const int n16 = 3 * (in_ps + rec_ps) / 8;
@@ -1183,39 +1263,40 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
         if (tid < TILE) live[tid] = NNN_TI(b.silence, 1, tile, tid)[0] == 0;
     }
     __syncthreads();
-    for (int k = wave; k < NFEAT; k += RNN_WAVES)
-        store_split(IN, in_ps, lane * pl.in_w + pl.cF + k, NNN_TI(b.feat, NFEAT, tile, lane)[(size_t)k * TILE]);
+#pragma unroll
+    for (int i = 0; i < (NFEAT + RNN_WAVES - 1) / RNN_WAVES; i++) {
+        const int k = wave + i * RNN_WAVES;
+        if (k < NFEAT) store_split(IN, in_ps, lane * pl.in_w + pl.cF + k, fpre[i]);
+    }
     __syncthreads();
     {   // input dense (ref: src/rnn.rs:353-355)
         f32x4 o;
         int neuron, mb0;
-        if (dense_unit(pl.dense, pl, lds, Wq, fpar, wave, lane, o, neuron, mb0)) {
+        if (dense_unit(pl.dense, pl, lds, Wq, fpar, wave, lane, f_dense, o, neuron, mb0)) {
 #pragma unroll
             for (int q = 0; q < 4; q++) store_split(IN, in_ps, (mb0 * 16 + 4 * (lane >> 4) + q) * pl.in_w + pl.dense.out_col + neuron, o[q]);
         }
     }
     __syncthreads();
-    float *sv = b.gru_v + (size_t)tile * TILE * pl.vad.n, *sn = b.gru_n + (size_t)tile * TILE * pl.noise.n,
-          *sdn = b.gru_dn + (size_t)tile * TILE * pl.dn.n;
-#define NNN_GRU(L, st)                                                        \
-    switch ((L).mb) {                                                         \
-    case 4: gru_layer<4>(L, pl, lds, st, Wq, fpar, wave, lane); break;        \
-    case 2: gru_layer<2>(L, pl, lds, st, Wq, fpar, wave, lane); break;        \
-    default: gru_layer<1>(L, pl, lds, st, Wq, fpar, wave, lane); break;       \
+#define NNN_GRU(L, st, pre)                                                        \
+    switch ((L).mb) {                                                              \
+    case 4: gru_layer<4>(L, pl, lds, st, pre, Wq, fpar, wave, lane); break;        \
+    case 2: gru_layer<2>(L, pl, lds, st, pre, Wq, fpar, wave, lane); break;        \
+    default: gru_layer<1>(L, pl, lds, st, pre, Wq, fpar, wave, lane); break;       \
     }
-    NNN_GRU(pl.vad, sv)                                                        // ref: src/rnn.rs:356-358
+    NNN_GRU(pl.vad, sv, pre_v)                                                 // ref: src/rnn.rs:356-358
     if (wave == RNN_WAVES - 1) {   // vad output, 1 x nv, lane = stream (ref: src/rnn.rs:359)
         float acc = fpar[pl.vo_b];
         for (int k = 0; k < pl.vad.n; k++) acc = fmaf(fpar[pl.vo_w + k], load_split(IN, in_ps, lane * pl.in_w + pl.cV + k), acc);
         NNN_TI(b.vad, 1, tile, lane)[0] = live[lane] ? activate(pl.act_vo, acc * (1.0f / 256.0f), tab) : 0.0f;
     }
-    NNN_GRU(pl.noise, sn)                                                      // ref: src/rnn.rs:361-366
-    NNN_GRU(pl.dn, sdn)                                                        // ref: src/rnn.rs:368-377
+    NNN_GRU(pl.noise, sn, pre_n)                                               // ref: src/rnn.rs:361-366
+    NNN_GRU(pl.dn, sdn, pre_d)                                                 // ref: src/rnn.rs:368-377
 #undef NNN_GRU
     {   // gains (ref: src/rnn.rs:378) and smoothing g = max(g, 0.6 lastg) (ref: src/denoise.rs:106-109)
         f32x4 o;
         int band, mb0;
-        if (dense_unit(pl.out, pl, lds, Wq, fpar, wave, lane, o, band, mb0)) {
+        if (dense_unit(pl.out, pl, lds, Wq, fpar, wave, lane, f_out, o, band, mb0)) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int row = mb0 * 16 + 4 * (lane >> 4) + q;
@@ -1252,87 +1333,131 @@ __global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
     float *out = sp->out;
     const size_t out_stride = sp->stream_stride;
     float *vad_out = sp->vad;
-    __shared__ float2 A[FREQ + 3], B[FREQ + 3], C[NFFT];
+    __shared__ float2 A[FREQ + 3];
+    __shared__ float ebuf[400];
     __shared__ float r[NB], r2[NB], gg[NB];
     __shared__ float part[2 * 64];
     const int lane = threadIdx.x, s = blockIdx.x, tile = s >> 6, sl = s & 63;
-    const bool live = NNN_TI(b.silence, 1, tile, sl)[0] == 0;
     const float2 *Xg = b.X + (size_t)s * FREQ, *Pg = b.P + (size_t)s * FREQ;
-    float *ebuf = (float *)C;  // 400 floats of scratch for band energies
-    float exb = 0.0f;
+    float *sm = b.synth_mem + (size_t)s * FRAME;
+    // every global load of this block is independent of its own results: issue them all now
+    const bool live = NNN_TI(b.silence, 1, tile, sl)[0] == 0;
+    float2 Xr[8], Pr[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = lane + 64 * u;
+        Xr[u] = k < FREQ ? Xg[k] : make_float2(0.0f, 0.0f);
+        Pr[u] = k < FREQ ? Pg[k] : make_float2(0.0f, 0.0f);
+    }
+    float b_ex = 0.0f, b_ep = 0.0f, b_xp = 0.0f, b_graw = 0.0f, b_g = 0.0f;
+    if (lane < NB) {
+        b_ex = NNN_TI(b.ex, NB, tile, sl)[(size_t)lane * TILE];
+        b_ep = NNN_TI(b.ep, NB, tile, sl)[(size_t)lane * TILE];
+        b_xp = NNN_TI(b.exp_, NB, tile, sl)[(size_t)lane * TILE];
+        b_graw = NNN_TI(b.g_raw, NB, tile, sl)[(size_t)lane * TILE];
+        b_g = NNN_TI(b.g, NB, tile, sl)[(size_t)lane * TILE];
+    }
+    float2 smv[4], wlo[4], whi[4];   // overlap memory and the two window halves, as sample pairs
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int n = lane + 64 * u;
+        const bool on = n < FRAME / 2;
+        smv[u] = on ? ((const float2 *)sm)[n] : make_float2(0.0f, 0.0f);
+        wlo[u] = on ? ((const float2 *)b.window)[n] : make_float2(0.0f, 0.0f);
+        whi[u] = on ? ((const float2 *)b.window)[FRAME / 2 + n] : make_float2(0.0f, 0.0f);
+    }
+    const float vadv = NNN_TI(b.vad, 1, tile, sl)[0];
+    const bool pair_ok = ((out_stride & 1) == 0) && ((((size_t)out) & 7) == 0);   // 8-byte stores need even strides
     if (live) {
         if (lane < NB) {
-            float ex = NNN_TI(b.ex, NB, tile, sl)[(size_t)lane * TILE], ep = NNN_TI(b.ep, NB, tile, sl)[(size_t)lane * TILE];
-            float xp = NNN_TI(b.exp_, NB, tile, sl)[(size_t)lane * TILE], g = NNN_TI(b.g_raw, NB, tile, sl)[(size_t)lane * TILE];
             float v;
-            if (xp > g) v = 1.0f;
+            if (b_xp > b_graw) v = 1.0f;
             else {
-                float exp_sq = xp * xp, g_sq = g * g;
+                float exp_sq = b_xp * b_xp, g_sq = b_graw * b_graw;
                 v = exp_sq * (1.0f - g_sq) / (0.001f + g_sq * (1.0f - exp_sq));
             }
             v = sqrtf(fminf(fmaxf(v, 0.0f), 1.0f));
-            v *= sqrtf(ex / (1e-8f + ep));
+            v *= sqrtf(b_ex / (1e-8f + b_ep));
             r[lane] = v;
-            gg[lane] = NNN_TI(b.g, NB, tile, sl)[(size_t)lane * TILE];
-            exb = ex;
+            gg[lane] = b_g;
         }
         __syncthreads();
-        for (int k = lane; k < FREQ; k += 64) {
-            float2 X = Xg[k], P = Pg[k];
-            float rf = interp_gain(r, k, b.bin_frac, b.bin_band);
-            X.x = X.x + P.x * rf;
-            X.y = X.y + P.y * rf;
-            A[k] = X;
-            if (k < 400) ebuf[k] = X.x * X.x + X.y * X.y;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = lane + 64 * u;
+            if (k < FREQ) {
+                float2 X = Xr[u];
+                const float rf = interp_gain(r, k, b.bin_frac, b.bin_band);
+                X.x = X.x + Pr[u].x * rf;
+                X.y = X.y + Pr[u].y * rf;
+                Xr[u] = X;
+                if (k < 400) ebuf[k] = X.x * X.x + X.y * X.y;
+            }
         }
         __syncthreads();
         {
             const float *const v[1] = {ebuf};
             float ne[1];
             band_sums_par<1>(b, v, part, ne, lane);
-            if (lane < NB) r2[lane] = sqrtf(exb / (1e-8f + ne[0]));
+            if (lane < NB) r2[lane] = sqrtf(b_ex / (1e-8f + ne[0]));
         }
         __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = lane + 64 * u;
+            if (k < FREQ) {
+                const float rf = interp_gain(r2, k, b.bin_frac, b.bin_band);
+                Xr[u].x *= rf; Xr[u].y *= rf;
+                const float gf = interp_gain(gg, k, b.bin_frac, b.bin_band);
+                Xr[u].x *= gf; Xr[u].y *= gf;
+            }
+        }
     }
-    // filtered spectrum -> B[0..480]
-    for (int k = lane; k < FREQ; k += 64) {
-        float2 X;
-        if (live) {
-            X = A[k];
-            float rf = interp_gain(r2, k, b.bin_frac, b.bin_band);
-            X.x *= rf; X.y *= rf;
-            float gf = interp_gain(gg, k, b.bin_frac, b.bin_band);
-            X.x *= gf; X.y *= gf;
-        } else X = Xg[k];
-        B[k] = X;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = lane + 64 * u;
+        if (k < FREQ) A[k] = Xr[u];
     }
     __syncthreads();
     // complex-to-real 960-point inverse as a 480-point complex inverse: Zin[k] = (X[k] + conj X[480-k])
     // + i e^{+2 pi i k/960} (X[k] - conj X[480-k]); stored re/im-swapped so the forward FFT inverts.
-    for (int k = lane; k < NFFT; k += 64) {
-        float2 a = B[k], c = B[NFFT - k];
-        float2 e2 = make_float2(a.x + c.x, a.y - c.y);
-        float2 d = make_float2(a.x - c.x, a.y + c.y);
-        float2 w = b.tw960[k];
-        w.y = -w.y;
-        float2 o2 = cmulf(d, w);
-        float2 z = make_float2(e2.x - o2.y, e2.y + o2.x);
-        A[k] = make_float2(z.y, z.x);
+    float2 zin[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = lane + 64 * u;
+        if (k < NFFT) {
+            float2 a = A[k], c = A[NFFT - k];
+            float2 e2 = make_float2(a.x + c.x, a.y - c.y);
+            float2 d = make_float2(a.x - c.x, a.y + c.y);
+            float2 w = b.tw960[k];
+            w.y = -w.y;
+            float2 o2 = cmulf(d, w);
+            zin[u] = make_float2(e2.y + o2.x, e2.x - o2.y);
+        }
     }
     __syncthreads();
-    fft480(A, C, b.tw960, lane);   // time samples: x[2n] = C[n].y, x[2n+1] = C[n].x
-    if (lane == 0 && vad_out && s < b.S) vad_out[s] = NNN_TI(b.vad, 1, tile, sl)[0];
-    float *sm = b.synth_mem + (size_t)s * FRAME;
-    for (int n = lane; n < FRAME / 2; n += 64) {
-        float2 lo = C[n], hi = C[n + FRAME / 2];
-        float v0 = lo.y / 2.0f * b.window[2 * n], v1 = lo.x / 2.0f * b.window[2 * n + 1];
-        float u0 = hi.y / 2.0f * b.window[FRAME + 2 * n], u1 = hi.x / 2.0f * b.window[FRAME + 2 * n + 1];
-        if (s < b.S) {
-            out[(size_t)s * out_stride + 2 * n] = v0 + sm[2 * n];
-            out[(size_t)s * out_stride + 2 * n + 1] = v1 + sm[2 * n + 1];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = lane + 64 * u;
+        if (k < NFFT) A[k] = zin[u];
+    }
+    __syncthreads();
+    fft480(A, b.tw960, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
+    if (lane == 0 && vad_out && s < b.S) vad_out[s] = vadv;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int n = lane + 64 * u;
+        if (n < FRAME / 2) {
+            float2 lo = A[n], hi = A[n + FRAME / 2];
+            float v0 = lo.y / 2.0f * wlo[u].x, v1 = lo.x / 2.0f * wlo[u].y;
+            float u0 = hi.y / 2.0f * whi[u].x, u1 = hi.x / 2.0f * whi[u].y;
+            if (s < b.S) {
+                float *o = out + (size_t)s * out_stride;
+                if (pair_ok) ((float2 *)o)[n] = make_float2(v0 + smv[u].x, v1 + smv[u].y);
+                else { o[2 * n] = v0 + smv[u].x; o[2 * n + 1] = v1 + smv[u].y; }
+            }
+            ((float2 *)sm)[n] = make_float2(u0, u1);
         }
-        sm[2 * n] = u0;
-        sm[2 * n + 1] = u1;
     }
 }
 
