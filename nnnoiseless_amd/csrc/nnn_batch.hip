@@ -35,9 +35,9 @@ static int fail(const char *fmt, ...)
         if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));  \
     } while (0)
 
-enum KernelId { K_HP, K_DECIM, K_LPC, K_FIR, K_XCORR, K_BEST1, K_REFINE, K_BEST2, K_YY, K_DOUBLING, K_FFT_X, K_FFT_P, K_FEATURES, K_RNN, K_SYNTH, K_ADVANCE, K_COUNT };
-static const char *kKernelNames[K_COUNT] = {"k_hp", "k_decim", "k_lpc", "k_fir", "k_xcorr", "k_best1", "k_refine", "k_best2",
-                                            "k_yy", "k_doubling", "k_fft_x", "k_fft_p", "k_features", "k_rnn", "k_synth", "k_advance"};
+enum KernelId { K_HP, K_LPC, K_XCORR, K_BEST1, K_REFINE, K_BEST2, K_YY, K_DOUBLING, K_FFT_X, K_FFT_P, K_RNN, K_SYNTH, K_ADVANCE, K_COUNT };
+static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_xcorr", "k_best1", "k_refine", "k_best2",
+                                            "k_yy", "k_doubling", "k_fft_x", "k_fft_p", "k_rnn", "k_synth", "k_advance"};
 
 struct nnn_batch {
     Buffers b;
@@ -192,6 +192,8 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     // persistent state
     HIPCHK(dalloc(h, &b.hist, Sp * RING, true));
     HIPCHK(dalloc(h, &b.hp_mem, Sp * 2, true));
+    HIPCHK(dalloc(h, &b.hp_last, Sp, true));
+    HIPCHK(dalloc(h, &b.dec, Sp * DEC_RING, true));
     HIPCHK(dalloc(h, &b.ceps_mem, Sp * CEPS_MEM * NB, true));
     HIPCHK(dalloc(h, &b.mem_id, Sp, true));
     HIPCHK(dalloc(h, &b.synth_mem, Sp * FRAME, true));
@@ -202,7 +204,7 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     HIPCHK(dalloc(h, &b.gru_n, Sp * md.nn, true));
     HIPCHK(dalloc(h, &b.gru_dn, Sp * md.ndn, true));
     // scratch
-    HIPCHK(dalloc(h, &b.xlp_raw, Sp * XLP, false));
+    HIPCHK(dalloc(h, &b.xlp0, Sp, false));
     HIPCHK(dalloc(h, &b.lpc, Sp * 10, false));
     HIPCHK(dalloc(h, &b.xlp_ti, Sp * XLP, false));
     HIPCHK(dalloc(h, &b.xlp_sm, Sp * XLP, false));
@@ -342,9 +344,7 @@ static void enqueue_frame(nnn_batch *h, hipStream_t st, bool prof)
     }
     L0.go(K_FFT_X, k_fft_x, dim3(Sp), dim3(64), 0, b, sp);
     if (br) hipEventRecord(h->ev_join[0], h->side[0]);
-    L.go(K_DECIM, k_decim, dim3(NT, XLP / 32), dim3(256), 0, b, sp);
-    L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b);
-    L.go(K_FIR, k_fir, dim3(NT, XLP / 32), dim3(64), 0, b);
+    L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp);
     if (br) {
         hipEventRecord(h->ev_fork[1], st);
         hipStreamWaitEvent(h->side[1], h->ev_fork[1], 0);
@@ -362,7 +362,6 @@ static void enqueue_frame(nnn_batch *h, hipStream_t st, bool prof)
     L.go(K_DOUBLING, k_doubling, dim3(Sp / 4), dim3(256), 0, b);
     if (br) hipStreamWaitEvent(st, h->ev_join[0], 0);
     L.go(K_FFT_P, k_fft_p, dim3(Sp), dim3(64), 0, b, sp);
-    L.go(K_FEATURES, k_features, dim3(NT), dim3(64), 0, b);
     L.go(K_RNN, k_rnn, dim3(NT), dim3(64 * RNN_WAVES), h->rnn_lds, b, h->plan, h->wq, h->fpar);
     L.go(K_SYNTH, k_synth, dim3(Sp), dim3(64), 0, b, sp);
     L.go(K_ADVANCE, k_advance, dim3(1), dim3(1), 0, h->sp);

@@ -24,10 +24,13 @@ __constant__ int kEband[NB] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24
 __constant__ int kSecondCheck[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};
 
 // ---------------------------------------------------------------------------------------------
-// K1  hp_filter: high-pass biquad (f64 arithmetic, f32 state) + append to the history ring.
-//     ref: src/features.rs:97-104, src/util.rs:95-107.  lane = stream; the 480-step recurrence is
-//     inherently serial per stream.  Input and history are stream-major, so 64x32 tiles are
-//     transposed through LDS to keep every global access coalesced.
+// K1  hp_filter: high-pass biquad (f64 arithmetic, f32 state) + append to the history ring
+//     (ref: src/features.rs:97-104, src/util.rs:95-107), and the 2:1 decimation of pitch_downsample
+//     (ref: src/pitch.rs:455-458) done incrementally: decimated sample d = ((s[2d-1] + s[2d+1])/2 + s[2d])/2
+//     depends only on absolute samples, so each frame adds 240 values to a persistent ring instead of
+//     recomputing all 864; only the reference's special first element is per frame.
+//     lane = stream; the 480-step recurrence is inherently serial per stream.  Input and history are
+//     stream-major, so 64x32 tiles are transposed through LDS to keep every global access coalesced.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp)
 {
@@ -38,9 +41,16 @@ __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp)
     const int lane = threadIdx.x, tile = blockIdx.x;
     float *hp = NNN_TI(b.hp_mem, 2, tile, lane);
     float m0 = hp[0], m1 = hp[TILE];
+    float prev = NNN_TI(b.hp_last, 1, tile, lane)[0];
+    {   // x_lp[0] = (x[1] / 2 + x[0]) / 2 on the oldest two samples of this frame's 1728-sample history
+        const float *h = b.hist + (size_t)(tile * TILE + lane) * RING;
+        const int rb = ring_base(slot);
+        const float x0 = h[rb], x1 = h[(rb + 1) % RING];
+        NNN_TI(b.xlp0, 1, tile, lane)[0] = (x1 / 2.0f + x0) / 2.0f;
+    }
+    float *dec = NNN_TI(b.dec, DEC_RING, tile, lane) + (size_t)(240 * slot) * TILE;
     const double a0 = (double)-1.99599f, a1 = (double)0.99600f, b0 = (double)-2.0f, b1 = (double)1.0f;
     const int sub = lane >> 5, col = lane & 31;
-    // row pointers of the two streams this lane moves per transposed access (nullptr = padding stream)
     float stage[32];
 #pragma unroll
     for (int r = 0; r < 32; r++) {
@@ -70,6 +80,12 @@ __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp)
             xs[j] = (float)y64;
         }
 #pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const float a = t == 0 ? prev : xs[2 * t - 1], m = xs[2 * t], n = xs[2 * t + 1];
+            dec[(size_t)(16 * c + t) * TILE] = ((a + n) / 2.0f + m) / 2.0f;
+        }
+        prev = xs[31];
+#pragma unroll
         for (int j = 0; j < 32; j++) tl[lane][j] = xs[j];
         __syncthreads();
 #pragma unroll
@@ -81,59 +97,44 @@ __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp)
     }
     hp[0] = m0;
     hp[TILE] = m1;
+    NNN_TI(b.hp_last, 1, tile, lane)[0] = prev;
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2  decimate: 2:1 decimation with [.25 .5 .25], ref: src/pitch.rs:455-458.  Elementwise, so any
-//     mapping is exact; a block takes 32 outputs of one 64-stream tile, reads the SM history ring
-//     coalesced, transposes through LDS and writes TI rows.
+// K3  lpc + fir5: 5-lag autocorrelation (strictly sequential per lag), lag window, order-4 Levinson,
+//     bandwidth expansion and the extra zero (ref: src/pitch.rs:433-446, 460-480, 257-292), then
+//     pitch_buf = FIR5(decimated history) with zero initial memory (ref: src/pitch.rs:407-429).
+//     lane = stream; the five sequential chains run on the five waves of the block, which then share the
+//     (elementwise) FIR and write pitch_buf as TI (scans, coarse xcorr) and SM (wave = stream kernels).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_decim(Buffers b, const StepParams *sp)
-{
-    const int slot = sp->slot;
-    __shared__ float tl[64][67];
-    const int tid = threadIdx.x, tile = blockIdx.x, c = blockIdx.y;
-    const int rb = ring_base(slot);
-    for (int idx = tid; idx < 64 * 66; idx += 256) {
-        int row = idx / 66, col = idx - row * 66;
-        int li = 64 * c - 1 + col;
-        float v = 0.0f;
-        if (li >= 0 && li < HIST) {
-            int ph = rb + li;
-            if (ph >= RING) ph -= RING;
-            v = b.hist[(size_t)(tile * TILE + row) * RING + ph];
-        }
-        tl[row][col] = v;
+struct DecRing {   // logical decimated history x_lp[0..863] on top of the ring
+    const float *ring;
+    float x0;
+    int base;
+    __device__ __forceinline__ float operator()(int j) const
+    {
+        int ph = base + j;
+        if (ph >= DEC_RING) ph -= DEC_RING;
+        float v = ring[(size_t)ph * TILE];
+        return j == 0 ? x0 : v;
     }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    float *o = NNN_TI(b.xlp_raw, XLP, tile, lane);
-    for (int k = wave; k < 32; k += 4) {
-        int i = 32 * c + k;
-        float a = tl[lane][2 * k], m = tl[lane][2 * k + 1], n = tl[lane][2 * k + 2];
-        float v = (i == 0) ? (n / 2.0f + m) / 2.0f : ((a + n) / 2.0f + m) / 2.0f;
-        o[(size_t)i * TILE] = v;
-    }
-}
+};
 
-// ---------------------------------------------------------------------------------------------
-// K3  lpc: 5-lag autocorrelation (strictly sequential per lag), lag window, order-4 Levinson,
-//     bandwidth expansion and the extra zero.  ref: src/pitch.rs:433-446, 460-480, 257-292.
-//     lane = stream; the five strictly sequential chains run on five waves of the block.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(320) k_lpc(Buffers b)
+__global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
 {
     __shared__ float acs[5][64];
+    __shared__ float coef[5][64];
+    __shared__ float tl[5][64][33];
     const int lane = threadIdx.x & 63, tile = blockIdx.x;
     const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // this wave's lag
-    const float *x = NNN_TI(b.xlp_raw, XLP, tile, lane);
+    DecRing x{NNN_TI(b.dec, DEC_RING, tile, lane), NNN_TI(b.xlp0, 1, tile, lane)[0], dec_base(sp->slot)};
     const int fast_n = XLP - 4;   // 860 = 43 blocks of 20 rows; a block's loads are issued together
     constexpr int BL = 20;
     {
         float c = 0.0f;
         float na[BL], nb[BL];
 #pragma unroll
-        for (int i = 0; i < BL; i++) { na[i] = x[(size_t)i * TILE]; nb[i] = x[(size_t)(i + k) * TILE]; }
+        for (int i = 0; i < BL; i++) { na[i] = x(i); nb[i] = x(i + k); }
         for (int j0 = 0; j0 < fast_n; j0 += BL) {
             float ca[BL], cb[BL];
 #pragma unroll
@@ -141,8 +142,8 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b)
             if (j0 + BL < fast_n) {
 #pragma unroll
                 for (int i = 0; i < BL; i++) {
-                    na[i] = x[(size_t)(j0 + BL + i) * TILE];
-                    nb[i] = x[(size_t)(j0 + BL + i + k) * TILE];
+                    na[i] = x(j0 + BL + i);
+                    nb[i] = x(j0 + BL + i + k);
                 }
             }
 #pragma unroll
@@ -150,87 +151,85 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b)
         }
         // tail d_k = sum_{i = k+860}^{863} x[i] x[i-k], added after the main sum (ref: src/pitch.rs:439-445)
         float d = 0.0f;
-        for (int i = k + fast_n; i < XLP; i++) d += x[(size_t)i * TILE] * x[(size_t)(i - k) * TILE];
+        for (int i = k + fast_n; i < XLP; i++) d += x(i) * x(i - k);
         acs[k][lane] = c + d;
     }
     __syncthreads();
-    if (k != 0) return;
-    float ac[5];
+    if (k == 0) {
+        float ac[5];
 #pragma unroll
-    for (int i = 0; i < 5; i++) ac[i] = acs[i][lane];
-    ac[0] *= 1.0001f;
+        for (int i = 0; i < 5; i++) ac[i] = acs[i][lane];
+        ac[0] *= 1.0001f;
 #pragma unroll
-    for (int i = 1; i < 5; i++) ac[i] -= ac[i] * (0.008f * (float)i) * (0.008f * (float)i);
+        for (int i = 1; i < 5; i++) ac[i] -= ac[i] * (0.008f * (float)i) * (0.008f * (float)i);
 
-    float lpc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (ac[0] != 0.0f) {
-        float error = ac[0];
-        bool done = false;
+        float lpc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (ac[0] != 0.0f) {
+            float error = ac[0];
+            bool done = false;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (!done) {
-                float rr = 0.0f;
+            for (int i = 0; i < 4; i++) {
+                if (!done) {
+                    float rr = 0.0f;
 #pragma unroll
-                for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
-                rr += ac[i + 1];
-                float r = -rr / error;
-                lpc[i] = r;
+                    for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
+                    rr += ac[i + 1];
+                    float r = -rr / error;
+                    lpc[i] = r;
 #pragma unroll
-                for (int j = 0; j < (i + 1) / 2; j++) {
-                    float t1 = lpc[j], t2 = lpc[i - 1 - j];
-                    lpc[j] = t1 + r * t2;
-                    lpc[i - 1 - j] = t2 + r * t1;
+                    for (int j = 0; j < (i + 1) / 2; j++) {
+                        float t1 = lpc[j], t2 = lpc[i - 1 - j];
+                        lpc[j] = t1 + r * t2;
+                        lpc[i - 1 - j] = t2 + r * t1;
+                    }
+                    error = error - r * r * error;
+                    if (error < 0.001f * ac[0]) done = true;
                 }
-                error = error - r * r * error;
-                if (error < 0.001f * ac[0]) done = true;
             }
         }
-    }
-    float tmp = 1.0f;
+        float tmp = 1.0f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) { tmp *= 0.9f; lpc[i] *= tmp; }
-    float l2[5];
-    l2[0] = lpc[0] + 0.8f;
-    l2[1] = lpc[1] + 0.8f * lpc[0];
-    l2[2] = lpc[2] + 0.8f * lpc[1];
-    l2[3] = lpc[3] + 0.8f * lpc[2];
-    l2[4] = 0.8f * lpc[3];
-    float *o = NNN_TI(b.lpc, 10, tile, lane);
+        for (int i = 0; i < 4; i++) { tmp *= 0.9f; lpc[i] *= tmp; }
+        float l2[5];
+        l2[0] = lpc[0] + 0.8f;
+        l2[1] = lpc[1] + 0.8f * lpc[0];
+        l2[2] = lpc[2] + 0.8f * lpc[1];
+        l2[3] = lpc[3] + 0.8f * lpc[2];
+        l2[4] = 0.8f * lpc[3];
+        float *o = NNN_TI(b.lpc, 10, tile, lane);
 #pragma unroll
-    for (int i = 0; i < 5; i++) { o[(size_t)i * TILE] = ac[i]; o[(size_t)(5 + i) * TILE] = l2[i]; }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K4  fir5: pitch_buf = FIR5(decimated history), zero initial memory each frame.
-//     ref: src/pitch.rs:407-429.  Elementwise in i; writes the TI copy (scans, coarse xcorr) and
-//     the SM copy (wave = stream inner products) of pitch_buf.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_fir(Buffers b)
-{
-    __shared__ float tl[64][33];
-    const int lane = threadIdx.x, tile = blockIdx.x, c = blockIdx.y;
-    const float *x = NNN_TI(b.xlp_raw, XLP, tile, lane);
-    const float *l = NNN_TI(b.lpc, 10, tile, lane);
-    const float n0 = l[5 * TILE], n1 = l[6 * TILE], n2 = l[7 * TILE], n3 = l[8 * TILE], n4 = l[9 * TILE];
-    const int i0 = 32 * c;
-    float m0 = i0 >= 1 ? x[(size_t)(i0 - 1) * TILE] : 0.0f;
-    float m1 = i0 >= 2 ? x[(size_t)(i0 - 2) * TILE] : 0.0f;
-    float m2 = i0 >= 3 ? x[(size_t)(i0 - 3) * TILE] : 0.0f;
-    float m3 = i0 >= 4 ? x[(size_t)(i0 - 4) * TILE] : 0.0f;
-    float m4 = i0 >= 5 ? x[(size_t)(i0 - 5) * TILE] : 0.0f;
-    float *o = NNN_TI(b.xlp_ti, XLP, tile, lane);
-    for (int k = 0; k < 32; k++) {
-        float xi = x[(size_t)(i0 + k) * TILE];
-        float out = xi + n0 * m0 + n1 * m1 + n2 * m2 + n3 * m3 + n4 * m4;
-        m4 = m3; m3 = m2; m2 = m1; m1 = m0; m0 = xi;
-        o[(size_t)(i0 + k) * TILE] = out;
-        tl[lane][k] = out;
+        for (int i = 0; i < 5; i++) { o[(size_t)i * TILE] = ac[i]; o[(size_t)(5 + i) * TILE] = l2[i]; coef[i][lane] = l2[i]; }
     }
     __syncthreads();
+    // FIR5 over 27 chunks of 32 outputs, 5 waves round-robin (every wave runs 6 rounds so barriers match)
+    const float n0 = coef[0][lane], n1 = coef[1][lane], n2 = coef[2][lane], n3 = coef[3][lane], n4 = coef[4][lane];
+    float *o = NNN_TI(b.xlp_ti, XLP, tile, lane);
     const int sub = lane >> 5, col = lane & 31;
-    for (int r = 0; r < 32; r++) {
-        int row = r * 2 + sub;
-        b.xlp_sm[(size_t)(tile * TILE + row) * XLP + i0 + col] = tl[row][col];
+    for (int round = 0; round < 6; round++) {
+        const int c = round * 5 + k;
+        const bool on = c < XLP / 32;
+        if (on) {
+            const int i0 = 32 * c;
+            float v[37];
+#pragma unroll
+            for (int u = 0; u < 37; u++) v[u] = (i0 + u - 5 >= 0) ? x(i0 + u - 5) : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 32; u++) {
+                // out = x + n0 m0 + n1 m1 + n2 m2 + n3 m3 + n4 m4, left to right (m0 = previous input, ...)
+                float out = v[u + 5] + n0 * v[u + 4] + n1 * v[u + 3] + n2 * v[u + 2] + n3 * v[u + 1] + n4 * v[u];
+                o[(size_t)(i0 + u) * TILE] = out;
+                tl[k][lane][u] = out;
+            }
+        }
+        __syncthreads();
+        if (on) {
+#pragma unroll
+            for (int r = 0; r < 32; r++) {
+                int row = r * 2 + sub;
+                b.xlp_sm[(size_t)(tile * TILE + row) * XLP + 32 * c + col] = tl[k][row][col];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -902,7 +901,7 @@ __global__ void __launch_bounds__(64) k_fft_p(Buffers b, const StepParams *sp)
 
 // ---------------------------------------------------------------------------------------------
 // K9  features: the 42 RNN inputs from band energies, pitch and the cepstral history.
-//     ref: src/features.rs:135-219, src/lib.rs:139-148.  lane = stream.
+//     ref: src/features.rs:135-219, src/lib.rs:139-148.  lane = stream; runs on wave 0 of the RNN kernel.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dct_out(const float *x, const float *dct, int i)
 {
@@ -912,9 +911,9 @@ __device__ __forceinline__ float dct_out(const float *x, const float *dct, int i
     return (float)((double)sum * 0.30151134457776363 /* sqrt(2/22) */);
 }
 
-__global__ void __launch_bounds__(64) k_features(Buffers b)
+// lane = stream; returns true if the frame is silent.  fr[] receives the 42 features (also written to b.feat).
+__device__ __forceinline__ bool features_tile(const Buffers &b, int tile, int lane, float (&fr)[NFEAT])
 {
-    const int lane = threadIdx.x, tile = blockIdx.x;
     float ex[NB], ly[NB], tmp[NB];
     const float *exg = NNN_TI(b.ex, NB, tile, lane), *epg = NNN_TI(b.ep, NB, tile, lane);
     float *xpg = NNN_TI(b.exp_, NB, tile, lane);
@@ -945,8 +944,9 @@ __global__ void __launch_bounds__(64) k_features(Buffers b)
     const bool silent = e < 0.04f;
     NNN_TI(b.silence, 1, tile, lane)[0] = silent ? 1 : 0;
     if (silent) {
-        for (int i = 0; i < NFEAT; i++) f[(size_t)i * TILE] = 0.0f;
-        return;
+#pragma unroll
+        for (int i = 0; i < NFEAT; i++) { f[(size_t)i * TILE] = 0.0f; fr[i] = 0.0f; }
+        return true;
     }
     float c[NB];
 #pragma unroll
@@ -964,16 +964,16 @@ __global__ void __launch_bounds__(64) k_features(Buffers b)
     if (mem_id == CEPS_MEM) mem_id = 0;
     midp[0] = mem_id;
 #pragma unroll
-    for (int i = 0; i < NB; i++) f[(size_t)i * TILE] = c[i];
+    for (int i = 0; i < NB; i++) fr[i] = c[i];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         float v0 = c[i], v1 = cm[(size_t)(c1 * NB + i) * TILE], v2 = cm[(size_t)(c2 * NB + i) * TILE];
-        f[(size_t)i * TILE] = v0 + v1 + v2;
-        f[(size_t)(NB + i) * TILE] = v0 - v2;
-        f[(size_t)(NB + 6 + i) * TILE] = v0 - 2.0f * v1 + v2;
-        f[(size_t)(NB + 12 + i) * TILE] = fpc[i];
+        fr[i] = v0 + v1 + v2;
+        fr[NB + i] = v0 - v2;
+        fr[NB + 6 + i] = v0 - 2.0f * v1 + v2;
+        fr[NB + 12 + i] = fpc[i];
     }
-    f[(size_t)40 * TILE] = fpitch;
+    fr[40] = fpitch;
     // spectral variability: mean over i of min_{j != i} |c_i - c_j|^2 ; dist(i,j) == dist(j,i) exactly
     float mind[CEPS_MEM];
 #pragma unroll
@@ -998,7 +998,10 @@ __global__ void __launch_bounds__(64) k_features(Buffers b)
     float sv = 0.0f;
 #pragma unroll
     for (int i = 0; i < CEPS_MEM; i++) sv += mind[i];
-    f[(size_t)41 * TILE] = sv / (float)CEPS_MEM - 2.1f;
+    fr[41] = sv / (float)CEPS_MEM - 2.1f;
+#pragma unroll
+    for (int i = 0; i < NFEAT; i++) f[(size_t)i * TILE] = fr[i];
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1055,32 +1058,47 @@ __device__ __forceinline__ float load_split(const unsigned short *P, int plane_s
     return (bf16_f32(P[idx]) + bf16_f32(P[idx + plane_stride])) + bf16_f32(P[idx + 2 * plane_stride]);
 }
 
-// acc[G0 + g][mb] += A[16 (mb0 + mb) .. +15][kbase ..] * B(gate G0 + g), g < NG, mb < MB, over all k-steps and
-// the three activation planes.  Bnb points at this neuron block's fragments ([gate][k-step][lane]); the
-// fragments of k-step 0 are passed in (`first`) so that the caller can have them in flight early.
+// Weight fragments of one GEMM group: all k-steps (up to KSMAX) are requested together so that a layer pays
+// one trip to the Infinity Cache / HBM instead of one per k-step.
+constexpr int KSMAX = 4;
+template <int NG> struct Frags { uint4 f[KSMAX][NG]; };
+
 template <int NG, int G0>
-__device__ __forceinline__ void load_first(uint4 (&first)[NG], const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane)
+__device__ __forceinline__ void load_frags(Frags<NG> &fr, const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane)
 {
 #pragma unroll
-    for (int gi = 0; gi < NG; gi++) first[gi] = Bnb[((G0 + gi) * g.ksteps) * 64 + lane];
+    for (int ks = 0; ks < KSMAX; ks++)
+#pragma unroll
+        for (int gi = 0; gi < NG; gi++)
+            fr.f[ks][gi] = ks < g.ksteps ? Bnb[((G0 + gi) * g.ksteps + ks) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
 }
 
+// acc[G0 + g][mb] += A[16 (mb0 + mb) .. +15][kbase ..] * B(gate G0 + g), g < NG, mb < MB, over all k-steps and
+// the three activation planes.  Bnb points at this neuron block's fragments ([gate][k-step][lane]).
 template <int NG, int MB, int G0>
 __device__ __forceinline__ void gemm_acc(f32x4 (&acc)[3][4], const unsigned short *A, int plane_stride, int row_w, int mb0,
-                                         const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane, const uint4 (&first)[NG])
+                                         const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane, const Frags<NG> &fr)
 {
     const int arow = lane & 15, akg = 8 * (lane >> 4);
-    uint4 bnext[NG];
 #pragma unroll
-    for (int gi = 0; gi < NG; gi++) bnext[gi] = first[gi];
-    for (int ks = 0; ks < g.ksteps; ks++) {
+    for (int ks = 0; ks < KSMAX; ks++) {
+        if (ks < g.ksteps) {
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++) {
+                const unsigned short *ap = A + (size_t)((mb0 + mb) * 16 + arow) * row_w + g.kbase + ks * 32 + akg;
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) {
+                    const uint4 af = *(const uint4 *)(ap + (size_t)pl * plane_stride);
+#pragma unroll
+                    for (int gi = 0; gi < NG; gi++) acc[G0 + gi][mb] = mfma_16x16x32_bf16(af, fr.f[ks][gi], acc[G0 + gi][mb]);
+                }
+            }
+        }
+    }
+    for (int ks = KSMAX; ks < g.ksteps; ks++) {   // models wider than 128 columns: fetch as we go
         uint4 bfr[NG];
 #pragma unroll
-        for (int gi = 0; gi < NG; gi++) bfr[gi] = bnext[gi];
-        if (ks + 1 < g.ksteps) {   // next k-step's weight fragments travel while this one multiplies
-#pragma unroll
-            for (int gi = 0; gi < NG; gi++) bnext[gi] = Bnb[((G0 + gi) * g.ksteps + ks + 1) * 64 + lane];
-        }
+        for (int gi = 0; gi < NG; gi++) bfr[gi] = Bnb[((G0 + gi) * g.ksteps + ks) * 64 + lane];
 #pragma unroll
         for (int mb = 0; mb < MB; mb++) {
             const unsigned short *ap = A + (size_t)((mb0 + mb) * 16 + arow) * row_w + g.kbase + ks * 32 + akg;
@@ -1129,11 +1147,13 @@ __device__ __forceinline__ void gru_layer(const LayerDesc &L, const RnnPlan &pl,
     const bool nvalid = mine && neuron < L.n;
     const uint4 *Bin = Wq + L.in.wofs + (size_t)nbi * 3 * L.in.ksteps * 64;
     const uint4 *Brec = Wq + L.rec.wofs + (size_t)nbi * 3 * L.rec.ksteps * 64;
-    // weight fragments of every GEMM's first k-step start travelling now
-    uint4 f_in[3], f_zr[2], f_h[1];
-    load_first<3, 0>(f_in, L.in, Bin, lane);
-    load_first<2, 0>(f_zr, L.rec, Brec, lane);
-    load_first<1, 2>(f_h, L.rec, Brec, lane);
+    // all weight fragments of this layer start travelling now
+    Frags<3> f_in;
+    Frags<2> f_zr;
+    Frags<1> f_h;
+    load_frags<3, 0>(f_in, L.in, Bin, lane);
+    load_frags<2, 0>(f_zr, L.rec, Brec, lane);
+    load_frags<1, 2>(f_h, L.rec, Brec, lane);
     // old state (loaded at kernel start) -> recurrent operand planes (columns >= n stay zero)
 #pragma unroll
     for (int i = 0; i < RNN_PRE; i++) {
@@ -1205,7 +1225,7 @@ __device__ __forceinline__ const uint4 *dense_frags(const LayerDesc &L, const ui
 }
 
 __device__ __forceinline__ bool dense_unit(const LayerDesc &L, const RnnPlan &pl, const RnnLds &lds, const uint4 *__restrict__ Wq,
-                                           const float *__restrict__ fpar, int wave, int lane, const uint4 (&first)[1],
+                                           const float *__restrict__ fpar, int wave, int lane, const Frags<1> &first,
                                            f32x4 &out, int &neuron, int &mb0)
 {
     const int units = L.nb * 4;
@@ -1240,33 +1260,31 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     float *sv = b.gru_v + (size_t)tile * TILE * pl.vad.n, *sn = b.gru_n + (size_t)tile * TILE * pl.noise.n,
           *sdn = b.gru_dn + (size_t)tile * TILE * pl.dn.n;
     // Everything this block needs from HBM that does not depend on its own results starts travelling now:
-    // features, the three old GRU states, the first weight fragments of the two dense layers.
-    float fpre[(NFEAT + RNN_WAVES - 1) / RNN_WAVES];
-#pragma unroll
-    for (int i = 0; i < (NFEAT + RNN_WAVES - 1) / RNN_WAVES; i++) {
-        const int k = wave + i * RNN_WAVES;
-        fpre[i] = k < NFEAT ? NNN_TI(b.feat, NFEAT, tile, lane)[(size_t)k * TILE] : 0.0f;
-    }
+    // the three old GRU states and the weight fragments of the two dense layers.
     float pre_v[RNN_PRE], pre_n[RNN_PRE], pre_d[RNN_PRE];
     preload_state(pre_v, sv, pl.vad.n);
     preload_state(pre_n, sn, pl.noise.n);
     preload_state(pre_d, sdn, pl.dn.n);
-    uint4 f_dense[1], f_out[1];
-    load_first<1, 0>(f_dense, pl.dense.in, dense_frags(pl.dense, Wq, wave), lane);
-    load_first<1, 0>(f_out, pl.out.in, dense_frags(pl.out, Wq, wave), lane);
-    // zero both operand matrices (padding columns must read as 0), load table and flags
-    {
+    Frags<1> f_dense, f_out;
+    load_frags<1, 0>(f_dense, pl.dense.in, dense_frags(pl.dense, Wq, wave), lane);
+    load_frags<1, 0>(f_out, pl.out.in, dense_frags(pl.out, Wq, wave), lane);
+    // wave 0 turns band energies into the 42 features (lane = stream) while the other waves zero both operand
+    // matrices (padding columns must read as 0) and fetch the activation table
+    float fr[NFEAT];
+    bool silent = false;
+    if (wave == 0) {
+        silent = features_tile(b, tile, lane, fr);
+    } else {
         uint4 *z = (uint4 *)IN;
         const int n16 = 3 * (in_ps + rec_ps) / 8;
-        for (int i = tid; i < n16; i += 64 * RNN_WAVES) z[i] = make_uint4(0u, 0u, 0u, 0u);
-        for (int i = tid; i < 201; i += 64 * RNN_WAVES) tab[i] = b.tansig[i];
-        if (tid < TILE) live[tid] = NNN_TI(b.silence, 1, tile, tid)[0] == 0;
+        for (int i = tid - 64; i < n16; i += 64 * (RNN_WAVES - 1)) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = tid - 64; i < 201; i += 64 * (RNN_WAVES - 1)) tab[i] = b.tansig[i];
     }
     __syncthreads();
+    if (wave == 0) {
+        live[lane] = silent ? 0 : 1;
 #pragma unroll
-    for (int i = 0; i < (NFEAT + RNN_WAVES - 1) / RNN_WAVES; i++) {
-        const int k = wave + i * RNN_WAVES;
-        if (k < NFEAT) store_split(IN, in_ps, lane * pl.in_w + pl.cF + k, fpre[i]);
+        for (int k = 0; k < NFEAT; k++) store_split(IN, in_ps, lane * pl.in_w + pl.cF + k, fr[k]);
     }
     __syncthreads();
     {   // input dense (ref: src/rnn.rs:353-355)

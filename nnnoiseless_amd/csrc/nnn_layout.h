@@ -71,6 +71,8 @@ struct Buffers {
     // ---- persistent per-stream state (src/denoise.rs:37-42, features.rs:18-46, pitch.rs:4-17, rnn.rs:65-70)
     float *hist;         // SM [RING]   high-passed input history, ring of 4 frames
     float *hp_mem;       // TI [2]      biquad state
+    float *hp_last;      // TI [1]      last filtered sample of the previous frame
+    float *dec;          // TI [960]    2:1 decimated history, ring of 4 x 240 (only 240 values are new per frame)
     float *ceps_mem;     // TI [8*22]
     int *mem_id;         // TI [1]
     float *synth_mem;    // SM [480]
@@ -79,7 +81,7 @@ struct Buffers {
     float *last_gain;    // TI [1]
     float *gru_v, *gru_n, *gru_dn;  // SM [nv], [nn], [ndn]
     // ---- per-frame scratch (doubles as the parity taps)
-    float *xlp_raw;      // TI [864]    decimated history before the LPC FIR
+    float *xlp0;         // TI [1]      pitch_downsample's special first element (x[1]/2 + x[0])/2
     float *lpc;          // TI [10]     ac[5], lpc2[5]
     float *xlp_ti;       // TI [864]    pitch_buf
     float *xlp_sm;       // SM [864]    pitch_buf
@@ -122,5 +124,8 @@ struct StepParams {
 
 // ring position of logical input_mem[0] when the newest frame sits in slot `slot`
 __host__ __device__ inline int ring_base(int slot) { return (FRAME * slot + 672) % RING; }
+// ring position of logical decimated index 0 (864 logical values, the newest 240 in slot `slot`)
+constexpr int DEC_RING = 960;
+__host__ __device__ inline int dec_base(int slot) { return (240 * (slot + 1) + 96) % DEC_RING; }
 
 }  // namespace nnn

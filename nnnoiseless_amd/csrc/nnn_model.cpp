@@ -196,8 +196,8 @@ size_t nnn_model_pack(const RNNModel &m, std::vector<uint16_t> &wq, std::vector<
     auto need = [&](const nnn::GemmDesc &g) { width = std::max(width, g.kbase + 32 * g.ksteps); };
     need(plan.dense.in); need(plan.vad.in); need(plan.noise.in); need(plan.dn.in); need(plan.out.in);
     width = std::max(width, pad_to(ndn, 8));
-    plan.in_w = pad_to(width, 8) + 8;   // +16 bytes per row keeps 16-byte fragment reads off one bank group
-    plan.rec_w = 32 * ks_of(std::max(nv, std::max(nn, ndn))) + 8;
+    plan.in_w = pad_to(width, 16) + 8;  // row stride = 16 bytes (mod 32): 16-byte fragment reads of 16 rows spread over all banks
+    plan.rec_w = pad_to(32 * ks_of(std::max(nv, std::max(nn, ndn))), 16) + 8;
     (void)cN;
     // dynamic LDS: tanh table (256 floats) + live flags (64 ints) + 3 planes of both matrices
     return 256 * 4 + 64 * 4 + (size_t)3 * 64 * (plan.in_w + plan.rec_w) * 2;
