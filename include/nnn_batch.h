@@ -91,6 +91,10 @@ int nnn_batch_num_kernels(void);
 const char *nnn_batch_kernel_name(int k);
 int nnn_batch_read_kernel_times(nnn_batch *b, double *total_ms, int64_t *launches, int n);
 
+/* Developer instrumentation: 64 shader-clock stamps of block 0 (zeros unless the library was built with
+ * -DNNN_STAMPS). */
+int nnn_batch_read_stamps(nnn_batch *b, long long *dst64);
+
 /* 1 = replay each frame step from a captured hipGraph (default), 0 = eager launches. */
 int nnn_batch_set_graph(nnn_batch *b, int on);
 

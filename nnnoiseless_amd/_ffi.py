@@ -15,7 +15,8 @@ BATCH_SYMBOLS = [
     "nnn_batch_create", "nnn_batch_destroy", "nnn_batch_num_streams", "nnn_batch_reset",
     "nnn_batch_process_device", "nnn_batch_process_host", "nnn_batch_synchronize",
     "nnn_tap_info", "nnn_batch_read_tap", "nnn_batch_set_profiling", "nnn_batch_num_kernels",
-    "nnn_batch_kernel_name", "nnn_batch_read_kernel_times", "nnn_batch_set_graph", "nnn_last_error",
+    "nnn_batch_kernel_name", "nnn_batch_read_kernel_times", "nnn_batch_set_graph", "nnn_batch_read_stamps",
+    "nnn_last_error",
 ]
 RNNOISE_SYMBOLS = [
     "rnnoise_get_frame_size", "rnnoise_get_size", "rnnoise_init", "rnnoise_create", "rnnoise_destroy",

@@ -193,7 +193,7 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     HIPCHK(dalloc(h, &b.hist, Sp * RING, true));
     HIPCHK(dalloc(h, &b.hp_mem, Sp * 2, true));
     HIPCHK(dalloc(h, &b.hp_last, Sp, true));
-    HIPCHK(dalloc(h, &b.dec, Sp * DEC_RING, true));
+    HIPCHK(dalloc(h, &b.dec, Sp * 2 * DEC_RING, true));
     HIPCHK(dalloc(h, &b.ceps_mem, Sp * CEPS_MEM * NB, true));
     HIPCHK(dalloc(h, &b.mem_id, Sp, true));
     HIPCHK(dalloc(h, &b.synth_mem, Sp * FRAME, true));
@@ -204,7 +204,6 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     HIPCHK(dalloc(h, &b.gru_n, Sp * md.nn, true));
     HIPCHK(dalloc(h, &b.gru_dn, Sp * md.ndn, true));
     // scratch
-    HIPCHK(dalloc(h, &b.xlp0, Sp, false));
     HIPCHK(dalloc(h, &b.lpc, Sp * 10, false));
     HIPCHK(dalloc(h, &b.xlp_ti, Sp * XLP, false));
     HIPCHK(dalloc(h, &b.xlp_sm, Sp * XLP, false));
@@ -227,6 +226,7 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     HIPCHK(dalloc(h, &b.g, Sp * NB, false));
     HIPCHK(dalloc(h, &b.vad, Sp, false));
     HIPCHK(dalloc(h, &h->sp, 1, false));
+    HIPCHK(dalloc(h, &b.stamps, 64, false));
     // tables
     std::vector<float> window, dct, tansig, bin_frac;
     std::vector<float2> tw;
@@ -531,6 +531,15 @@ extern "C" int nnn_batch_read_tap(nnn_batch *h, int tap, void *host_dst, size_t 
         int slot = (int)((h->frame_count + 3) & 3);  // slot of the most recent frame
         for (int s = 0; s < h->S; s++) memcpy(dst + (size_t)s * FRAME, tmp.data() + (size_t)s * RING + slot * FRAME, FRAME * 4);
     }
+    return 0;
+}
+
+extern "C" int nnn_batch_read_stamps(nnn_batch *h, long long *dst64)
+{
+    if (!h) return fail("null batch");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(dst64, h->b.stamps, 64 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

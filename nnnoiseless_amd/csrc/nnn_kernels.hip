@@ -19,6 +19,14 @@ namespace nnn {
 
 #define NNN_TI(ptr, len, tile, lane) ((ptr) + ((size_t)(tile) * (len)) * TILE + (lane))
 
+// Optional phase stamps (developer instrumentation, off in the shipped build): block 0 / thread 0 records the
+// shader clock at labelled points so a phase breakdown can be read back through nnn_batch_read_stamps.
+#ifdef NNN_STAMPS
+#define NNN_STAMP(b, i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) (b).stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define NNN_STAMP(b, i) do { } while (0)
+#endif
+
 // Bark-ish band edges in units of 4 bins (ref: src/lib.rs:55-58) and SECOND_CHECK (ref: src/pitch.rs:489)
 __constant__ int kEband[NB] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100};
 __constant__ int kSecondCheck[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};
@@ -28,7 +36,8 @@ __constant__ int kSecondCheck[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3
 //     (ref: src/features.rs:97-104, src/util.rs:95-107), and the 2:1 decimation of pitch_downsample
 //     (ref: src/pitch.rs:455-458) done incrementally: decimated sample d = ((s[2d-1] + s[2d+1])/2 + s[2d])/2
 //     depends only on absolute samples, so each frame adds 240 values to a persistent ring instead of
-//     recomputing all 864; only the reference's special first element is per frame.
+//     recomputing all 864; only the reference's special first element is per frame.  The ring is stored
+//     twice (p, p + 960): every frame's 864-value window is then one contiguous run for its readers.
 //     lane = stream; the 480-step recurrence is inherently serial per stream.  Input and history are
 //     stream-major, so 64x32 tiles are transposed through LDS to keep every global access coalesced.
 // ---------------------------------------------------------------------------------------------
@@ -42,13 +51,18 @@ __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp)
     float *hp = NNN_TI(b.hp_mem, 2, tile, lane);
     float m0 = hp[0], m1 = hp[TILE];
     float prev = NNN_TI(b.hp_last, 1, tile, lane)[0];
-    {   // x_lp[0] = (x[1] / 2 + x[0]) / 2 on the oldest two samples of this frame's 1728-sample history
+    NNN_STAMP(b, 24);
+    float *ring = NNN_TI(b.dec, 2 * DEC_RING, tile, lane);
+    {   // x_lp[0] = (x[1] / 2 + x[0]) / 2 on the oldest two samples of this frame's 1728-sample history replaces the
+        // regular decimated value at that position; no later frame's window reaches back to it
         const float *h = b.hist + (size_t)(tile * TILE + lane) * RING;
-        const int rb = ring_base(slot);
+        const int rb = ring_base(slot), db = dec_base(slot);
         const float x0 = h[rb], x1 = h[(rb + 1) % RING];
-        NNN_TI(b.xlp0, 1, tile, lane)[0] = (x1 / 2.0f + x0) / 2.0f;
+        const float v = (x1 / 2.0f + x0) / 2.0f;
+        ring[(size_t)db * TILE] = v;
+        ring[(size_t)(db + DEC_RING) * TILE] = v;
     }
-    float *dec = NNN_TI(b.dec, DEC_RING, tile, lane) + (size_t)(240 * slot) * TILE;
+    float *dec = ring + (size_t)(240 * slot) * TILE;
     const double a0 = (double)-1.99599f, a1 = (double)0.99600f, b0 = (double)-2.0f, b1 = (double)1.0f;
     const int sub = lane >> 5, col = lane & 31;
     float stage[32];
@@ -82,7 +96,9 @@ __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp)
 #pragma unroll
         for (int t = 0; t < 16; t++) {
             const float a = t == 0 ? prev : xs[2 * t - 1], m = xs[2 * t], n = xs[2 * t + 1];
-            dec[(size_t)(16 * c + t) * TILE] = ((a + n) / 2.0f + m) / 2.0f;
+            const float dv = ((a + n) / 2.0f + m) / 2.0f;
+            dec[(size_t)(16 * c + t) * TILE] = dv;
+            dec[(size_t)(DEC_RING + 16 * c + t) * TILE] = dv;
         }
         prev = xs[31];
 #pragma unroll
@@ -98,6 +114,7 @@ __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp)
     hp[0] = m0;
     hp[TILE] = m1;
     NNN_TI(b.hp_last, 1, tile, lane)[0] = prev;
+    NNN_STAMP(b, 25);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -107,19 +124,6 @@ __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp)
 //     lane = stream; the five sequential chains run on the five waves of the block, which then share the
 //     (elementwise) FIR and write pitch_buf as TI (scans, coarse xcorr) and SM (wave = stream kernels).
 // ---------------------------------------------------------------------------------------------
-struct DecRing {   // logical decimated history x_lp[0..863] on top of the ring
-    const float *ring;
-    float x0;
-    int base;
-    __device__ __forceinline__ float operator()(int j) const
-    {
-        int ph = base + j;
-        if (ph >= DEC_RING) ph -= DEC_RING;
-        float v = ring[(size_t)ph * TILE];
-        return j == 0 ? x0 : v;
-    }
-};
-
 __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
 {
     __shared__ float acs[5][64];
@@ -127,7 +131,9 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
     __shared__ float tl[5][64][33];
     const int lane = threadIdx.x & 63, tile = blockIdx.x;
     const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // this wave's lag
-    DecRing x{NNN_TI(b.dec, DEC_RING, tile, lane), NNN_TI(b.xlp0, 1, tile, lane)[0], dec_base(sp->slot)};
+    NNN_STAMP(b, 0);
+    const float *xw = NNN_TI(b.dec, 2 * DEC_RING, tile, lane) + (size_t)dec_base(sp->slot) * TILE;   // x_lp[0..863]
+#define x(j) xw[(size_t)(j) * TILE]
     const int fast_n = XLP - 4;   // 860 = 43 blocks of 20 rows; a block's loads are issued together
     constexpr int BL = 20;
     {
@@ -155,6 +161,7 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
         acs[k][lane] = c + d;
     }
     __syncthreads();
+    NNN_STAMP(b, 1);
     if (k == 0) {
         float ac[5];
 #pragma unroll
@@ -201,6 +208,7 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
         for (int i = 0; i < 5; i++) { o[(size_t)i * TILE] = ac[i]; o[(size_t)(5 + i) * TILE] = l2[i]; coef[i][lane] = l2[i]; }
     }
     __syncthreads();
+    NNN_STAMP(b, 2);
     // FIR5 over 27 chunks of 32 outputs, 5 waves round-robin (every wave runs 6 rounds so barriers match)
     const float n0 = coef[0][lane], n1 = coef[1][lane], n2 = coef[2][lane], n3 = coef[3][lane], n4 = coef[4][lane];
     float *o = NNN_TI(b.xlp_ti, XLP, tile, lane);
@@ -231,6 +239,8 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
         }
         __syncthreads();
     }
+#undef x
+    NNN_STAMP(b, 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -912,20 +922,33 @@ __device__ __forceinline__ float dct_out(const float *x, const float *dct, int i
 }
 
 // lane = stream; returns true if the frame is silent.  fr[] receives the 42 features (also written to b.feat).
-__device__ __forceinline__ bool features_tile(const Buffers &b, int tile, int lane, float (&fr)[NFEAT])
+// All loads (band energies, pitch, ring index, the whole 8 x 22 cepstral ring) are issued up front: the
+// function runs on a single wave while its block waits, so it should pay one memory round trip, not six.
+__device__ __forceinline__ bool features_tile(const Buffers &b, int tile, int lane, float (&fr)[NFEAT], float *crs /* LDS [8*22][64] */)
 {
-    float ex[NB], ly[NB], tmp[NB];
+    float ex[NB], ep[NB], ly[NB], tmp[NB];
     const float *exg = NNN_TI(b.ex, NB, tile, lane), *epg = NNN_TI(b.ep, NB, tile, lane);
     float *xpg = NNN_TI(b.exp_, NB, tile, lane);
     float *f = NNN_TI(b.feat, NFEAT, tile, lane);
+    int *midp = NNN_TI(b.mem_id, 1, tile, lane);
+    float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, lane);
 #pragma unroll
     for (int i = 0; i < NB; i++) {
         ex[i] = exg[(size_t)i * TILE];
-        float v = xpg[(size_t)i * TILE] / sqrtf(0.001f + ex[i] * epg[(size_t)i * TILE]);
+        ep[i] = epg[(size_t)i * TILE];
+        tmp[i] = xpg[(size_t)i * TILE];
+    }
+    const int pitch = NNN_TI(b.pitch, 1, tile, lane)[0];
+    int mem_id = midp[0];
+    // the cepstral ring is staged in LDS: the loads are all in flight now, the values are needed last
+#pragma unroll 8
+    for (int i = 0; i < CEPS_MEM * NB; i++) crs[i * TILE + lane] = cm[(size_t)i * TILE];
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        float v = tmp[i] / sqrtf(0.001f + ex[i] * ep[i]);
         tmp[i] = v;
         xpg[(size_t)i * TILE] = v;
     }
-    const int pitch = NNN_TI(b.pitch, 1, tile, lane)[0];
     float fpc[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) fpc[i] = dct_out(tmp, b.dct, i);
@@ -953,21 +976,22 @@ __device__ __forceinline__ bool features_tile(const Buffers &b, int tile, int la
     for (int i = 0; i < NB; i++) c[i] = dct_out(ly, b.dct, i);
     c[0] -= 12.0f;
     c[1] -= 4.0f;
-    int *midp = NNN_TI(b.mem_id, 1, tile, lane);
-    int mem_id = midp[0];
     const int c0 = mem_id, c1 = mem_id < 1 ? CEPS_MEM + mem_id - 1 : mem_id - 1;
     const int c2 = mem_id < 2 ? CEPS_MEM + mem_id - 2 : mem_id - 2;
-    float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, lane);
 #pragma unroll
     for (int i = 0; i < NB; i++) cm[(size_t)(c0 * NB + i) * TILE] = c[i];
     mem_id += 1;
     if (mem_id == CEPS_MEM) mem_id = 0;
     midp[0] = mem_id;
+    // the staged copy of the ring gets the new cepstrum in row c0 (c0 differs per lane)
+#pragma unroll
+    for (int k = 0; k < NB; k++) crs[(c0 * NB + k) * TILE + lane] = c[k];
 #pragma unroll
     for (int i = 0; i < NB; i++) fr[i] = c[i];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        float v0 = c[i], v1 = cm[(size_t)(c1 * NB + i) * TILE], v2 = cm[(size_t)(c2 * NB + i) * TILE];
+        const float v1 = crs[(c1 * NB + i) * TILE + lane], v2 = crs[(c2 * NB + i) * TILE + lane];
+        const float v0 = c[i];
         fr[i] = v0 + v1 + v2;
         fr[NB + i] = v0 - v2;
         fr[NB + 6 + i] = v0 - 2.0f * v1 + v2;
@@ -982,13 +1006,13 @@ __device__ __forceinline__ bool features_tile(const Buffers &b, int tile, int la
     for (int i = 0; i < CEPS_MEM; i++) {
         float ri[NB];
 #pragma unroll
-        for (int k = 0; k < NB; k++) ri[k] = cm[(size_t)(i * NB + k) * TILE];
+        for (int k = 0; k < NB; k++) ri[k] = crs[(i * NB + k) * TILE + lane];
 #pragma unroll
         for (int j = i + 1; j < CEPS_MEM; j++) {
             float dist = 0.0f;
 #pragma unroll
             for (int k = 0; k < NB; k++) {
-                float d = ri[k] - cm[(size_t)(j * NB + k) * TILE];
+                float d = ri[k] - crs[(j * NB + k) * TILE + lane];
                 dist += d * d;
             }
             mind[i] = fminf(mind[i], dist);
@@ -1083,16 +1107,19 @@ __device__ __forceinline__ void gemm_acc(f32x4 (&acc)[3][4], const unsigned shor
 #pragma unroll
     for (int ks = 0; ks < KSMAX; ks++) {
         if (ks < g.ksteps) {
+            uint4 af[MB][3];   // every LDS read of this k-step is issued before its first MFMA
 #pragma unroll
             for (int mb = 0; mb < MB; mb++) {
                 const unsigned short *ap = A + (size_t)((mb0 + mb) * 16 + arow) * row_w + g.kbase + ks * 32 + akg;
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) {
-                    const uint4 af = *(const uint4 *)(ap + (size_t)pl * plane_stride);
-#pragma unroll
-                    for (int gi = 0; gi < NG; gi++) acc[G0 + gi][mb] = mfma_16x16x32_bf16(af, fr.f[ks][gi], acc[G0 + gi][mb]);
-                }
+                for (int pl = 0; pl < 3; pl++) af[mb][pl] = *(const uint4 *)(ap + (size_t)pl * plane_stride);
             }
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                    for (int gi = 0; gi < NG; gi++) acc[G0 + gi][mb] = mfma_16x16x32_bf16(af[mb][pl], fr.f[ks][gi], acc[G0 + gi][mb]);
         }
     }
     for (int ks = KSMAX; ks < g.ksteps; ks++) {   // models wider than 128 columns: fetch as we go
@@ -1123,19 +1150,21 @@ struct RnnLds {
 // (neuron block, MB stream blocks) unit: z, r and the input part of the candidate accumulate together,
 // r * state goes back through LDS (every candidate needs all of it), then the recurrent part of the
 // candidate and the state update.  z and the old state stay in registers in the C-fragment layout.
-constexpr int RNN_PRE = (TILE * MAXN + 64 * RNN_WAVES - 1) / (64 * RNN_WAVES);   // state values per thread (<= 16)
+// Old GRU states are fetched by waves 1..7 (wave 0 is busy with the features and needs its registers)
+constexpr int RNN_LOADERS = 64 * (RNN_WAVES - 1);
+constexpr int RNN_PRE = (TILE * MAXN + RNN_LOADERS - 1) / RNN_LOADERS;   // state values per loader thread (<= 19)
 
 __device__ __forceinline__ void preload_state(float (&pre)[RNN_PRE], const float *state, int n)
 {
 #pragma unroll
     for (int i = 0; i < RNN_PRE; i++) {
-        const int e = threadIdx.x + i * 64 * RNN_WAVES;
+        const int e = (int)threadIdx.x - 64 + i * RNN_LOADERS;
         pre[i] = e < TILE * n ? state[e] : 0.0f;
     }
 }
 
 template <int MB>
-__device__ __forceinline__ void gru_layer(const LayerDesc &L, const RnnPlan &pl, const RnnLds &lds, float *state,
+__device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, const RnnPlan &pl, const RnnLds &lds, float *state,
                                           const float (&pre)[RNN_PRE], const uint4 *__restrict__ Wq,
                                           const float *__restrict__ fpar, int wave, int lane)
 {
@@ -1155,15 +1184,18 @@ __device__ __forceinline__ void gru_layer(const LayerDesc &L, const RnnPlan &pl,
     load_frags<2, 0>(f_zr, L.rec, Brec, lane);
     load_frags<1, 2>(f_h, L.rec, Brec, lane);
     // old state (loaded at kernel start) -> recurrent operand planes (columns >= n stay zero)
+    if (threadIdx.x >= 64) {
 #pragma unroll
-    for (int i = 0; i < RNN_PRE; i++) {
-        const int e = threadIdx.x + i * 64 * RNN_WAVES;
-        if (e < TILE * L.n) {
-            int row = e / L.n, col = e - row * L.n;
-            store_split(lds.REC, lds.rec_ps, row * pl.rec_w + col, pre[i]);
+        for (int i = 0; i < RNN_PRE; i++) {
+            const int e = (int)threadIdx.x - 64 + i * RNN_LOADERS;
+            if (e < TILE * L.n) {
+                int row = e / L.n, col = e - row * L.n;
+                store_split(lds.REC, lds.rec_ps, row * pl.rec_w + col, pre[i]);
+            }
         }
     }
     __syncthreads();
+    NNN_STAMP(b, 16);
     f32x4 acc[3][4];
     float sold[4][4], zz[4][4], rs[4][4];
     if (mine) {
@@ -1188,6 +1220,7 @@ __device__ __forceinline__ void gru_layer(const LayerDesc &L, const RnnPlan &pl,
             }
     }
     __syncthreads();   // every wave is done reading the old state planes
+    NNN_STAMP(b, 17);
     if (nvalid) {
 #pragma unroll
         for (int mb = 0; mb < MB; mb++)
@@ -1198,6 +1231,7 @@ __device__ __forceinline__ void gru_layer(const LayerDesc &L, const RnnPlan &pl,
             }
     }
     __syncthreads();
+    NNN_STAMP(b, 18);
     if (mine) {
         gemm_acc<1, MB, 2>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Brec, lane, f_h);
         if (nvalid) {
@@ -1259,34 +1293,36 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     RnnLds lds{tab, live, IN, REC, in_ps, rec_ps};
     float *sv = b.gru_v + (size_t)tile * TILE * pl.vad.n, *sn = b.gru_n + (size_t)tile * TILE * pl.noise.n,
           *sdn = b.gru_dn + (size_t)tile * TILE * pl.dn.n;
-    // Everything this block needs from HBM that does not depend on its own results starts travelling now:
-    // the three old GRU states and the weight fragments of the two dense layers.
+    // wave 0 turns band energies into the 42 features (lane = stream); meanwhile waves 1..7 request everything
+    // else this block needs from HBM (the three old GRU states), zero both operand matrices (padding columns
+    // must read as 0) and fetch the activation table
+    NNN_STAMP(b, 8);
     float pre_v[RNN_PRE], pre_n[RNN_PRE], pre_d[RNN_PRE];
-    preload_state(pre_v, sv, pl.vad.n);
-    preload_state(pre_n, sn, pl.noise.n);
-    preload_state(pre_d, sdn, pl.dn.n);
-    Frags<1> f_dense, f_out;
-    load_frags<1, 0>(f_dense, pl.dense.in, dense_frags(pl.dense, Wq, wave), lane);
-    load_frags<1, 0>(f_out, pl.out.in, dense_frags(pl.out, Wq, wave), lane);
-    // wave 0 turns band energies into the 42 features (lane = stream) while the other waves zero both operand
-    // matrices (padding columns must read as 0) and fetch the activation table
     float fr[NFEAT];
     bool silent = false;
     if (wave == 0) {
-        silent = features_tile(b, tile, lane, fr);
+        silent = features_tile(b, tile, lane, fr, (float *)(REC + 3 * rec_ps));
+#pragma unroll
+        for (int i = 0; i < RNN_PRE; i++) pre_v[i] = 0.0f;
     } else {
+        preload_state(pre_v, sv, pl.vad.n);
         uint4 *z = (uint4 *)IN;
         const int n16 = 3 * (in_ps + rec_ps) / 8;
-        for (int i = tid - 64; i < n16; i += 64 * (RNN_WAVES - 1)) z[i] = make_uint4(0u, 0u, 0u, 0u);
-        for (int i = tid - 64; i < 201; i += 64 * (RNN_WAVES - 1)) tab[i] = b.tansig[i];
+        for (int i = tid - 64; i < n16; i += RNN_LOADERS) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = tid - 64; i < 201; i += RNN_LOADERS) tab[i] = b.tansig[i];
     }
+    Frags<1> f_dense, f_out;
+    load_frags<1, 0>(f_dense, pl.dense.in, dense_frags(pl.dense, Wq, wave), lane);
+    load_frags<1, 0>(f_out, pl.out.in, dense_frags(pl.out, Wq, wave), lane);
     __syncthreads();
+    NNN_STAMP(b, 9);
     if (wave == 0) {
         live[lane] = silent ? 0 : 1;
 #pragma unroll
         for (int k = 0; k < NFEAT; k++) store_split(IN, in_ps, lane * pl.in_w + pl.cF + k, fr[k]);
     }
     __syncthreads();
+    NNN_STAMP(b, 10);
     {   // input dense (ref: src/rnn.rs:353-355)
         f32x4 o;
         int neuron, mb0;
@@ -1298,18 +1334,33 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     __syncthreads();
 #define NNN_GRU(L, st, pre)                                                        \
     switch ((L).mb) {                                                              \
-    case 4: gru_layer<4>(L, pl, lds, st, pre, Wq, fpar, wave, lane); break;        \
-    case 2: gru_layer<2>(L, pl, lds, st, pre, Wq, fpar, wave, lane); break;        \
-    default: gru_layer<1>(L, pl, lds, st, pre, Wq, fpar, wave, lane); break;       \
+    case 4: gru_layer<4>(b, L, pl, lds, st, pre, Wq, fpar, wave, lane); break;        \
+    case 2: gru_layer<2>(b, L, pl, lds, st, pre, Wq, fpar, wave, lane); break;        \
+    default: gru_layer<1>(b, L, pl, lds, st, pre, Wq, fpar, wave, lane); break;       \
+    }
+    NNN_STAMP(b, 11);
+    // each layer's old state is requested one layer ahead (hidden behind the previous layer's GEMMs)
+    if (wave != 0) preload_state(pre_n, sn, pl.noise.n);
+    else {
+#pragma unroll
+        for (int i = 0; i < RNN_PRE; i++) pre_n[i] = 0.0f;
     }
     NNN_GRU(pl.vad, sv, pre_v)                                                 // ref: src/rnn.rs:356-358
+    NNN_STAMP(b, 12);
     if (wave == RNN_WAVES - 1) {   // vad output, 1 x nv, lane = stream (ref: src/rnn.rs:359)
         float acc = fpar[pl.vo_b];
         for (int k = 0; k < pl.vad.n; k++) acc = fmaf(fpar[pl.vo_w + k], load_split(IN, in_ps, lane * pl.in_w + pl.cV + k), acc);
         NNN_TI(b.vad, 1, tile, lane)[0] = live[lane] ? activate(pl.act_vo, acc * (1.0f / 256.0f), tab) : 0.0f;
     }
+    if (wave != 0) preload_state(pre_d, sdn, pl.dn.n);
+    else {
+#pragma unroll
+        for (int i = 0; i < RNN_PRE; i++) pre_d[i] = 0.0f;
+    }
     NNN_GRU(pl.noise, sn, pre_n)                                               // ref: src/rnn.rs:361-366
+    NNN_STAMP(b, 13);
     NNN_GRU(pl.dn, sdn, pre_d)                                                 // ref: src/rnn.rs:368-377
+    NNN_STAMP(b, 14);
 #undef NNN_GRU
     {   // gains (ref: src/rnn.rs:378) and smoothing g = max(g, 0.6 lastg) (ref: src/denoise.rs:106-109)
         f32x4 o;
@@ -1331,6 +1382,7 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
             }
         }
     }
+    NNN_STAMP(b, 15);
 }
 
 // interpolated band gain at bin k (ref: src/lib.rs:84-97): zero for k >= 400

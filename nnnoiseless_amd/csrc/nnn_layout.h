@@ -72,7 +72,8 @@ struct Buffers {
     float *hist;         // SM [RING]   high-passed input history, ring of 4 frames
     float *hp_mem;       // TI [2]      biquad state
     float *hp_last;      // TI [1]      last filtered sample of the previous frame
-    float *dec;          // TI [960]    2:1 decimated history, ring of 4 x 240 (only 240 values are new per frame)
+    float *dec;          // TI [1920]   2:1 decimated history: ring of 4 x 240 stored twice (p and p + 960) so that the
+                         //             864-value window of any frame is one contiguous run (240 values are new per frame)
     float *ceps_mem;     // TI [8*22]
     int *mem_id;         // TI [1]
     float *synth_mem;    // SM [480]
@@ -81,7 +82,6 @@ struct Buffers {
     float *last_gain;    // TI [1]
     float *gru_v, *gru_n, *gru_dn;  // SM [nv], [nn], [ndn]
     // ---- per-frame scratch (doubles as the parity taps)
-    float *xlp0;         // TI [1]      pitch_downsample's special first element (x[1]/2 + x[0])/2
     float *lpc;          // TI [10]     ac[5], lpc2[5]
     float *xlp_ti;       // TI [864]    pitch_buf
     float *xlp_sm;       // SM [864]    pitch_buf
@@ -106,6 +106,7 @@ struct Buffers {
     const float *tansig;     // [201]
     const float *bin_frac;   // [400]  j / band_size
     const int *bin_band;     // [400]
+    long long *stamps;       // [64] optional phase time stamps of block 0 (built with -DNNN_STAMPS)
     const int *seg;          // [192] band-sum segments: k0[64], count[64], first segment[32], segments[32] per interval
     float wnorm;
     int S, S_pad, NT;
