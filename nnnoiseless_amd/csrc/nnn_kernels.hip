@@ -1103,38 +1103,44 @@ template <int NG, int MB, int G0>
 __device__ __forceinline__ void gemm_acc(f32x4 (&acc)[3][4], const unsigned short *A, int plane_stride, int row_w, int mb0,
                                          const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane, const Frags<NG> &fr)
 {
-    const int arow = lane & 15, akg = 8 * (lane >> 4);
+    const unsigned short *a0 = A + (size_t)(mb0 * 16 + (lane & 15)) * row_w + g.kbase + 8 * (lane >> 4);
+    const size_t mb_stride = (size_t)16 * row_w;
+    // Software pipeline over (k-step, stream block): the three plane fragments of the next step are read from
+    // LDS before the current step's 3*NG MFMAs issue, so LDS latency hides behind matrix work.
+    const int steps = g.ksteps * MB;
+    uint4 cur[3], nxt[3];
 #pragma unroll
-    for (int ks = 0; ks < KSMAX; ks++) {
-        if (ks < g.ksteps) {
-            uint4 af[MB][3];   // every LDS read of this k-step is issued before its first MFMA
+    for (int pl = 0; pl < 3; pl++) cur[pl] = *(const uint4 *)(a0 + (size_t)pl * plane_stride);
+    for (int ks = 0; ks < g.ksteps; ks++) {
+        uint4 bfr[NG];
+        if (ks < KSMAX) {
 #pragma unroll
-            for (int mb = 0; mb < MB; mb++) {
-                const unsigned short *ap = A + (size_t)((mb0 + mb) * 16 + arow) * row_w + g.kbase + ks * 32 + akg;
+            for (int gi = 0; gi < NG; gi++) {
+                bfr[gi] = fr.f[0][gi];
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) af[mb][pl] = *(const uint4 *)(ap + (size_t)pl * plane_stride);
+                for (int u = 1; u < KSMAX; u++) bfr[gi] = (ks == u) ? fr.f[u][gi] : bfr[gi];
             }
+        } else {   // models wider than 128 columns: fetch as we go
+#pragma unroll
+            for (int gi = 0; gi < NG; gi++) bfr[gi] = Bnb[((G0 + gi) * g.ksteps + ks) * 64 + lane];
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) {
+            const int step = ks * MB + mb;
+            if (step + 1 < steps) {
+                const int ks1 = (mb + 1 < MB) ? ks : ks + 1, mb1 = (mb + 1 < MB) ? mb + 1 : 0;
+                const unsigned short *ap = a0 + mb1 * mb_stride + ks1 * 32;
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) nxt[pl] = *(const uint4 *)(ap + (size_t)pl * plane_stride);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pl = 0; pl < 3; pl++)
 #pragma unroll
-                for (int mb = 0; mb < MB; mb++)
+                for (int gi = 0; gi < NG; gi++) acc[G0 + gi][mb] = mfma_16x16x32_bf16(cur[pl], bfr[gi], acc[G0 + gi][mb]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int gi = 0; gi < NG; gi++) acc[G0 + gi][mb] = mfma_16x16x32_bf16(af[mb][pl], fr.f[ks][gi], acc[G0 + gi][mb]);
-        }
-    }
-    for (int ks = KSMAX; ks < g.ksteps; ks++) {   // models wider than 128 columns: fetch as we go
-        uint4 bfr[NG];
-#pragma unroll
-        for (int gi = 0; gi < NG; gi++) bfr[gi] = Bnb[((G0 + gi) * g.ksteps + ks) * 64 + lane];
-#pragma unroll
-        for (int mb = 0; mb < MB; mb++) {
-            const unsigned short *ap = A + (size_t)((mb0 + mb) * 16 + arow) * row_w + g.kbase + ks * 32 + akg;
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
-                const uint4 af = *(const uint4 *)(ap + (size_t)pl * plane_stride);
-#pragma unroll
-                for (int gi = 0; gi < NG; gi++) acc[G0 + gi][mb] = mfma_16x16x32_bf16(af, bfr[gi], acc[G0 + gi][mb]);
-            }
+            for (int pl = 0; pl < 3; pl++) cur[pl] = nxt[pl];
         }
     }
 }
@@ -1150,23 +1156,21 @@ struct RnnLds {
 // (neuron block, MB stream blocks) unit: z, r and the input part of the candidate accumulate together,
 // r * state goes back through LDS (every candidate needs all of it), then the recurrent part of the
 // candidate and the state update.  z and the old state stay in registers in the C-fragment layout.
-// Old GRU states are fetched by waves 1..7 (wave 0 is busy with the features and needs its registers)
-constexpr int RNN_LOADERS = 64 * (RNN_WAVES - 1);
-constexpr int RNN_PRE = (TILE * MAXN + RNN_LOADERS - 1) / RNN_LOADERS;   // state values per loader thread (<= 19)
+constexpr int RNN_LOADERS = 64 * (RNN_WAVES - 1);   // waves 1..7 set up the block while wave 0 computes the features
+constexpr int RNN_PRE = (TILE * MAXN + 64 * RNN_WAVES - 1) / (64 * RNN_WAVES);   // state values per thread (<= 16)
 
 __device__ __forceinline__ void preload_state(float (&pre)[RNN_PRE], const float *state, int n)
 {
 #pragma unroll
     for (int i = 0; i < RNN_PRE; i++) {
-        const int e = (int)threadIdx.x - 64 + i * RNN_LOADERS;
+        const int e = (int)threadIdx.x + i * 64 * RNN_WAVES;
         pre[i] = e < TILE * n ? state[e] : 0.0f;
     }
 }
 
 template <int MB>
 __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, const RnnPlan &pl, const RnnLds &lds, float *state,
-                                          const float (&pre)[RNN_PRE], const uint4 *__restrict__ Wq,
-                                          const float *__restrict__ fpar, int wave, int lane)
+                                          const uint4 *__restrict__ Wq, const float *__restrict__ fpar, int wave, int lane)
 {
     const float scale = 1.0f / 256.0f;
     const int groups = 4 / MB, units = L.nb * groups;
@@ -1179,15 +1183,17 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
     // all weight fragments of this layer start travelling now
     Frags<3> f_in;
     Frags<2> f_zr;
-    Frags<1> f_h;
+    Frags<1> f_h;   // requested after the z|r GEMMs: it travels during the gate epilogue and the two barriers
     load_frags<3, 0>(f_in, L.in, Bin, lane);
     load_frags<2, 0>(f_zr, L.rec, Brec, lane);
-    load_frags<1, 2>(f_h, L.rec, Brec, lane);
-    // old state (loaded at kernel start) -> recurrent operand planes (columns >= n stay zero)
-    if (threadIdx.x >= 64) {
+    // old state -> recurrent operand planes (columns >= n stay zero); these loads share the latency window of
+    // the weight fragments requested above
+    {
+        float pre[RNN_PRE];
+        preload_state(pre, state, L.n);
 #pragma unroll
         for (int i = 0; i < RNN_PRE; i++) {
-            const int e = (int)threadIdx.x - 64 + i * RNN_LOADERS;
+            const int e = (int)threadIdx.x + i * 64 * RNN_WAVES;
             if (e < TILE * L.n) {
                 int row = e / L.n, col = e - row * L.n;
                 store_split(lds.REC, lds.rec_ps, row * pl.rec_w + col, pre[i]);
@@ -1207,6 +1213,7 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
         }
         gemm_acc<3, MB, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, Bin, lane, f_in);
         gemm_acc<2, MB, 0>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Brec, lane, f_zr);
+        load_frags<1, 2>(f_h, L.rec, Brec, lane);
 #pragma unroll
         for (int mb = 0; mb < MB; mb++)
 #pragma unroll
@@ -1297,15 +1304,11 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     // else this block needs from HBM (the three old GRU states), zero both operand matrices (padding columns
     // must read as 0) and fetch the activation table
     NNN_STAMP(b, 8);
-    float pre_v[RNN_PRE], pre_n[RNN_PRE], pre_d[RNN_PRE];
     float fr[NFEAT];
     bool silent = false;
     if (wave == 0) {
         silent = features_tile(b, tile, lane, fr, (float *)(REC + 3 * rec_ps));
-#pragma unroll
-        for (int i = 0; i < RNN_PRE; i++) pre_v[i] = 0.0f;
     } else {
-        preload_state(pre_v, sv, pl.vad.n);
         uint4 *z = (uint4 *)IN;
         const int n16 = 3 * (in_ps + rec_ps) / 8;
         for (int i = tid - 64; i < n16; i += RNN_LOADERS) z[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1332,34 +1335,23 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
         }
     }
     __syncthreads();
-#define NNN_GRU(L, st, pre)                                                        \
-    switch ((L).mb) {                                                              \
-    case 4: gru_layer<4>(b, L, pl, lds, st, pre, Wq, fpar, wave, lane); break;        \
-    case 2: gru_layer<2>(b, L, pl, lds, st, pre, Wq, fpar, wave, lane); break;        \
-    default: gru_layer<1>(b, L, pl, lds, st, pre, Wq, fpar, wave, lane); break;       \
+#define NNN_GRU(L, st)                                                           \
+    switch ((L).mb) {                                                            \
+    case 4: gru_layer<4>(b, L, pl, lds, st, Wq, fpar, wave, lane); break;        \
+    case 2: gru_layer<2>(b, L, pl, lds, st, Wq, fpar, wave, lane); break;        \
+    default: gru_layer<1>(b, L, pl, lds, st, Wq, fpar, wave, lane); break;       \
     }
     NNN_STAMP(b, 11);
-    // each layer's old state is requested one layer ahead (hidden behind the previous layer's GEMMs)
-    if (wave != 0) preload_state(pre_n, sn, pl.noise.n);
-    else {
-#pragma unroll
-        for (int i = 0; i < RNN_PRE; i++) pre_n[i] = 0.0f;
-    }
-    NNN_GRU(pl.vad, sv, pre_v)                                                 // ref: src/rnn.rs:356-358
+    NNN_GRU(pl.vad, sv)                                                 // ref: src/rnn.rs:356-358
     NNN_STAMP(b, 12);
     if (wave == RNN_WAVES - 1) {   // vad output, 1 x nv, lane = stream (ref: src/rnn.rs:359)
         float acc = fpar[pl.vo_b];
         for (int k = 0; k < pl.vad.n; k++) acc = fmaf(fpar[pl.vo_w + k], load_split(IN, in_ps, lane * pl.in_w + pl.cV + k), acc);
         NNN_TI(b.vad, 1, tile, lane)[0] = live[lane] ? activate(pl.act_vo, acc * (1.0f / 256.0f), tab) : 0.0f;
     }
-    if (wave != 0) preload_state(pre_d, sdn, pl.dn.n);
-    else {
-#pragma unroll
-        for (int i = 0; i < RNN_PRE; i++) pre_d[i] = 0.0f;
-    }
-    NNN_GRU(pl.noise, sn, pre_n)                                               // ref: src/rnn.rs:361-366
+    NNN_GRU(pl.noise, sn)                                               // ref: src/rnn.rs:361-366
     NNN_STAMP(b, 13);
-    NNN_GRU(pl.dn, sdn, pre_d)                                                 // ref: src/rnn.rs:368-377
+    NNN_GRU(pl.dn, sdn)                                                 // ref: src/rnn.rs:368-377
     NNN_STAMP(b, 14);
 #undef NNN_GRU
     {   // gains (ref: src/rnn.rs:378) and smoothing g = max(g, 0.6 lastg) (ref: src/denoise.rs:106-109)

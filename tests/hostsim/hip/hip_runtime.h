@@ -90,6 +90,7 @@ template <class T> static inline T max(T a, T b) { return a < b ? b : a; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline int hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return 0; }
 
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline unsigned long long __builtin_readcyclecounter() { return 0; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
