@@ -124,40 +124,61 @@ __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp)
 //     lane = stream; the five sequential chains run on the five waves of the block, which then share the
 //     (elementwise) FIR and write pitch_buf as TI (scans, coarse xcorr) and SM (wave = stream kernels).
 // ---------------------------------------------------------------------------------------------
+constexpr int LPC_CH = 216;                 // rows per staged chunk (864 = 4 chunks), + 4 look-ahead rows
+constexpr int LPC_ROWS = LPC_CH + 4;
+constexpr int LPC_PER_WAVE = LPC_ROWS / 5;  // 44 row loads in flight per wave
+
 __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
 {
+    __shared__ float buf[2][LPC_ROWS][64];   // double-buffered window chunks; reused as the FIR transpose tiles
     __shared__ float acs[5][64];
     __shared__ float coef[5][64];
-    __shared__ float tl[5][64][33];
+    float (*tl)[64][33] = (float (*)[64][33])buf;
     const int lane = threadIdx.x & 63, tile = blockIdx.x;
     const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // this wave's lag
     NNN_STAMP(b, 0);
     const float *xw = NNN_TI(b.dec, 2 * DEC_RING, tile, lane) + (size_t)dec_base(sp->slot) * TILE;   // x_lp[0..863]
 #define x(j) xw[(size_t)(j) * TILE]
-    const int fast_n = XLP - 4;   // 860 = 43 blocks of 20 rows; a block's loads are issued together
-    constexpr int BL = 20;
+    const int fast_n = XLP - 4;
     {
+        // Every row of the window is fetched once per block (wave w takes rows w, w+5, ...), parked in LDS, and
+        // read from there by the five chains; chunk c+1 travels while chunk c is being summed.
+        float st[LPC_PER_WAVE];
+#pragma unroll
+        for (int i = 0; i < LPC_PER_WAVE; i++) st[i] = x(k + 5 * i);
+#pragma unroll
+        for (int i = 0; i < LPC_PER_WAVE; i++) buf[0][k + 5 * i][lane] = st[i];
+        __syncthreads();
         float c = 0.0f;
-        float na[BL], nb[BL];
+        for (int ch = 0; ch < XLP / LPC_CH; ch++) {
+            const int j0 = ch * LPC_CH;
+            if (ch + 1 < XLP / LPC_CH) {
 #pragma unroll
-        for (int i = 0; i < BL; i++) { na[i] = x(i); nb[i] = x(i + k); }
-        for (int j0 = 0; j0 < fast_n; j0 += BL) {
-            float ca[BL], cb[BL];
-#pragma unroll
-            for (int i = 0; i < BL; i++) { ca[i] = na[i]; cb[i] = nb[i]; }
-            if (j0 + BL < fast_n) {
-#pragma unroll
-                for (int i = 0; i < BL; i++) {
-                    na[i] = x(j0 + BL + i);
-                    nb[i] = x(j0 + BL + i + k);
+                for (int i = 0; i < LPC_PER_WAVE; i++) {
+                    const int r = j0 + LPC_CH + k + 5 * i;
+                    st[i] = r < XLP ? x(r) : 0.0f;
                 }
             }
+            const float (*cb)[64] = buf[ch & 1];
+            const int n = (j0 + LPC_CH <= fast_n) ? LPC_CH : fast_n - j0;   // 216, 216, 216, 212
+            for (int i0 = 0; i0 < n; i0 += 4) {
+                float a[4], bb[4];
 #pragma unroll
-            for (int i = 0; i < BL; i++) c += ca[i] * cb[i];
+                for (int i = 0; i < 4; i++) { a[i] = cb[i0 + i][lane]; bb[i] = cb[i0 + i + k][lane]; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) c += a[i] * bb[i];
+            }
+            if (ch + 1 < XLP / LPC_CH) {
+#pragma unroll
+                for (int i = 0; i < LPC_PER_WAVE; i++) buf[(ch + 1) & 1][k + 5 * i][lane] = st[i];
+            }
+            __syncthreads();
         }
-        // tail d_k = sum_{i = k+860}^{863} x[i] x[i-k], added after the main sum (ref: src/pitch.rs:439-445)
+        // tail d_k = sum_{i = k+860}^{863} x[i] x[i-k], added after the main sum (ref: src/pitch.rs:439-445);
+        // rows 856..863 sit in the last chunk (buffer 1) at offset row - 648
+        const float (*cb)[64] = buf[1];
         float d = 0.0f;
-        for (int i = k + fast_n; i < XLP; i++) d += x(i) * x(i - k);
+        for (int i = k + fast_n; i < XLP; i++) d += cb[i - 3 * LPC_CH][lane] * cb[i - k - 3 * LPC_CH][lane];
         acs[k][lane] = c + d;
     }
     __syncthreads();
@@ -921,17 +942,22 @@ __device__ __forceinline__ float dct_out(const float *x, const float *dct, int i
     return (float)((double)sum * 0.30151134457776363 /* sqrt(2/22) */);
 }
 
-// lane = stream; returns true if the frame is silent.  fr[] receives the 42 features (also written to b.feat).
-// All loads (band energies, pitch, ring index, the whole 8 x 22 cepstral ring) are issued up front: the
-// function runs on a single wave while its block waits, so it should pay one memory round trip, not six.
-__device__ __forceinline__ bool features_tile(const Buffers &b, int tile, int lane, float (&fr)[NFEAT], float *crs /* LDS [8*22][64] */)
+// The feature stage runs inside the RNN kernel, lane = stream, in three steps so that only the truly serial part
+// sits on one wave: (1) wave 0: band energies -> correlation DCT, log-energy DCT (the new cepstrum), silence
+// flag, while waves 1..7 stage the 8 x 22 cepstral ring in LDS; (2) wave 0: ring update and delta features;
+// (3) all waves: the 28 pairwise cepstral distances of the spectral-variability feature; wave 0 finishes.
+struct FeatHead {
+    float c[NB];      // new cepstrum
+    float fpc[6];     // pitch-correlation DCT
+    float fpitch;
+    bool silent;
+};
+
+__device__ __forceinline__ void features_head(const Buffers &b, int tile, int lane, FeatHead &h)
 {
     float ex[NB], ep[NB], ly[NB], tmp[NB];
     const float *exg = NNN_TI(b.ex, NB, tile, lane), *epg = NNN_TI(b.ep, NB, tile, lane);
     float *xpg = NNN_TI(b.exp_, NB, tile, lane);
-    float *f = NNN_TI(b.feat, NFEAT, tile, lane);
-    int *midp = NNN_TI(b.mem_id, 1, tile, lane);
-    float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, lane);
 #pragma unroll
     for (int i = 0; i < NB; i++) {
         ex[i] = exg[(size_t)i * TILE];
@@ -939,22 +965,17 @@ __device__ __forceinline__ bool features_tile(const Buffers &b, int tile, int la
         tmp[i] = xpg[(size_t)i * TILE];
     }
     const int pitch = NNN_TI(b.pitch, 1, tile, lane)[0];
-    int mem_id = midp[0];
-    // the cepstral ring is staged in LDS: the loads are all in flight now, the values are needed last
-#pragma unroll 8
-    for (int i = 0; i < CEPS_MEM * NB; i++) crs[i * TILE + lane] = cm[(size_t)i * TILE];
 #pragma unroll
     for (int i = 0; i < NB; i++) {
         float v = tmp[i] / sqrtf(0.001f + ex[i] * ep[i]);
         tmp[i] = v;
         xpg[(size_t)i * TILE] = v;
     }
-    float fpc[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) fpc[i] = dct_out(tmp, b.dct, i);
-    fpc[0] -= 1.3f;
-    fpc[1] -= 0.9f;
-    const float fpitch = 0.01f * ((float)pitch - 300.0f);
+    for (int i = 0; i < 6; i++) h.fpc[i] = dct_out(tmp, b.dct, i);
+    h.fpc[0] -= 1.3f;
+    h.fpc[1] -= 0.9f;
+    h.fpitch = 0.01f * ((float)pitch - 300.0f);
     float log_max = -2.0f, follow = -2.0f, e = 0.0f;
 #pragma unroll
     for (int i = 0; i < NB; i++) {
@@ -964,68 +985,98 @@ __device__ __forceinline__ bool features_tile(const Buffers &b, int tile, int la
         follow = fmaxf(follow - 1.5f, l);
         e += ex[i];
     }
-    const bool silent = e < 0.04f;
-    NNN_TI(b.silence, 1, tile, lane)[0] = silent ? 1 : 0;
-    if (silent) {
+    h.silent = e < 0.04f;
+    NNN_TI(b.silence, 1, tile, lane)[0] = h.silent ? 1 : 0;
 #pragma unroll
-        for (int i = 0; i < NFEAT; i++) { f[(size_t)i * TILE] = 0.0f; fr[i] = 0.0f; }
-        return true;
+    for (int i = 0; i < NB; i++) h.c[i] = dct_out(ly, b.dct, i);
+    h.c[0] -= 12.0f;
+    h.c[1] -= 4.0f;
+}
+
+// ring update + delta features (wave 0, after the ring has been staged in crs)
+__device__ __forceinline__ void features_deltas(const Buffers &b, int tile, int lane, const FeatHead &h, float *crs,
+                                                float (&fr)[NFEAT])
+{
+    if (h.silent) {   // "if there's no audio, avoid messing up the state" (ref: src/features.rs:160-166)
+#pragma unroll
+        for (int i = 0; i < NFEAT; i++) fr[i] = 0.0f;
+        return;
     }
-    float c[NB];
-#pragma unroll
-    for (int i = 0; i < NB; i++) c[i] = dct_out(ly, b.dct, i);
-    c[0] -= 12.0f;
-    c[1] -= 4.0f;
+    int *midp = NNN_TI(b.mem_id, 1, tile, lane);
+    float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, lane);
+    int mem_id = midp[0];
     const int c0 = mem_id, c1 = mem_id < 1 ? CEPS_MEM + mem_id - 1 : mem_id - 1;
     const int c2 = mem_id < 2 ? CEPS_MEM + mem_id - 2 : mem_id - 2;
 #pragma unroll
-    for (int i = 0; i < NB; i++) cm[(size_t)(c0 * NB + i) * TILE] = c[i];
+    for (int k = 0; k < NB; k++) {
+        cm[(size_t)(c0 * NB + k) * TILE] = h.c[k];
+        crs[(c0 * NB + k) * TILE + lane] = h.c[k];
+    }
     mem_id += 1;
     if (mem_id == CEPS_MEM) mem_id = 0;
     midp[0] = mem_id;
-    // the staged copy of the ring gets the new cepstrum in row c0 (c0 differs per lane)
 #pragma unroll
-    for (int k = 0; k < NB; k++) crs[(c0 * NB + k) * TILE + lane] = c[k];
-#pragma unroll
-    for (int i = 0; i < NB; i++) fr[i] = c[i];
+    for (int i = 0; i < NB; i++) fr[i] = h.c[i];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         const float v1 = crs[(c1 * NB + i) * TILE + lane], v2 = crs[(c2 * NB + i) * TILE + lane];
-        const float v0 = c[i];
+        const float v0 = h.c[i];
         fr[i] = v0 + v1 + v2;
         fr[NB + i] = v0 - v2;
         fr[NB + 6 + i] = v0 - 2.0f * v1 + v2;
-        fr[NB + 12 + i] = fpc[i];
+        fr[NB + 12 + i] = h.fpc[i];
     }
-    fr[40] = fpitch;
-    // spectral variability: mean over i of min_{j != i} |c_i - c_j|^2 ; dist(i,j) == dist(j,i) exactly
+    fr[40] = h.fpitch;
+    fr[41] = 0.0f;
+}
+
+// pair p of the 28 unordered pairs (i < j) of ring rows
+__device__ __forceinline__ void pair_of(int p, int &i, int &j)
+{
+    i = 0;
+    int rem = p;
+#pragma unroll
+    for (int u = 0; u < 7; u++) {
+        const int cnt = 7 - u;
+        if (i == u && rem >= cnt) { rem -= cnt; i = u + 1; }
+    }
+    j = i + 1 + rem;
+}
+
+// squared cepstral distance of one pair, summed over the 22 bands in order (ref: src/features.rs:203-208)
+__device__ __forceinline__ float pair_dist(const float *crs, int p, int lane)
+{
+    int i, j;
+    pair_of(p, i, j);
+    float dist = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        float d = crs[(i * NB + k) * TILE + lane] - crs[(j * NB + k) * TILE + lane];
+        dist += d * d;
+    }
+    return dist;
+}
+
+// spectral variability = mean_i min_{j != i} dist(i, j) - 2.1 from the 28 staged pair distances
+__device__ __forceinline__ float spectral_variability(const float *dists, int lane)
+{
     float mind[CEPS_MEM];
 #pragma unroll
     for (int i = 0; i < CEPS_MEM; i++) mind[i] = 1e15f;
+    int p = 0;
 #pragma unroll
-    for (int i = 0; i < CEPS_MEM; i++) {
-        float ri[NB];
-#pragma unroll
-        for (int k = 0; k < NB; k++) ri[k] = crs[(i * NB + k) * TILE + lane];
+    for (int i = 0; i < CEPS_MEM; i++)
 #pragma unroll
         for (int j = i + 1; j < CEPS_MEM; j++) {
-            float dist = 0.0f;
-#pragma unroll
-            for (int k = 0; k < NB; k++) {
-                float d = ri[k] - crs[(j * NB + k) * TILE + lane];
-                dist += d * d;
-            }
-            mind[i] = fminf(mind[i], dist);
-            mind[j] = fminf(mind[j], dist);
+            const float d = dists[p * TILE + lane];
+            mind[i] = fminf(mind[i], d);
+            mind[j] = fminf(mind[j], d);
+            p++;
         }
-    }
     float sv = 0.0f;
 #pragma unroll
     for (int i = 0; i < CEPS_MEM; i++) sv += mind[i];
-    fr[41] = sv / (float)CEPS_MEM - 2.1f;
-#pragma unroll
-    for (int i = 0; i < NFEAT; i++) f[(size_t)i * TILE] = fr[i];
-    return false;
+    return sv / (float)CEPS_MEM - 2.1f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1037,16 +1088,18 @@ __device__ __forceinline__ bool features_tile(const Buffers &b, int tile, int la
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float tansig_approx(float x, const float *tab)
 {
-    if (!(x < 8.0f)) return 1.0f;
-    if (!(x > -8.0f)) return -1.0f;
-    float sign = 1.0f;
-    if (x < 0.0f) { x = -x; sign = -1.0f; }
-    float fi = floorf(0.5f + 25.0f * x);
-    x -= 0.04f * fi;
-    float y = tab[(int)fi];
-    float dy = 1.0f - y * y;
-    y = y + x * dy * (1.0f - y * x);
-    return sign * y;
+    // ref: src/util.rs:29-45, written without branches so that a lane's many evaluations overlap (the table
+    // read is a dependent LDS access).  Same arithmetic for |x| < 8; the saturation tests (which also catch
+    // NaN exactly like the reference's reversed comparisons) select the result at the end.
+    const float ax = fabsf(x);
+    float fi = floorf(0.5f + 25.0f * ax);
+    fi = fminf(fi, 200.0f);   // only reached when the result is discarded (|x| >= 8 or NaN)
+    const float xr = ax - 0.04f * fi;
+    const float y0 = tab[(int)fi];
+    const float dy = 1.0f - y0 * y0;
+    const float y = y0 + xr * dy * (1.0f - y0 * xr);
+    const float r = x < 0.0f ? -y : y;
+    return !(x < 8.0f) ? 1.0f : (!(x > -8.0f) ? -1.0f : r);
 }
 __device__ __forceinline__ float sigmoid_approx(float x, const float *tab) { return 0.5f + 0.5f * tansig_approx(0.5f * x, tab); }
 __device__ __forceinline__ float activate(int act, float x, const float *tab)
@@ -1186,6 +1239,9 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
     Frags<1> f_h;   // requested after the z|r GEMMs: it travels during the gate epilogue and the two barriers
     load_frags<3, 0>(f_in, L.in, Bin, lane);
     load_frags<2, 0>(f_zr, L.rec, Brec, lane);
+    float bias[3];
+#pragma unroll
+    for (int g = 0; g < 3; g++) bias[g] = (neuron < L.n) ? fpar[L.bias + g * L.n + neuron] : 0.0f;
     // old state -> recurrent operand planes (columns >= n stay zero); these loads share the latency window of
     // the weight fragments requested above
     {
@@ -1207,9 +1263,8 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
     if (mine) {
 #pragma unroll
         for (int g = 0; g < 3; g++) {
-            const float bv = (neuron < L.n) ? fpar[L.bias + g * L.n + neuron] : 0.0f;
 #pragma unroll
-            for (int mb = 0; mb < MB; mb++) acc[g][mb] = f32x4{bv, bv, bv, bv};
+            for (int mb = 0; mb < MB; mb++) acc[g][mb] = f32x4{bias[g], bias[g], bias[g], bias[g]};
         }
         gemm_acc<3, MB, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, Bin, lane, f_in);
         gemm_acc<2, MB, 0>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Brec, lane, f_zr);
@@ -1259,6 +1314,12 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
 }
 
 // dense layer on the matrix cores: returns act(W x + b) for this wave's (neuron block, stream block) unit
+__device__ __forceinline__ float dense_bias(const LayerDesc &L, const float *__restrict__ fpar, int wave, int lane)
+{
+    const int neuron = (wave / 4) * 16 + (lane & 15);
+    return (wave < L.nb * 4 && neuron < L.n) ? fpar[L.bias + neuron] : 0.0f;
+}
+
 __device__ __forceinline__ const uint4 *dense_frags(const LayerDesc &L, const uint4 *__restrict__ Wq, int wave)
 {
     const int nbi = wave < L.nb * 4 ? wave / 4 : 0;
@@ -1266,7 +1327,7 @@ __device__ __forceinline__ const uint4 *dense_frags(const LayerDesc &L, const ui
 }
 
 __device__ __forceinline__ bool dense_unit(const LayerDesc &L, const RnnPlan &pl, const RnnLds &lds, const uint4 *__restrict__ Wq,
-                                           const float *__restrict__ fpar, int wave, int lane, const Frags<1> &first,
+                                           float bv, int wave, int lane, const Frags<1> &first,
                                            f32x4 &out, int &neuron, int &mb0)
 {
     const int units = L.nb * 4;
@@ -1275,7 +1336,6 @@ __device__ __forceinline__ bool dense_unit(const LayerDesc &L, const RnnPlan &pl
     neuron = nbi * 16 + (lane & 15);
     if (wave >= units) return false;
     f32x4 acc[3][4];
-    const float bv = (neuron < L.n) ? fpar[L.bias + neuron] : 0.0f;
     acc[0][0] = f32x4{bv, bv, bv, bv};
     gemm_acc<1, 1, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, dense_frags(L, Wq, wave), lane, first);
 #pragma unroll
@@ -1300,36 +1360,62 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     RnnLds lds{tab, live, IN, REC, in_ps, rec_ps};
     float *sv = b.gru_v + (size_t)tile * TILE * pl.vad.n, *sn = b.gru_n + (size_t)tile * TILE * pl.noise.n,
           *sdn = b.gru_dn + (size_t)tile * TILE * pl.dn.n;
-    // wave 0 turns band energies into the 42 features (lane = stream); meanwhile waves 1..7 request everything
-    // else this block needs from HBM (the three old GRU states), zero both operand matrices (padding columns
-    // must read as 0) and fetch the activation table
     NNN_STAMP(b, 8);
+    float *crs = (float *)(REC + 3 * rec_ps);          // staged cepstral ring [8 * 22][64]
+    float *dists = crs + CEPS_MEM * NB * TILE;         // pair distances [28][64]
+    FeatHead fh;
     float fr[NFEAT];
-    bool silent = false;
     if (wave == 0) {
-        silent = features_tile(b, tile, lane, fr, (float *)(REC + 3 * rec_ps));
+        features_head(b, tile, lane, fh);
     } else {
+        // waves 1..7: stage the cepstral ring, zero both operand matrices (padding columns must read as 0),
+        // fetch the activation table
+        const float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, lane);
+        constexpr int PER = (CEPS_MEM * NB + RNN_WAVES - 2) / (RNN_WAVES - 1);   // 26 rows per wave, all in flight
+        float st[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int r = (wave - 1) + i * (RNN_WAVES - 1);
+            st[i] = r < CEPS_MEM * NB ? cm[(size_t)r * TILE] : 0.0f;
+        }
         uint4 *z = (uint4 *)IN;
         const int n16 = 3 * (in_ps + rec_ps) / 8;
         for (int i = tid - 64; i < n16; i += RNN_LOADERS) z[i] = make_uint4(0u, 0u, 0u, 0u);
         for (int i = tid - 64; i < 201; i += RNN_LOADERS) tab[i] = b.tansig[i];
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int r = (wave - 1) + i * (RNN_WAVES - 1);
+            if (r < CEPS_MEM * NB) crs[r * TILE + lane] = st[i];
+        }
     }
     Frags<1> f_dense, f_out;
     load_frags<1, 0>(f_dense, pl.dense.in, dense_frags(pl.dense, Wq, wave), lane);
     load_frags<1, 0>(f_out, pl.out.in, dense_frags(pl.out, Wq, wave), lane);
+    const float bias_dense = dense_bias(pl.dense, fpar, wave, lane), bias_out = dense_bias(pl.out, fpar, wave, lane);
+    __syncthreads();
+    if (wave == 0) {
+        features_deltas(b, tile, lane, fh, crs, fr);
+        live[lane] = fh.silent ? 0 : 1;
+    }
+    __syncthreads();
+    for (int p = wave; p < 28; p += RNN_WAVES) dists[p * TILE + lane] = pair_dist(crs, p, lane);
     __syncthreads();
     NNN_STAMP(b, 9);
     if (wave == 0) {
-        live[lane] = silent ? 0 : 1;
+        if (!fh.silent) fr[41] = spectral_variability(dists, lane);
+        float *f = NNN_TI(b.feat, NFEAT, tile, lane);
 #pragma unroll
-        for (int k = 0; k < NFEAT; k++) store_split(IN, in_ps, lane * pl.in_w + pl.cF + k, fr[k]);
+        for (int k = 0; k < NFEAT; k++) {
+            f[(size_t)k * TILE] = fr[k];
+            store_split(IN, in_ps, lane * pl.in_w + pl.cF + k, fr[k]);
+        }
     }
     __syncthreads();
     NNN_STAMP(b, 10);
     {   // input dense (ref: src/rnn.rs:353-355)
         f32x4 o;
         int neuron, mb0;
-        if (dense_unit(pl.dense, pl, lds, Wq, fpar, wave, lane, f_dense, o, neuron, mb0)) {
+        if (dense_unit(pl.dense, pl, lds, Wq, bias_dense, wave, lane, f_dense, o, neuron, mb0)) {
 #pragma unroll
             for (int q = 0; q < 4; q++) store_split(IN, in_ps, (mb0 * 16 + 4 * (lane >> 4) + q) * pl.in_w + pl.dense.out_col + neuron, o[q]);
         }
@@ -1357,7 +1443,7 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     {   // gains (ref: src/rnn.rs:378) and smoothing g = max(g, 0.6 lastg) (ref: src/denoise.rs:106-109)
         f32x4 o;
         int band, mb0;
-        if (dense_unit(pl.out, pl, lds, Wq, fpar, wave, lane, f_out, o, band, mb0)) {
+        if (dense_unit(pl.out, pl, lds, Wq, bias_out, wave, lane, f_out, o, band, mb0)) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int row = mb0 * 16 + 4 * (lane >> 4) + q;

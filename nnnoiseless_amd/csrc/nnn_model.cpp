@@ -200,6 +200,6 @@ size_t nnn_model_pack(const RNNModel &m, std::vector<uint16_t> &wq, std::vector<
     plan.rec_w = pad_to(32 * ks_of(std::max(nv, std::max(nn, ndn))), 16) + 8;
     (void)cN;
     // dynamic LDS: tanh table (256 floats) + live flags (64 ints) + 3 planes of both matrices + the staged
-    // cepstral ring of the feature stage (8 x 22 rows of 64 floats)
-    return 256 * 4 + 64 * 4 + (size_t)3 * 64 * (plan.in_w + plan.rec_w) * 2 + (size_t)8 * 22 * 64 * 4;
+    // cepstral ring of the feature stage (8 x 22 rows of 64 floats) and its 28 pair distances
+    return 256 * 4 + 64 * 4 + (size_t)3 * 64 * (plan.in_w + plan.rec_w) * 2 + (size_t)(8 * 22 + 28) * 64 * 4;
 }
