@@ -947,13 +947,13 @@ __device__ __forceinline__ float dct_out(const float *x, const float *dct, int i
 // flag, while waves 1..7 stage the 8 x 22 cepstral ring in LDS; (2) wave 0: ring update and delta features;
 // (3) all waves: the 28 pairwise cepstral distances of the spectral-variability feature; wave 0 finishes.
 struct FeatHead {
-    float c[NB];      // new cepstrum
-    float fpc[6];     // pitch-correlation DCT
     float fpitch;
     bool silent;
 };
 
-__device__ __forceinline__ void features_head(const Buffers &b, int tile, int lane, FeatHead &h)
+// The two DCTs are rolled loops over the output index (their fully unrolled form needs ~500 live table values);
+// the new cepstrum (rows 0..21) and the pitch-correlation DCT (rows 22..27) are parked in LDS (`cn`).
+__device__ __forceinline__ void features_head(const Buffers &b, int tile, int lane, FeatHead &h, float *cn)
 {
     float ex[NB], ep[NB], ly[NB], tmp[NB];
     const float *exg = NNN_TI(b.ex, NB, tile, lane), *epg = NNN_TI(b.ep, NB, tile, lane);
@@ -971,10 +971,12 @@ __device__ __forceinline__ void features_head(const Buffers &b, int tile, int la
         tmp[i] = v;
         xpg[(size_t)i * TILE] = v;
     }
-#pragma unroll
-    for (int i = 0; i < 6; i++) h.fpc[i] = dct_out(tmp, b.dct, i);
-    h.fpc[0] -= 1.3f;
-    h.fpc[1] -= 0.9f;
+#pragma unroll 1
+    for (int i = 0; i < 6; i++) {
+        float v = dct_out(tmp, b.dct, i);
+        v -= i == 0 ? 1.3f : (i == 1 ? 0.9f : 0.0f);
+        cn[(NB + i) * TILE + lane] = v;
+    }
     h.fpitch = 0.01f * ((float)pitch - 300.0f);
     float log_max = -2.0f, follow = -2.0f, e = 0.0f;
 #pragma unroll
@@ -987,15 +989,17 @@ __device__ __forceinline__ void features_head(const Buffers &b, int tile, int la
     }
     h.silent = e < 0.04f;
     NNN_TI(b.silence, 1, tile, lane)[0] = h.silent ? 1 : 0;
-#pragma unroll
-    for (int i = 0; i < NB; i++) h.c[i] = dct_out(ly, b.dct, i);
-    h.c[0] -= 12.0f;
-    h.c[1] -= 4.0f;
+#pragma unroll 1
+    for (int i = 0; i < NB; i++) {
+        float v = dct_out(ly, b.dct, i);
+        v -= i == 0 ? 12.0f : (i == 1 ? 4.0f : 0.0f);
+        cn[i * TILE + lane] = v;
+    }
 }
 
 // ring update + delta features (wave 0, after the ring has been staged in crs)
 __device__ __forceinline__ void features_deltas(const Buffers &b, int tile, int lane, const FeatHead &h, float *crs,
-                                                float (&fr)[NFEAT])
+                                                const float *cn, float (&fr)[NFEAT])
 {
     if (h.silent) {   // "if there's no audio, avoid messing up the state" (ref: src/features.rs:160-166)
 #pragma unroll
@@ -1007,24 +1011,26 @@ __device__ __forceinline__ void features_deltas(const Buffers &b, int tile, int 
     int mem_id = midp[0];
     const int c0 = mem_id, c1 = mem_id < 1 ? CEPS_MEM + mem_id - 1 : mem_id - 1;
     const int c2 = mem_id < 2 ? CEPS_MEM + mem_id - 2 : mem_id - 2;
+    float c[NB];
 #pragma unroll
     for (int k = 0; k < NB; k++) {
-        cm[(size_t)(c0 * NB + k) * TILE] = h.c[k];
-        crs[(c0 * NB + k) * TILE + lane] = h.c[k];
+        c[k] = cn[k * TILE + lane];
+        cm[(size_t)(c0 * NB + k) * TILE] = c[k];
+        crs[(c0 * NB + k) * TILE + lane] = c[k];
     }
     mem_id += 1;
     if (mem_id == CEPS_MEM) mem_id = 0;
     midp[0] = mem_id;
 #pragma unroll
-    for (int i = 0; i < NB; i++) fr[i] = h.c[i];
+    for (int i = 0; i < NB; i++) fr[i] = c[i];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         const float v1 = crs[(c1 * NB + i) * TILE + lane], v2 = crs[(c2 * NB + i) * TILE + lane];
-        const float v0 = h.c[i];
+        const float v0 = c[i];
         fr[i] = v0 + v1 + v2;
         fr[NB + i] = v0 - v2;
         fr[NB + 6 + i] = v0 - 2.0f * v1 + v2;
-        fr[NB + 12 + i] = h.fpc[i];
+        fr[NB + 12 + i] = cn[(NB + i) * TILE + lane];
     }
     fr[40] = h.fpitch;
     fr[41] = 0.0f;
@@ -1366,7 +1372,7 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     FeatHead fh;
     float fr[NFEAT];
     if (wave == 0) {
-        features_head(b, tile, lane, fh);
+        features_head(b, tile, lane, fh, dists);
     } else {
         // waves 1..7: stage the cepstral ring, zero both operand matrices (padding columns must read as 0),
         // fetch the activation table
@@ -1388,17 +1394,18 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
             if (r < CEPS_MEM * NB) crs[r * TILE + lane] = st[i];
         }
     }
-    Frags<1> f_dense, f_out;
-    load_frags<1, 0>(f_dense, pl.dense.in, dense_frags(pl.dense, Wq, wave), lane);
-    load_frags<1, 0>(f_out, pl.out.in, dense_frags(pl.out, Wq, wave), lane);
-    const float bias_dense = dense_bias(pl.dense, fpar, wave, lane), bias_out = dense_bias(pl.out, fpar, wave, lane);
     __syncthreads();
     if (wave == 0) {
-        features_deltas(b, tile, lane, fh, crs, fr);
+        features_deltas(b, tile, lane, fh, crs, dists, fr);
         live[lane] = fh.silent ? 0 : 1;
     }
     __syncthreads();
     for (int p = wave; p < 28; p += RNN_WAVES) dists[p * TILE + lane] = pair_dist(crs, p, lane);
+    // the dense layers' weights and biases travel during the rest of the prologue
+    Frags<1> f_dense, f_out;
+    load_frags<1, 0>(f_dense, pl.dense.in, dense_frags(pl.dense, Wq, wave), lane);
+    load_frags<1, 0>(f_out, pl.out.in, dense_frags(pl.out, Wq, wave), lane);
+    const float bias_dense = dense_bias(pl.dense, fpar, wave, lane), bias_out = dense_bias(pl.out, fpar, wave, lane);
     __syncthreads();
     NNN_STAMP(b, 9);
     if (wave == 0) {
