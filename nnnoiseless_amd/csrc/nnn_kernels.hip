@@ -1242,9 +1242,10 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
     // all weight fragments of this layer start travelling now
     Frags<3> f_in;
     Frags<2> f_zr;
-    Frags<1> f_h;   // requested after the z|r GEMMs: it travels during the gate epilogue and the two barriers
+    Frags<1> f_h;
     load_frags<3, 0>(f_in, L.in, Bin, lane);
     load_frags<2, 0>(f_zr, L.rec, Brec, lane);
+    load_frags<1, 2>(f_h, L.rec, Brec, lane);
     float bias[3];
 #pragma unroll
     for (int g = 0; g < 3; g++) bias[g] = (neuron < L.n) ? fpar[L.bias + g * L.n + neuron] : 0.0f;
@@ -1262,7 +1263,7 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     NNN_STAMP(b, 16);
     f32x4 acc[3][4];
     float sold[4][4], zz[4][4], rs[4][4];
@@ -1274,7 +1275,6 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
         }
         gemm_acc<3, MB, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, Bin, lane, f_in);
         gemm_acc<2, MB, 0>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Brec, lane, f_zr);
-        load_frags<1, 2>(f_h, L.rec, Brec, lane);
 #pragma unroll
         for (int mb = 0; mb < MB; mb++)
 #pragma unroll
@@ -1287,7 +1287,7 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
                 rs[mb][q] = so * sigmoid_approx(scale * acc[1][mb][q], lds.tab);
             }
     }
-    __syncthreads();   // every wave is done reading the old state planes
+    lds_barrier();   // every wave is done reading the old state planes
     NNN_STAMP(b, 17);
     if (nvalid) {
 #pragma unroll
@@ -1298,7 +1298,7 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
                 store_split(lds.REC, lds.rec_ps, row * pl.rec_w + neuron, rs[mb][q]);
             }
     }
-    __syncthreads();
+    lds_barrier();
     NNN_STAMP(b, 18);
     if (mine) {
         gemm_acc<1, MB, 2>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Brec, lane, f_h);
@@ -1316,7 +1316,7 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
                 }
         }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // dense layer on the matrix cores: returns act(W x + b) for this wave's (neuron block, stream block) unit
@@ -1394,19 +1394,19 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
             if (r < CEPS_MEM * NB) crs[r * TILE + lane] = st[i];
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (wave == 0) {
         features_deltas(b, tile, lane, fh, crs, dists, fr);
         live[lane] = fh.silent ? 0 : 1;
     }
-    __syncthreads();
+    lds_barrier();
     for (int p = wave; p < 28; p += RNN_WAVES) dists[p * TILE + lane] = pair_dist(crs, p, lane);
     // the dense layers' weights and biases travel during the rest of the prologue
     Frags<1> f_dense, f_out;
     load_frags<1, 0>(f_dense, pl.dense.in, dense_frags(pl.dense, Wq, wave), lane);
     load_frags<1, 0>(f_out, pl.out.in, dense_frags(pl.out, Wq, wave), lane);
     const float bias_dense = dense_bias(pl.dense, fpar, wave, lane), bias_out = dense_bias(pl.out, fpar, wave, lane);
-    __syncthreads();
+    lds_barrier();
     NNN_STAMP(b, 9);
     if (wave == 0) {
         if (!fh.silent) fr[41] = spectral_variability(dists, lane);
@@ -1417,7 +1417,7 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
             store_split(IN, in_ps, lane * pl.in_w + pl.cF + k, fr[k]);
         }
     }
-    __syncthreads();
+    lds_barrier();
     NNN_STAMP(b, 10);
     {   // input dense (ref: src/rnn.rs:353-355)
         f32x4 o;
@@ -1427,7 +1427,7 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
             for (int q = 0; q < 4; q++) store_split(IN, in_ps, (mb0 * 16 + 4 * (lane >> 4) + q) * pl.in_w + pl.dense.out_col + neuron, o[q]);
         }
     }
-    __syncthreads();
+    lds_barrier();
 #define NNN_GRU(L, st)                                                           \
     switch ((L).mb) {                                                            \
     case 4: gru_layer<4>(b, L, pl, lds, st, Wq, fpar, wave, lane); break;        \

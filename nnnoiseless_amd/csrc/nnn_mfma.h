@@ -1,4 +1,4 @@
-// nnn_mfma.h -- the one CDNA4 matrix instruction the RNN kernel uses.
+// nnn_mfma.h -- the CDNA4-specific primitives of the RNN kernel: one matrix instruction and an LDS-only barrier.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -13,6 +13,16 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier, no vmcnt(0).  Unlike
+// __syncthreads() it does not drain outstanding global loads/stores, so requests issued early (weights, states)
+// keep travelling across phase boundaries.  Only for phases that exchange data through LDS.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 }  // namespace nnn

@@ -51,4 +51,6 @@ static inline f32x4 mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c)
     return d;
 }
 
+static inline void lds_barrier() { __syncthreads(); }
+
 }  // namespace nnn
