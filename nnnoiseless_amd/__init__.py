@@ -115,6 +115,9 @@ class BatchDenoiser:
     def set_graph(self, on):
         self._lib.check(self._lib.L.nnn_batch_set_graph(self._h, int(on)))
 
+    def set_pipeline(self, on):
+        self._lib.check(self._lib.L.nnn_batch_set_pipeline(self._h, int(on)))
+
     def kernel_times(self):
         """{kernel: (total_ms, launches)} accumulated while profiling; resets the counters."""
         n = self._lib.L.nnn_batch_num_kernels()

@@ -15,7 +15,7 @@ BATCH_SYMBOLS = [
     "nnn_batch_create", "nnn_batch_destroy", "nnn_batch_num_streams", "nnn_batch_reset",
     "nnn_batch_process_device", "nnn_batch_process_host", "nnn_batch_synchronize",
     "nnn_tap_info", "nnn_batch_read_tap", "nnn_batch_set_profiling", "nnn_batch_num_kernels",
-    "nnn_batch_kernel_name", "nnn_batch_read_kernel_times", "nnn_batch_set_graph", "nnn_batch_read_stamps",
+    "nnn_batch_kernel_name", "nnn_batch_read_kernel_times", "nnn_batch_set_graph", "nnn_batch_set_pipeline", "nnn_batch_read_stamps",
     "nnn_last_error",
 ]
 RNNOISE_SYMBOLS = [
@@ -55,6 +55,7 @@ class Library:
         L.nnn_batch_kernel_name.argtypes = [i32]
         L.nnn_batch_read_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
         L.nnn_batch_set_graph.argtypes = [vp, i32]
+        L.nnn_batch_set_pipeline.argtypes = [vp, i32]
         L.nnn_last_error.restype = C.c_char_p
         L.rnnoise_create.restype = vp
         L.rnnoise_create.argtypes = [vp]

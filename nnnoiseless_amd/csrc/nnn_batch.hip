@@ -39,8 +39,10 @@ enum KernelId { K_HP, K_LPC, K_XCORR, K_BEST1, K_REFINE, K_BEST2, K_YY, K_DOUBLI
 static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_xcorr", "k_best1", "k_refine", "k_best2",
                                             "k_yy", "k_doubling", "k_fft_x", "k_fft_p", "k_rnn", "k_synth", "k_advance"};
 
+constexpr int PIPE_FRAMES = 8;   // frames per pipelined graph (two frames in flight)
+
 struct nnn_batch {
-    Buffers b;
+    Buffers b[2];                  // same state, two scratch sets: frame f works in set f & 1
     ModelDims md;
     RnnPlan plan;
     const uint4 *wq = nullptr;     // packed bf16 weights (device)
@@ -50,14 +52,17 @@ struct nnn_batch {
     uint64_t frame_count = 0;
     std::vector<void *> allocs;     // everything hipMalloc'ed
     std::vector<std::pair<void *, size_t>> state_bufs;  // zeroed by reset
-    StepParams *sp = nullptr;       // device
-    hipStream_t stream = nullptr;
+    StepParams *sp = nullptr;       // device, [2]: launch parameters of the next even / odd frame
+    hipStream_t stream = nullptr;   // default launch stream
+    hipStream_t lane1 = nullptr;    // second frame lane of the pipelined graph
+    hipStream_t side[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // per lane: fft_x branch, yy branch
+    hipEvent_t ev_fork[2][2] = {}, ev_join[2][2] = {};
+    hipEvent_t ev_chain[2][4] = {};  // per frame parity: hp, doubling, rnn, synth done (the cross-frame recurrences)
+    hipEvent_t ev_lane = nullptr, ev_lane_done = nullptr;
     size_t rnn_lds = 0;
-    bool use_graph = true;
-    hipGraphExec_t graph_exec = nullptr;
-    hipStream_t graph_stream = nullptr;  // stream the graph was captured on
-    hipStream_t side[2] = {nullptr, nullptr};        // branches of the per-frame DAG
-    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
+    bool use_graph = true, use_pipeline = true;
+    hipGraphExec_t g_single[2] = {nullptr, nullptr}, g_pipe = nullptr;
+    hipStream_t graph_stream = nullptr;  // stream the graphs were captured on
     bool use_branches = true;
     int xcorr_chunk = 0;            // lags per k_xcorr wave: 4, 8 or 16 (0 = by batch size); env NNN_XCORR_CHUNK
     bool profiling = false;
@@ -137,12 +142,21 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
-    for (int i = 0; i < 2; i++) {
-        if (h->side[i]) hipStreamDestroy(h->side[i]);
-        if (h->ev_fork[i]) hipEventDestroy(h->ev_fork[i]);
-        if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
+    for (int i = 0; i < 2; i++)
+        if (h->g_single[i]) hipGraphExecDestroy(h->g_single[i]);
+    if (h->g_pipe) hipGraphExecDestroy(h->g_pipe);
+    for (int l = 0; l < 2; l++) {
+        for (int i = 0; i < 2; i++) {
+            if (h->side[l][i]) hipStreamDestroy(h->side[l][i]);
+            if (h->ev_fork[l][i]) hipEventDestroy(h->ev_fork[l][i]);
+            if (h->ev_join[l][i]) hipEventDestroy(h->ev_join[l][i]);
+        }
+        for (int i = 0; i < 4; i++)
+            if (h->ev_chain[l][i]) hipEventDestroy(h->ev_chain[l][i]);
     }
+    if (h->ev_lane) hipEventDestroy(h->ev_lane);
+    if (h->ev_lane_done) hipEventDestroy(h->ev_lane_done);
+    if (h->lane1) hipStreamDestroy(h->lane1);
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -157,11 +171,18 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     HIPCHK(hipSetDevice(device));
     h->device = device;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
-        HIPCHK(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_fork[i], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    HIPCHK(hipStreamCreateWithFlags(&h->lane1, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_lane, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_lane_done, hipEventDisableTiming));
+    for (int l = 0; l < 2; l++) {
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(hipStreamCreateWithFlags(&h->side[l][i], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_fork[l][i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_join[l][i], hipEventDisableTiming));
+        }
+        for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_chain[l][i], hipEventDisableTiming));
     }
+    if (const char *e = getenv("NNN_PIPELINE")) h->use_pipeline = atoi(e) != 0;
     if (const char *e = getenv("NNN_XCORR_CHUNK")) {
         int v = atoi(e);
         if (v == 4 || v == 8 || v == 16) h->xcorr_chunk = v;
@@ -186,7 +207,7 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     const ModelDims &md = h->md;
     if (h->rnn_lds > 160 * 1024) return fail("model too large for the RNN kernel's LDS operand matrices (%zu bytes)", h->rnn_lds);
 
-    Buffers &b = h->b;
+    Buffers &b = h->b[0];
     memset(&b, 0, sizeof(b));
     b.S = h->S; b.S_pad = h->S_pad; b.NT = h->NT;
     // persistent state
@@ -203,29 +224,7 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     HIPCHK(dalloc(h, &b.gru_v, Sp * md.nv, true));
     HIPCHK(dalloc(h, &b.gru_n, Sp * md.nn, true));
     HIPCHK(dalloc(h, &b.gru_dn, Sp * md.ndn, true));
-    // scratch
-    HIPCHK(dalloc(h, &b.lpc, Sp * 10, false));
-    HIPCHK(dalloc(h, &b.xlp_ti, Sp * XLP, false));
-    HIPCHK(dalloc(h, &b.xlp_sm, Sp * XLP, false));
-    HIPCHK(dalloc(h, &b.xc1, Sp * NLAG1, false));
-    HIPCHK(dalloc(h, &b.best1, Sp * 2, false));
-    HIPCHK(dalloc(h, &b.xc2, Sp * 10, false));
-    HIPCHK(dalloc(h, &b.ysq2, Sp * NLAG2, false));
-    HIPCHK(dalloc(h, &b.psearch, Sp, false));
-    HIPCHK(dalloc(h, &b.xx_yy, Sp * 386, false));
-    HIPCHK(dalloc(h, &b.pitch, Sp, false));
-    HIPCHK(dalloc(h, &b.pgain, Sp, false));
-    HIPCHK(dalloc(h, &b.X, Sp * FREQ, false));
-    HIPCHK(dalloc(h, &b.P, Sp * FREQ, false));
-    HIPCHK(dalloc(h, &b.ex, Sp * NB, false));
-    HIPCHK(dalloc(h, &b.ep, Sp * NB, false));
-    HIPCHK(dalloc(h, &b.exp_, Sp * NB, false));
-    HIPCHK(dalloc(h, &b.feat, Sp * NFEAT, false));
-    HIPCHK(dalloc(h, &b.silence, Sp, false));
-    HIPCHK(dalloc(h, &b.g_raw, Sp * NB, false));
-    HIPCHK(dalloc(h, &b.g, Sp * NB, false));
-    HIPCHK(dalloc(h, &b.vad, Sp, false));
-    HIPCHK(dalloc(h, &h->sp, 1, false));
+    HIPCHK(dalloc(h, &h->sp, 2, false));
     HIPCHK(dalloc(h, &b.stamps, 64, false));
     // tables
     std::vector<float> window, dct, tansig, bin_frac;
@@ -262,6 +261,32 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
         HIPCHK(upload(h, &dq, wq));
         h->wq = (const uint4 *)dq;
         HIPCHK(upload(h, &h->fpar, fpar));
+    }
+    h->b[1] = h->b[0];
+    for (int set = 0; set < 2; set++) {   // per-frame scratch (doubles as parity taps), one set per frame parity
+        Buffers &q = h->b[set];
+        HIPCHK(dalloc(h, &q.xlp0, Sp, false));
+        HIPCHK(dalloc(h, &q.lpc, Sp * 10, false));
+        HIPCHK(dalloc(h, &q.xlp_ti, Sp * XLP, false));
+        HIPCHK(dalloc(h, &q.xlp_sm, Sp * XLP, false));
+        HIPCHK(dalloc(h, &q.xc1, Sp * NLAG1, false));
+        HIPCHK(dalloc(h, &q.best1, Sp * 2, false));
+        HIPCHK(dalloc(h, &q.xc2, Sp * 10, false));
+        HIPCHK(dalloc(h, &q.ysq2, Sp * NLAG2, false));
+        HIPCHK(dalloc(h, &q.psearch, Sp, false));
+        HIPCHK(dalloc(h, &q.xx_yy, Sp * 386, false));
+        HIPCHK(dalloc(h, &q.pitch, Sp, false));
+        HIPCHK(dalloc(h, &q.pgain, Sp, false));
+        HIPCHK(dalloc(h, &q.X, Sp * FREQ, false));
+        HIPCHK(dalloc(h, &q.P, Sp * FREQ, false));
+        HIPCHK(dalloc(h, &q.ex, Sp * NB, false));
+        HIPCHK(dalloc(h, &q.ep, Sp * NB, false));
+        HIPCHK(dalloc(h, &q.exp_, Sp * NB, false));
+        HIPCHK(dalloc(h, &q.feat, Sp * NFEAT, false));
+        HIPCHK(dalloc(h, &q.silence, Sp, false));
+        HIPCHK(dalloc(h, &q.g_raw, Sp * NB, false));
+        HIPCHK(dalloc(h, &q.g, Sp * NB, false));
+        HIPCHK(dalloc(h, &q.vad, Sp, false));
     }
     if (h->rnn_lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->rnn_lds));
@@ -327,30 +352,44 @@ struct Launcher {
     }
 };
 
-// Per-frame DAG.  Critical path: hp -> decim -> lpc -> fir -> xcorr -> best1 -> refine -> best2 -> doubling
-// -> fft_p -> features -> rnn -> synth.  Two branches run beside it: fft_x (needs only the filtered
-// history) and yy (needs only pitch_buf).  With `branches` off (profiling) everything is serial on `st`.
-static void enqueue_frame(nnn_batch *h, hipStream_t st, bool prof)
+// Per-frame DAG.  Critical path: hp -> lpc -> xcorr -> best1 -> refine -> best2 -> doubling -> fft_p -> rnn -> synth.
+// Two branches run beside it: fft_x (needs only the filtered history) and yy (needs only pitch_buf).
+// `lane` selects the side streams / events; with `chain` the frame waits for the previous frame (other lane) only
+// at its true recurrences -- biquad state, last pitch, RNN state + cepstral ring + last gains, overlap memory --
+// so that frame f+1's front half overlaps frame f's back half.  With branches off (profiling) everything is
+// serial on `st`.
+enum { CH_HP, CH_DBL, CH_RNN, CH_SYN };
+static void enqueue_frame(nnn_batch *h, int parity, hipStream_t st, int lane, bool chain, bool first_in_graph, bool prof)
 {
-    const Buffers &b = h->b;
+    const Buffers &b = h->b[parity];
     const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad;
-    const StepParams *sp = h->sp;
+    StepParams *spw = h->sp + parity;
+    const StepParams *sp = spw;
     const bool br = h->use_branches && !prof;
-    Launcher L{h, st, prof}, L0{h, br ? h->side[0] : st, prof}, L1{h, br ? h->side[1] : st, prof};
+    hipStream_t s0 = br ? h->side[lane][0] : st, s1 = br ? h->side[lane][1] : st;
+    Launcher L{h, st, prof}, L0{h, s0, prof}, L1{h, s1, prof};
+    auto wait_prev = [&](int which) {
+        if (chain && !first_in_graph) hipStreamWaitEvent(st, h->ev_chain[parity ^ 1][which], 0);
+    };
+    auto mark = [&](int which) {
+        if (chain) hipEventRecord(h->ev_chain[parity][which], st);
+    };
+    wait_prev(CH_HP);
     L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp);
+    mark(CH_HP);
     if (br) {
-        hipEventRecord(h->ev_fork[0], st);
-        hipStreamWaitEvent(h->side[0], h->ev_fork[0], 0);
+        hipEventRecord(h->ev_fork[lane][0], st);
+        hipStreamWaitEvent(s0, h->ev_fork[lane][0], 0);
     }
     L0.go(K_FFT_X, k_fft_x, dim3(Sp), dim3(64), 0, b, sp);
-    if (br) hipEventRecord(h->ev_join[0], h->side[0]);
+    if (br) hipEventRecord(h->ev_join[lane][0], s0);
     L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp);
     if (br) {
-        hipEventRecord(h->ev_fork[1], st);
-        hipStreamWaitEvent(h->side[1], h->ev_fork[1], 0);
+        hipEventRecord(h->ev_fork[lane][1], st);
+        hipStreamWaitEvent(s1, h->ev_fork[lane][1], 0);
     }
     L1.go(K_YY, k_yy, dim3(NT), dim3(64), 0, b);
-    if (br) hipEventRecord(h->ev_join[1], h->side[1]);
+    if (br) hipEventRecord(h->ev_join[lane][1], s1);
     const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
     if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4), dim3(64), 0, b);
     else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8), dim3(64), 0, b);
@@ -358,13 +397,41 @@ static void enqueue_frame(nnn_batch *h, hipStream_t st, bool prof)
     L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
     L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
     L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
-    if (br) hipStreamWaitEvent(st, h->ev_join[1], 0);
+    if (br) hipStreamWaitEvent(st, h->ev_join[lane][1], 0);
+    wait_prev(CH_DBL);
     L.go(K_DOUBLING, k_doubling, dim3(Sp / 4), dim3(256), 0, b);
-    if (br) hipStreamWaitEvent(st, h->ev_join[0], 0);
+    mark(CH_DBL);
+    if (br) hipStreamWaitEvent(st, h->ev_join[lane][0], 0);
     L.go(K_FFT_P, k_fft_p, dim3(Sp), dim3(64), 0, b, sp);
+    wait_prev(CH_RNN);
     L.go(K_RNN, k_rnn, dim3(NT), dim3(64 * RNN_WAVES), h->rnn_lds, b, h->plan, h->wq, h->fpar);
+    mark(CH_RNN);
+    wait_prev(CH_SYN);
     L.go(K_SYNTH, k_synth, dim3(Sp), dim3(64), 0, b, sp);
-    L.go(K_ADVANCE, k_advance, dim3(1), dim3(1), 0, h->sp);
+    mark(CH_SYN);
+    L.go(K_ADVANCE, k_advance, dim3(1), dim3(1), 0, spw, 2);
+}
+
+// PIPE_FRAMES consecutive frames (starting at an even frame) on two lanes, two frames in flight.
+static void enqueue_pipeline(nnn_batch *h, hipStream_t st)
+{
+    hipEventRecord(h->ev_lane, st);
+    hipStreamWaitEvent(h->lane1, h->ev_lane, 0);
+    for (int f = 0; f < PIPE_FRAMES; f++) enqueue_frame(h, f & 1, (f & 1) ? h->lane1 : st, f & 1, true, f == 0, false);
+    hipEventRecord(h->ev_lane_done, h->lane1);
+    hipStreamWaitEvent(st, h->ev_lane_done, 0);
+}
+
+template <class F> static hipGraphExec_t capture(hipStream_t st, F &&body)
+{
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ex = nullptr;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
+    body();
+    if (hipStreamEndCapture(st, &g) != hipSuccess || !g) return nullptr;
+    if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) ex = nullptr;
+    hipGraphDestroy(g);
+    return ex;
 }
 
 static int drain_profile(nnn_batch *h)
@@ -391,34 +458,47 @@ extern "C" int nnn_batch_process_device(nnn_batch *h, const float *d_in, float *
     if (!d_in || !d_out) return fail("null buffer");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
-    StepParams v;
-    v.in = d_in; v.out = d_out; v.vad = d_vad;
-    v.stream_stride = stream_stride; v.frame_stride = frame_stride;
-    v.slot = (int)(h->frame_count & 3);
-    v.n_streams = h->S;
-    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, h->sp, v);
+    // launch parameters of the next frame of each parity
+    const int p0 = (int)(h->frame_count & 1);
+    for (int i = 0; i < 2; i++) {
+        StepParams v;
+        v.in = d_in + (size_t)i * frame_stride;
+        v.out = d_out + (size_t)i * frame_stride;
+        v.vad = d_vad ? d_vad + (size_t)i * h->S : nullptr;
+        v.stream_stride = stream_stride;
+        v.frame_stride = frame_stride;
+        v.slot = (int)((h->frame_count + i) % NSLOT);
+        v.n_streams = h->S;
+        hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, h->sp + (p0 ^ i), v);
+    }
     const bool graph = h->use_graph && !h->profiling;
-    if (graph && (!h->graph_exec || h->graph_stream != st)) {
-        if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-        hipGraph_t g = nullptr;
-        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            enqueue_frame(h, st, false);
-            if (hipStreamEndCapture(st, &g) == hipSuccess && g &&
-                hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
-                h->graph_stream = st;
-            } else {
-                h->graph_exec = nullptr;
-            }
-            if (g) hipGraphDestroy(g);
+    if (graph && (!h->g_single[0] || h->graph_stream != st)) {
+        for (int i = 0; i < 2; i++)
+            if (h->g_single[i]) { hipGraphExecDestroy(h->g_single[i]); h->g_single[i] = nullptr; }
+        if (h->g_pipe) { hipGraphExecDestroy(h->g_pipe); h->g_pipe = nullptr; }
+        for (int i = 0; i < 2; i++) h->g_single[i] = capture(st, [&] { enqueue_frame(h, i, st, 0, false, true, false); });
+        if (h->g_single[0] && h->g_single[1]) {
+            h->graph_stream = st;
+            if (h->use_pipeline && h->use_branches) h->g_pipe = capture(st, [&] { enqueue_pipeline(h, st); });
+        } else {
+            h->use_graph = false;  // capture unsupported here: stay eager
         }
-        if (!h->graph_exec) h->use_graph = false;  // capture unsupported here: stay eager
         (void)hipGetLastError();
     }
-    for (int t = 0; t < n_frames; t++) {
-        if (graph && h->graph_exec) HIPCHK(hipGraphLaunch(h->graph_exec, st));
-        else enqueue_frame(h, st, h->profiling);
+    int left = n_frames;
+    while (left > 0) {
+        const int par = (int)(h->frame_count & 1);
+        if (graph && h->g_pipe && par == 0 && left >= PIPE_FRAMES) {
+            HIPCHK(hipGraphLaunch(h->g_pipe, st));
+            h->frame_count += PIPE_FRAMES;
+            left -= PIPE_FRAMES;
+        } else {
+            if (graph && h->g_single[par]) HIPCHK(hipGraphLaunch(h->g_single[par], st));
+            else enqueue_frame(h, par, st, 0, false, true, h->profiling);
+            h->frame_count += 1;
+            left -= 1;
+        }
     }
-    h->frame_count += (uint64_t)n_frames;
     HIPCHK(hipGetLastError());
     if (h->profiling) {
         HIPCHK(hipStreamSynchronize(st));
@@ -465,7 +545,7 @@ extern "C" int nnn_batch_process_host(nnn_batch *h, const float *in, float *out,
 struct TapDesc { int len; int is_int; int layout; /* 0 TI, 1 SM float, 2 SM float2, 3 hist ring */ int sub_ofs; int sub_len; };
 static bool tap_desc(const nnn_batch *h, int tap, TapDesc &d, const void **ptr)
 {
-    const Buffers *b = h ? &h->b : nullptr;
+    const Buffers *b = h ? &h->b[(h->frame_count + 1) & 1] : nullptr;   // scratch set of the most recent frame
 #define TP(field) (b ? (const void *)b->field : nullptr)
     switch (tap) {
     case NNN_TAP_FILTERED: d = {FRAME, 0, 3, 0, FRAME}; *ptr = TP(hist); return true;
@@ -528,7 +608,7 @@ extern "C" int nnn_batch_read_tap(nnn_batch *h, int tap, void *host_dst, size_t 
     } else {  // newest frame in the history ring
         std::vector<uint32_t> tmp(Sp * RING);
         HIPCHK(hipMemcpy(tmp.data(), p, tmp.size() * 4, hipMemcpyDeviceToHost));
-        int slot = (int)((h->frame_count + 3) & 3);  // slot of the most recent frame
+        int slot = (int)((h->frame_count + NSLOT - 1) % NSLOT);  // slot of the most recent frame
         for (int s = 0; s < h->S; s++) memcpy(dst + (size_t)s * FRAME, tmp.data() + (size_t)s * RING + slot * FRAME, FRAME * 4);
     }
     return 0;
@@ -539,7 +619,7 @@ extern "C" int nnn_batch_read_stamps(nnn_batch *h, long long *dst64)
     if (!h) return fail("null batch");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(dst64, h->b.stamps, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dst64, h->b[0].stamps, 64 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -567,6 +647,17 @@ extern "C" int nnn_batch_set_graph(nnn_batch *h, int on)
 {
     if (!h) return fail("null batch");
     h->use_graph = on != 0;
+    return 0;
+}
+extern "C" int nnn_batch_set_pipeline(nnn_batch *h, int on)
+{
+    if (!h) return fail("null batch");
+    if ((on != 0) != h->use_pipeline) {
+        h->use_pipeline = on != 0;
+        if (h->g_pipe) { hipGraphExecDestroy(h->g_pipe); h->g_pipe = nullptr; }
+        for (int i = 0; i < 2; i++)
+            if (h->g_single[i]) { hipGraphExecDestroy(h->g_single[i]); h->g_single[i] = nullptr; }
+    }
     return 0;
 }
 

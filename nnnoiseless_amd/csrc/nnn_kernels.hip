@@ -53,14 +53,13 @@ __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp)
     float prev = NNN_TI(b.hp_last, 1, tile, lane)[0];
     NNN_STAMP(b, 24);
     float *ring = NNN_TI(b.dec, 2 * DEC_RING, tile, lane);
-    {   // x_lp[0] = (x[1] / 2 + x[0]) / 2 on the oldest two samples of this frame's 1728-sample history replaces the
-        // regular decimated value at that position; no later frame's window reaches back to it
+    {   // x_lp[0] = (x[1] / 2 + x[0]) / 2 on the oldest two samples of this frame's 1728-sample history: kept in
+        // per-frame scratch (the ring position it replaces is still a regular value for the previous frame,
+        // which may be in flight)
         const float *h = b.hist + (size_t)(tile * TILE + lane) * RING;
-        const int rb = ring_base(slot), db = dec_base(slot);
+        const int rb = ring_base(slot);
         const float x0 = h[rb], x1 = h[(rb + 1) % RING];
-        const float v = (x1 / 2.0f + x0) / 2.0f;
-        ring[(size_t)db * TILE] = v;
-        ring[(size_t)(db + DEC_RING) * TILE] = v;
+        NNN_TI(b.xlp0, 1, tile, lane)[0] = (x1 / 2.0f + x0) / 2.0f;
     }
     float *dec = ring + (size_t)(240 * slot) * TILE;
     const double a0 = (double)-1.99599f, a1 = (double)0.99600f, b0 = (double)-2.0f, b1 = (double)1.0f;
@@ -139,6 +138,7 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
     NNN_STAMP(b, 0);
     const float *xw = NNN_TI(b.dec, 2 * DEC_RING, tile, lane) + (size_t)dec_base(sp->slot) * TILE;   // x_lp[0..863]
 #define x(j) xw[(size_t)(j) * TILE]
+    const float x_first = NNN_TI(b.xlp0, 1, tile, lane)[0];   // x_lp[0] is special (ref: src/pitch.rs:458)
     const int fast_n = XLP - 4;
     {
         // Every row of the window is fetched once per block (wave w takes rows w, w+5, ...), parked in LDS, and
@@ -146,6 +146,7 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
         float st[LPC_PER_WAVE];
 #pragma unroll
         for (int i = 0; i < LPC_PER_WAVE; i++) st[i] = x(k + 5 * i);
+        if (k == 0) st[0] = x_first;
 #pragma unroll
         for (int i = 0; i < LPC_PER_WAVE; i++) buf[0][k + 5 * i][lane] = st[i];
         __syncthreads();
@@ -242,6 +243,7 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
             float v[37];
 #pragma unroll
             for (int u = 0; u < 37; u++) v[u] = (i0 + u - 5 >= 0) ? x(i0 + u - 5) : 0.0f;
+            if (c == 0) v[5] = x_first;
 #pragma unroll
             for (int u = 0; u < 32; u++) {
                 // out = x + n0 m0 + n1 m1 + n2 m2 + n3 m3 + n4 m4, left to right (m0 = previous input, ...)
@@ -1273,8 +1275,11 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
 #pragma unroll
             for (int mb = 0; mb < MB; mb++) acc[g][mb] = f32x4{bias[g], bias[g], bias[g], bias[g]};
         }
+        NNN_STAMP(b, 19);
         gemm_acc<3, MB, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, Bin, lane, f_in);
+        NNN_STAMP(b, 20);
         gemm_acc<2, MB, 0>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Brec, lane, f_zr);
+        NNN_STAMP(b, 21);
 #pragma unroll
         for (int mb = 0; mb < MB; mb++)
 #pragma unroll
@@ -1286,6 +1291,7 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
                 zz[mb][q] = sigmoid_approx(scale * acc[0][mb][q], lds.tab);
                 rs[mb][q] = so * sigmoid_approx(scale * acc[1][mb][q], lds.tab);
             }
+        NNN_STAMP(b, 22);
     }
     lds_barrier();   // every wave is done reading the old state planes
     NNN_STAMP(b, 17);
@@ -1302,6 +1308,7 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
     NNN_STAMP(b, 18);
     if (mine) {
         gemm_acc<1, MB, 2>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Brec, lane, f_h);
+        NNN_STAMP(b, 23);
         if (nvalid) {
 #pragma unroll
             for (int mb = 0; mb < MB; mb++)
@@ -1315,6 +1322,7 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
                     if (lds.live[row]) state[(size_t)row * L.n + neuron] = snew;   // silent frames leave the state alone
                 }
         }
+        NNN_STAMP(b, 26);
     }
     lds_barrier();
 }
@@ -1619,12 +1627,12 @@ __global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
 // Launch-parameter bookkeeping (one thread each): set at the start of a process call, stepped
 // after every frame so the captured graph of one frame can be replayed unchanged.
 __global__ void k_set_params(StepParams *sp, StepParams v) { *sp = v; }
-__global__ void k_advance(StepParams *sp)
+__global__ void k_advance(StepParams *sp, int nstep)
 {
-    sp->in += sp->frame_stride;
-    sp->out += sp->frame_stride;
-    if (sp->vad) sp->vad += sp->n_streams;
-    sp->slot = (sp->slot + 1) & 3;
+    sp->in += (size_t)nstep * sp->frame_stride;
+    sp->out += (size_t)nstep * sp->frame_stride;
+    if (sp->vad) sp->vad += (size_t)nstep * sp->n_streams;
+    sp->slot = (sp->slot + nstep) % NSLOT;
 }
 
 }  // namespace nnn

@@ -22,7 +22,9 @@ constexpr int NB = 22;            // src/lib.rs:49
 constexpr int NFEAT = 42;         // src/lib.rs:53
 constexpr int CEPS_MEM = 8;       // src/lib.rs:50
 constexpr int HIST = 1728;        // PITCH_BUF_SIZE, src/lib.rs:46
-constexpr int RING = 1920;        // history ring: 4 frame slots instead of the reference's memmove
+constexpr int NSLOT = 5;          // ring slots: 4 cover the 1728-sample history, the 5th lets the next frame's
+                                  // high-pass run while this frame is still being analysed (two frames in flight)
+constexpr int RING = NSLOT * 480; // history ring instead of the reference's memmove
 constexpr int XLP = 864;          // HIST / 2
 constexpr int PITCH_MIN = 60, PITCH_MAX = 768;
 constexpr int NLAG1 = 147;        // coarse lags  (PITCH_MAX - 3*PITCH_MIN) / 4
@@ -69,10 +71,10 @@ struct RnnPlan {
 
 struct Buffers {
     // ---- persistent per-stream state (src/denoise.rs:37-42, features.rs:18-46, pitch.rs:4-17, rnn.rs:65-70)
-    float *hist;         // SM [RING]   high-passed input history, ring of 4 frames
+    float *hist;         // SM [RING]   high-passed input history, ring of 5 frame slots
     float *hp_mem;       // TI [2]      biquad state
     float *hp_last;      // TI [1]      last filtered sample of the previous frame
-    float *dec;          // TI [1920]   2:1 decimated history: ring of 4 x 240 stored twice (p and p + 960) so that the
+    float *dec;          // TI [2400]   2:1 decimated history: ring of 5 x 240 stored twice (p and p + 1200) so that the
                          //             864-value window of any frame is one contiguous run (240 values are new per frame)
     float *ceps_mem;     // TI [8*22]
     int *mem_id;         // TI [1]
@@ -83,6 +85,7 @@ struct Buffers {
     float *gru_v, *gru_n, *gru_dn;  // SM [nv], [nn], [ndn]
     // ---- per-frame scratch (doubles as the parity taps)
     float *lpc;          // TI [10]     ac[5], lpc2[5]
+    float *xlp0;         // TI [1]      pitch_downsample's special first element (x[1]/2 + x[0])/2
     float *xlp_ti;       // TI [864]    pitch_buf
     float *xlp_sm;       // SM [864]    pitch_buf
     float *xc1;          // TI [147]
@@ -119,14 +122,14 @@ struct StepParams {
     float *out;
     float *vad;        // [n_streams] for this frame, may be null
     unsigned long long stream_stride, frame_stride;
-    int slot;          // history ring slot that receives this frame (frame index mod 4)
+    int slot;          // history ring slot that receives this frame (frame index mod NSLOT)
     int n_streams;
 };
 
 // ring position of logical input_mem[0] when the newest frame sits in slot `slot`
-__host__ __device__ inline int ring_base(int slot) { return (FRAME * slot + 672) % RING; }
+__host__ __device__ inline int ring_base(int slot) { return (FRAME * slot + RING - (HIST - FRAME)) % RING; }
 // ring position of logical decimated index 0 (864 logical values, the newest 240 in slot `slot`)
-constexpr int DEC_RING = 960;
-__host__ __device__ inline int dec_base(int slot) { return (240 * (slot + 1) + 96) % DEC_RING; }
+constexpr int DEC_RING = NSLOT * 240;
+__host__ __device__ inline int dec_base(int slot) { return (240 * slot + DEC_RING - (XLP - 240)) % DEC_RING; }
 
 }  // namespace nnn

@@ -26,5 +26,7 @@ for S in (4096, 65536):
     print("  k_lpc: autocorr", d(0, 1), "lpc", d(1, 2), "fir", d(2, 3))
     print("  k_rnn: preload+features+zero", d(8, 9), "split feats", d(9, 10), "dense", d(10, 11), "vad", d(11, 12), "noise(+vadout)", d(12, 13), "dn", d(13, 14), "out", d(14, 15))
     print("  dn layer: stateload->phaseA", d(13, 16), "phaseA", d(16, 17), "rs store", d(17, 18), "phaseB", d(18, 14))
+    print("  dn phase A: bias init", d(16, 19), "gemm in", d(19, 20), "gemm zr", d(20, 21), "sigmoids", d(21, 22), "barrier", d(22, 17))
+    print("  dn phase B: gemm h", d(18, 23), "epilogue", d(23, 26), "barrier", d(26, 14))
     bd.close()
 PY

@@ -14,6 +14,12 @@ k=d["kernels"]
 print("S=$S value=%.3e ms/step=%.3f prof_ms=%.3f" % (d["value"], d["ms_per_step"], d["roofline"]["profiled_ms_per_step"]), " ".join(f"{n[2:]}={v['avg_us']:.0f}" for n,v in k.items()))
 PY
 done
+for F in ${FPS_SWEEP:-8 32}; do
+  for S in ${FPS_STREAMS:-4096 16384}; do
+    timeout 600 python bench.py --streams $S --frames-per-step $F --steps 40 --warmup 5 --no-cpu-baseline --no-roofline > $O/fps_${S}_$F.json 2> $O/fps_${S}_$F.err
+    python -c "import json; d=json.load(open('$O/fps_${S}_$F.json')); print('S=$S frames/step=$F value=%.3e ms/step=%.3f' % (d['value'], d['ms_per_step']))"
+  done
+done
 cd /tmp && export TMPDIR=/tmp
 PS=${PMC_STREAMS:-16384}
 for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS" "FETCH_SIZE" "WRITE_SIZE"; do

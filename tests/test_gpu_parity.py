@@ -147,6 +147,28 @@ def test_full_size_properties(nn, oracle_mod, weights_bytes, S):
     assert np.array_equal(out_e, out) and np.array_equal(vad_e, vad)
 
 
+def test_two_frames_in_flight_is_bit_identical(nn):
+    """Multi-frame calls replay a graph that keeps two frames in flight (frame t+1's high-pass, pitch search and
+    X transform overlap frame t's RNN and synthesis).  Same bits as one frame at a time, for odd/even starts,
+    lengths that are not a multiple of the graph size, and in place."""
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T = 512, 37
+    x = make_streams(50, S, T)
+    ref = nn.BatchDenoiser(S)
+    ref.set_pipeline(False)
+    want, want_vad = ref.process(x)
+    bd = nn.BatchDenoiser(S)
+    got, got_vad = bd.process(x)                       # 4 pipelined graphs + 5 single frames
+    assert np.array_equal(got, want) and np.array_equal(got_vad, want_vad)
+    bd.reset()
+    a, va = bd.process(x[:, :3])                       # odd frame count first: the next call starts on an odd frame
+    b2, vb = bd.process(x[:, 3:])
+    assert np.array_equal(np.concatenate([a, b2], axis=1), want)
+    assert np.array_equal(np.concatenate([va, vb], axis=0), want_vad)
+    for k in ("pitch", "g", "features"):
+        assert np.array_equal(bd.tap(k), ref.tap(k)), k
+
+
 def test_custom_model(nn, oracle_mod):
     """BASELINE config 5 shape: a converted RNNoise-nu model (tanh/relu/tanh GRUs)."""
     from nnnoiseless_amd.synthetic import make_streams
