@@ -56,9 +56,11 @@ struct nnn_batch {
     hipStream_t stream = nullptr;   // default launch stream
     hipStream_t lane1 = nullptr;    // second frame lane of the pipelined graph
     hipStream_t side[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // per lane: fft_x branch, yy branch
-    hipEvent_t ev_fork[2][2] = {}, ev_join[2][2] = {};
-    hipEvent_t ev_chain[2][4] = {};  // per frame parity: hp, doubling, rnn, synth done (the cross-frame recurrences)
+    // one set of events per frame of the pipelined graph (index 0 also serves the single-frame graphs)
+    hipEvent_t ev_fork[PIPE_FRAMES][2] = {}, ev_join[PIPE_FRAMES][2] = {};
+    hipEvent_t ev_chain[PIPE_FRAMES][4] = {};  // hp, doubling, rnn, synth done (the cross-frame recurrences)
     hipEvent_t ev_lane = nullptr, ev_lane_done = nullptr;
+    bool pipe_failed = false;
     size_t rnn_lds = 0;
     bool use_graph = true, use_pipeline = true;
     hipGraphExec_t g_single[2] = {nullptr, nullptr}, g_pipe = nullptr;
@@ -145,14 +147,16 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
     for (int i = 0; i < 2; i++)
         if (h->g_single[i]) hipGraphExecDestroy(h->g_single[i]);
     if (h->g_pipe) hipGraphExecDestroy(h->g_pipe);
-    for (int l = 0; l < 2; l++) {
-        for (int i = 0; i < 2; i++) {
+    for (int l = 0; l < 2; l++)
+        for (int i = 0; i < 2; i++)
             if (h->side[l][i]) hipStreamDestroy(h->side[l][i]);
-            if (h->ev_fork[l][i]) hipEventDestroy(h->ev_fork[l][i]);
-            if (h->ev_join[l][i]) hipEventDestroy(h->ev_join[l][i]);
+    for (int f = 0; f < PIPE_FRAMES; f++) {
+        for (int i = 0; i < 2; i++) {
+            if (h->ev_fork[f][i]) hipEventDestroy(h->ev_fork[f][i]);
+            if (h->ev_join[f][i]) hipEventDestroy(h->ev_join[f][i]);
         }
         for (int i = 0; i < 4; i++)
-            if (h->ev_chain[l][i]) hipEventDestroy(h->ev_chain[l][i]);
+            if (h->ev_chain[f][i]) hipEventDestroy(h->ev_chain[f][i]);
     }
     if (h->ev_lane) hipEventDestroy(h->ev_lane);
     if (h->ev_lane_done) hipEventDestroy(h->ev_lane_done);
@@ -174,13 +178,14 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     HIPCHK(hipStreamCreateWithFlags(&h->lane1, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_lane, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_lane_done, hipEventDisableTiming));
-    for (int l = 0; l < 2; l++) {
+    for (int l = 0; l < 2; l++)
+        for (int i = 0; i < 2; i++) HIPCHK(hipStreamCreateWithFlags(&h->side[l][i], hipStreamNonBlocking));
+    for (int f = 0; f < PIPE_FRAMES; f++) {
         for (int i = 0; i < 2; i++) {
-            HIPCHK(hipStreamCreateWithFlags(&h->side[l][i], hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&h->ev_fork[l][i], hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&h->ev_join[l][i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_fork[f][i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_join[f][i], hipEventDisableTiming));
         }
-        for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_chain[l][i], hipEventDisableTiming));
+        for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_chain[f][i], hipEventDisableTiming));
     }
     if (const char *e = getenv("NNN_PIPELINE")) h->use_pipeline = atoi(e) != 0;
     if (const char *e = getenv("NNN_XCORR_CHUNK")) {
@@ -359,37 +364,42 @@ struct Launcher {
 // so that frame f+1's front half overlaps frame f's back half.  With branches off (profiling) everything is
 // serial on `st`.
 enum { CH_HP, CH_DBL, CH_RNN, CH_SYN };
-static void enqueue_frame(nnn_batch *h, int parity, hipStream_t st, int lane, bool chain, bool first_in_graph, bool prof)
+// `fi` = index of the frame inside the pipelined graph (0 for a stand-alone frame): selects the frame's events;
+// frame fi runs on lane fi & 1 and, when chained, waits for frame fi - 1.  Returns false if a stream/event call failed.
+static bool enqueue_frame(nnn_batch *h, int parity, hipStream_t st, int fi, bool chain, bool prof)
 {
     const Buffers &b = h->b[parity];
     const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad;
     StepParams *spw = h->sp + parity;
     const StepParams *sp = spw;
     const bool br = h->use_branches && !prof;
+    const int lane = fi & 1;
     hipStream_t s0 = br ? h->side[lane][0] : st, s1 = br ? h->side[lane][1] : st;
     Launcher L{h, st, prof}, L0{h, s0, prof}, L1{h, s1, prof};
+    bool ok = true;
+    auto chk = [&](hipError_t e) { ok = ok && e == hipSuccess; };
     auto wait_prev = [&](int which) {
-        if (chain && !first_in_graph) hipStreamWaitEvent(st, h->ev_chain[parity ^ 1][which], 0);
+        if (chain && fi > 0) chk(hipStreamWaitEvent(st, h->ev_chain[fi - 1][which], 0));
     };
     auto mark = [&](int which) {
-        if (chain) hipEventRecord(h->ev_chain[parity][which], st);
+        if (chain) chk(hipEventRecord(h->ev_chain[fi][which], st));
     };
     wait_prev(CH_HP);
     L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp);
     mark(CH_HP);
     if (br) {
-        hipEventRecord(h->ev_fork[lane][0], st);
-        hipStreamWaitEvent(s0, h->ev_fork[lane][0], 0);
+        chk(hipEventRecord(h->ev_fork[fi][0], st));
+        chk(hipStreamWaitEvent(s0, h->ev_fork[fi][0], 0));
     }
     L0.go(K_FFT_X, k_fft_x, dim3(Sp), dim3(64), 0, b, sp);
-    if (br) hipEventRecord(h->ev_join[lane][0], s0);
+    if (br) chk(hipEventRecord(h->ev_join[fi][0], s0));
     L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp);
     if (br) {
-        hipEventRecord(h->ev_fork[lane][1], st);
-        hipStreamWaitEvent(s1, h->ev_fork[lane][1], 0);
+        chk(hipEventRecord(h->ev_fork[fi][1], st));
+        chk(hipStreamWaitEvent(s1, h->ev_fork[fi][1], 0));
     }
     L1.go(K_YY, k_yy, dim3(NT), dim3(64), 0, b);
-    if (br) hipEventRecord(h->ev_join[lane][1], s1);
+    if (br) chk(hipEventRecord(h->ev_join[fi][1], s1));
     const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
     if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4), dim3(64), 0, b);
     else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8), dim3(64), 0, b);
@@ -397,11 +407,11 @@ static void enqueue_frame(nnn_batch *h, int parity, hipStream_t st, int lane, bo
     L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
     L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
     L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
-    if (br) hipStreamWaitEvent(st, h->ev_join[lane][1], 0);
+    if (br) chk(hipStreamWaitEvent(st, h->ev_join[fi][1], 0));
     wait_prev(CH_DBL);
     L.go(K_DOUBLING, k_doubling, dim3(Sp / 4), dim3(256), 0, b);
     mark(CH_DBL);
-    if (br) hipStreamWaitEvent(st, h->ev_join[lane][0], 0);
+    if (br) chk(hipStreamWaitEvent(st, h->ev_join[fi][0], 0));
     L.go(K_FFT_P, k_fft_p, dim3(Sp), dim3(64), 0, b, sp);
     wait_prev(CH_RNN);
     L.go(K_RNN, k_rnn, dim3(NT), dim3(64 * RNN_WAVES), h->rnn_lds, b, h->plan, h->wq, h->fpar);
@@ -410,16 +420,18 @@ static void enqueue_frame(nnn_batch *h, int parity, hipStream_t st, int lane, bo
     L.go(K_SYNTH, k_synth, dim3(Sp), dim3(64), 0, b, sp);
     mark(CH_SYN);
     L.go(K_ADVANCE, k_advance, dim3(1), dim3(1), 0, spw, 2);
+    return ok;
 }
 
 // PIPE_FRAMES consecutive frames (starting at an even frame) on two lanes, two frames in flight.
-static void enqueue_pipeline(nnn_batch *h, hipStream_t st)
+static bool enqueue_pipeline(nnn_batch *h, hipStream_t st)
 {
-    hipEventRecord(h->ev_lane, st);
-    hipStreamWaitEvent(h->lane1, h->ev_lane, 0);
-    for (int f = 0; f < PIPE_FRAMES; f++) enqueue_frame(h, f & 1, (f & 1) ? h->lane1 : st, f & 1, true, f == 0, false);
-    hipEventRecord(h->ev_lane_done, h->lane1);
-    hipStreamWaitEvent(st, h->ev_lane_done, 0);
+    bool ok = hipEventRecord(h->ev_lane, st) == hipSuccess;
+    ok = ok && hipStreamWaitEvent(h->lane1, h->ev_lane, 0) == hipSuccess;
+    for (int f = 0; f < PIPE_FRAMES && ok; f++) ok = enqueue_frame(h, f & 1, (f & 1) ? h->lane1 : st, f, true, false);
+    ok = ok && hipEventRecord(h->ev_lane_done, h->lane1) == hipSuccess;
+    ok = ok && hipStreamWaitEvent(st, h->ev_lane_done, 0) == hipSuccess;
+    return ok;
 }
 
 template <class F> static hipGraphExec_t capture(hipStream_t st, F &&body)
@@ -427,9 +439,9 @@ template <class F> static hipGraphExec_t capture(hipStream_t st, F &&body)
     hipGraph_t g = nullptr;
     hipGraphExec_t ex = nullptr;
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
-    body();
+    const bool ok = body();
     if (hipStreamEndCapture(st, &g) != hipSuccess || !g) return nullptr;
-    if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) ex = nullptr;
+    if (ok && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) ex = nullptr;
     hipGraphDestroy(g);
     return ex;
 }
@@ -476,13 +488,16 @@ extern "C" int nnn_batch_process_device(nnn_batch *h, const float *d_in, float *
         for (int i = 0; i < 2; i++)
             if (h->g_single[i]) { hipGraphExecDestroy(h->g_single[i]); h->g_single[i] = nullptr; }
         if (h->g_pipe) { hipGraphExecDestroy(h->g_pipe); h->g_pipe = nullptr; }
-        for (int i = 0; i < 2; i++) h->g_single[i] = capture(st, [&] { enqueue_frame(h, i, st, 0, false, true, false); });
-        if (h->g_single[0] && h->g_single[1]) {
-            h->graph_stream = st;
-            if (h->use_pipeline && h->use_branches) h->g_pipe = capture(st, [&] { enqueue_pipeline(h, st); });
-        } else {
-            h->use_graph = false;  // capture unsupported here: stay eager
-        }
+        for (int i = 0; i < 2; i++) h->g_single[i] = capture(st, [&] { return enqueue_frame(h, i, st, 0, false, false); });
+        if (h->g_single[0] && h->g_single[1]) h->graph_stream = st;
+        else h->use_graph = false;  // capture unsupported here: stay eager
+        h->pipe_failed = false;
+        (void)hipGetLastError();
+    }
+    if (graph && h->use_graph && h->use_pipeline && h->use_branches && !h->g_pipe && !h->pipe_failed &&
+        n_frames >= PIPE_FRAMES) {   // built on first use
+        h->g_pipe = capture(st, [&] { return enqueue_pipeline(h, st); });
+        if (!h->g_pipe) h->pipe_failed = true;
         (void)hipGetLastError();
     }
     int left = n_frames;
@@ -494,7 +509,7 @@ extern "C" int nnn_batch_process_device(nnn_batch *h, const float *d_in, float *
             left -= PIPE_FRAMES;
         } else {
             if (graph && h->g_single[par]) HIPCHK(hipGraphLaunch(h->g_single[par], st));
-            else enqueue_frame(h, par, st, 0, false, true, h->profiling);
+            else enqueue_frame(h, par, st, 0, false, h->profiling);
             h->frame_count += 1;
             left -= 1;
         }
