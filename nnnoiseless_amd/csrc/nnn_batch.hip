@@ -39,7 +39,7 @@ enum KernelId { K_HP, K_LPC, K_XCORR, K_BEST1, K_REFINE, K_BEST2, K_YY, K_DOUBLI
 static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_xcorr", "k_best1", "k_refine", "k_best2",
                                             "k_yy", "k_doubling", "k_fft_x", "k_fft_p", "k_rnn", "k_synth", "k_advance"};
 
-constexpr int PIPE_FRAMES = 8;   // frames per pipelined graph (two frames in flight)
+constexpr int PIPE_FRAMES = 2;   // event sets: one per frame lane
 
 struct nnn_batch {
     Buffers b[2];                  // same state, two scratch sets: frame f works in set f & 1
@@ -56,14 +56,14 @@ struct nnn_batch {
     hipStream_t stream = nullptr;   // default launch stream
     hipStream_t lane1 = nullptr;    // second frame lane of the pipelined graph
     hipStream_t side[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // per lane: fft_x branch, yy branch
-    // one set of events per frame of the pipelined graph (index 0 also serves the single-frame graphs)
+    // one set of events per frame lane (set 0 also serves the single-frame graphs)
     hipEvent_t ev_fork[PIPE_FRAMES][2] = {}, ev_join[PIPE_FRAMES][2] = {};
     hipEvent_t ev_chain[PIPE_FRAMES][4] = {};  // hp, doubling, rnn, synth done (the cross-frame recurrences)
     hipEvent_t ev_lane = nullptr, ev_lane_done = nullptr;
-    bool pipe_failed = false;
+
     size_t rnn_lds = 0;
     bool use_graph = true, use_pipeline = true;
-    hipGraphExec_t g_single[2] = {nullptr, nullptr}, g_pipe = nullptr;
+    hipGraphExec_t g_single[2] = {nullptr, nullptr};
     hipStream_t graph_stream = nullptr;  // stream the graphs were captured on
     bool use_branches = true;
     int xcorr_chunk = 0;            // lags per k_xcorr wave: 4, 8 or 16 (0 = by batch size); env NNN_XCORR_CHUNK
@@ -146,7 +146,6 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     for (int i = 0; i < 2; i++)
         if (h->g_single[i]) hipGraphExecDestroy(h->g_single[i]);
-    if (h->g_pipe) hipGraphExecDestroy(h->g_pipe);
     for (int l = 0; l < 2; l++)
         for (int i = 0; i < 2; i++)
             if (h->side[l][i]) hipStreamDestroy(h->side[l][i]);
@@ -178,6 +177,7 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     HIPCHK(hipStreamCreateWithFlags(&h->lane1, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_lane, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_lane_done, hipEventDisableTiming));
+
     for (int l = 0; l < 2; l++)
         for (int i = 0; i < 2; i++) HIPCHK(hipStreamCreateWithFlags(&h->side[l][i], hipStreamNonBlocking));
     for (int f = 0; f < PIPE_FRAMES; f++) {
@@ -364,8 +364,8 @@ struct Launcher {
 // so that frame f+1's front half overlaps frame f's back half.  With branches off (profiling) everything is
 // serial on `st`.
 enum { CH_HP, CH_DBL, CH_RNN, CH_SYN };
-// `fi` = index of the frame inside the pipelined graph (0 for a stand-alone frame): selects the frame's events;
-// frame fi runs on lane fi & 1 and, when chained, waits for frame fi - 1.  Returns false if a stream/event call failed.
+// `fi` = index of the frame inside a pipelined call (0 for a stand-alone frame): frame fi runs on lane fi & 1 with
+// that lane's events and, when chained, waits for frame fi - 1 (other lane).  Returns false if a stream/event call failed.
 static bool enqueue_frame(nnn_batch *h, int parity, hipStream_t st, int fi, bool chain, bool prof)
 {
     const Buffers &b = h->b[parity];
@@ -373,33 +373,33 @@ static bool enqueue_frame(nnn_batch *h, int parity, hipStream_t st, int fi, bool
     StepParams *spw = h->sp + parity;
     const StepParams *sp = spw;
     const bool br = h->use_branches && !prof;
-    const int lane = fi & 1;
+    const int lane = fi & 1, es = fi & 1;   // event set
     hipStream_t s0 = br ? h->side[lane][0] : st, s1 = br ? h->side[lane][1] : st;
     Launcher L{h, st, prof}, L0{h, s0, prof}, L1{h, s1, prof};
     bool ok = true;
     auto chk = [&](hipError_t e) { ok = ok && e == hipSuccess; };
     auto wait_prev = [&](int which) {
-        if (chain && fi > 0) chk(hipStreamWaitEvent(st, h->ev_chain[fi - 1][which], 0));
+        if (chain && fi > 0) chk(hipStreamWaitEvent(st, h->ev_chain[es ^ 1][which], 0));
     };
     auto mark = [&](int which) {
-        if (chain) chk(hipEventRecord(h->ev_chain[fi][which], st));
+        if (chain) chk(hipEventRecord(h->ev_chain[es][which], st));
     };
     wait_prev(CH_HP);
     L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp);
     mark(CH_HP);
     if (br) {
-        chk(hipEventRecord(h->ev_fork[fi][0], st));
-        chk(hipStreamWaitEvent(s0, h->ev_fork[fi][0], 0));
+        chk(hipEventRecord(h->ev_fork[es][0], st));
+        chk(hipStreamWaitEvent(s0, h->ev_fork[es][0], 0));
     }
     L0.go(K_FFT_X, k_fft_x, dim3(Sp), dim3(64), 0, b, sp);
-    if (br) chk(hipEventRecord(h->ev_join[fi][0], s0));
+    if (br) chk(hipEventRecord(h->ev_join[es][0], s0));
     L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp);
     if (br) {
-        chk(hipEventRecord(h->ev_fork[fi][1], st));
-        chk(hipStreamWaitEvent(s1, h->ev_fork[fi][1], 0));
+        chk(hipEventRecord(h->ev_fork[es][1], st));
+        chk(hipStreamWaitEvent(s1, h->ev_fork[es][1], 0));
     }
     L1.go(K_YY, k_yy, dim3(NT), dim3(64), 0, b);
-    if (br) chk(hipEventRecord(h->ev_join[fi][1], s1));
+    if (br) chk(hipEventRecord(h->ev_join[es][1], s1));
     const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
     if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4), dim3(64), 0, b);
     else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8), dim3(64), 0, b);
@@ -407,11 +407,11 @@ static bool enqueue_frame(nnn_batch *h, int parity, hipStream_t st, int fi, bool
     L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
     L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
     L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
-    if (br) chk(hipStreamWaitEvent(st, h->ev_join[fi][1], 0));
+    if (br) chk(hipStreamWaitEvent(st, h->ev_join[es][1], 0));
     wait_prev(CH_DBL);
     L.go(K_DOUBLING, k_doubling, dim3(Sp / 4), dim3(256), 0, b);
     mark(CH_DBL);
-    if (br) chk(hipStreamWaitEvent(st, h->ev_join[fi][0], 0));
+    if (br) chk(hipStreamWaitEvent(st, h->ev_join[es][0], 0));
     L.go(K_FFT_P, k_fft_p, dim3(Sp), dim3(64), 0, b, sp);
     wait_prev(CH_RNN);
     L.go(K_RNN, k_rnn, dim3(NT), dim3(64 * RNN_WAVES), h->rnn_lds, b, h->plan, h->wq, h->fpar);
@@ -423,17 +423,7 @@ static bool enqueue_frame(nnn_batch *h, int parity, hipStream_t st, int fi, bool
     return ok;
 }
 
-// PIPE_FRAMES consecutive frames (starting at an even frame) on two lanes, two frames in flight.
-static bool enqueue_pipeline(nnn_batch *h, hipStream_t st)
-{
-    bool ok = hipEventRecord(h->ev_lane, st) == hipSuccess;
-    ok = ok && hipStreamWaitEvent(h->lane1, h->ev_lane, 0) == hipSuccess;
-    for (int f = 0; f < PIPE_FRAMES && ok; f++) ok = enqueue_frame(h, f & 1, (f & 1) ? h->lane1 : st, f, true, false);
-    ok = ok && hipEventRecord(h->ev_lane_done, h->lane1) == hipSuccess;
-    ok = ok && hipStreamWaitEvent(st, h->ev_lane_done, 0) == hipSuccess;
-    return ok;
-}
-
+// captures body() on `st` and instantiates an executable graph from it
 template <class F> static hipGraphExec_t capture(hipStream_t st, F &&body)
 {
     hipGraph_t g = nullptr;
@@ -484,34 +474,33 @@ extern "C" int nnn_batch_process_device(nnn_batch *h, const float *d_in, float *
         hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, h->sp + (p0 ^ i), v);
     }
     const bool graph = h->use_graph && !h->profiling;
-    if (graph && (!h->g_single[0] || h->graph_stream != st)) {
-        for (int i = 0; i < 2; i++)
-            if (h->g_single[i]) { hipGraphExecDestroy(h->g_single[i]); h->g_single[i] = nullptr; }
-        if (h->g_pipe) { hipGraphExecDestroy(h->g_pipe); h->g_pipe = nullptr; }
-        for (int i = 0; i < 2; i++) h->g_single[i] = capture(st, [&] { return enqueue_frame(h, i, st, 0, false, false); });
-        if (h->g_single[0] && h->g_single[1]) h->graph_stream = st;
-        else h->use_graph = false;  // capture unsupported here: stay eager
-        h->pipe_failed = false;
-        (void)hipGetLastError();
-    }
-    if (graph && h->use_graph && h->use_pipeline && h->use_branches && !h->g_pipe && !h->pipe_failed &&
-        n_frames >= PIPE_FRAMES) {   // built on first use
-        h->g_pipe = capture(st, [&] { return enqueue_pipeline(h, st); });
-        if (!h->g_pipe) h->pipe_failed = true;
-        (void)hipGetLastError();
-    }
-    int left = n_frames;
-    while (left > 0) {
-        const int par = (int)(h->frame_count & 1);
-        if (graph && h->g_pipe && par == 0 && left >= PIPE_FRAMES) {
-            HIPCHK(hipGraphLaunch(h->g_pipe, st));
-            h->frame_count += PIPE_FRAMES;
-            left -= PIPE_FRAMES;
-        } else {
+    const bool pipe = h->use_pipeline && h->use_branches && !h->profiling && n_frames >= 2;
+    if (pipe) {
+        // Two frames in flight: even frames of the call on `st`, odd ones on lane1, cross-lane waits only at the
+        // recurrences.  Launched eagerly: replaying this shape as a captured multi-stream graph back to back crashes
+        // the ROCm 7.2 runtime, and the host cost (~15 launches + events per frame) stays below the GPU's frame interval.
+        bool ok = hipEventRecord(h->ev_lane, st) == hipSuccess && hipStreamWaitEvent(h->lane1, h->ev_lane, 0) == hipSuccess;
+        for (int f = 0; f < n_frames && ok; f++) {
+            const int par = (int)(h->frame_count & 1);
+            ok = enqueue_frame(h, par, (f & 1) ? h->lane1 : st, f, true, false);
+            h->frame_count += 1;
+        }
+        ok = ok && hipEventRecord(h->ev_lane_done, h->lane1) == hipSuccess && hipStreamWaitEvent(st, h->ev_lane_done, 0) == hipSuccess;
+        if (!ok) return fail("stream/event call failed while enqueueing pipelined frames: %s", hipGetErrorString(hipGetLastError()));
+    } else {
+        if (graph && (!h->g_single[0] || h->graph_stream != st)) {
+            for (int i = 0; i < 2; i++)
+                if (h->g_single[i]) { hipGraphExecDestroy(h->g_single[i]); h->g_single[i] = nullptr; }
+            for (int i = 0; i < 2; i++) h->g_single[i] = capture(st, [&] { return enqueue_frame(h, i, st, 0, false, false); });
+            if (h->g_single[0] && h->g_single[1]) h->graph_stream = st;
+            else h->use_graph = false;  // capture unsupported here: stay eager
+            (void)hipGetLastError();
+        }
+        for (int f = 0; f < n_frames; f++) {
+            const int par = (int)(h->frame_count & 1);
             if (graph && h->g_single[par]) HIPCHK(hipGraphLaunch(h->g_single[par], st));
             else enqueue_frame(h, par, st, 0, false, h->profiling);
             h->frame_count += 1;
-            left -= 1;
         }
     }
     HIPCHK(hipGetLastError());
@@ -667,12 +656,7 @@ extern "C" int nnn_batch_set_graph(nnn_batch *h, int on)
 extern "C" int nnn_batch_set_pipeline(nnn_batch *h, int on)
 {
     if (!h) return fail("null batch");
-    if ((on != 0) != h->use_pipeline) {
-        h->use_pipeline = on != 0;
-        if (h->g_pipe) { hipGraphExecDestroy(h->g_pipe); h->g_pipe = nullptr; }
-        for (int i = 0; i < 2; i++)
-            if (h->g_single[i]) { hipGraphExecDestroy(h->g_single[i]); h->g_single[i] = nullptr; }
-    }
+    h->use_pipeline = on != 0;
     return 0;
 }
 
