@@ -39,10 +39,9 @@ enum KernelId { K_HP, K_LPC, K_XCORR, K_BEST1, K_REFINE, K_BEST2, K_YY, K_DOUBLI
 static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_xcorr", "k_best1", "k_refine", "k_best2",
                                             "k_yy", "k_doubling", "k_fft_x", "k_fft_p", "k_rnn", "k_synth", "k_advance"};
 
-constexpr int PIPE_FRAMES = 2;   // event sets: one per frame lane
 
 struct nnn_batch {
-    Buffers b[2];                  // same state, two scratch sets: frame f works in set f & 1
+    Buffers b[NLANE];              // same state, NLANE scratch sets: frame f works in set f % NLANE
     ModelDims md;
     RnnPlan plan;
     const uint4 *wq = nullptr;     // packed bf16 weights (device)
@@ -52,18 +51,19 @@ struct nnn_batch {
     uint64_t frame_count = 0;
     std::vector<void *> allocs;     // everything hipMalloc'ed
     std::vector<std::pair<void *, size_t>> state_bufs;  // zeroed by reset
-    StepParams *sp = nullptr;       // device, [2]: launch parameters of the next even / odd frame
+    StepParams *sp = nullptr;       // device, [NLANE]: launch parameters of the next frame of each scratch set (graph mode)
+    StepParams *sp_tab = nullptr;   // device, per-frame parameter table of a pipelined call
+    int sp_tab_cap = 0;
     hipStream_t stream = nullptr;   // default launch stream
-    hipStream_t lane1 = nullptr;    // second frame lane of the pipelined graph
-    hipStream_t side[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // per lane: fft_x branch, yy branch
-    // one set of events per frame lane (set 0 also serves the single-frame graphs)
-    hipEvent_t ev_fork[PIPE_FRAMES][2] = {}, ev_join[PIPE_FRAMES][2] = {};
-    hipEvent_t ev_chain[PIPE_FRAMES][4] = {};  // hp, doubling, rnn, synth done (the cross-frame recurrences)
-    hipEvent_t ev_lane = nullptr, ev_lane_done = nullptr;
+    hipStream_t lanes[NLANE] = {};  // frame lanes 1.. of a pipelined call (lane 0 is the caller's stream)
+    hipStream_t side[2] = {nullptr, nullptr};   // branches of a stand-alone frame: fft_x, yy
+    hipEvent_t ev_fork[2] = {}, ev_join[2] = {};
+    hipEvent_t ev_chain[NLANE][4] = {};  // per lane: hp, doubling, rnn, synth done (the cross-frame recurrences)
+    hipEvent_t ev_lane = nullptr, ev_lane_done[NLANE] = {};
 
     size_t rnn_lds = 0;
     bool use_graph = true, use_pipeline = true;
-    hipGraphExec_t g_single[2] = {nullptr, nullptr};
+    hipGraphExec_t g_single[NLANE] = {};
     hipStream_t graph_stream = nullptr;  // stream the graphs were captured on
     bool use_branches = true;
     int xcorr_chunk = 0;            // lags per k_xcorr wave: 4, 8 or 16 (0 = by batch size); env NNN_XCORR_CHUNK
@@ -144,24 +144,23 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < NLANE; i++)
         if (h->g_single[i]) hipGraphExecDestroy(h->g_single[i]);
-    for (int l = 0; l < 2; l++)
-        for (int i = 0; i < 2; i++)
-            if (h->side[l][i]) hipStreamDestroy(h->side[l][i]);
-    for (int f = 0; f < PIPE_FRAMES; f++) {
-        for (int i = 0; i < 2; i++) {
-            if (h->ev_fork[f][i]) hipEventDestroy(h->ev_fork[f][i]);
-            if (h->ev_join[f][i]) hipEventDestroy(h->ev_join[f][i]);
-        }
+    for (int i = 0; i < 2; i++) {
+        if (h->side[i]) hipStreamDestroy(h->side[i]);
+        if (h->ev_fork[i]) hipEventDestroy(h->ev_fork[i]);
+        if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
+    }
+    for (int l = 0; l < NLANE; l++) {
         for (int i = 0; i < 4; i++)
-            if (h->ev_chain[f][i]) hipEventDestroy(h->ev_chain[f][i]);
+            if (h->ev_chain[l][i]) hipEventDestroy(h->ev_chain[l][i]);
+        if (h->ev_lane_done[l]) hipEventDestroy(h->ev_lane_done[l]);
+        if (h->lanes[l]) hipStreamDestroy(h->lanes[l]);
     }
     if (h->ev_lane) hipEventDestroy(h->ev_lane);
-    if (h->ev_lane_done) hipEventDestroy(h->ev_lane_done);
-    if (h->lane1) hipStreamDestroy(h->lane1);
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
+    if (h->sp_tab) hipFree(h->sp_tab);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -174,18 +173,16 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     HIPCHK(hipSetDevice(device));
     h->device = device;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&h->lane1, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_lane, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_lane_done, hipEventDisableTiming));
-
-    for (int l = 0; l < 2; l++)
-        for (int i = 0; i < 2; i++) HIPCHK(hipStreamCreateWithFlags(&h->side[l][i], hipStreamNonBlocking));
-    for (int f = 0; f < PIPE_FRAMES; f++) {
-        for (int i = 0; i < 2; i++) {
-            HIPCHK(hipEventCreateWithFlags(&h->ev_fork[f][i], hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&h->ev_join[f][i], hipEventDisableTiming));
-        }
-        for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_chain[f][i], hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_fork[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    }
+    for (int l = 0; l < NLANE; l++) {
+        if (l > 0) HIPCHK(hipStreamCreateWithFlags(&h->lanes[l], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_lane_done[l], hipEventDisableTiming));
+        for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_chain[l][i], hipEventDisableTiming));
     }
     if (const char *e = getenv("NNN_PIPELINE")) h->use_pipeline = atoi(e) != 0;
     if (const char *e = getenv("NNN_XCORR_CHUNK")) {
@@ -229,7 +226,7 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     HIPCHK(dalloc(h, &b.gru_v, Sp * md.nv, true));
     HIPCHK(dalloc(h, &b.gru_n, Sp * md.nn, true));
     HIPCHK(dalloc(h, &b.gru_dn, Sp * md.ndn, true));
-    HIPCHK(dalloc(h, &h->sp, 2, false));
+    HIPCHK(dalloc(h, &h->sp, NLANE, false));
     HIPCHK(dalloc(h, &b.stamps, 64, false));
     // tables
     std::vector<float> window, dct, tansig, bin_frac;
@@ -267,8 +264,8 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
         h->wq = (const uint4 *)dq;
         HIPCHK(upload(h, &h->fpar, fpar));
     }
-    h->b[1] = h->b[0];
-    for (int set = 0; set < 2; set++) {   // per-frame scratch (doubles as parity taps), one set per frame parity
+    for (int set = 1; set < NLANE; set++) h->b[set] = h->b[0];
+    for (int set = 0; set < NLANE; set++) {   // per-frame scratch (doubles as parity taps), one set per frame in flight
         Buffers &q = h->b[set];
         HIPCHK(dalloc(h, &q.xlp0, Sp, false));
         HIPCHK(dalloc(h, &q.lpc, Sp * 10, false));
@@ -364,42 +361,43 @@ struct Launcher {
 // so that frame f+1's front half overlaps frame f's back half.  With branches off (profiling) everything is
 // serial on `st`.
 enum { CH_HP, CH_DBL, CH_RNN, CH_SYN };
-// `fi` = index of the frame inside a pipelined call (0 for a stand-alone frame): frame fi runs on lane fi & 1 with
-// that lane's events and, when chained, waits for frame fi - 1 (other lane).  Returns false if a stream/event call failed.
-static bool enqueue_frame(nnn_batch *h, int parity, hipStream_t st, int fi, bool chain, bool prof)
+// One frame.  Stand-alone (`lane` < 0): on `st` with fft_x and yy on side branches, parameters in h->sp[set].
+// Pipelined (`lane` >= 0): frame on lane stream `st`, serial inside the frame (the other frames in flight provide
+// the overlap, and every event call costs host time), waits for the previous frame (lane `prev`) only at the true
+// recurrences -- biquad state, last pitch, RNN state + cepstral ring + last gains, overlap memory.
+// Returns false if a stream/event call failed.
+static bool enqueue_frame(nnn_batch *h, int set, hipStream_t st, const StepParams *sp, int lane, int prev, bool prof)
 {
-    const Buffers &b = h->b[parity];
+    const Buffers &b = h->b[set];
     const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad;
-    StepParams *spw = h->sp + parity;
-    const StepParams *sp = spw;
-    const bool br = h->use_branches && !prof;
-    const int lane = fi & 1, es = fi & 1;   // event set
-    hipStream_t s0 = br ? h->side[lane][0] : st, s1 = br ? h->side[lane][1] : st;
+    const bool chain = lane >= 0;
+    const bool br = h->use_branches && !prof && !chain;
+    hipStream_t s0 = br ? h->side[0] : st, s1 = br ? h->side[1] : st;
     Launcher L{h, st, prof}, L0{h, s0, prof}, L1{h, s1, prof};
     bool ok = true;
     auto chk = [&](hipError_t e) { ok = ok && e == hipSuccess; };
     auto wait_prev = [&](int which) {
-        if (chain && fi > 0) chk(hipStreamWaitEvent(st, h->ev_chain[es ^ 1][which], 0));
+        if (chain && prev >= 0) chk(hipStreamWaitEvent(st, h->ev_chain[prev][which], 0));
     };
     auto mark = [&](int which) {
-        if (chain) chk(hipEventRecord(h->ev_chain[es][which], st));
+        if (chain) chk(hipEventRecord(h->ev_chain[lane][which], st));
     };
     wait_prev(CH_HP);
     L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp);
     mark(CH_HP);
     if (br) {
-        chk(hipEventRecord(h->ev_fork[es][0], st));
-        chk(hipStreamWaitEvent(s0, h->ev_fork[es][0], 0));
+        chk(hipEventRecord(h->ev_fork[0], st));
+        chk(hipStreamWaitEvent(s0, h->ev_fork[0], 0));
     }
     L0.go(K_FFT_X, k_fft_x, dim3(Sp), dim3(64), 0, b, sp);
-    if (br) chk(hipEventRecord(h->ev_join[es][0], s0));
+    if (br) chk(hipEventRecord(h->ev_join[0], s0));
     L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp);
     if (br) {
-        chk(hipEventRecord(h->ev_fork[es][1], st));
-        chk(hipStreamWaitEvent(s1, h->ev_fork[es][1], 0));
+        chk(hipEventRecord(h->ev_fork[1], st));
+        chk(hipStreamWaitEvent(s1, h->ev_fork[1], 0));
     }
     L1.go(K_YY, k_yy, dim3(NT), dim3(64), 0, b);
-    if (br) chk(hipEventRecord(h->ev_join[es][1], s1));
+    if (br) chk(hipEventRecord(h->ev_join[1], s1));
     const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
     if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4), dim3(64), 0, b);
     else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8), dim3(64), 0, b);
@@ -407,11 +405,11 @@ static bool enqueue_frame(nnn_batch *h, int parity, hipStream_t st, int fi, bool
     L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
     L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
     L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
-    if (br) chk(hipStreamWaitEvent(st, h->ev_join[es][1], 0));
+    if (br) chk(hipStreamWaitEvent(st, h->ev_join[1], 0));
     wait_prev(CH_DBL);
     L.go(K_DOUBLING, k_doubling, dim3(Sp / 4), dim3(256), 0, b);
     mark(CH_DBL);
-    if (br) chk(hipStreamWaitEvent(st, h->ev_join[es][0], 0));
+    if (br) chk(hipStreamWaitEvent(st, h->ev_join[0], 0));
     L.go(K_FFT_P, k_fft_p, dim3(Sp), dim3(64), 0, b, sp);
     wait_prev(CH_RNN);
     L.go(K_RNN, k_rnn, dim3(NT), dim3(64 * RNN_WAVES), h->rnn_lds, b, h->plan, h->wq, h->fpar);
@@ -419,7 +417,7 @@ static bool enqueue_frame(nnn_batch *h, int parity, hipStream_t st, int fi, bool
     wait_prev(CH_SYN);
     L.go(K_SYNTH, k_synth, dim3(Sp), dim3(64), 0, b, sp);
     mark(CH_SYN);
-    L.go(K_ADVANCE, k_advance, dim3(1), dim3(1), 0, spw, 2);
+    if (!chain) L.go(K_ADVANCE, k_advance, dim3(1), dim3(1), 0, h->sp + set, (int)NLANE);
     return ok;
 }
 
@@ -460,46 +458,65 @@ extern "C" int nnn_batch_process_device(nnn_batch *h, const float *d_in, float *
     if (!d_in || !d_out) return fail("null buffer");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
-    // launch parameters of the next frame of each parity
-    const int p0 = (int)(h->frame_count & 1);
-    for (int i = 0; i < 2; i++) {
-        StepParams v;
-        v.in = d_in + (size_t)i * frame_stride;
-        v.out = d_out + (size_t)i * frame_stride;
-        v.vad = d_vad ? d_vad + (size_t)i * h->S : nullptr;
-        v.stream_stride = stream_stride;
-        v.frame_stride = frame_stride;
-        v.slot = (int)((h->frame_count + i) % NSLOT);
-        v.n_streams = h->S;
-        hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, h->sp + (p0 ^ i), v);
-    }
+    StepParams v0;
+    v0.in = d_in;
+    v0.out = d_out;
+    v0.vad = d_vad;
+    v0.stream_stride = stream_stride;
+    v0.frame_stride = frame_stride;
+    v0.slot = (int)(h->frame_count % NSLOT);
+    v0.n_streams = h->S;
     const bool graph = h->use_graph && !h->profiling;
     const bool pipe = h->use_pipeline && h->use_branches && !h->profiling && n_frames >= 2;
     if (pipe) {
-        // Two frames in flight: even frames of the call on `st`, odd ones on lane1, cross-lane waits only at the
-        // recurrences.  Launched eagerly: replaying this shape as a captured multi-stream graph back to back crashes
-        // the ROCm 7.2 runtime, and the host cost (~15 launches + events per frame) stays below the GPU's frame interval.
-        bool ok = hipEventRecord(h->ev_lane, st) == hipSuccess && hipStreamWaitEvent(h->lane1, h->ev_lane, 0) == hipSuccess;
-        for (int f = 0; f < n_frames && ok; f++) {
-            const int par = (int)(h->frame_count & 1);
-            ok = enqueue_frame(h, par, (f & 1) ? h->lane1 : st, f, true, false);
+        // Up to NLANE frames in flight: frame t of the call on lane t % NLANE (lane 0 = `st`), cross-lane waits only at
+        // the recurrences.  Launched eagerly (replaying this shape as a captured multi-stream graph back to back crashes
+        // the ROCm 7.2 runtime); the per-frame parameters come from a table filled by one small kernel.
+        if (n_frames > h->sp_tab_cap) {
+            HIPCHK(hipStreamSynchronize(st));
+            if (h->sp_tab) HIPCHK(hipFree(h->sp_tab));
+            h->sp_tab = nullptr;
+            h->sp_tab_cap = 0;
+            HIPCHK(hipMalloc((void **)&h->sp_tab, (size_t)n_frames * sizeof(StepParams)));
+            h->sp_tab_cap = n_frames;
+        }
+        hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, st, h->sp_tab, v0, n_frames);
+        const int nl = n_frames < NLANE ? n_frames : NLANE;
+        bool ok = hipEventRecord(h->ev_lane, st) == hipSuccess;
+        for (int l = 1; l < nl && ok; l++) ok = hipStreamWaitEvent(h->lanes[l], h->ev_lane, 0) == hipSuccess;
+        for (int t = 0; t < n_frames && ok; t++) {
+            const int lane = t % NLANE, set = (int)(h->frame_count % NLANE);
+            ok = enqueue_frame(h, set, lane ? h->lanes[lane] : st, h->sp_tab + t, lane, t > 0 ? (t - 1) % NLANE : -1, false);
             h->frame_count += 1;
         }
-        ok = ok && hipEventRecord(h->ev_lane_done, h->lane1) == hipSuccess && hipStreamWaitEvent(st, h->ev_lane_done, 0) == hipSuccess;
+        for (int l = 1; l < nl && ok; l++)
+            ok = hipEventRecord(h->ev_lane_done[l], h->lanes[l]) == hipSuccess && hipStreamWaitEvent(st, h->ev_lane_done[l], 0) == hipSuccess;
         if (!ok) return fail("stream/event call failed while enqueueing pipelined frames: %s", hipGetErrorString(hipGetLastError()));
     } else {
+        // parameters of the next frame of each scratch set, stepped on the device after every frame
+        for (int i = 0; i < NLANE; i++) {
+            StepParams v = v0;
+            v.in = d_in + (size_t)i * frame_stride;
+            v.out = d_out + (size_t)i * frame_stride;
+            v.vad = d_vad ? d_vad + (size_t)i * h->S : nullptr;
+            v.slot = (int)((h->frame_count + i) % NSLOT);
+            hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, h->sp + (int)((h->frame_count + i) % NLANE), v);
+        }
         if (graph && (!h->g_single[0] || h->graph_stream != st)) {
-            for (int i = 0; i < 2; i++)
+            bool all = true;
+            for (int i = 0; i < NLANE; i++) {
                 if (h->g_single[i]) { hipGraphExecDestroy(h->g_single[i]); h->g_single[i] = nullptr; }
-            for (int i = 0; i < 2; i++) h->g_single[i] = capture(st, [&] { return enqueue_frame(h, i, st, 0, false, false); });
-            if (h->g_single[0] && h->g_single[1]) h->graph_stream = st;
+                h->g_single[i] = capture(st, [&] { return enqueue_frame(h, i, st, h->sp + i, -1, -1, false); });
+                all = all && h->g_single[i];
+            }
+            if (all) h->graph_stream = st;
             else h->use_graph = false;  // capture unsupported here: stay eager
             (void)hipGetLastError();
         }
         for (int f = 0; f < n_frames; f++) {
-            const int par = (int)(h->frame_count & 1);
-            if (graph && h->g_single[par]) HIPCHK(hipGraphLaunch(h->g_single[par], st));
-            else enqueue_frame(h, par, st, 0, false, h->profiling);
+            const int set = (int)(h->frame_count % NLANE);
+            if (graph && h->use_graph && h->g_single[set]) HIPCHK(hipGraphLaunch(h->g_single[set], st));
+            else enqueue_frame(h, set, st, h->sp + set, -1, -1, h->profiling);
             h->frame_count += 1;
         }
     }
@@ -549,7 +566,7 @@ extern "C" int nnn_batch_process_host(nnn_batch *h, const float *in, float *out,
 struct TapDesc { int len; int is_int; int layout; /* 0 TI, 1 SM float, 2 SM float2, 3 hist ring */ int sub_ofs; int sub_len; };
 static bool tap_desc(const nnn_batch *h, int tap, TapDesc &d, const void **ptr)
 {
-    const Buffers *b = h ? &h->b[(h->frame_count + 1) & 1] : nullptr;   // scratch set of the most recent frame
+    const Buffers *b = h ? &h->b[(h->frame_count + NLANE - 1) % NLANE] : nullptr;   // scratch set of the most recent frame
 #define TP(field) (b ? (const void *)b->field : nullptr)
     switch (tap) {
     case NNN_TAP_FILTERED: d = {FRAME, 0, 3, 0, FRAME}; *ptr = TP(hist); return true;

@@ -1627,6 +1627,18 @@ __global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
 // Launch-parameter bookkeeping (one thread each): set at the start of a process call, stepped
 // after every frame so the captured graph of one frame can be replayed unchanged.
 __global__ void k_set_params(StepParams *sp, StepParams v) { *sp = v; }
+// per-frame parameter table of a pipelined call: entry t describes frame t of the call (v = frame 0)
+__global__ void k_fill_params(StepParams *tab, StepParams v, int n)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    StepParams p = v;
+    p.in = v.in + (size_t)t * v.frame_stride;
+    p.out = v.out + (size_t)t * v.frame_stride;
+    p.vad = v.vad ? v.vad + (size_t)t * v.n_streams : nullptr;
+    p.slot = (v.slot + t) % NSLOT;
+    tab[t] = p;
+}
 __global__ void k_advance(StepParams *sp, int nstep)
 {
     sp->in += (size_t)nstep * sp->frame_stride;

@@ -22,8 +22,9 @@ constexpr int NB = 22;            // src/lib.rs:49
 constexpr int NFEAT = 42;         // src/lib.rs:53
 constexpr int CEPS_MEM = 8;       // src/lib.rs:50
 constexpr int HIST = 1728;        // PITCH_BUF_SIZE, src/lib.rs:46
-constexpr int NSLOT = 5;          // ring slots: 4 cover the 1728-sample history, the 5th lets the next frame's
-                                  // high-pass run while this frame is still being analysed (two frames in flight)
+constexpr int NLANE = 4;          // frames in flight in a multi-frame call (frame lanes / scratch sets)
+constexpr int NSLOT = 3 + NLANE;  // ring slots: 4 cover the 1728-sample history of a frame, one more per extra frame in
+                                  // flight so that a later frame's high-pass never overwrites what an earlier one reads
 constexpr int RING = NSLOT * 480; // history ring instead of the reference's memmove
 constexpr int XLP = 864;          // HIST / 2
 constexpr int PITCH_MIN = 60, PITCH_MAX = 768;
