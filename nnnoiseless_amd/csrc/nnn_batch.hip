@@ -64,6 +64,8 @@ struct nnn_batch {
     size_t rnn_lds = 0;
     bool use_graph = true, use_pipeline = true;
     hipGraphExec_t g_single[NLANE] = {};
+    hipGraphExec_t g_front[NLANE] = {};   // per scratch set: fft_x, lpc, yy, xcorr, best1, refine, best2 (pipelined calls)
+    bool front_failed = false;
     hipStream_t graph_stream = nullptr;  // stream the graphs were captured on
     bool use_branches = true;
     int xcorr_chunk = 0;            // lags per k_xcorr wave: 4, 8 or 16 (0 = by batch size); env NNN_XCORR_CHUNK
@@ -144,8 +146,10 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    for (int i = 0; i < NLANE; i++)
+    for (int i = 0; i < NLANE; i++) {
         if (h->g_single[i]) hipGraphExecDestroy(h->g_single[i]);
+        if (h->g_front[i]) hipGraphExecDestroy(h->g_front[i]);
+    }
     for (int i = 0; i < 2; i++) {
         if (h->side[i]) hipStreamDestroy(h->side[i]);
         if (h->ev_fork[i]) hipEventDestroy(h->ev_fork[i]);
@@ -383,29 +387,34 @@ static bool enqueue_frame(nnn_batch *h, int set, hipStream_t st, const StepParam
         if (chain) chk(hipEventRecord(h->ev_chain[lane][which], st));
     };
     wait_prev(CH_HP);
-    L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp);
+    const bool replay_front = chain && h->g_front[set] != nullptr;
+    L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp, replay_front ? h->sp + set : (StepParams *)nullptr);
     mark(CH_HP);
-    if (br) {
-        chk(hipEventRecord(h->ev_fork[0], st));
-        chk(hipStreamWaitEvent(s0, h->ev_fork[0], 0));
+    if (replay_front) {
+        chk(hipGraphLaunch(h->g_front[set], st));   // the seven kernels below as one replayed single-stream graph
+    } else {
+        if (br) {
+            chk(hipEventRecord(h->ev_fork[0], st));
+            chk(hipStreamWaitEvent(s0, h->ev_fork[0], 0));
+        }
+        L0.go(K_FFT_X, k_fft_x, dim3(Sp), dim3(64), 0, b, sp);
+        if (br) chk(hipEventRecord(h->ev_join[0], s0));
+        L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp);
+        if (br) {
+            chk(hipEventRecord(h->ev_fork[1], st));
+            chk(hipStreamWaitEvent(s1, h->ev_fork[1], 0));
+        }
+        L1.go(K_YY, k_yy, dim3(NT), dim3(64), 0, b);
+        if (br) chk(hipEventRecord(h->ev_join[1], s1));
+        const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
+        if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4), dim3(64), 0, b);
+        else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8), dim3(64), 0, b);
+        else L.go(K_XCORR, k_xcorr<16>, dim3(NT, (NLAG1 + 15) / 16), dim3(64), 0, b);
+        L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
+        L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
+        L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
+        if (br) chk(hipStreamWaitEvent(st, h->ev_join[1], 0));
     }
-    L0.go(K_FFT_X, k_fft_x, dim3(Sp), dim3(64), 0, b, sp);
-    if (br) chk(hipEventRecord(h->ev_join[0], s0));
-    L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp);
-    if (br) {
-        chk(hipEventRecord(h->ev_fork[1], st));
-        chk(hipStreamWaitEvent(s1, h->ev_fork[1], 0));
-    }
-    L1.go(K_YY, k_yy, dim3(NT), dim3(64), 0, b);
-    if (br) chk(hipEventRecord(h->ev_join[1], s1));
-    const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
-    if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4), dim3(64), 0, b);
-    else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8), dim3(64), 0, b);
-    else L.go(K_XCORR, k_xcorr<16>, dim3(NT, (NLAG1 + 15) / 16), dim3(64), 0, b);
-    L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
-    L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
-    L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
-    if (br) chk(hipStreamWaitEvent(st, h->ev_join[1], 0));
     wait_prev(CH_DBL);
     L.go(K_DOUBLING, k_doubling, dim3(Sp / 4), dim3(256), 0, b);
     mark(CH_DBL);
@@ -419,6 +428,26 @@ static bool enqueue_frame(nnn_batch *h, int set, hipStream_t st, const StepParam
     mark(CH_SYN);
     if (!chain) L.go(K_ADVANCE, k_advance, dim3(1), dim3(1), 0, h->sp + set, (int)NLANE);
     return ok;
+}
+
+// the pitch-front segment of a pipelined frame (serial, single stream), parameters read from h->sp[set]
+static bool enqueue_front(nnn_batch *h, int set, hipStream_t st)
+{
+    const Buffers &b = h->b[set];
+    const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad;
+    const StepParams *sp = h->sp + set;
+    Launcher L{h, st, false};
+    L.go(K_FFT_X, k_fft_x, dim3(Sp), dim3(64), 0, b, sp);
+    L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp);
+    L.go(K_YY, k_yy, dim3(NT), dim3(64), 0, b);
+    const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
+    if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4), dim3(64), 0, b);
+    else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8), dim3(64), 0, b);
+    else L.go(K_XCORR, k_xcorr<16>, dim3(NT, (NLAG1 + 15) / 16), dim3(64), 0, b);
+    L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
+    L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
+    L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
+    return true;
 }
 
 // captures body() on `st` and instantiates an executable graph from it
@@ -479,6 +508,19 @@ extern "C" int nnn_batch_process_device(nnn_batch *h, const float *d_in, float *
             h->sp_tab_cap = 0;
             HIPCHK(hipMalloc((void **)&h->sp_tab, (size_t)n_frames * sizeof(StepParams)));
             h->sp_tab_cap = n_frames;
+        }
+        if (h->use_graph && !h->g_front[0] && !h->front_failed) {   // built on first use
+            bool all = true;
+            for (int i = 0; i < NLANE && all; i++) {
+                h->g_front[i] = capture(st, [&] { return enqueue_front(h, i, st); });
+                all = h->g_front[i] != nullptr;
+            }
+            if (!all) {
+                for (int i = 0; i < NLANE; i++)
+                    if (h->g_front[i]) { hipGraphExecDestroy(h->g_front[i]); h->g_front[i] = nullptr; }
+                h->front_failed = true;
+            }
+            (void)hipGetLastError();
         }
         hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, st, h->sp_tab, v0, n_frames);
         const int nl = n_frames < NLANE ? n_frames : NLANE;

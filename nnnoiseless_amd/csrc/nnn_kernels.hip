@@ -41,8 +41,10 @@ __constant__ int kSecondCheck[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3
 //     lane = stream; the 480-step recurrence is inherently serial per stream.  Input and history are
 //     stream-major, so 64x32 tiles are transposed through LDS to keep every global access coalesced.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp)
+__global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp, StepParams *publish)
 {
+    // pipelined calls: the frame's parameters are republished where this frame's replayed graph segment reads them
+    if (publish && blockIdx.x == 0 && threadIdx.x == 0) *publish = *sp;
     const float *in = sp->in;
     const size_t stream_stride = sp->stream_stride;
     const int slot = sp->slot;
