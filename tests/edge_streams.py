@@ -1,0 +1,54 @@
+"""Edge-case inputs for parity tests: each exercises a branch the synthetic sine+noise mix rarely reaches."""
+import numpy as np
+
+
+def make_edge_streams(n_frames):
+    n = n_frames * 480
+    t = np.arange(n)
+    rng = np.random.default_rng(12345)
+    s = []
+    s.append(np.where((t // 55) % 2 == 0, 32767.0, -32768.0))                 # full-scale square wave (i16 limits)
+    s.append(np.full(n, 10000.0))                                             # DC: the high-pass must kill it
+    imp = np.zeros(n); imp[::4801] = 30000.0; s.append(imp)                    # sparse impulses
+    s.append(rng.integers(-1, 2, n).astype(np.float64))                       # +-1 LSB noise: energies near the >= 1 clamps
+    burst = np.zeros(n); on = (t // 2400) % 2 == 1                            # silence / tone bursts: onsets, e < 0.04 gate toggling
+    burst[on] = 8000.0 * np.sin(2 * np.pi * 220.0 * t[on] / 48000.0); s.append(burst)
+    s.append(12000.0 * np.sin(2 * np.pi * 48000.0 / 61.0 * t / 48000.0))      # period ~61 samples: the PITCH_MIN_PERIOD floor
+    s.append(9000.0 * np.sin(2 * np.pi * 63.0 * t / 48000.0))                 # period ~762: the PITCH_MAX_PERIOD end
+    sweep = 6000.0 * np.sin(2 * np.pi * (100.0 + 900.0 * t / n) * t / 48000.0); s.append(sweep)  # chirp: pitch doubling logic
+    s.append(np.clip(40000.0 * rng.standard_normal(n), -32768, 32767))        # clipped loud noise
+    s.append(np.zeros(n))                                                     # digital silence
+    x = np.round(np.stack(s)).astype(np.float32)
+    return x.reshape(len(s), n_frames, 480)
+
+
+def oracle_reference(oracle_mod, weights_bytes, x, margin=2e-3):
+    """Oracle outputs plus a per-(stream, frame) mask of frames on which the REFERENCE itself is ill-conditioned.
+
+    pitch_filter (ref: src/denoise.rs:365-402) picks r = 1 when exp > g and the closed form otherwise; when both
+    are ~1 (a pure tone the network passes unattenuated) the closed form gives r ~ 0, so the branch is a jump
+    discontinuity and f32 rounding noise in the FFT decides which side a frame lands on: the oracle's own f32-FFT
+    and f64-FFT builds disagree by >1e-2 of full scale there.  Such a frame (and the next one, through the
+    overlap-add memory) is excused from the AUDIO comparison only; pitch, vad and gains are still checked.
+    """
+    n_s, n_f = x.shape[:2]
+    out = np.empty_like(x)
+    vad = np.empty((n_s, n_f), np.float32)
+    pitch = np.empty((n_s, n_f), np.int32)
+    gains = np.empty((n_s, n_f, 22), np.float32)
+    ill = np.zeros((n_s, n_f), bool)
+    model = oracle_mod.Model(weights_bytes)
+    for s in range(n_s):
+        st = oracle_mod.State(model)
+        for t in range(n_f):
+            out[s, t], vad[s, t] = st.process_frame(x[s, t])
+            tp = st.taps()
+            pitch[s, t] = tp["pitch_idx"]
+            gains[s, t] = tp["g"]
+            e, g = tp["exp_"].astype(np.float64), tp["g"].astype(np.float64)
+            jump = 1.0 - e * e * (1.0 - g * g) / (0.001 + g * g * (1.0 - e * e))   # 1 - closed form, at the branch point
+            if not tp["silence"] and np.any((np.abs(e - g) < margin) & (jump > 0.01)):
+                ill[s, t] = True
+                if t + 1 < n_f:
+                    ill[s, t + 1] = True
+    return {"out": out, "vad": vad, "pitch": pitch, "g": gains, "ill": ill}

@@ -41,3 +41,53 @@ def test_aggregate_world2():
         p.join(60)
         assert p.exitcode == 0
     assert res == [(0, 1000.0, 2.0), (1, 1000.0, 2.0)]  # sum of frames, max of elapsed
+
+
+def _shard_worker(rank, world, port, q, lib_path):
+    """One rank of the sharded data path: its block of streams through the kernels (CPU SIMT interpreter build of
+    the product sources, tests/hostsim), outputs gathered to rank 0.  No data-path collective."""
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd import _ffi
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(77, 7, 3)                       # every rank derives the same global input, keeps its block
+    lo, hi = shard_range(7, rank, world)
+    bd = nn.BatchDenoiser(hi - lo, lib=_ffi.Library(lib_path))
+    out, vad = bd.process(x[lo:hi])
+    got = [None] * world
+    dist.all_gather_object(got, (lo, hi, out, vad))
+    frames, _ = aggregate(dist, (hi - lo) * 3, 1.0)
+    if rank == 0:
+        q.put((got, frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_streams_match_unsharded_world2():
+    """A stream's result must not depend on which rank owns it or where it sits in a 64-stream tile."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "hostsim"))
+    import build_hostsim
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd import _ffi
+    from nnnoiseless_amd.synthetic import make_streams
+    lib_path = build_hostsim.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q, lib_path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, frames = q.get(timeout=600)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    x = make_streams(77, 7, 3)
+    out, vad = nn.BatchDenoiser(7, lib=_ffi.Library(lib_path)).process(x)
+    assert frames == 21.0
+    assert [(lo, hi) for lo, hi, _, _ in got] == [(0, 4), (4, 7)]
+    assert np.array_equal(np.concatenate([g[2] for g in got]), out)
+    assert np.array_equal(np.concatenate([g[3] for g in got], axis=1), vad)

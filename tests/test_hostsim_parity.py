@@ -107,3 +107,42 @@ def test_xcorr_chunk_variants_bit_identical(hostsim_lib, monkeypatch, chunk):
     other = nn.BatchDenoiser(3, lib=hostsim_lib)
     other.process(x)
     assert np.array_equal(other.tap("xcorr1").view(np.uint32), want.view(np.uint32))
+
+
+def test_edge_case_inputs(hostsim_lib, oracle_mod, weights_bytes):
+    """Full scale, DC, impulses, +-1 LSB noise, onsets, pitch-range ends, chirp, clipped noise, silence."""
+    import nnnoiseless_amd as nn
+    from edge_streams import make_edge_streams, oracle_reference
+    x = make_edge_streams(12)
+    ref = oracle_reference(oracle_mod, weights_bytes, x)
+    bd = nn.BatchDenoiser(x.shape[0], lib=hostsim_lib)
+    out = np.empty_like(x)
+    for t in range(x.shape[1]):
+        o, v = bd.process(x[:, t:t + 1])
+        out[:, t] = o[:, 0]
+        assert np.array_equal(bd.tap("pitch")[:, 0], ref["pitch"][:, t]), t
+        assert np.abs(v[0] - ref["vad"][:, t]).max() < 1e-4
+        assert np.abs(bd.tap("g") - ref["g"][:, t]).max() < 1e-3   # oracle f32-vs-f64 FFT spread here is ~2e-4
+    scale = np.maximum(np.abs(ref["out"]).max(axis=(1, 2)), 1.0)[:, None]
+    err = np.abs(out - ref["out"]).max(axis=2) / scale
+    # 1e-4 of the stream's peak on every frame the reference itself is well conditioned on (see oracle_reference);
+    # a sanity bound on the few frames where its pitch-filter branch is decided by rounding noise
+    assert err[~ref["ill"]].max() <= 1e-4, np.argwhere((err > 1e-4) & ~ref["ill"])
+    assert err.max() <= 5e-2
+    assert ref["ill"].mean() < 0.2
+
+
+def test_long_run_ring_wrap(hostsim_lib, oracle_mod, weights_bytes):
+    """150 frames (the 7-slot rings wrap 21 times) in uneven multi-frame calls."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(200, 3, 150)
+    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x)
+    bd = nn.BatchDenoiser(3, lib=hostsim_lib)
+    outs, pos = [], 0
+    for n in (1, 7, 13, 2, 40, 5, 82):
+        outs.append(bd.process(x[:, pos:pos + n])[0])
+        pos += n
+    out = np.concatenate(outs, axis=1)
+    assert np.array_equal(bd.tap("pitch")[:, 0], ref["pitch"][:, -1])
+    assert rel_rms(out[:, 1:], ref["out"][:, 1:]) < 1e-5
