@@ -85,6 +85,10 @@ def main():
     ap.add_argument("--streams", type=int, default=4096, help="concurrent streams PER GPU")
     ap.add_argument("--frames-per-step", type=int, default=16)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--pcm", choices=["f32", "i16", "unit"], default="f32",
+                    help="boundary sample format (SURVEY 8(f) #1): f32 = process_frame's own (headline), i16 = the CLI's "
+                         "packed int16, unit = DenoiseSignal's [-1, 1] floats")
+    ap.add_argument("--channels", type=int, default=1, help="interleaved channels per group (with --pcm i16/unit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -111,21 +115,35 @@ def main():
     while S * pool * 480 * 4 > 6e9 and pool > 8:
         pool //= 2
     x_host = make_streams_fast(S, pool, seed=rank)
-    x = torch.from_numpy(x_host).to(dev)              # [S][pool][480], resident in HBM
+    fmt = {"f32": 0, "i16": 1, "unit": 2}[args.pcm]
+    Cc = args.channels
+    assert S % Cc == 0
+    if fmt or Cc > 1:   # packed PCM: [groups][pool * 480][channels], channel-interleaved
+        x_host = x_host.reshape(S // Cc, Cc, pool * 480).transpose(0, 2, 1)
+        x_host = np.ascontiguousarray(x_host.astype(np.int16) if fmt == 1 else (x_host / 32768.0 if fmt == 2 else x_host))
+    x = torch.from_numpy(x_host).to(dev)              # resident in HBM
     y = torch.empty_like(x)
     vad = torch.empty((pool, S), dtype=torch.float32, device=dev)
     del x_host
+    esz = x.element_size()
     bd = nn.BatchDenoiser(S, device=local_rank)
     bd.set_graph(not args.no_graph)
     stream = torch.cuda.current_stream().cuda_stream
 
+    def run(f0, n):   # n frames of every stream starting at frame f0 of the pool
+        off = f0 * 480 * Cc * esz
+        if fmt or Cc > 1:
+            bd.process_pcm_device(x.data_ptr() + off, y.data_ptr() + off, vad.data_ptr() + f0 * S * 4, n, fmt, Cc,
+                                  pool * 480 * Cc, 480 * Cc, False, stream)
+        else:
+            bd.process_device(x.data_ptr() + off, y.data_ptr() + off, vad.data_ptr() + f0 * S * 4, n, pool * 480, 480, stream)
+
     def step(i):
         f0 = (i * fps) % pool
         n = min(fps, pool - f0)  # a step never wraps inside the pool unless fps does not divide it
-        bd.process_device(x.data_ptr() + f0 * 480 * 4, y.data_ptr() + f0 * 480 * 4, vad.data_ptr() + f0 * S * 4,
-                          n, pool * 480, 480, stream)
+        run(f0, n)
         if n < fps:
-            bd.process_device(x.data_ptr(), y.data_ptr(), vad.data_ptr(), fps - n, pool * 480, 480, stream)
+            run(0, fps - n)
 
     def barrier():
         torch.cuda.synchronize()
@@ -144,7 +162,7 @@ def main():
     frames_done, elapsed_max = aggregate(dist if world > 1 else None, S * fps * K, elapsed, dev)
     ms_per_step = elapsed_max * 1e3 / K
     value = frames_done / elapsed_max
-    finite = bool(torch.isfinite(y).all().item())
+    finite = bool(torch.isfinite(y.float()).all().item())
 
     # the same workload at one frame per call (live 10 ms tick): no frames in flight, one graph replay per frame
     tick = None
@@ -152,9 +170,7 @@ def main():
         kt = min(200, max(20, K * fps // 4))
         pos = (W + K) * fps
         def tick_step(j):
-            f0 = (pos + j) % pool
-            bd.process_device(x.data_ptr() + f0 * 480 * 4, y.data_ptr() + f0 * 480 * 4, vad.data_ptr() + f0 * S * 4,
-                              1, pool * 480, 480, stream)
+            run((pos + j) % pool, 1)
         for j in range(10):
             tick_step(j)
         barrier()
@@ -174,9 +190,7 @@ def main():
         kp = min(K, 50)
         t1 = time.perf_counter()
         for i in range(W + K, W + K + kp):
-            f0 = (i * fps) % pool
-            bd.process_device(x.data_ptr() + f0 * 480 * 4, y.data_ptr() + f0 * 480 * 4, vad.data_ptr() + f0 * S * 4,
-                              1, pool * 480, 480, stream)
+            run((i * fps) % pool, 1)
         torch.cuda.synchronize()
         prof_ms_per_step = (time.perf_counter() - t1) * 1e3 / kp   # per FRAME: the instrumented pass runs single frames
         times = bd.kernel_times()
@@ -213,6 +227,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{S} concurrent mono streams per GPU, built-in weights.rnn, synthetic 48 kHz sine+noise "
                                    f"(BASELINE.json configs[1]), {fps} frame(s) per stream per step",
+                       "boundary_format": {"f32": "f32 planar (process_frame's own)", "i16": "packed int16",
+                                           "unit": "unit-range f32"}[args.pcm] + (f", {Cc} interleaved channels" if Cc > 1 else ""),
                        "streams_per_gpu": S, "streams_total": S * world, "frames_per_step": fps,
                        "launch": ("up to 4 frames in flight on 4 HIP streams, pitch-front segment replayed as a hipGraph"
                                   if fps > 1 else ("eager" if args.no_graph else "one hipGraph replay per frame")),

@@ -56,6 +56,35 @@ int nnn_batch_process_device(nnn_batch *b, const float *d_in, float *d_out, floa
 /* Same with host buffers (copies over PCIe, synchronous). */
 int nnn_batch_process_host(nnn_batch *b, const float *in, float *out, float *vad, int n_frames,
                            size_t stream_stride, size_t frame_stride);
+
+/*
+ * The same with the sample formats and channel interleave of the reference's callers fused into the first and last
+ * kernels, so a CLI / DenoiseSignal style per-channel loop is ONE batched call on packed PCM:
+ *   NNN_PCM_F32       floats in i16 range, what process_frame itself takes (src/denoise.rs:86-90)
+ *   NNN_PCM_I16       int16 in; out = round-half-away(clamp(x, -32768, 32767)) as the CLI's frame writers do
+ *                     (src/nnnoiseless.rs:147-177)
+ *   NNN_PCM_F32_UNIT  floats in [-1, 1]: in * 32768, out = clamp(x / 32768, -1, 1)  (DenoiseSignal,
+ *                     src/signal.rs:95-100 and :123-127)
+ * Streams are `channels`-interleaved groups: stream s is channel s % channels of group s / channels, and
+ *   sample i of frame t of stream s = buf[(s / channels) * group_stride + t * frame_stride + i * channels + s % channels]
+ * in ELEMENTS of the format (a C-channel 16-bit file is one group with frame_stride = 480 * C).  n_streams must be a
+ * multiple of channels.  discard_first != 0 reproduces the callers' dropped first frame (src/nnnoiseless.rs:322-330,
+ * src/signal.rs:83-87): if the batch has processed no frame since create/reset, frame 0 produces no audio and the
+ * call writes n_frames - 1 frames starting at frame position 0 of d_out.  VAD values are written for every frame.
+ */
+enum nnn_pcm_format { NNN_PCM_F32 = 0, NNN_PCM_I16 = 1, NNN_PCM_F32_UNIT = 2 };
+typedef struct nnn_pcm_layout {
+    int format;          /* enum nnn_pcm_format */
+    int channels;
+    int discard_first;
+    int reserved;        /* 0 */
+    size_t group_stride; /* elements */
+    size_t frame_stride; /* elements, >= 480 * channels */
+} nnn_pcm_layout;
+int nnn_batch_process_pcm_device(nnn_batch *b, const void *d_in, void *d_out, float *d_vad, int n_frames,
+                                 const nnn_pcm_layout *layout, void *hip_stream);
+int nnn_batch_process_pcm_host(nnn_batch *b, const void *in, void *out, float *vad, int n_frames,
+                               const nnn_pcm_layout *layout);
 int nnn_batch_synchronize(nnn_batch *b);
 
 /* Parity taps: intermediate quantities of the most recent frame, copied to the host as

@@ -77,6 +77,7 @@ class BatchDenoiser:
         self._h = self._lib.L.nnn_batch_create(model._h if model is not None else None, self.n_streams, device)
         if not self._h:
             raise RuntimeError("nnnoiseless_amd: " + self._lib.error())
+        self.frames_done = 0
 
     def process(self, x):
         """x: float32 [n_streams, n_frames, 480] on the host -> (out same shape, vad [n_frames, n_streams])."""
@@ -87,18 +88,45 @@ class BatchDenoiser:
         vad = np.empty((T, S), np.float32)
         self._lib.check(self._lib.L.nnn_batch_process_host(self._h, _ffi.ptr(x), _ffi.ptr(out), _ffi.ptr(vad), T,
                                                            T * FRAME_SIZE, FRAME_SIZE))
+        self.frames_done += T
         return out, vad
+
+    def process_pcm(self, x, fmt, channels=1, discard_first=False):
+        """Packed PCM in the reference callers' formats, x: [n_groups, n_frames * 480, channels] (int16 for PCM_I16,
+        float32 otherwise), n_groups * channels == n_streams.  Returns (out [n_groups, n_out_frames * 480, channels],
+        vad [n_frames, n_streams]); n_out_frames = n_frames - 1 if discard_first drops the first frame after a reset."""
+        x = np.ascontiguousarray(x, dtype=_ffi.PCM_DTYPE[fmt])
+        G, N, Cc = x.shape
+        assert Cc == channels and G * channels == self.n_streams and N % FRAME_SIZE == 0
+        T = N // FRAME_SIZE
+        out = np.zeros_like(x)
+        vad = np.empty((T, self.n_streams), np.float32)
+        L = _ffi.PcmLayout(fmt, channels, int(bool(discard_first)), 0, N * channels, FRAME_SIZE * channels)
+        fresh = self.frames_done == 0
+        self._lib.check(self._lib.L.nnn_batch_process_pcm_host(self._h, _ffi.ptr(x), _ffi.ptr(out), _ffi.ptr(vad), T, C.byref(L)))
+        self.frames_done += T
+        n_out = T - 1 if (discard_first and fresh) else T
+        return out[:, :n_out * FRAME_SIZE], vad
 
     def process_device(self, d_in, d_out, d_vad, n_frames, stream_stride, frame_stride, hip_stream=0):
         """Raw device pointers (ints); asynchronous on hip_stream (0 = the batch's own stream)."""
         self._lib.check(self._lib.L.nnn_batch_process_device(self._h, d_in, d_out, d_vad, n_frames, stream_stride,
                                                              frame_stride, hip_stream))
+        self.frames_done += n_frames
+
+    def process_pcm_device(self, d_in, d_out, d_vad, n_frames, fmt, channels, group_stride, frame_stride, discard_first=False,
+                           hip_stream=0):
+        """Raw device pointers, strides in elements of the format (include/nnn_batch.h); asynchronous."""
+        L = _ffi.PcmLayout(fmt, channels, int(bool(discard_first)), 0, group_stride, frame_stride)
+        self._lib.check(self._lib.L.nnn_batch_process_pcm_device(self._h, d_in, d_out, d_vad, n_frames, C.byref(L), hip_stream))
+        self.frames_done += n_frames
 
     def synchronize(self):
         self._lib.check(self._lib.L.nnn_batch_synchronize(self._h))
 
     def reset(self):
         self._lib.check(self._lib.L.nnn_batch_reset(self._h))
+        self.frames_done = 0
 
     def tap(self, name):
         """Intermediate quantity of the most recent frame as [n_streams, len] (parity checks)."""

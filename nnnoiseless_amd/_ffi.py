@@ -13,7 +13,8 @@ TAPS = ["filtered", "xlp", "ac", "lpc2", "xcorr1", "best1", "xcorr2c", "pitch_se
 BATCH_SYMBOLS = [
     "nnn_model_from_bytes", "nnn_model_default", "nnn_model_free", "nnn_model_shape",
     "nnn_batch_create", "nnn_batch_destroy", "nnn_batch_num_streams", "nnn_batch_reset",
-    "nnn_batch_process_device", "nnn_batch_process_host", "nnn_batch_synchronize",
+    "nnn_batch_process_device", "nnn_batch_process_host", "nnn_batch_process_pcm_device", "nnn_batch_process_pcm_host",
+    "nnn_batch_synchronize",
     "nnn_tap_info", "nnn_batch_read_tap", "nnn_batch_set_profiling", "nnn_batch_num_kernels",
     "nnn_batch_kernel_name", "nnn_batch_read_kernel_times", "nnn_batch_set_graph", "nnn_batch_set_pipeline", "nnn_batch_read_stamps",
     "nnn_last_error",
@@ -22,6 +23,16 @@ RNNOISE_SYMBOLS = [
     "rnnoise_get_frame_size", "rnnoise_get_size", "rnnoise_init", "rnnoise_create", "rnnoise_destroy",
     "rnnoise_process_frame", "rnnoise_model_from_file", "rnnoise_model_free",
 ]
+
+
+PCM_F32, PCM_I16, PCM_F32_UNIT = 0, 1, 2
+PCM_DTYPE = {PCM_F32: np.float32, PCM_I16: np.int16, PCM_F32_UNIT: np.float32}
+
+
+class PcmLayout(C.Structure):
+    """struct nnn_pcm_layout (include/nnn_batch.h)."""
+    _fields_ = [("format", C.c_int), ("channels", C.c_int), ("discard_first", C.c_int), ("reserved", C.c_int),
+                ("group_stride", C.c_size_t), ("frame_stride", C.c_size_t)]
 
 
 class Library:
@@ -47,6 +58,8 @@ class Library:
         L.nnn_batch_reset.argtypes = [vp]
         L.nnn_batch_process_device.argtypes = [vp, vp, vp, vp, i32, sz, sz, vp]
         L.nnn_batch_process_host.argtypes = [vp, vp, vp, vp, i32, sz, sz]
+        L.nnn_batch_process_pcm_device.argtypes = [vp, vp, vp, vp, i32, C.POINTER(PcmLayout), vp]
+        L.nnn_batch_process_pcm_host.argtypes = [vp, vp, vp, vp, i32, C.POINTER(PcmLayout)]
         L.nnn_batch_synchronize.argtypes = [vp]
         L.nnn_tap_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
         L.nnn_batch_read_tap.argtypes = [vp, i32, vp, sz]

@@ -479,20 +479,21 @@ static int drain_profile(nnn_batch *h)
     return 0;
 }
 
-extern "C" int nnn_batch_process_device(nnn_batch *h, const float *d_in, float *d_out, float *d_vad, int n_frames,
-                                        size_t stream_stride, size_t frame_stride, void *hip_stream)
+// Common body of the process entry points: strides in BYTES, `drop` leading frames of the call produce no audio.
+static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_vad, int n_frames, int fmt, int channels,
+                          long long group_stride, long long frame_stride, int drop, void *hip_stream)
 {
-    if (!h) return fail("null batch");
-    if (n_frames <= 0) return 0;
-    if (!d_in || !d_out) return fail("null buffer");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
     StepParams v0;
-    v0.in = d_in;
-    v0.out = d_out;
+    v0.in = (const char *)d_in;
+    v0.out = (char *)d_out;
     v0.vad = d_vad;
-    v0.stream_stride = stream_stride;
+    v0.group_stride = group_stride;
     v0.frame_stride = frame_stride;
+    v0.fmt = fmt;
+    v0.channels = channels;
+    v0.discard = drop;
     v0.slot = (int)(h->frame_count % NSLOT);
     v0.n_streams = h->S;
     const bool graph = h->use_graph && !h->profiling;
@@ -538,8 +539,9 @@ extern "C" int nnn_batch_process_device(nnn_batch *h, const float *d_in, float *
         // parameters of the next frame of each scratch set, stepped on the device after every frame
         for (int i = 0; i < NLANE; i++) {
             StepParams v = v0;
-            v.in = d_in + (size_t)i * frame_stride;
-            v.out = d_out + (size_t)i * frame_stride;
+            v.in = v0.in + (long long)i * frame_stride;
+            v.out = (char *)((intptr_t)v0.out + (long long)(i - drop) * frame_stride);
+            v.discard = i < drop;
             v.vad = d_vad ? d_vad + (size_t)i * h->S : nullptr;
             v.slot = (int)((h->frame_count + i) % NSLOT);
             hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, h->sp + (int)((h->frame_count + i) % NLANE), v);
@@ -570,38 +572,90 @@ extern "C" int nnn_batch_process_device(nnn_batch *h, const float *d_in, float *
     return 0;
 }
 
+static int check_layout(const nnn_batch *h, const nnn_pcm_layout *L)
+{
+    if (!L) return fail("null layout");
+    if (L->format != NNN_PCM_F32 && L->format != NNN_PCM_I16 && L->format != NNN_PCM_F32_UNIT) return fail("unknown sample format %d", L->format);
+    if (L->channels < 1 || h->S % L->channels) return fail("n_streams (%d) is not a multiple of channels (%d)", h->S, L->channels);
+    if (L->frame_stride < (size_t)FRAME * L->channels) return fail("frame_stride smaller than one frame of all channels");
+    return 0;
+}
+
+extern "C" int nnn_batch_process_device(nnn_batch *h, const float *d_in, float *d_out, float *d_vad, int n_frames,
+                                        size_t stream_stride, size_t frame_stride, void *hip_stream)
+{
+    if (!h) return fail("null batch");
+    if (n_frames <= 0) return 0;
+    if (!d_in || !d_out) return fail("null buffer");
+    return process_frames(h, d_in, d_out, d_vad, n_frames, PCM_F32, 1, (long long)stream_stride * 4, (long long)frame_stride * 4, 0,
+                          hip_stream);
+}
+
+extern "C" int nnn_batch_process_pcm_device(nnn_batch *h, const void *d_in, void *d_out, float *d_vad, int n_frames,
+                                            const nnn_pcm_layout *L, void *hip_stream)
+{
+    if (!h) return fail("null batch");
+    if (n_frames <= 0) return 0;
+    if (!d_in || !d_out) return fail("null buffer");
+    if (int rc = check_layout(h, L)) return rc;
+    const long long e = pcm_elem_bytes(L->format);
+    const int drop = (L->discard_first && h->frame_count == 0) ? 1 : 0;
+    return process_frames(h, d_in, d_out, d_vad, n_frames, L->format, L->channels, (long long)L->group_stride * e,
+                          (long long)L->frame_stride * e, drop, hip_stream);
+}
+
+// Host buffers: ship the bounding span of the (possibly strided) layout, run, bring the written frames back.
+static int process_host_span(nnn_batch *h, const void *in, void *out, float *vad, int n_frames, const nnn_pcm_layout *L)
+{
+    HIPCHK(hipSetDevice(h->device));
+    const size_t e = (size_t)pcm_elem_bytes(L->format), groups = (size_t)(h->S / L->channels), fr = (size_t)FRAME * L->channels * e;
+    const size_t span = (groups - 1) * L->group_stride * e + (size_t)(n_frames - 1) * L->frame_stride * e + fr;
+    const int drop = (L->discard_first && h->frame_count == 0) ? 1 : 0;
+    char *d = nullptr;
+    float *dv = nullptr;
+    HIPCHK(hipMalloc((void **)&d, span));
+    hipError_t err = hipMemcpyAsync(d, in, span, hipMemcpyHostToDevice, h->stream);
+    if (err == hipSuccess && vad) err = hipMalloc((void **)&dv, (size_t)n_frames * h->S * sizeof(float));
+    int rc = 0;
+    if (err != hipSuccess) rc = fail("host staging failed: %s", hipGetErrorString(err));
+    if (!rc) rc = nnn_batch_process_pcm_device(h, d, d, dv, n_frames, L, h->stream);
+    if (!rc) {
+        // `out` may alias `in` and may be strided: bring the span back and copy only real frames
+        std::vector<char> tmp(span);
+        err = hipStreamSynchronize(h->stream);
+        if (err == hipSuccess) err = hipMemcpy(tmp.data(), d, span, hipMemcpyDeviceToHost);
+        if (err == hipSuccess)
+            for (size_t g = 0; g < groups; g++)
+                for (int t = 0; t < n_frames - drop; t++) {
+                    size_t o = g * L->group_stride * e + (size_t)t * L->frame_stride * e;
+                    memcpy((char *)out + o, tmp.data() + o, fr);
+                }
+        if (err == hipSuccess && vad) err = hipMemcpy(vad, dv, (size_t)n_frames * h->S * sizeof(float), hipMemcpyDeviceToHost);
+        if (err != hipSuccess) rc = fail("copy back failed: %s", hipGetErrorString(err));
+    }
+    hipFree(d);
+    if (dv) hipFree(dv);
+    return rc;
+}
+
 extern "C" int nnn_batch_process_host(nnn_batch *h, const float *in, float *out, float *vad, int n_frames,
                                       size_t stream_stride, size_t frame_stride)
 {
     if (!h) return fail("null batch");
     if (n_frames <= 0) return 0;
-    HIPCHK(hipSetDevice(h->device));
-    // the host buffer may be strided; ship the bounding span
-    size_t span = (size_t)(h->S - 1) * stream_stride + (size_t)(n_frames - 1) * frame_stride + FRAME;
-    float *d = nullptr, *dv = nullptr;
-    HIPCHK(hipMalloc((void **)&d, span * sizeof(float)));
-    hipError_t e = hipMemcpyAsync(d, in, span * sizeof(float), hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess && vad) e = hipMalloc((void **)&dv, (size_t)n_frames * h->S * sizeof(float));
-    int rc = 0;
-    if (e != hipSuccess) rc = fail("host staging failed: %s", hipGetErrorString(e));
-    if (!rc) rc = nnn_batch_process_device(h, d, d, dv, n_frames, stream_stride, frame_stride, h->stream);
-    if (!rc) {
-        // `out` may alias `in` and may be strided: bring the span back and copy only real frames
-        std::vector<float> tmp(span);
-        e = hipStreamSynchronize(h->stream);
-        if (e == hipSuccess) e = hipMemcpy(tmp.data(), d, span * sizeof(float), hipMemcpyDeviceToHost);
-        if (e == hipSuccess)
-            for (int s = 0; s < h->S; s++)
-                for (int t = 0; t < n_frames; t++) {
-                    size_t o = (size_t)s * stream_stride + (size_t)t * frame_stride;
-                    memcpy(out + o, tmp.data() + o, FRAME * sizeof(float));
-                }
-        if (e == hipSuccess && vad) e = hipMemcpy(vad, dv, (size_t)n_frames * h->S * sizeof(float), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail("copy back failed: %s", hipGetErrorString(e));
-    }
-    hipFree(d);
-    if (dv) hipFree(dv);
-    return rc;
+    if (!in || !out) return fail("null buffer");
+    nnn_pcm_layout L = {NNN_PCM_F32, 1, 0, 0, stream_stride, frame_stride};
+    return process_host_span(h, in, out, vad, n_frames, &L);
+}
+
+extern "C" int nnn_batch_process_pcm_host(nnn_batch *h, const void *in, void *out, float *vad, int n_frames,
+                                          const nnn_pcm_layout *L)
+{
+    if (!h) return fail("null batch");
+    if (n_frames <= 0) return 0;
+    if (!in || !out) return fail("null buffer");
+    if (int rc = check_layout(h, L)) return rc;
+    return process_host_span(h, in, out, vad, n_frames, L);
 }
 
 // ---- taps ---------------------------------------------------------------------------------------

@@ -31,6 +31,77 @@ namespace nnn {
 __constant__ int kEband[NB] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100};
 __constant__ int kSecondCheck[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};
 
+// ---- PCM formats at the boundary ------------------------------------------------------------------
+// Input conversions of the reference's callers: i16 samples are used as they are (src/nnnoiseless.rs:179-228 hands
+// i16-range floats to process_frame), unit-range floats are scaled by 32768 (src/signal.rs:95-100).
+template <int FMT> __device__ __forceinline__ float pcm_load(const char *p)
+{
+    if (FMT == PCM_I16) return (float)ld_global<short>(p);
+    const float v = ld_global<float>(p);
+    return FMT == PCM_F32_UNIT ? v * 32768.0f : v;
+}
+// Output conversions: round-half-away + clamp to i16 (RawFrameWriter / WavFrameWriter, src/nnnoiseless.rs:147-177),
+// /32768 then clamp to [-1, 1] (DenoiseSignal::next, src/signal.rs:123-127).
+__device__ __forceinline__ short pcm_to_i16(float v) { return (short)roundf(fminf(fmaxf(v, -32768.0f), 32767.0f)); }
+__device__ __forceinline__ float pcm_to_unit(float v)
+{
+    v = v / 32768.0f;
+    if (v < -1.0f) v = -1.0f;
+    if (v > 1.0f) v = 1.0f;
+    return v;
+}
+__device__ __forceinline__ void pcm_store(char *p, int fmt, float v)
+{
+    if (fmt == PCM_I16) *(short *)p = pcm_to_i16(v);
+    else *(float *)p = fmt == PCM_F32_UNIT ? pcm_to_unit(v) : v;
+}
+// One lane's next 32 samples of its own stream, kept in raw form until the recurrence of the previous 32 is done (so
+// the loads stay in flight behind it).  VEC: mono stream with 16-byte aligned rows, 16 bytes per load.
+template <int FMT, bool VEC> struct HpChunk {
+    static constexpr int NV = FMT == PCM_I16 ? 4 : 8;
+    uint4 v[VEC ? NV : 1];
+    unsigned w[VEC ? 1 : 32];
+    __device__ __forceinline__ void load(const char *p, int sstride)
+    {
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < NV; q++) v[q] = ld_global_u4(p + 16 * q);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; j++)
+                w[j] = FMT == PCM_I16 ? (unsigned)(int)ld_global<short>(p + (long long)j * sstride)
+                                      : ld_global<unsigned>(p + (long long)j * sstride);
+        }
+    }
+    __device__ __forceinline__ void get(float (&x)[32]) const
+    {
+        if (VEC && FMT == PCM_I16) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned u[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    x[8 * q + 2 * e] = (float)(short)(u[e] & 0xffffu);
+                    x[8 * q + 2 * e + 1] = (float)((int)u[e] >> 16);
+                }
+            }
+        } else if (VEC) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                x[4 * q] = __uint_as_float(v[q].x); x[4 * q + 1] = __uint_as_float(v[q].y);
+                x[4 * q + 2] = __uint_as_float(v[q].z); x[4 * q + 3] = __uint_as_float(v[q].w);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; j++) x[j] = FMT == PCM_I16 ? (float)(int)w[j] : __uint_as_float(w[j]);
+        }
+        if (FMT == PCM_F32_UNIT) {
+#pragma unroll
+            for (int j = 0; j < 32; j++) x[j] *= 32768.0f;
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // K1  hp_filter: high-pass biquad (f64 arithmetic, f32 state) + append to the history ring
 //     (ref: src/features.rs:97-104, src/util.rs:95-107), and the 2:1 decimation of pitch_downsample
@@ -38,84 +109,85 @@ __constant__ int kSecondCheck[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3
 //     depends only on absolute samples, so each frame adds 240 values to a persistent ring instead of
 //     recomputing all 864; only the reference's special first element is per frame.  The ring is stored
 //     twice (p, p + 960): every frame's 864-value window is then one contiguous run for its readers.
-//     lane = stream; the 480-step recurrence is inherently serial per stream.  Input and history are
-//     stream-major, so 64x32 tiles are transposed through LDS to keep every global access coalesced.
+//     lane = stream; the 480-step recurrence is inherently serial per stream and a lone wave is bound by
+//     instruction issue, so each lane moves its own stream's samples with 16-byte accesses (a full 128-byte
+//     line per 32 samples) instead of transposing tiles through LDS for coalescing.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp, StepParams *publish)
+template <int FMT, bool VEC>
+__device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp, int tile, int lane)
 {
-    // pipelined calls: the frame's parameters are republished where this frame's replayed graph segment reads them
-    if (publish && blockIdx.x == 0 && threadIdx.x == 0) *publish = *sp;
-    const float *in = sp->in;
-    const size_t stream_stride = sp->stream_stride;
     const int slot = sp->slot;
-    __shared__ float tl[64][33];
-    const int lane = threadIdx.x, tile = blockIdx.x;
+    const int elem = pcm_elem_bytes(FMT), ch = sp->channels, sstride = ch * elem;
+    const int s = tile * TILE + lane;
+    // padding lanes of the last tile re-read the last real stream: their state is never looked at
+    const int sc = s < b.S ? s : b.S - 1, grp = sc / ch;
+    const char *in = sp->in + (long long)grp * sp->group_stride + (long long)(sc - grp * ch) * elem;
+    HpChunk<FMT, VEC> nxt;
+    nxt.load(in, sstride);
     float *hp = NNN_TI(b.hp_mem, 2, tile, lane);
     float m0 = hp[0], m1 = hp[TILE];
     float prev = NNN_TI(b.hp_last, 1, tile, lane)[0];
     NNN_STAMP(b, 24);
     float *ring = NNN_TI(b.dec, 2 * DEC_RING, tile, lane);
+    float *h = b.hist + (size_t)s * RING;
     {   // x_lp[0] = (x[1] / 2 + x[0]) / 2 on the oldest two samples of this frame's 1728-sample history: kept in
         // per-frame scratch (the ring position it replaces is still a regular value for the previous frame,
         // which may be in flight)
-        const float *h = b.hist + (size_t)(tile * TILE + lane) * RING;
         const int rb = ring_base(slot);
         const float x0 = h[rb], x1 = h[(rb + 1) % RING];
         NNN_TI(b.xlp0, 1, tile, lane)[0] = (x1 / 2.0f + x0) / 2.0f;
     }
     float *dec = ring + (size_t)(240 * slot) * TILE;
+    float4 *hw = (float4 *)(h + slot * FRAME);   // RING * 4 and FRAME * 4 are multiples of 16
     const double a0 = (double)-1.99599f, a1 = (double)0.99600f, b0 = (double)-2.0f, b1 = (double)1.0f;
-    const int sub = lane >> 5, col = lane & 31;
-    float stage[32];
-#pragma unroll
-    for (int r = 0; r < 32; r++) {
-        int s = tile * TILE + r * 2 + sub;
-        stage[r] = (s < b.S) ? in[(size_t)s * stream_stride + col] : 0.0f;
-    }
-    for (int c = 0; c < FRAME / 32; c++) {
-#pragma unroll
-        for (int r = 0; r < 32; r++) tl[r * 2 + sub][col] = stage[r];
-        __syncthreads();
-        if (c + 1 < FRAME / 32) {   // next chunk's loads stay in flight during the serial recurrence
-#pragma unroll
-            for (int r = 0; r < 32; r++) {
-                int s = tile * TILE + r * 2 + sub;
-                stage[r] = (s < b.S) ? in[(size_t)s * stream_stride + (c + 1) * 32 + col] : 0.0f;
-            }
-        }
+    // Software pipeline over 32-sample chunks.  Loads and stores share one in-order counter (vmcnt), so waiting for
+    // chunk c's samples also waits for every store issued before: the stores of chunk c - 1 are therefore issued right
+    // after that wait, and both they and the loads of chunk c + 1 travel behind the ~0.7 us recurrence of chunk c.
+    float ys[32], dvs[16];
+    for (int c = 0; c <= FRAME / 32; c++) {
         float xs[32];
+        if (c < FRAME / 32) nxt.get(xs);
+        if (c > 0) {
 #pragma unroll
-        for (int j = 0; j < 32; j++) xs[j] = tl[lane][j];
+            for (int t = 0; t < 16; t++) {
+                dec[(size_t)(16 * (c - 1) + t) * TILE] = dvs[t];
+                dec[(size_t)(DEC_RING + 16 * (c - 1) + t) * TILE] = dvs[t];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) hw[8 * (c - 1) + q] = make_float4(ys[4 * q], ys[4 * q + 1], ys[4 * q + 2], ys[4 * q + 3]);
+        }
+        if (c == FRAME / 32) break;
+        if (c + 1 < FRAME / 32) nxt.load(in + (long long)(c + 1) * 32 * sstride, sstride);
 #pragma unroll
         for (int j = 0; j < 32; j++) {
             double x64 = (double)xs[j];
             double y64 = x64 + (double)m0;
             m0 = (float)((double)m1 + (b0 * x64 - a0 * y64));
             m1 = (float)(b1 * x64 - a1 * y64);
-            xs[j] = (float)y64;
+            ys[j] = (float)y64;
         }
 #pragma unroll
         for (int t = 0; t < 16; t++) {
-            const float a = t == 0 ? prev : xs[2 * t - 1], m = xs[2 * t], n = xs[2 * t + 1];
-            const float dv = ((a + n) / 2.0f + m) / 2.0f;
-            dec[(size_t)(16 * c + t) * TILE] = dv;
-            dec[(size_t)(DEC_RING + 16 * c + t) * TILE] = dv;
+            const float a = t == 0 ? prev : ys[2 * t - 1], m = ys[2 * t], n = ys[2 * t + 1];
+            dvs[t] = ((a + n) / 2.0f + m) / 2.0f;
         }
-        prev = xs[31];
-#pragma unroll
-        for (int j = 0; j < 32; j++) tl[lane][j] = xs[j];
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 32; r++) {
-            int row = r * 2 + sub, s = tile * TILE + row;
-            b.hist[(size_t)s * RING + slot * FRAME + c * 32 + col] = tl[row][col];
-        }
-        __syncthreads();
+        prev = ys[31];
     }
     hp[0] = m0;
     hp[TILE] = m1;
     NNN_TI(b.hp_last, 1, tile, lane)[0] = prev;
     NNN_STAMP(b, 25);
+}
+
+__global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp, StepParams *publish)
+{
+    // pipelined calls: the frame's parameters are republished where this frame's replayed graph segment reads them
+    if (publish && blockIdx.x == 0 && threadIdx.x == 0) *publish = *sp;
+    const int lane = threadIdx.x, tile = blockIdx.x, fmt = sp->fmt;
+    const bool vec = sp->channels == 1 && ((((size_t)sp->in) | (size_t)sp->group_stride) & 15) == 0;
+    if (fmt == PCM_F32) { if (vec) hp_frame<PCM_F32, true>(b, sp, tile, lane); else hp_frame<PCM_F32, false>(b, sp, tile, lane); }
+    else if (fmt == PCM_I16) { if (vec) hp_frame<PCM_I16, true>(b, sp, tile, lane); else hp_frame<PCM_I16, false>(b, sp, tile, lane); }
+    else { if (vec) hp_frame<PCM_F32_UNIT, true>(b, sp, tile, lane); else hp_frame<PCM_F32_UNIT, false>(b, sp, tile, lane); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1495,9 +1567,8 @@ __device__ __forceinline__ float interp_gain(const float *g, int k, const float 
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
 {
-    float *out = sp->out;
-    const size_t out_stride = sp->stream_stride;
     float *vad_out = sp->vad;
+    const int fmt = sp->fmt;
     __shared__ float2 A[FREQ + 3];
     __shared__ float ebuf[400];
     __shared__ float r[NB], r2[NB], gg[NB];
@@ -1532,7 +1603,11 @@ __global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
         whi[u] = on ? ((const float2 *)b.window)[FRAME / 2 + n] : make_float2(0.0f, 0.0f);
     }
     const float vadv = NNN_TI(b.vad, 1, tile, sl)[0];
-    const bool pair_ok = ((out_stride & 1) == 0) && ((((size_t)out) & 7) == 0);   // 8-byte stores need even strides
+    // this stream's first output sample; mono streams of matching alignment take one store per sample pair
+    const int ch = sp->channels, grp = s / ch, elem = pcm_elem_bytes(fmt), sstride = ch * elem;
+    char *o = sp->out + (long long)grp * sp->group_stride + (long long)(s - grp * ch) * elem;
+    const bool store = s < b.S && !sp->discard;
+    const bool pair_ok = ch == 1 && (((size_t)o) & (size_t)(2 * elem - 1)) == 0;
     if (live) {
         if (lane < NB) {
             float v;
@@ -1616,10 +1691,16 @@ __global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
             float2 lo = A[n], hi = A[n + FRAME / 2];
             float v0 = lo.y / 2.0f * wlo[u].x, v1 = lo.x / 2.0f * wlo[u].y;
             float u0 = hi.y / 2.0f * whi[u].x, u1 = hi.x / 2.0f * whi[u].y;
-            if (s < b.S) {
-                float *o = out + (size_t)s * out_stride;
-                if (pair_ok) ((float2 *)o)[n] = make_float2(v0 + smv[u].x, v1 + smv[u].y);
-                else { o[2 * n] = v0 + smv[u].x; o[2 * n + 1] = v1 + smv[u].y; }
+            if (store) {
+                const float y0 = v0 + smv[u].x, y1 = v1 + smv[u].y;
+                if (pair_ok && fmt == PCM_F32) ((float2 *)o)[n] = make_float2(y0, y1);
+                else if (pair_ok && fmt == PCM_I16)
+                    ((unsigned *)o)[n] = (unsigned)(unsigned short)pcm_to_i16(y0) | ((unsigned)(unsigned short)pcm_to_i16(y1) << 16);
+                else if (pair_ok) ((float2 *)o)[n] = make_float2(pcm_to_unit(y0), pcm_to_unit(y1));
+                else {
+                    pcm_store(o + (long long)(2 * n) * sstride, fmt, y0);
+                    pcm_store(o + (long long)(2 * n + 1) * sstride, fmt, y1);
+                }
             }
             ((float2 *)sm)[n] = make_float2(u0, u1);
         }
@@ -1635,16 +1716,18 @@ __global__ void k_fill_params(StepParams *tab, StepParams v, int n)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     StepParams p = v;
-    p.in = v.in + (size_t)t * v.frame_stride;
-    p.out = v.out + (size_t)t * v.frame_stride;
+    p.in = v.in + (long long)t * v.frame_stride;
+    p.out = v.out + (long long)(t - v.discard) * v.frame_stride;   // dropped frames take no room in the output
+    p.discard = t < v.discard;
     p.vad = v.vad ? v.vad + (size_t)t * v.n_streams : nullptr;
     p.slot = (v.slot + t) % NSLOT;
     tab[t] = p;
 }
 __global__ void k_advance(StepParams *sp, int nstep)
 {
-    sp->in += (size_t)nstep * sp->frame_stride;
-    sp->out += (size_t)nstep * sp->frame_stride;
+    sp->in += (long long)nstep * sp->frame_stride;
+    sp->out += (long long)nstep * sp->frame_stride;
+    sp->discard = 0;
     if (sp->vad) sp->vad += (size_t)nstep * sp->n_streams;
     sp->slot = (sp->slot + nstep) % NSLOT;
 }

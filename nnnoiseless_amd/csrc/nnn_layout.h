@@ -118,11 +118,19 @@ struct Buffers {
 
 // Per-frame launch parameters, resident in device memory so that one captured hipGraph can be
 // replayed for every frame: k_advance steps it at the end of each frame.
+// PCM sample formats at the batch boundary (values match enum nnn_pcm_format in include/nnn_batch.h)
+enum { PCM_F32 = 0, PCM_I16 = 1, PCM_F32_UNIT = 2 };
+__host__ __device__ inline int pcm_elem_bytes(int fmt) { return fmt == PCM_I16 ? 2 : 4; }
+
 struct StepParams {
-    const float *in;   // frame t of stream s at in[s * stream_stride + i]
-    float *out;
+    // sample i of stream s (channel s % channels of group s / channels), all in BYTES:
+    //   in + (s / channels) * group_stride + ((s % channels) + i * channels) * elem
+    const char *in;
+    char *out;
     float *vad;        // [n_streams] for this frame, may be null
-    unsigned long long stream_stride, frame_stride;
+    long long group_stride, frame_stride;   // bytes
+    int fmt, channels;
+    int discard;       // frame tables: != 0 = this frame's audio is not written; call parameters: frames to drop
     int slot;          // history ring slot that receives this frame (frame index mod NSLOT)
     int n_streams;
 };

@@ -1,4 +1,5 @@
-// nnn_mfma.h -- the CDNA4-specific primitives of the RNN kernel: one matrix instruction and an LDS-only barrier.
+// nnn_mfma.h -- the CDNA4-specific primitives of the kernels: one matrix instruction, an LDS-only barrier and
+// explicitly-global memory accesses.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -23,6 +24,23 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Loads/stores through pointers that reach a kernel inside a struct read from memory (the per-frame StepParams):
+// the compiler cannot prove them global and would emit flat_* instructions, which also occupy the LDS counter.
+template <class T> __device__ __forceinline__ T ld_global(const void *p)
+{
+    return *(const __attribute__((address_space(1))) T *)p;
+}
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_global_u4(const void *p)   // 16 bytes, 16-byte aligned
+{
+    const u32x4_t v = *(const __attribute__((address_space(1))) u32x4_t *)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <class T> __device__ __forceinline__ void st_global(void *p, T v)
+{
+    *(__attribute__((address_space(1))) T *)p = v;
 }
 
 }  // namespace nnn

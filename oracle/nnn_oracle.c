@@ -921,3 +921,76 @@ int nnno_run_streams(const nnno_model *m, int n_streams, int n_frames, const flo
     }
     return used;
 }
+
+/* ---- the reference's multi-channel callers ------------------------------------------------------- */
+
+/* ref: src/nnnoiseless.rs:301-331 (frame loop: `break 'outer` on a short read drops the partial frame; `first`
+ * suppresses the first write) and :147-160 (RawFrameWriter: max(i16::MIN).min(i16::MAX).round() as i16). */
+long nnno_cli_raw_i16(const nnno_model *m, const int16_t *in, long n, int channels, int16_t *out)
+{
+    nnno_state **st = (nnno_state **)malloc(sizeof(*st) * (size_t)channels);
+    float ibuf[FRAME_SIZE], obuf[FRAME_SIZE];
+    long written = 0;
+    for (int c = 0; c < channels; c++) st[c] = nnno_create(m);
+    for (long t = 0; (t + 1) * FRAME_SIZE <= n; t++) {
+        for (int c = 0; c < channels; c++) {
+            for (int i = 0; i < FRAME_SIZE; i++) ibuf[i] = (float)in[((size_t)t * FRAME_SIZE + i) * channels + c];
+            nnno_process_frame(st[c], obuf, ibuf);
+            if (t == 0) continue;
+            for (int i = 0; i < FRAME_SIZE; i++) {
+                float v = obuf[i];
+                v = v > -32768.0f ? v : -32768.0f;   /* f32::max / f32::min return the non-NaN operand */
+                v = v < 32767.0f ? v : 32767.0f;
+                out[((size_t)(t - 1) * FRAME_SIZE + i) * channels + c] = (int16_t)roundf(v);
+            }
+        }
+        if (t > 0) written += FRAME_SIZE;
+    }
+    for (int c = 0; c < channels; c++) nnno_destroy(st[c]);
+    free(st);
+    return written;
+}
+
+/* ref: src/signal.rs:83-137.  refill_out_bufs (:90-106) returns false without touching anything when the input is
+ * already exhausted, otherwise reads 480 sample frames (equilibrium = 0 past the end), scales by 32768 (:98), runs
+ * every channel's state and returns !exhausted.  The constructor refills twice (:83-87); next() (:116-137) hands out
+ * out_bufs / 32768 clamped to [-1, 1] and refills after the 480th sample, rewinding only if that refill said true. */
+/* one refill_out_bufs (src/signal.rs:90-106); returns its bool */
+static int signal_refill(nnno_state **st, float *ob, const float *in, long n, int channels, long *consumed)
+{
+    float ibuf[FRAME_SIZE];
+    if (*consumed >= n) return 0;
+    for (int c = 0; c < channels; c++) {
+        for (int i = 0; i < FRAME_SIZE; i++) {
+            long k = *consumed + i;
+            ibuf[i] = (k < n ? in[(size_t)k * channels + c] : 0.0f) * 32768.0f;
+        }
+        nnno_process_frame(st[c], ob + (size_t)c * FRAME_SIZE, ibuf);
+    }
+    *consumed += FRAME_SIZE;
+    return *consumed < n;
+}
+
+long nnno_denoise_signal(const nnno_model *m, const float *in, long n, int channels, float *out)
+{
+    nnno_state **st = (nnno_state **)malloc(sizeof(*st) * (size_t)channels);
+    float *ob = (float *)calloc((size_t)channels * FRAME_SIZE, sizeof(float));
+    long consumed = 0, written = 0;
+    for (int c = 0; c < channels; c++) st[c] = nnno_create(m);
+    signal_refill(st, ob, in, n, channels, &consumed);   /* discard_first_frame, :83-87 */
+    signal_refill(st, ob, in, n, channels, &consumed);
+    do {                                                  /* next() until is_exhausted(), :108-137 */
+        for (int i = 0; i < FRAME_SIZE; i++)
+            for (int c = 0; c < channels; c++) {
+                float v = ob[(size_t)c * FRAME_SIZE + i] / 32768.0f;
+                if (v < -1.0f) v = -1.0f;
+                if (v > 1.0f) v = 1.0f;
+                out[(size_t)(written + i) * channels + c] = v;
+            }
+        written += FRAME_SIZE;
+    } while (signal_refill(st, ob, in, n, channels, &consumed));
+    for (int c = 0; c < channels; c++) nnno_destroy(st[c]);
+    free(st);
+    free(ob);
+    return written;
+}

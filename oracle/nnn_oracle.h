@@ -89,6 +89,21 @@ int nnno_run_streams(const nnno_model *m, int n_streams, int n_frames, const flo
                      float *out, float *vad, int32_t *pitch, float *gains, float *feats,
                      int n_threads);
 
+/*
+ * The reference's two multi-channel callers of process_frame, restated around the oracle state.
+ * Both return the number of sample frames (one sample per channel) written to `out`.
+ *
+ * nnno_cli_raw_i16: the CLI's raw-PCM loop, src/nnnoiseless.rs:301-331 with RawFrameWriter :147-160 --
+ *   `in` = n sample frames of `channels` interleaved int16; a trailing partial frame is dropped, the first processed
+ *   frame is not written, every sample is clamped to the i16 range and rounded half away from zero.
+ * nnno_denoise_signal: the dasp adapter DenoiseSignal, src/signal.rs:83-137, fed by an n-sample-frame signal of
+ *   unit-range floats that reports exhaustion once all n were consumed (dasp_signal 0.11.0 `from_iter`, a crate that
+ *   is not part of the reference tree: its end-of-signal behaviour is restated from its documentation, unpinned).
+ *   `out` needs room for (n / 480 + 2) * 480 sample frames.
+ */
+long nnno_cli_raw_i16(const nnno_model *m, const int16_t *in, long n, int channels, int16_t *out);
+long nnno_denoise_signal(const nnno_model *m, const float *in, long n, int channels, float *out);
+
 /* Stand-alone FFT entry points so tests can pin the restated FFT against a naive DFT. */
 void nnno_rfft960(const float *in960, float *out_re_im_481x2);   /* un-normalised forward  */
 void nnno_irfft960(const float *in_re_im_481x2, float *out960);  /* un-normalised inverse  */

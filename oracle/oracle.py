@@ -158,6 +158,28 @@ def run_streams(model: Model, x, n_threads=1, want=("out", "vad", "pitch", "gain
     return res
 
 
+def cli_raw_i16(model: Model, pcm, channels=1):
+    """The CLI's raw-PCM loop (src/nnnoiseless.rs:301-331): pcm int16 [n, channels] -> int16 [n_out, channels]."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16).reshape(-1, channels)
+    out = np.zeros_like(pcm)
+    fn = model._L.nnno_cli_raw_i16
+    fn.restype = C.c_long
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
+    n = fn(model._h, _ptr(pcm), len(pcm), channels, _ptr(out))
+    return out[:n]
+
+
+def denoise_signal(model: Model, x, channels=1):
+    """DenoiseSignal (src/signal.rs:83-137) over unit-range floats [n, channels] -> float32 [n_out, channels]."""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, channels)
+    out = np.zeros(((len(x) // FRAME_SIZE + 2) * FRAME_SIZE, channels), np.float32)
+    fn = model._L.nnno_denoise_signal
+    fn.restype = C.c_long
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
+    n = fn(model._h, _ptr(x), len(x), channels, _ptr(out))
+    return out[:n]
+
+
 def rfft960(x, f32_fft=False):
     x = np.ascontiguousarray(x, dtype=np.float32)
     out = np.empty(962, np.float32)

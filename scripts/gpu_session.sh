@@ -1,18 +1,18 @@
 #!/bin/bash
-# One GPU-box session: smoke, parity tests, bench, rocprofv3 kernel trace.  Outputs under gpurun_out/.
+# One GPU-box session: parity tests, smoke, bench (headline + packed int16 boundary), rocprofv3 kernel stats.
+# Usage on the dev box:  gpurun --timeout 1500 -- 'bash scripts/gpu_session.sh'
 set -u
-R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out
-mkdir -p $O
-cd $R
-nproc > $O/host.txt; lscpu | grep "Model name" >> $O/host.txt; rocm-smi --showproductname 2>/dev/null | head -8 >> $O/host.txt
-echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5
-echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q -s 2>&1 | tail -40 | tee $O/pytest_gpu.txt
-echo "== bench"; timeout 900 python bench.py ${BENCH_ARGS:-} > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err; cat $O/bench.json
-if [ "${SKIP_PROF:-0}" != "1" ]; then
-  echo "== rocprofv3"; cd /tmp && export TMPDIR=/tmp
-  timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o trace -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-roofline > $O/prof_bench.json 2> $O/prof.err
-  tail -2 $O/prof.err; cat $O/prof_bench.json
-  find $O/prof -name "*kernel_stats*" | head -3
-  f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"
-fi
+mkdir -p gpurun_out
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/pytest_gpu.log
+tail -5 gpurun_out/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"
+timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cut -c1-600 gpurun_out/bench.json
+timeout 300 python bench.py --pcm i16 --no-cpu-baseline > gpurun_out/bench_i16.json 2> gpurun_out/bench_i16.err; echo "bench i16 rc=$?"; cut -c1-400 gpurun_out/bench_i16.json
+timeout 300 python bench.py --pcm i16 --channels 2 --no-cpu-baseline --no-roofline > gpurun_out/bench_i16_stereo.json 2> gpurun_out/bench_i16_stereo.err; echo "bench i16x2 rc=$?"; cut -c1-300 gpurun_out/bench_i16_stereo.json
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -- python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof.log" 2>&1; echo "rocprof rc=$?"
+cd "$GRAFT_REPO_ROOT"
+DB=$(find gpurun_out/prof -name '*_results.db' | head -1)
+[ -n "$DB" ] && python scripts/rocpd_kernel_stats.py "$DB" > gpurun_out/kernel_stats.md 2>&1 && head -20 gpurun_out/kernel_stats.md
+find gpurun_out/prof -name '*.db' -size +20M -delete

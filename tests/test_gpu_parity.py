@@ -266,3 +266,72 @@ def test_denoise_state_mirror(nn, golden_io):
     assert 0.0 <= vad <= 1.0 and np.isfinite(out).all()
     with pytest.raises(ValueError):
         st.process_frame(out, frames[0][:100])
+
+
+# ---- the reference callers' sample formats, channel interleave and dropped first frame ----------
+
+def test_cli_raw_i16_golden(nn, oracle_mod, weights_bytes):
+    """testing.raw through the CLI-shaped int16 path IS reference_output.raw (the fixture was made by that path:
+    99 frames, first frame dropped, 44 trailing samples dropped): every sample within 1 LSB, >99.9 % identical."""
+    from nnnoiseless_amd.pcm import denoise_raw_i16
+    pcm = np.fromfile(os.path.join(GOLDEN, "testing.raw"), dtype="<i2")
+    ref = np.fromfile(os.path.join(GOLDEN, "reference_output.raw"), dtype="<i2")
+    out = denoise_raw_i16(pcm, 1)[:, 0]
+    assert out.shape == ref.shape
+    d = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3, (d.max(), (d != 0).mean())
+    orc = oracle_mod.cli_raw_i16(oracle_mod.Model(weights_bytes), pcm, 1)[:, 0]
+    d = np.abs(out.astype(np.int32) - orc.astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+
+
+def test_packed_i16_many_files(nn, oracle_mod, weights_bytes):
+    """70 stereo 'files' (140 streams across 3 tiles) as one batched call vs the oracle's per-file CLI loop; block
+    boundaries (block_frames=7) must not show."""
+    from nnnoiseless_amd.pcm import denoise_raw_i16
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(11, 140, 20)                                          # [140][20][480]
+    pcm = np.round(x).astype(np.int16).reshape(70, 2, 9600).transpose(0, 2, 1)[:, :-13]   # [files][n][2], ragged tail
+    out = denoise_raw_i16(pcm, 2, block_frames=7)
+    model = oracle_mod.Model(weights_bytes)
+    assert out.shape == (70, 18 * 480, 2)
+    bad = 0
+    for f in range(70):
+        ref = oracle_mod.cli_raw_i16(model, pcm[f], 2)
+        d = np.abs(out[f].astype(np.int32) - ref.astype(np.int32))
+        assert d.max() <= 1, f
+        bad += int((d != 0).sum())
+    assert bad / out.size < 5e-3    # f32 differences ~1e-6 of a 1e4 amplitude flip about 0.1 % of the roundings
+
+
+def test_interleaved_formats_match_planar(nn):
+    """Packed layouts are a pure re-addressing of the same streams: f32 interleaved is bit-identical to planar, unit
+    floats are the planar result / 32768 (clamped), and discard_first only drops frame 0."""
+    from nnnoiseless_amd import _ffi
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T, Cc = 192, 12, 3
+    x = make_streams(5, S, T)
+    ref, vref = nn.BatchDenoiser(S).process(x)
+    inter = np.ascontiguousarray(x.reshape(S // Cc, Cc, T * 480).transpose(0, 2, 1))
+    bd = nn.BatchDenoiser(S)
+    out, vad = bd.process_pcm(inter, _ffi.PCM_F32, Cc)
+    want = ref.reshape(S // Cc, Cc, T * 480).transpose(0, 2, 1)
+    assert np.array_equal(out, want) and np.array_equal(vad, vref)
+    bd.reset()
+    out, _ = bd.process_pcm(inter, _ffi.PCM_F32, Cc, discard_first=True)
+    assert np.array_equal(out, want[:, 480:])
+    bd.reset()
+    out, _ = bd.process_pcm(inter / np.float32(32768.0), _ffi.PCM_F32_UNIT, Cc)
+    assert np.abs(out - np.clip(want / np.float32(32768.0), -1, 1)).max() <= 1e-6
+
+
+def test_denoise_signal(nn, oracle_mod, weights_bytes):
+    from nnnoiseless_amd.pcm import DenoiseSignal
+    model = oracle_mod.Model(weights_bytes)
+    pcm = np.fromfile(os.path.join(GOLDEN, "testing.raw"), dtype="<i2").astype(np.float32) / 32768.0
+    x = np.stack([pcm, pcm[::-1] * 3.0], axis=1)                             # channel 1 overdriven: clamp engages
+    for n in (0, 100, 480, 961, 4800, len(x)):
+        ref = oracle_mod.denoise_signal(model, x[:n], 2)
+        out = DenoiseSignal(x[:n]).collect()
+        assert out.shape == ref.shape, n
+        assert np.abs(out - ref).max() <= 2e-5, n
