@@ -230,7 +230,7 @@ def main():
                        "boundary_format": {"f32": "f32 planar (process_frame's own)", "i16": "packed int16",
                                            "unit": "unit-range f32"}[args.pcm] + (f", {Cc} interleaved channels" if Cc > 1 else ""),
                        "streams_per_gpu": S, "streams_total": S * world, "frames_per_step": fps,
-                       "launch": ("up to 4 frames in flight on 4 HIP streams, pitch-front segment replayed as a hipGraph"
+                       "launch": ("up to 3 frames in flight on 3 HIP streams, pitch-front segment replayed as a hipGraph"
                                   if fps > 1 else ("eager" if args.no_graph else "one hipGraph replay per frame")),
                        "parallelism": f"streams sharded x{world}"},
             "tick": tick,

@@ -32,6 +32,13 @@ typedef struct RNNModel RNNModel;
 RNNModel *nnn_model_from_bytes(const uint8_t *bytes, size_t len);
 /* RnnModel::default (src/rnn.rs:235-240): the built-in weights.rnn. */
 RNNModel *nnn_model_default(void);
+/* RNNoise / rnnoise-nu TEXT model ("rnnoise-nu model file version 1" + whitespace-separated integers) -> the binary
+ * .rnn format: what the reference's train/convert_rnnoise.py:18-29 does (drop the header line, every integer modulo
+ * 256 as one byte).  nnn_convert_rnnoise_text writes the bytes to out (cap bytes of room) and returns their count, or
+ * -1 on a wrong header / a token that is not an integer / too little room (pass out = NULL to get the count only).
+ * nnn_model_from_rnnoise_text = convert + nnn_model_from_bytes. */
+long nnn_convert_rnnoise_text(const char *text, size_t len, uint8_t *out, size_t cap);
+RNNModel *nnn_model_from_rnnoise_text(const char *text, size_t len);
 void nnn_model_free(RNNModel *m);
 /* shape[0..5] = input_dense in/out, vad/noise/denoise GRU neurons, gains out; shape[6..11] = activations */
 void nnn_model_shape(const RNNModel *m, int32_t shape[12]);
@@ -39,6 +46,11 @@ void nnn_model_shape(const RNNModel *m, int32_t shape[12]);
 /* n_streams x DenoiseState::with_model(model) (src/denoise.rs:72-74); model NULL = DenoiseState::new().
  * The model is copied to the device; it need not outlive the batch.  device = HIP device ordinal. */
 nnn_batch *nnn_batch_create(const RNNModel *model, int n_streams, int device);
+/* Several models resident at once (e.g. the rnnoise-nu model zoo, one model per audience): streams
+ * [0, group_streams[0]) run models[0], the next group_streams[1] run models[1], ...  Every group but the last must be
+ * a multiple of 64 streams (the kernels' tile).  models == NULL or models[i] == NULL selects the built-in model.
+ * Everything except the RNN kernel is model-independent; the RNN runs as one launch per group. */
+nnn_batch *nnn_batch_create_grouped(const RNNModel *const *models, const int *group_streams, int n_groups, int device);
 void nnn_batch_destroy(nnn_batch *b);
 int nnn_batch_num_streams(const nnn_batch *b);
 /* Back to freshly-created state (all zeros, src/features.rs:58-74). */

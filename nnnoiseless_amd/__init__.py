@@ -52,6 +52,14 @@ class RnnModel:
     from_static_bytes = from_bytes
 
     @classmethod
+    def from_rnnoise_text(cls, text, lib=None):
+        """An RNNoise / rnnoise-nu text model (what train/convert_rnnoise.py turns into a .rnn file first)."""
+        lib = lib or library()
+        data = text.encode() if isinstance(text, str) else bytes(text)
+        h = lib.L.nnn_model_from_rnnoise_text(data, len(data))
+        return cls(h, lib) if h else None
+
+    @classmethod
     def default(cls, lib=None):
         lib = lib or library()
         return cls(lib.L.nnn_model_default(), lib)
@@ -70,11 +78,21 @@ class RnnModel:
 class BatchDenoiser:
     """n_streams DenoiseStates in lock-step on one GPU."""
 
-    def __init__(self, n_streams, model=None, device=0, lib=None):
+    def __init__(self, n_streams, model=None, device=0, lib=None, groups=None):
+        """groups: [(model_or_None, n_streams), ...] keeps several models resident, one per run of streams (every run
+        but the last a multiple of 64); it replaces `model` and must add up to n_streams."""
         self._lib = lib or library()
         self._model = model
         self.n_streams = int(n_streams)
-        self._h = self._lib.L.nnn_batch_create(model._h if model is not None else None, self.n_streams, device)
+        if groups:
+            if sum(n for _, n in groups) != self.n_streams:
+                raise ValueError("group sizes must add up to n_streams")
+            self._model = [m for m, _ in groups]
+            hs = (C.c_void_p * len(groups))(*[m._h if m is not None else None for m, _ in groups])
+            ns = (C.c_int * len(groups))(*[int(n) for _, n in groups])
+            self._h = self._lib.L.nnn_batch_create_grouped(hs, ns, len(groups), device)
+        else:
+            self._h = self._lib.L.nnn_batch_create(model._h if model is not None else None, self.n_streams, device)
         if not self._h:
             raise RuntimeError("nnnoiseless_amd: " + self._lib.error())
         self.frames_done = 0

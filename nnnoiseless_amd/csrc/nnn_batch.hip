@@ -42,13 +42,21 @@ static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_xcorr", "k_best1
 
 struct nnn_batch {
     Buffers b[NLANE];              // same state, NLANE scratch sets: frame f works in set f % NLANE
-    ModelDims md;
-    RnnPlan plan;
-    const uint4 *wq = nullptr;     // packed bf16 weights (device)
-    const float *fpar = nullptr;   // biases + vad output layer (device)
+    ModelDims md;                  // state widths: the maxima over the resident models
+    struct ModelGroup {            // a run of whole tiles sharing one model
+        RnnPlan plan;
+        const uint4 *wq = nullptr;     // packed bf16 weights (device)
+        const float *fpar = nullptr;   // biases + vad output layer (device)
+        size_t rnn_lds = 0;            // dynamic LDS bytes at `rows`
+        int rows = TILE;               // stream rows per RNN block: 64, 32 or 16
+        int tile0 = 0, ntiles = 0;
+    };
+    int rnn_rows = 0;              // forced rows per RNN block (env NNN_RNN_ROWS), 0 = by model size and batch size
+    std::vector<ModelGroup> groups;
     int device = 0;
     int S = 0, S_pad = 0, NT = 0;
     uint64_t frame_count = 0;
+    int n_lanes = 3;   // frames in flight in pipelined calls; measured 2: 20.4, 3: 23.4, 4: 19.7 M frames/s at 4096 streams
     std::vector<void *> allocs;     // everything hipMalloc'ed
     std::vector<std::pair<void *, size_t>> state_bufs;  // zeroed by reset
     StepParams *sp = nullptr;       // device, [NLANE]: launch parameters of the next frame of each scratch set (graph mode)
@@ -61,7 +69,6 @@ struct nnn_batch {
     hipEvent_t ev_chain[NLANE][4] = {};  // per lane: hp, doubling, rnn, synth done (the cross-frame recurrences)
     hipEvent_t ev_lane = nullptr, ev_lane_done[NLANE] = {};
 
-    size_t rnn_lds = 0;
     bool use_graph = true, use_pipeline = true;
     hipGraphExec_t g_single[NLANE] = {};
     hipGraphExec_t g_front[NLANE] = {};   // per scratch set: fft_x, lpc, yy, xcorr, best1, refine, best2 (pipelined calls)
@@ -169,8 +176,31 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
     delete h;
 }
 
-static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int device)
+// dynamic LDS of k_rnn: tanh table (256 floats) + live flags (64 ints) + 3 bf16 planes of both operand matrices for
+// `rows` streams + the feature stage's staged cepstral ring and pair distances ((8 x 22 + 28) rows of 64 floats)
+static size_t rnn_lds_bytes(const RnnPlan &pl, int rows)
 {
+    return 256 * 4 + 64 * 4 + (size_t)3 * rows * (pl.in_w + pl.rec_w) * 2 + (size_t)(CEPS_MEM * NB + 28) * TILE * 4;
+}
+// below this many RNN blocks a launch leaves compute units idle and the per-block chain dominates
+static int rnn_small_batch_blocks()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("NNN_RNN_MIN_BLOCKS");
+        v = e ? atoi(e) : 128;   // measured at 1024 / 4096 / 16384 streams (profiles/r1_e_rnn_rows.txt)
+    }
+    return v;
+}
+
+static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *group_streams, int n_groups, int device)
+{
+    int n_streams = 0;
+    for (int g = 0; g < n_groups; g++) {
+        if (group_streams[g] <= 0) return fail("group %d: stream count must be positive", g);
+        if (g + 1 < n_groups && group_streams[g] % TILE) return fail("group %d: every group but the last must be a multiple of %d streams", g, TILE);
+        n_streams += group_streams[g];
+    }
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("no HIP device %d (found %d)", device, ndev);
@@ -189,6 +219,14 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
         for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_chain[l][i], hipEventDisableTiming));
     }
     if (const char *e = getenv("NNN_PIPELINE")) h->use_pipeline = atoi(e) != 0;
+    if (const char *e = getenv("NNN_LANES")) {   // lane streams used by pipelined calls (<= NLANE scratch sets)
+        const int n = atoi(e);
+        if (n >= 2 && n <= NLANE) h->n_lanes = n;
+    }
+    if (const char *e = getenv("NNN_RNN_ROWS")) {
+        const int v = atoi(e);
+        if (v == 16 || v == 32 || v == 64) h->rnn_rows = v;
+    }
     if (const char *e = getenv("NNN_XCORR_CHUNK")) {
         int v = atoi(e);
         if (v == 4 || v == 8 || v == 16) h->xcorr_chunk = v;
@@ -198,24 +236,49 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
     h->NT = h->S_pad / TILE;
     const size_t Sp = (size_t)h->S_pad;
 
-    RNNModel *own = nullptr;
-    if (!model) {
-        size_t len;
-        const uint8_t *w = nnn_builtin_weights(&len);
-        own = nnn_model_parse(w, len);
-        if (!own) return fail("built-in weights failed to parse");
-        model = own;
+    // pack every group's model; the recurrent state is allocated at the widest layer sizes among them
+    std::vector<std::vector<uint16_t>> wqs(n_groups);
+    std::vector<std::vector<float>> fpars(n_groups);
+    h->groups.resize(n_groups);
+    memset(&h->md, 0, sizeof(h->md));
+    size_t lds_max = 0;
+    for (int g = 0, tile0 = 0; g < n_groups; g++) {
+        const RNNModel *model = models ? models[g] : nullptr;
+        RNNModel *own = nullptr;
+        if (!model) {
+            size_t len;
+            const uint8_t *w = nnn_builtin_weights(&len);
+            own = nnn_model_parse(w, len);
+            if (!own) return fail("built-in weights failed to parse");
+            model = own;
+        }
+        nnn_batch::ModelGroup &G = h->groups[g];
+        ModelDims md;
+        nnn_model_pack(*model, wqs[g], fpars[g], G.plan, md);
+        delete own;
+        G.tile0 = tile0;
+        G.ntiles = (group_streams[g] + TILE - 1) / TILE;
+        // rows per block: the most that fit the LDS; fewer (more, shorter blocks) while the launch cannot fill the GPU
+        G.rows = 0;
+        for (int rows = TILE; rows >= 16 && !G.rows; rows /= 2)
+            if (rnn_lds_bytes(G.plan, rows) <= 160 * 1024) G.rows = rows;
+        if (!G.rows) return fail("model too large for the RNN kernel's LDS operand matrices");
+        while (G.rows > 16 && G.ntiles * (TILE / G.rows) < rnn_small_batch_blocks()) G.rows /= 2;
+        if (h->rnn_rows && rnn_lds_bytes(G.plan, h->rnn_rows) <= 160 * 1024) G.rows = h->rnn_rows;
+        G.rnn_lds = rnn_lds_bytes(G.plan, G.rows);
+        tile0 += G.ntiles;
+        h->md.nd = md.nd > h->md.nd ? md.nd : h->md.nd;
+        h->md.nv = md.nv > h->md.nv ? md.nv : h->md.nv;
+        h->md.nn = md.nn > h->md.nn ? md.nn : h->md.nn;
+        h->md.ndn = md.ndn > h->md.ndn ? md.ndn : h->md.ndn;
+        lds_max = G.rnn_lds > lds_max ? G.rnn_lds : lds_max;
     }
-    std::vector<uint16_t> wq;
-    std::vector<float> fpar;
-    h->rnn_lds = nnn_model_pack(*model, wq, fpar, h->plan, h->md);
-    delete own;
     const ModelDims &md = h->md;
-    if (h->rnn_lds > 160 * 1024) return fail("model too large for the RNN kernel's LDS operand matrices (%zu bytes)", h->rnn_lds);
 
     Buffers &b = h->b[0];
     memset(&b, 0, sizeof(b));
     b.S = h->S; b.S_pad = h->S_pad; b.NT = h->NT;
+    b.gru_v_w = md.nv; b.gru_n_w = md.nn; b.gru_dn_w = md.ndn;
     // persistent state
     HIPCHK(dalloc(h, &b.hist, Sp * RING, true));
     HIPCHK(dalloc(h, &b.hp_mem, Sp * 2, true));
@@ -262,11 +325,11 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
         if (ns > 64) return fail("band segmentation overflow");
         HIPCHK(upload(h, &b.seg, seg));
     }
-    {
+    for (int g = 0; g < n_groups; g++) {
         const uint16_t *dq = nullptr;
-        HIPCHK(upload(h, &dq, wq));
-        h->wq = (const uint4 *)dq;
-        HIPCHK(upload(h, &h->fpar, fpar));
+        HIPCHK(upload(h, &dq, wqs[g]));
+        h->groups[g].wq = (const uint4 *)dq;
+        HIPCHK(upload(h, &h->groups[g].fpar, fpars[g]));
     }
     for (int set = 1; set < NLANE; set++) h->b[set] = h->b[0];
     for (int set = 0; set < NLANE; set++) {   // per-frame scratch (doubles as parity taps), one set per frame in flight
@@ -294,10 +357,26 @@ static int create_impl(nnn_batch *h, const RNNModel *model, int n_streams, int d
         HIPCHK(dalloc(h, &q.g, Sp * NB, false));
         HIPCHK(dalloc(h, &q.vad, Sp, false));
     }
-    if (h->rnn_lds > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void *)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->rnn_lds));
+    if (lds_max > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     HIPCHK(hipDeviceSynchronize());
     return 0;
+}
+
+extern "C" nnn_batch *nnn_batch_create_grouped(const RNNModel *const *models, const int *group_streams, int n_groups, int device)
+{
+    if (n_groups <= 0 || !group_streams) {
+        fail("need at least one group of streams");
+        return nullptr;
+    }
+    nnn_batch *h = new nnn_batch();
+    if (create_impl(h, models, group_streams, n_groups, device) != 0) {
+        std::string keep = g_err;
+        nnn_batch_destroy(h);
+        g_err = keep;
+        return nullptr;
+    }
+    return h;
 }
 
 extern "C" nnn_batch *nnn_batch_create(const RNNModel *model, int n_streams, int device)
@@ -306,14 +385,7 @@ extern "C" nnn_batch *nnn_batch_create(const RNNModel *model, int n_streams, int
         fail("n_streams must be positive");
         return nullptr;
     }
-    nnn_batch *h = new nnn_batch();
-    if (create_impl(h, model, n_streams, device) != 0) {
-        std::string keep = g_err;
-        nnn_batch_destroy(h);
-        g_err = keep;
-        return nullptr;
-    }
-    return h;
+    return nnn_batch_create_grouped(&model, &n_streams, 1, device);
 }
 
 extern "C" int nnn_batch_num_streams(const nnn_batch *h) { return h ? h->S : 0; }
@@ -421,7 +493,8 @@ static bool enqueue_frame(nnn_batch *h, int set, hipStream_t st, const StepParam
     if (br) chk(hipStreamWaitEvent(st, h->ev_join[0], 0));
     L.go(K_FFT_P, k_fft_p, dim3(Sp), dim3(64), 0, b, sp);
     wait_prev(CH_RNN);
-    L.go(K_RNN, k_rnn, dim3(NT), dim3(64 * RNN_WAVES), h->rnn_lds, b, h->plan, h->wq, h->fpar);
+    for (const nnn_batch::ModelGroup &G : h->groups)   // one launch per resident model (a run of whole tiles)
+        L.go(K_RNN, k_rnn, dim3((unsigned)(G.ntiles * (TILE / G.rows))), dim3(64 * RNN_WAVES), G.rnn_lds, b, G.plan, G.wq, G.fpar, G.tile0, G.rows);
     mark(CH_RNN);
     wait_prev(CH_SYN);
     L.go(K_SYNTH, k_synth, dim3(Sp), dim3(64), 0, b, sp);
@@ -524,12 +597,15 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
             (void)hipGetLastError();
         }
         hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, st, h->sp_tab, v0, n_frames);
-        const int nl = n_frames < NLANE ? n_frames : NLANE;
+        const int NL = h->n_lanes;
+        const int nl = n_frames < NL ? n_frames : NL;
         bool ok = hipEventRecord(h->ev_lane, st) == hipSuccess;
         for (int l = 1; l < nl && ok; l++) ok = hipStreamWaitEvent(h->lanes[l], h->ev_lane, 0) == hipSuccess;
         for (int t = 0; t < n_frames && ok; t++) {
-            const int lane = t % NLANE, set = (int)(h->frame_count % NLANE);
-            ok = enqueue_frame(h, set, lane ? h->lanes[lane] : st, h->sp_tab + t, lane, t > 0 ? (t - 1) % NLANE : -1, false);
+            // frame t - NLANE (same scratch set) precedes frame t - 1 on t - 1's lane whenever NL <= NLANE, and every
+            // frame waits for its predecessor's high-pass first: the set is free when this frame starts
+            const int lane = t % NL, set = (int)(h->frame_count % NLANE);
+            ok = enqueue_frame(h, set, lane ? h->lanes[lane] : st, h->sp_tab + t, lane, t > 0 ? (t - 1) % NL : -1, false);
             h->frame_count += 1;
         }
         for (int l = 1; l < nl && ok; l++)
@@ -785,6 +861,48 @@ extern "C" RNNModel *nnn_model_default(void)
     size_t len;
     const uint8_t *w = nnn_builtin_weights(&len);
     return nnn_model_parse(w, len);
+}
+// RNNoise text model -> .rnn bytes (ref: train/convert_rnnoise.py:18-29).  Python's str.strip / str.split / int():
+// ASCII whitespace separators, optional sign, decimal digits (int() also takes '_' separators and non-ASCII digits;
+// no model file uses them and they are rejected here).
+extern "C" long nnn_convert_rnnoise_text(const char *text, size_t len, uint8_t *out, size_t cap)
+{
+    static const char kHeader[] = "rnnoise-nu model file version 1";
+    auto is_ws = [](char c) { return c == ' ' || (c >= '\t' && c <= '\r'); };
+    if (!text) { fail("null text"); return -1; }
+    size_t eol = 0;
+    while (eol < len && text[eol] != '\n') eol++;
+    size_t a = 0, b = eol;
+    while (a < b && is_ws(text[a])) a++;
+    while (b > a && is_ws(text[b - 1])) b--;
+    if (b - a != sizeof(kHeader) - 1 || memcmp(text + a, kHeader, b - a) != 0) { fail("Unexpected input file format"); return -1; }
+    long n = 0;
+    size_t i = eol < len ? eol + 1 : len;
+    while (i < len) {
+        while (i < len && is_ws(text[i])) i++;
+        if (i >= len) break;
+        bool neg = false;
+        if (text[i] == '+' || text[i] == '-') neg = text[i++] == '-';
+        if (i >= len || text[i] < '0' || text[i] > '9') { fail("token %ld is not an integer", n); return -1; }
+        unsigned v = 0;   // only the value modulo 256 matters
+        while (i < len && text[i] >= '0' && text[i] <= '9') v = (v * 10u + (unsigned)(text[i++] - '0')) & 0xffffu;
+        if (i < len && !is_ws(text[i])) { fail("token %ld is not an integer", n); return -1; }
+        const uint8_t byte = (uint8_t)((neg ? 256u - (v & 255u) : v) & 255u);   // Python's non-negative modulo
+        if (out) {
+            if ((size_t)n >= cap) { fail("output buffer too small"); return -1; }
+            out[n] = byte;
+        }
+        n++;
+    }
+    return n;
+}
+extern "C" RNNModel *nnn_model_from_rnnoise_text(const char *text, size_t len)
+{
+    const long n = nnn_convert_rnnoise_text(text, len, nullptr, 0);
+    if (n < 0) return nullptr;
+    std::vector<uint8_t> bytes((size_t)n);
+    if (nnn_convert_rnnoise_text(text, len, bytes.data(), bytes.size()) != n) return nullptr;
+    return nnn_model_from_bytes(bytes.data(), bytes.size());
 }
 extern "C" void nnn_model_free(RNNModel *m) { delete m; }
 extern "C" void nnn_model_shape(const RNNModel *m, int32_t s[12])

@@ -1029,7 +1029,8 @@ struct FeatHead {
 
 // The two DCTs are rolled loops over the output index (their fully unrolled form needs ~500 live table values);
 // the new cepstrum (rows 0..21) and the pitch-correlation DCT (rows 22..27) are parked in LDS (`cn`).
-__device__ __forceinline__ void features_head(const Buffers &b, int tile, int lane, FeatHead &h, float *cn)
+// `lane` = the stream's row in its 64-stream tile (global layouts), `ll` = its column in the block's LDS staging.
+__device__ __forceinline__ void features_head(const Buffers &b, int tile, int lane, int ll, FeatHead &h, float *cn)
 {
     float ex[NB], ep[NB], ly[NB], tmp[NB];
     const float *exg = NNN_TI(b.ex, NB, tile, lane), *epg = NNN_TI(b.ep, NB, tile, lane);
@@ -1051,7 +1052,7 @@ __device__ __forceinline__ void features_head(const Buffers &b, int tile, int la
     for (int i = 0; i < 6; i++) {
         float v = dct_out(tmp, b.dct, i);
         v -= i == 0 ? 1.3f : (i == 1 ? 0.9f : 0.0f);
-        cn[(NB + i) * TILE + lane] = v;
+        cn[(NB + i) * TILE + ll] = v;
     }
     h.fpitch = 0.01f * ((float)pitch - 300.0f);
     float log_max = -2.0f, follow = -2.0f, e = 0.0f;
@@ -1069,12 +1070,12 @@ __device__ __forceinline__ void features_head(const Buffers &b, int tile, int la
     for (int i = 0; i < NB; i++) {
         float v = dct_out(ly, b.dct, i);
         v -= i == 0 ? 12.0f : (i == 1 ? 4.0f : 0.0f);
-        cn[i * TILE + lane] = v;
+        cn[i * TILE + ll] = v;
     }
 }
 
 // ring update + delta features (wave 0, after the ring has been staged in crs)
-__device__ __forceinline__ void features_deltas(const Buffers &b, int tile, int lane, const FeatHead &h, float *crs,
+__device__ __forceinline__ void features_deltas(const Buffers &b, int tile, int lane, int ll, const FeatHead &h, float *crs,
                                                 const float *cn, float (&fr)[NFEAT])
 {
     if (h.silent) {   // "if there's no audio, avoid messing up the state" (ref: src/features.rs:160-166)
@@ -1090,9 +1091,9 @@ __device__ __forceinline__ void features_deltas(const Buffers &b, int tile, int 
     float c[NB];
 #pragma unroll
     for (int k = 0; k < NB; k++) {
-        c[k] = cn[k * TILE + lane];
+        c[k] = cn[k * TILE + ll];
         cm[(size_t)(c0 * NB + k) * TILE] = c[k];
-        crs[(c0 * NB + k) * TILE + lane] = c[k];
+        crs[(c0 * NB + k) * TILE + ll] = c[k];
     }
     mem_id += 1;
     if (mem_id == CEPS_MEM) mem_id = 0;
@@ -1101,12 +1102,12 @@ __device__ __forceinline__ void features_deltas(const Buffers &b, int tile, int 
     for (int i = 0; i < NB; i++) fr[i] = c[i];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        const float v1 = crs[(c1 * NB + i) * TILE + lane], v2 = crs[(c2 * NB + i) * TILE + lane];
+        const float v1 = crs[(c1 * NB + i) * TILE + ll], v2 = crs[(c2 * NB + i) * TILE + ll];
         const float v0 = c[i];
         fr[i] = v0 + v1 + v2;
         fr[NB + i] = v0 - v2;
         fr[NB + 6 + i] = v0 - 2.0f * v1 + v2;
-        fr[NB + 12 + i] = cn[(NB + i) * TILE + lane];
+        fr[NB + 12 + i] = cn[(NB + i) * TILE + ll];
     }
     fr[40] = h.fpitch;
     fr[41] = 0.0f;
@@ -1285,6 +1286,7 @@ struct RnnLds {
     const int *live;
     unsigned short *IN, *REC;
     int in_ps, rec_ps;   // plane strides (elements)
+    int rm;              // stream rows of this block: 64, 32 or 16
 };
 
 // One GRU layer (ref: src/rnn.rs:292-327) as three GEMM groups on the matrix cores.  A wave owns one
@@ -1294,12 +1296,12 @@ struct RnnLds {
 constexpr int RNN_LOADERS = 64 * (RNN_WAVES - 1);   // waves 1..7 set up the block while wave 0 computes the features
 constexpr int RNN_PRE = (TILE * MAXN + 64 * RNN_WAVES - 1) / (64 * RNN_WAVES);   // state values per thread (<= 16)
 
-__device__ __forceinline__ void preload_state(float (&pre)[RNN_PRE], const float *state, int n)
+__device__ __forceinline__ void preload_state(float (&pre)[RNN_PRE], const float *state, int n, int rm)
 {
 #pragma unroll
     for (int i = 0; i < RNN_PRE; i++) {
         const int e = (int)threadIdx.x + i * 64 * RNN_WAVES;
-        pre[i] = e < TILE * n ? state[e] : 0.0f;
+        pre[i] = e < rm * n ? state[e] : 0.0f;
     }
 }
 
@@ -1308,7 +1310,7 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
                                           const uint4 *__restrict__ Wq, const float *__restrict__ fpar, int wave, int lane)
 {
     const float scale = 1.0f / 256.0f;
-    const int groups = 4 / MB, units = L.nb * groups;
+    const int groups = (lds.rm >> 4) / MB, units = L.nb * groups;
     const bool mine = wave < units;
     const int nbi = mine ? wave / groups : 0, mb0 = (wave % groups) * MB;
     const int neuron = nbi * 16 + (lane & 15);
@@ -1329,11 +1331,11 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
     // the weight fragments requested above
     {
         float pre[RNN_PRE];
-        preload_state(pre, state, L.n);
+        preload_state(pre, state, L.n, lds.rm);
 #pragma unroll
         for (int i = 0; i < RNN_PRE; i++) {
             const int e = (int)threadIdx.x + i * 64 * RNN_WAVES;
-            if (e < TILE * L.n) {
+            if (e < lds.rm * L.n) {
                 int row = e / L.n, col = e - row * L.n;
                 store_split(lds.REC, lds.rec_ps, row * pl.rec_w + col, pre[i]);
             }
@@ -1402,15 +1404,16 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
 }
 
 // dense layer on the matrix cores: returns act(W x + b) for this wave's (neuron block, stream block) unit
-__device__ __forceinline__ float dense_bias(const LayerDesc &L, const float *__restrict__ fpar, int wave, int lane)
+// (dense layers: a wave owns one (neuron block, 16-stream block) unit; mbt = 16-stream blocks of this thread block)
+__device__ __forceinline__ float dense_bias(const LayerDesc &L, const float *__restrict__ fpar, int wave, int lane, int mbt)
 {
-    const int neuron = (wave / 4) * 16 + (lane & 15);
-    return (wave < L.nb * 4 && neuron < L.n) ? fpar[L.bias + neuron] : 0.0f;
+    const int neuron = (wave / mbt) * 16 + (lane & 15);
+    return (wave < L.nb * mbt && neuron < L.n) ? fpar[L.bias + neuron] : 0.0f;
 }
 
-__device__ __forceinline__ const uint4 *dense_frags(const LayerDesc &L, const uint4 *__restrict__ Wq, int wave)
+__device__ __forceinline__ const uint4 *dense_frags(const LayerDesc &L, const uint4 *__restrict__ Wq, int wave, int mbt)
 {
-    const int nbi = wave < L.nb * 4 ? wave / 4 : 0;
+    const int nbi = wave < L.nb * mbt ? wave / mbt : 0;
     return Wq + L.in.wofs + (size_t)nbi * L.in.ksteps * 64;
 }
 
@@ -1418,53 +1421,63 @@ __device__ __forceinline__ bool dense_unit(const LayerDesc &L, const RnnPlan &pl
                                            float bv, int wave, int lane, const Frags<1> &first,
                                            f32x4 &out, int &neuron, int &mb0)
 {
-    const int units = L.nb * 4;
-    const int nbi = wave / 4;
-    mb0 = wave % 4;
+    const int mbt = lds.rm >> 4, units = L.nb * mbt;
+    const int nbi = wave / mbt;
+    mb0 = wave % mbt;
     neuron = nbi * 16 + (lane & 15);
     if (wave >= units) return false;
     f32x4 acc[3][4];
     acc[0][0] = f32x4{bv, bv, bv, bv};
-    gemm_acc<1, 1, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, dense_frags(L, Wq, wave), lane, first);
+    gemm_acc<1, 1, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, dense_frags(L, Wq, wave, mbt), lane, first);
 #pragma unroll
     for (int q = 0; q < 4; q++) out[q] = activate(L.act, acc[0][0][q] * (1.0f / 256.0f), lds.tab);
     return neuron < L.n;
 }
 
 // ---------------------------------------------------------------------------------------------
-// K10 rnn: one 64-stream tile per block, 8 waves.
+// K10 rnn: `rm` stream rows (64, 32 or 16 of a 64-stream tile) per block, 8 waves.  Fewer rows per block = more
+//     blocks and a shorter chain per block (small batches), and operand matrices that still fit the LDS for the
+//     widest models the format allows (127 neurons per layer).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, const uint4 *__restrict__ Wq,
-                                                          const float *__restrict__ fpar)
+                                                          const float *__restrict__ fpar, int tile0, int rm)
 {
     HIP_DYNAMIC_SHARED(float, lds_raw)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63, tile = blockIdx.x, tid = threadIdx.x;
+    const int lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int per = TILE / rm, mbt = rm >> 4;
+    const int tile = tile0 + (int)blockIdx.x / per;        // tile0: first tile of this model's run
+    const int r0 = ((int)blockIdx.x % per) * rm;           // first row of the tile handled here
+    const bool rowl = lane < rm;                           // lane = stream phases: this lane has a row
+    const int trow = r0 + (rowl ? lane : 0);               // its row in the tile
     float *tab = lds_raw;
     int *live = (int *)(lds_raw + 256);
     unsigned short *IN = (unsigned short *)(lds_raw + 256 + 64);
-    const int in_ps = TILE * pl.in_w, rec_ps = TILE * pl.rec_w;
+    const int in_ps = rm * pl.in_w, rec_ps = rm * pl.rec_w;
     unsigned short *REC = IN + 3 * in_ps;
-    RnnLds lds{tab, live, IN, REC, in_ps, rec_ps};
-    float *sv = b.gru_v + (size_t)tile * TILE * pl.vad.n, *sn = b.gru_n + (size_t)tile * TILE * pl.noise.n,
-          *sdn = b.gru_dn + (size_t)tile * TILE * pl.dn.n;
+    RnnLds lds{tab, live, IN, REC, in_ps, rec_ps, rm};
+    float *sv = b.gru_v + ((size_t)tile * TILE * b.gru_v_w + (size_t)r0 * pl.vad.n),
+          *sn = b.gru_n + ((size_t)tile * TILE * b.gru_n_w + (size_t)r0 * pl.noise.n),
+          *sdn = b.gru_dn + ((size_t)tile * TILE * b.gru_dn_w + (size_t)r0 * pl.dn.n);
     NNN_STAMP(b, 8);
-    float *crs = (float *)(REC + 3 * rec_ps);          // staged cepstral ring [8 * 22][64]
+    float *crs = (float *)(REC + 3 * rec_ps);          // staged cepstral ring [8 * 22][64] (columns >= rm unused)
     float *dists = crs + CEPS_MEM * NB * TILE;         // pair distances [28][64]
     FeatHead fh;
+    fh.silent = true;
+    fh.fpitch = 0.0f;
     float fr[NFEAT];
     if (wave == 0) {
-        features_head(b, tile, lane, fh, dists);
+        if (rowl) features_head(b, tile, trow, lane, fh, dists);
     } else {
         // waves 1..7: stage the cepstral ring, zero both operand matrices (padding columns must read as 0),
         // fetch the activation table
-        const float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, lane);
+        const float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, trow);
         constexpr int PER = (CEPS_MEM * NB + RNN_WAVES - 2) / (RNN_WAVES - 1);   // 26 rows per wave, all in flight
         float st[PER];
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             const int r = (wave - 1) + i * (RNN_WAVES - 1);
-            st[i] = r < CEPS_MEM * NB ? cm[(size_t)r * TILE] : 0.0f;
+            st[i] = (rowl && r < CEPS_MEM * NB) ? cm[(size_t)r * TILE] : 0.0f;
         }
         uint4 *z = (uint4 *)IN;
         const int n16 = 3 * (in_ps + rec_ps) / 8;
@@ -1478,21 +1491,21 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     }
     lds_barrier();
     if (wave == 0) {
-        features_deltas(b, tile, lane, fh, crs, dists, fr);
+        if (rowl) features_deltas(b, tile, trow, lane, fh, crs, dists, fr);
         live[lane] = fh.silent ? 0 : 1;
     }
     lds_barrier();
     for (int p = wave; p < 28; p += RNN_WAVES) dists[p * TILE + lane] = pair_dist(crs, p, lane);
     // the dense layers' weights and biases travel during the rest of the prologue
     Frags<1> f_dense, f_out;
-    load_frags<1, 0>(f_dense, pl.dense.in, dense_frags(pl.dense, Wq, wave), lane);
-    load_frags<1, 0>(f_out, pl.out.in, dense_frags(pl.out, Wq, wave), lane);
-    const float bias_dense = dense_bias(pl.dense, fpar, wave, lane), bias_out = dense_bias(pl.out, fpar, wave, lane);
+    load_frags<1, 0>(f_dense, pl.dense.in, dense_frags(pl.dense, Wq, wave, mbt), lane);
+    load_frags<1, 0>(f_out, pl.out.in, dense_frags(pl.out, Wq, wave, mbt), lane);
+    const float bias_dense = dense_bias(pl.dense, fpar, wave, lane, mbt), bias_out = dense_bias(pl.out, fpar, wave, lane, mbt);
     lds_barrier();
     NNN_STAMP(b, 9);
-    if (wave == 0) {
+    if (wave == 0 && rowl) {
         if (!fh.silent) fr[41] = spectral_variability(dists, lane);
-        float *f = NNN_TI(b.feat, NFEAT, tile, lane);
+        float *f = NNN_TI(b.feat, NFEAT, tile, trow);
 #pragma unroll
         for (int k = 0; k < NFEAT; k++) {
             f[(size_t)k * TILE] = fr[k];
@@ -1510,19 +1523,21 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
         }
     }
     lds_barrier();
-#define NNN_GRU(L, st)                                                           \
-    switch ((L).mb) {                                                            \
-    case 4: gru_layer<4>(b, L, pl, lds, st, Wq, fpar, wave, lane); break;        \
-    case 2: gru_layer<2>(b, L, pl, lds, st, Wq, fpar, wave, lane); break;        \
-    default: gru_layer<1>(b, L, pl, lds, st, Wq, fpar, wave, lane); break;       \
+    // stream blocks per wave unit: as few as keep (neuron blocks) x (stream-block groups) within the 8 waves
+#define NNN_GRU(L, st)                                                                       \
+    {                                                                                        \
+        const int mb = (L).nb * mbt <= RNN_WAVES ? 1 : ((L).nb * mbt <= 2 * RNN_WAVES ? 2 : 4); \
+        if (mb == 4) gru_layer<4>(b, L, pl, lds, st, Wq, fpar, wave, lane);                  \
+        else if (mb == 2) gru_layer<2>(b, L, pl, lds, st, Wq, fpar, wave, lane);             \
+        else gru_layer<1>(b, L, pl, lds, st, Wq, fpar, wave, lane);                          \
     }
     NNN_STAMP(b, 11);
     NNN_GRU(pl.vad, sv)                                                 // ref: src/rnn.rs:356-358
     NNN_STAMP(b, 12);
-    if (wave == RNN_WAVES - 1) {   // vad output, 1 x nv, lane = stream (ref: src/rnn.rs:359)
+    if (wave == RNN_WAVES - 1 && rowl) {   // vad output, 1 x nv, lane = stream (ref: src/rnn.rs:359)
         float acc = fpar[pl.vo_b];
         for (int k = 0; k < pl.vad.n; k++) acc = fmaf(fpar[pl.vo_w + k], load_split(IN, in_ps, lane * pl.in_w + pl.cV + k), acc);
-        NNN_TI(b.vad, 1, tile, lane)[0] = live[lane] ? activate(pl.act_vo, acc * (1.0f / 256.0f), tab) : 0.0f;
+        NNN_TI(b.vad, 1, tile, trow)[0] = live[lane] ? activate(pl.act_vo, acc * (1.0f / 256.0f), tab) : 0.0f;
     }
     NNN_GRU(pl.noise, sn)                                               // ref: src/rnn.rs:361-366
     NNN_STAMP(b, 13);
@@ -1535,8 +1550,8 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
         if (dense_unit(pl.out, pl, lds, Wq, bias_out, wave, lane, f_out, o, band, mb0)) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int row = mb0 * 16 + 4 * (lane >> 4) + q;
-                const bool lv = live[row] != 0;
+                const int lrow = mb0 * 16 + 4 * (lane >> 4) + q, row = r0 + lrow;
+                const bool lv = live[lrow] != 0;
                 const float gr = lv ? o[q] : 0.0f;
                 NNN_TI(b.g_raw, NB, tile, row)[(size_t)band * TILE] = gr;
                 float g = 0.0f;

@@ -83,7 +83,8 @@ struct Buffers {
     float *lastg;        // TI [22]
     int *last_period;    // TI [1]
     float *last_gain;    // TI [1]
-    float *gru_v, *gru_n, *gru_dn;  // SM [nv], [nn], [ndn]
+    float *gru_v, *gru_n, *gru_dn;  // SM, tile t at t * 64 * gru_*_w (the widest resident model), rows of the tile's own width
+    int gru_v_w, gru_n_w, gru_dn_w;
     // ---- per-frame scratch (doubles as the parity taps)
     float *lpc;          // TI [10]     ac[5], lpc2[5]
     float *xlp0;         // TI [1]      pitch_downsample's special first element (x[1]/2 + x[0])/2

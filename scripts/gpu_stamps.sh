@@ -13,7 +13,9 @@ from nnnoiseless_amd import _ffi
 from nnnoiseless_amd.synthetic import make_streams_fast
 lib = _ffi.Library('/tmp/libnnn_stamps.so')
 lib.L.nnn_batch_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
-for S in (4096, 65536):
+import os
+for S, rows in ((4096, 64), (4096, 16), (65536, 64)):
+    os.environ['NNN_RNN_ROWS'] = str(rows)
     bd = nn.BatchDenoiser(S, lib=lib)
     bd.set_graph(False)
     x = make_streams_fast(S, 6)
@@ -21,7 +23,7 @@ for S in (4096, 65536):
     st = np.zeros(64, np.int64)
     lib.L.nnn_batch_read_stamps(bd._h, st.ctypes.data_as(C.c_void_p))
     d = lambda a, b: (st[b] - st[a]) / 100.0   # s_memtime ticks at 100 MHz -> us
-    print(f"S={S}  [ticks are 100 MHz constant clock -> us]")
+    print(f"S={S} rnn rows={rows}  [ticks are 100 MHz constant clock -> us]")
     print("  k_hp total", d(24, 25))
     print("  k_lpc: autocorr", d(0, 1), "lpc", d(1, 2), "fir", d(2, 3))
     print("  k_rnn: preload+features+zero", d(8, 9), "split feats", d(9, 10), "dense", d(10, 11), "vad", d(11, 12), "noise(+vadout)", d(12, 13), "dn", d(13, 14), "out", d(14, 15))

@@ -335,3 +335,41 @@ def test_denoise_signal(nn, oracle_mod, weights_bytes):
         out = DenoiseSignal(x[:n]).collect()
         assert out.shape == ref.shape, n
         assert np.abs(out - ref).max() <= 2e-5, n
+
+
+# ---- model tooling, several models resident at once --------------------------------------------
+
+def test_grouped_models(nn, oracle_mod, weights_bytes):
+    """Four models resident in one batch (built-in, converted rnnoise-nu text model, a narrow and the widest synthetic
+    model the format allows), 20 frames, multi-frame call: every run of streams matches the oracle with ITS model."""
+    from model_fixtures import make_model
+    from nnnoiseless_amd.synthetic import make_streams
+    sh = open(os.path.join(GOLDEN, "sh.rnn"), "rb").read()
+    text = "rnnoise-nu model file version 1\n" + " ".join(str(int(v)) for v in np.frombuffer(sh, dtype=np.int8))
+    small, biggest = make_model(16, 20, 40, 72, seed=1), make_model(42, 43, 42, 127, seed=3)
+    m_sh = nn.RnnModel.from_rnnoise_text(text)
+    m_small, m_big = nn.RnnModel.from_bytes(small), nn.RnnModel.from_bytes(biggest)
+    assert m_sh is not None and m_small is not None and m_big is not None
+    sizes = [128, 192, 64, 70]
+    x = make_streams(41, sum(sizes), 20)
+    bd = nn.BatchDenoiser(sum(sizes), groups=list(zip([None, m_sh, m_small, m_big], sizes)))
+    out, vad = bd.process(x)
+    lo = 0
+    for blob, n in zip([weights_bytes, sh, small, biggest], sizes):
+        ref = oracle_mod.run_streams(oracle_mod.Model(blob), x[lo:lo + n], n_threads=os.cpu_count() or 1)
+        assert np.array_equal(bd.tap("pitch")[lo:lo + n, 0], ref["pitch"][:, -1])
+        assert rel_rms(out[lo:lo + n, 1:], ref["out"][:, 1:]) <= 1e-4
+        assert np.abs(vad.T[lo:lo + n] - ref["vad"]).max() < 1e-3
+        lo += n
+
+
+@pytest.mark.parametrize("rows", [64, 32, 16])
+def test_rnn_rows_per_block_variants(nn, oracle_mod, weights_bytes, rows, monkeypatch):
+    """The RNN kernel's 64/32/16-row block shapes give identical results (same arithmetic, different work split)."""
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(43, 200, 6)
+    monkeypatch.setenv("NNN_RNN_ROWS", str(rows))
+    out, vad = nn.BatchDenoiser(200).process(x)
+    monkeypatch.delenv("NNN_RNN_ROWS")
+    base, vbase = nn.BatchDenoiser(200).process(x)
+    assert np.array_equal(out, base) and np.array_equal(vad, vbase)
