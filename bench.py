@@ -40,11 +40,10 @@ FLOPS_PER_FRAME = 0.42e6
 KERNEL_BYTES = {
     "k_hp": 1920 + 1920 + 16 + 2 * 960 + 8,          # input, history slot, biquad state, 240 decimated values (stored twice)
     "k_lpc": 3456 + 40 + 2 * 3456,                    # decimated window in; taps + pitch_buf (TI + SM) out
-    "k_xcorr": 3456 + 588,
+    "k_xcorr": 3456 + 588 + 1544,                     # pitch_buf in; 147 coarse lags + xx / yy_lookup (386) out
     "k_best1": 1548 + 588 + 8,
     "k_refine": 3456 + 8 + 40,
     "k_best2": 3456 + 40 + 8 + 4 + 2 * 1176,
-    "k_yy": 3456 + 1544,
     "k_doubling": 3456 + 116 + 24,
     "k_fft_x": 3840 + 3848 + 88,
     "k_fft_p": 3840 + 4 + 3848 + 3848 + 176,
@@ -85,6 +84,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4096, help="concurrent streams PER GPU")
     ap.add_argument("--frames-per-step", type=int, default=16)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--workload", choices=["denoise", "train"], default="denoise",
+                    help="denoise = process_frame (the headline); train = 87-column training rows (SURVEY 8(f) #3)")
     ap.add_argument("--pcm", choices=["f32", "i16", "unit"], default="f32",
                     help="boundary sample format (SURVEY 8(f) #1): f32 = process_frame's own (headline), i16 = the CLI's "
                          "packed int16, unit = DenoiseSignal's [-1, 1] floats")
@@ -108,6 +109,8 @@ def main():
     from nnnoiseless_amd.synthetic import make_streams_fast
     from nnnoiseless_amd.shard import aggregate
 
+    if args.workload == "train":
+        return bench_train(args, rank, world, dev, local_rank, dist)
     S, fps, K, W = args.streams, args.frames_per_step, args.steps, args.warmup
     total_frames = (K + W) * fps
     # distinct audio for every step while it fits ~6 GB per GPU, else cycle through a pool of frames
@@ -238,6 +241,55 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
         }
         print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_train(args, rank, world, dev, local_rank, dist):
+    """Training-feature rows per second: three feature states per stream, no RNN, no synthesis."""
+    import torch
+    from nnnoiseless_amd.shard import aggregate
+    from nnnoiseless_amd.synthetic import make_streams_fast
+    from nnnoiseless_amd.training import ROW_WIDTH, TrainingFeatures
+    S, fps, K, W = args.streams, args.frames_per_step, args.steps, args.warmup
+    pool = max(fps, 16)
+    sig = torch.from_numpy(make_streams_fast(S, pool, seed=rank)).to(dev)
+    noise = torch.from_numpy(make_streams_fast(S, pool, seed=1000 + rank) * 0.3).to(dev)
+    comb = sig + noise
+    cutoff = torch.full((pool, S), 20, dtype=torch.int32, device=dev)
+    vad = torch.ones((pool, S), dtype=torch.float32, device=dev)
+    rows = torch.empty((pool, S, ROW_WIDTH), dtype=torch.float32, device=dev)
+    tf = TrainingFeatures(S, device=local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        tf.process_device(sig.data_ptr(), noise.data_ptr(), comb.data_ptr(), cutoff.data_ptr(), vad.data_ptr(), rows.data_ptr(),
+                          fps, pool * 480, 480, stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(W):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    done, tmax = aggregate(dist if world > 1 else None, S * fps * K, elapsed, dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training rows/sec (87 columns; 3 feature states per row)", "value": done / tmax, "unit": "rows/s",
+            "n_gpus": args.gpus, "steps": K, "warmup": W, "ms_per_step": tmax * 1e3 / K, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{S} (clean, noise, mix) stream triples per GPU, {fps} frame(s) per step (src/training.rs:113-160)",
+                       "streams_per_gpu": S, "frames_per_step": fps},
+            "outputs_finite": bool(torch.isfinite(rows).all().item())}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

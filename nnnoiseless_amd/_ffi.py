@@ -20,6 +20,9 @@ BATCH_SYMBOLS = [
     "nnn_batch_kernel_name", "nnn_batch_read_kernel_times", "nnn_batch_set_graph", "nnn_batch_set_pipeline", "nnn_batch_read_stamps",
     "nnn_last_error",
 ]
+TRAIN_SYMBOLS = [
+    "nnn_train_create", "nnn_train_destroy", "nnn_train_reset", "nnn_train_process_device", "nnn_train_process_host",
+]
 RNNOISE_SYMBOLS = [
     "rnnoise_get_frame_size", "rnnoise_get_size", "rnnoise_init", "rnnoise_create", "rnnoise_destroy",
     "rnnoise_process_frame", "rnnoise_model_from_file", "rnnoise_model_free",
@@ -76,6 +79,12 @@ class Library:
         L.nnn_batch_read_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
         L.nnn_batch_set_graph.argtypes = [vp, i32]
         L.nnn_batch_set_pipeline.argtypes = [vp, i32]
+        L.nnn_train_create.restype = vp
+        L.nnn_train_create.argtypes = [i32, i32]
+        L.nnn_train_destroy.argtypes = [vp]
+        L.nnn_train_reset.argtypes = [vp]
+        L.nnn_train_process_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, sz, sz, vp]
+        L.nnn_train_process_host.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32]
         L.nnn_last_error.restype = C.c_char_p
         L.rnnoise_create.restype = vp
         L.rnnoise_create.argtypes = [vp]

@@ -8,16 +8,24 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/nnn_batch.h"
+#include "../../include/nnn_train.h"
 #include "nnn_kernels.hip"
 #include "nnn_model.h"
 
 using namespace nnn;
 
 static thread_local std::string g_err;
+// States are independent and may be driven from different threads.  What must not overlap across
+// threads is stream capture on one thread with allocation, freeing or legacy-stream (synchronous memset / memcpy) calls
+// on another: the HIP runtime rejects those ("would make the legacy stream depend on a capturing blocking stream").
+// Those short sections -- never the per-frame launches -- take this lock.
+static std::recursive_mutex g_rt_mu;
+#define NNN_RT_LOCK std::lock_guard<std::recursive_mutex> rt_lock_(g_rt_mu)
 extern "C" const char *nnn_last_error(void) { return g_err.c_str(); }
 static int fail(const char *fmt, ...)
 {
@@ -35,9 +43,9 @@ static int fail(const char *fmt, ...)
         if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));  \
     } while (0)
 
-enum KernelId { K_HP, K_LPC, K_XCORR, K_BEST1, K_REFINE, K_BEST2, K_YY, K_DOUBLING, K_FFT_X, K_FFT_P, K_RNN, K_SYNTH, K_ADVANCE, K_COUNT };
+enum KernelId { K_HP, K_LPC, K_XCORR, K_BEST1, K_REFINE, K_BEST2, K_DOUBLING, K_FFT_X, K_FFT_P, K_RNN, K_SYNTH, K_ADVANCE, K_COUNT };
 static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_xcorr", "k_best1", "k_refine", "k_best2",
-                                            "k_yy", "k_doubling", "k_fft_x", "k_fft_p", "k_rnn", "k_synth", "k_advance"};
+                                            "k_doubling", "k_fft_x", "k_fft_p", "k_rnn", "k_synth", "k_advance"};
 
 
 struct nnn_batch {
@@ -151,6 +159,7 @@ static void make_tables(std::vector<float> &window, std::vector<float> &dct, std
 extern "C" void nnn_batch_destroy(nnn_batch *h)
 {
     if (!h) return;
+    NNN_RT_LOCK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (int i = 0; i < NLANE; i++) {
@@ -369,6 +378,7 @@ extern "C" nnn_batch *nnn_batch_create_grouped(const RNNModel *const *models, co
         fail("need at least one group of streams");
         return nullptr;
     }
+    NNN_RT_LOCK;
     nnn_batch *h = new nnn_batch();
     if (create_impl(h, models, group_streams, n_groups, device) != 0) {
         std::string keep = g_err;
@@ -399,6 +409,7 @@ extern "C" int nnn_batch_synchronize(nnn_batch *h)
 
 extern "C" int nnn_batch_reset(nnn_batch *h)
 {
+    NNN_RT_LOCK;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     for (auto &sb : h->state_bufs) HIPCHK(hipMemset(sb.first, 0, sb.second));
@@ -448,8 +459,8 @@ static bool enqueue_frame(nnn_batch *h, int set, hipStream_t st, const StepParam
     const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad;
     const bool chain = lane >= 0;
     const bool br = h->use_branches && !prof && !chain;
-    hipStream_t s0 = br ? h->side[0] : st, s1 = br ? h->side[1] : st;
-    Launcher L{h, st, prof}, L0{h, s0, prof}, L1{h, s1, prof};
+    hipStream_t s0 = br ? h->side[0] : st;
+    Launcher L{h, st, prof}, L0{h, s0, prof};
     bool ok = true;
     auto chk = [&](hipError_t e) { ok = ok && e == hipSuccess; };
     auto wait_prev = [&](int which) {
@@ -472,20 +483,13 @@ static bool enqueue_frame(nnn_batch *h, int set, hipStream_t st, const StepParam
         L0.go(K_FFT_X, k_fft_x, dim3(Sp), dim3(64), 0, b, sp);
         if (br) chk(hipEventRecord(h->ev_join[0], s0));
         L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp);
-        if (br) {
-            chk(hipEventRecord(h->ev_fork[1], st));
-            chk(hipStreamWaitEvent(s1, h->ev_fork[1], 0));
-        }
-        L1.go(K_YY, k_yy, dim3(NT), dim3(64), 0, b);
-        if (br) chk(hipEventRecord(h->ev_join[1], s1));
         const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
-        if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4), dim3(64), 0, b);
-        else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8), dim3(64), 0, b);
-        else L.go(K_XCORR, k_xcorr<16>, dim3(NT, (NLAG1 + 15) / 16), dim3(64), 0, b);
+        if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4 + 1), dim3(64), 0, b);
+        else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8 + 1), dim3(64), 0, b);
+        else L.go(K_XCORR, k_xcorr<16>, dim3(NT, (NLAG1 + 15) / 16 + 1), dim3(64), 0, b);
         L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
         L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
         L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
-        if (br) chk(hipStreamWaitEvent(st, h->ev_join[1], 0));
     }
     wait_prev(CH_DBL);
     L.go(K_DOUBLING, k_doubling, dim3(Sp / 4), dim3(256), 0, b);
@@ -512,11 +516,10 @@ static bool enqueue_front(nnn_batch *h, int set, hipStream_t st)
     Launcher L{h, st, false};
     L.go(K_FFT_X, k_fft_x, dim3(Sp), dim3(64), 0, b, sp);
     L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp);
-    L.go(K_YY, k_yy, dim3(NT), dim3(64), 0, b);
     const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
-    if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4), dim3(64), 0, b);
-    else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8), dim3(64), 0, b);
-    else L.go(K_XCORR, k_xcorr<16>, dim3(NT, (NLAG1 + 15) / 16), dim3(64), 0, b);
+    if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4 + 1), dim3(64), 0, b);
+    else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8 + 1), dim3(64), 0, b);
+    else L.go(K_XCORR, k_xcorr<16>, dim3(NT, (NLAG1 + 15) / 16 + 1), dim3(64), 0, b);
     L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
     L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
     L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
@@ -526,6 +529,7 @@ static bool enqueue_front(nnn_batch *h, int set, hipStream_t st)
 // captures body() on `st` and instantiates an executable graph from it
 template <class F> static hipGraphExec_t capture(hipStream_t st, F &&body)
 {
+    NNN_RT_LOCK;
     hipGraph_t g = nullptr;
     hipGraphExec_t ex = nullptr;
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
@@ -576,6 +580,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
         // the recurrences.  Launched eagerly (replaying this shape as a captured multi-stream graph back to back crashes
         // the ROCm 7.2 runtime); the per-frame parameters come from a table filled by one small kernel.
         if (n_frames > h->sp_tab_cap) {
+            NNN_RT_LOCK;
             HIPCHK(hipStreamSynchronize(st));
             if (h->sp_tab) HIPCHK(hipFree(h->sp_tab));
             h->sp_tab = nullptr;
@@ -689,28 +694,37 @@ static int process_host_span(nnn_batch *h, const void *in, void *out, float *vad
     const int drop = (L->discard_first && h->frame_count == 0) ? 1 : 0;
     char *d = nullptr;
     float *dv = nullptr;
-    HIPCHK(hipMalloc((void **)&d, span));
-    hipError_t err = hipMemcpyAsync(d, in, span, hipMemcpyHostToDevice, h->stream);
-    if (err == hipSuccess && vad) err = hipMalloc((void **)&dv, (size_t)n_frames * h->S * sizeof(float));
+    hipError_t err;
+    {
+        NNN_RT_LOCK;
+        HIPCHK(hipMalloc((void **)&d, span));
+        err = vad ? hipMalloc((void **)&dv, (size_t)n_frames * h->S * sizeof(float)) : hipSuccess;
+    }
+    if (err == hipSuccess) err = hipMemcpyAsync(d, in, span, hipMemcpyHostToDevice, h->stream);
     int rc = 0;
     if (err != hipSuccess) rc = fail("host staging failed: %s", hipGetErrorString(err));
     if (!rc) rc = nnn_batch_process_pcm_device(h, d, d, dv, n_frames, L, h->stream);
     if (!rc) {
         // `out` may alias `in` and may be strided: bring the span back and copy only real frames
         std::vector<char> tmp(span);
-        err = hipStreamSynchronize(h->stream);
-        if (err == hipSuccess) err = hipMemcpy(tmp.data(), d, span, hipMemcpyDeviceToHost);
+        err = hipMemcpyAsync(tmp.data(), d, span, hipMemcpyDeviceToHost, h->stream);
+        if (err == hipSuccess && vad) err = hipMemcpyAsync(vad, dv, (size_t)n_frames * h->S * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(h->stream);
         if (err == hipSuccess)
             for (size_t g = 0; g < groups; g++)
                 for (int t = 0; t < n_frames - drop; t++) {
                     size_t o = g * L->group_stride * e + (size_t)t * L->frame_stride * e;
                     memcpy((char *)out + o, tmp.data() + o, fr);
                 }
-        if (err == hipSuccess && vad) err = hipMemcpy(vad, dv, (size_t)n_frames * h->S * sizeof(float), hipMemcpyDeviceToHost);
         if (err != hipSuccess) rc = fail("copy back failed: %s", hipGetErrorString(err));
+    } else {
+        hipStreamSynchronize(h->stream);
     }
-    hipFree(d);
-    if (dv) hipFree(dv);
+    {
+        NNN_RT_LOCK;
+        hipFree(d);
+        if (dv) hipFree(dv);
+    }
     return rc;
 }
 
@@ -778,6 +792,7 @@ extern "C" int nnn_tap_info(int tap, int *len, int *is_int)
 
 extern "C" int nnn_batch_read_tap(nnn_batch *h, int tap, void *host_dst, size_t dst_bytes)
 {
+    NNN_RT_LOCK;
     if (!h) return fail("null batch");
     TapDesc d;
     const void *p;
@@ -809,6 +824,7 @@ extern "C" int nnn_batch_read_tap(nnn_batch *h, int tap, void *host_dst, size_t 
 
 extern "C" int nnn_batch_read_stamps(nnn_batch *h, long long *dst64)
 {
+    NNN_RT_LOCK;
     if (!h) return fail("null batch");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
@@ -847,6 +863,144 @@ extern "C" int nnn_batch_set_pipeline(nnn_batch *h, int on)
     if (!h) return fail("null batch");
     h->use_pipeline = on != 0;
     return 0;
+}
+
+// ---- training-feature rows (include/nnn_train.h) ---------------------------------------------------------------------
+struct nnn_train {
+    nnn_batch *comb = nullptr, *clean = nullptr, *noise = nullptr;   // three sets of DenoiseFeatures state
+};
+
+extern "C" void nnn_train_destroy(nnn_train *t)
+{
+    if (!t) return;
+    nnn_batch_destroy(t->comb);
+    nnn_batch_destroy(t->clean);
+    nnn_batch_destroy(t->noise);
+    delete t;
+}
+
+extern "C" nnn_train *nnn_train_create(int n_streams, int device)
+{
+    nnn_train *t = new nnn_train();
+    t->comb = nnn_batch_create(nullptr, n_streams, device);
+    t->clean = t->comb ? nnn_batch_create(nullptr, n_streams, device) : nullptr;
+    t->noise = t->clean ? nnn_batch_create(nullptr, n_streams, device) : nullptr;
+    if (!t->noise) {
+        std::string keep = g_err;
+        nnn_train_destroy(t);
+        g_err = keep;
+        return nullptr;
+    }
+    return t;
+}
+
+extern "C" int nnn_train_reset(nnn_train *t)
+{
+    if (!t) return fail("null handle");
+    if (int rc = nnn_batch_reset(t->comb)) return rc;
+    if (int rc = nnn_batch_reset(t->clean)) return rc;
+    return nnn_batch_reset(t->noise);
+}
+
+// shift_and_filter_input + the part of compute_frame_features the row needs: everything up to the 42 features for the
+// mix, only the band energies of X for the clean and noise states (src/training.rs:129-131 computes their full
+// features and says itself that only the transform and band energies are needed; nothing else of them is read).
+static void enqueue_feature_frame(nnn_batch *h, hipStream_t st, const float *in, size_t stream_stride, bool full)
+{
+    const Buffers &b = h->b[0];
+    const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad;
+    StepParams v;
+    v.in = (const char *)in;
+    v.out = nullptr;
+    v.vad = nullptr;
+    v.group_stride = (long long)stream_stride * 4;
+    v.frame_stride = 0;
+    v.fmt = PCM_F32;
+    v.channels = 1;
+    v.discard = 1;
+    v.slot = (int)(h->frame_count % NSLOT);
+    v.n_streams = h->S;
+    StepParams *sp = h->sp;
+    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, sp, v);
+    hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, sp, (StepParams *)nullptr);
+    hipLaunchKernelGGL(k_fft_x, dim3(Sp), dim3(64), 0, st, b, sp);
+    if (full) {
+        hipLaunchKernelGGL(k_lpc, dim3(NT), dim3(320), 0, st, b, sp);
+        const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
+        if (lc == 4) hipLaunchKernelGGL(k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4 + 1), dim3(64), 0, st, b);
+        else if (lc == 8) hipLaunchKernelGGL(k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8 + 1), dim3(64), 0, st, b);
+        else hipLaunchKernelGGL(k_xcorr<16>, dim3(NT, (NLAG1 + 15) / 16 + 1), dim3(64), 0, st, b);
+        hipLaunchKernelGGL(k_best1, dim3(NT), dim3(64), 0, st, b);
+        hipLaunchKernelGGL(k_refine, dim3(Sp / 4), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(k_best2, dim3(NT), dim3(64), 0, st, b);
+        hipLaunchKernelGGL(k_doubling, dim3(Sp / 4), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(k_fft_p, dim3(Sp), dim3(64), 0, st, b, sp);
+        hipLaunchKernelGGL(k_features, dim3(NT), dim3(64 * FEAT_WAVES), 0, st, b);
+    }
+    h->frame_count += 1;
+}
+
+extern "C" int nnn_train_process_device(nnn_train *t, const float *d_signal, const float *d_noise, const float *d_combined,
+                                        const int32_t *d_cutoff, const float *d_vad, float *d_rows, int n_frames,
+                                        size_t stream_stride, size_t frame_stride, void *hip_stream)
+{
+    if (!t) return fail("null handle");
+    if (n_frames <= 0) return 0;
+    if (!d_signal || !d_noise || !d_combined || !d_cutoff || !d_vad || !d_rows) return fail("null buffer");
+    nnn_batch *h = t->comb;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    const size_t S = (size_t)h->S;
+    for (int f = 0; f < n_frames; f++) {
+        const size_t off = (size_t)f * frame_stride;
+        enqueue_feature_frame(t->comb, st, d_combined + off, stream_stride, true);
+        enqueue_feature_frame(t->clean, st, d_signal + off, stream_stride, false);
+        enqueue_feature_frame(t->noise, st, d_noise + off, stream_stride, false);
+        hipLaunchKernelGGL(k_train_rows, dim3((unsigned)h->NT), dim3(64), 0, st, t->comb->b[0], t->clean->b[0], t->noise->b[0],
+                           (const int *)d_cutoff + f * S, d_vad + f * S, d_rows + f * S * TRAIN_COLS);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int nnn_train_process_host(nnn_train *t, const float *signal, const float *noise, const float *combined,
+                                      const int32_t *cutoff, const float *vad, float *rows, int n_frames)
+{
+    if (!t) return fail("null handle");
+    if (n_frames <= 0) return 0;
+    if (!signal || !noise || !combined || !cutoff || !vad || !rows) return fail("null buffer");
+    nnn_batch *h = t->comb;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t S = (size_t)h->S, na = S * n_frames * FRAME, nl = S * n_frames;
+    float *d = nullptr;   // [signal | noise | combined | vad | rows], cutoff apart
+    int32_t *dc = nullptr;
+    hipError_t e;
+    {
+        NNN_RT_LOCK;
+        HIPCHK(hipMalloc((void **)&d, (3 * na + nl + nl * TRAIN_COLS) * sizeof(float)));
+        e = hipMalloc((void **)&dc, nl * sizeof(int32_t));
+    }
+    float *dv = d + 3 * na, *dr = dv + nl;
+    if (e == hipSuccess) e = hipMemcpyAsync(d, signal, na * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + na, noise, na * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + 2 * na, combined, na * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dv, vad, nl * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dc, cutoff, nl * 4, hipMemcpyHostToDevice, h->stream);
+    int rc = e == hipSuccess ? 0 : fail("host staging failed: %s", hipGetErrorString(e));
+    if (!rc) rc = nnn_train_process_device(t, d, d + na, d + 2 * na, dc, dv, dr, n_frames, (size_t)n_frames * FRAME, FRAME, h->stream);
+    if (!rc) {
+        e = hipMemcpyAsync(rows, dr, nl * TRAIN_COLS * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail("copy back failed: %s", hipGetErrorString(e));
+    } else {
+        hipStreamSynchronize(h->stream);
+    }
+    {
+        NNN_RT_LOCK;
+        hipFree(d);
+        if (dc) hipFree(dc);
+    }
+    return rc;
 }
 
 // ---- model entry points -------------------------------------------------------------------------

@@ -341,6 +341,44 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
 }
 
 // ---------------------------------------------------------------------------------------------
+// K7y yy: xx = |x|^2 over the analysis frame (4 interleaved partial sums) and the 384-step running
+//     energy yy_lookup of remove_doubling (ref: src/pitch.rs:133-142).  Depends only on pitch_buf, so
+//     it rides in the coarse cross-correlation's launch as one more block row.  lane = stream.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void yy_lookup(const Buffers &b, int tile, int lane)
+{
+    const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (int j0 = 0; j0 < 480; j0 += 24) {
+        float v[24];
+#pragma unroll
+        for (int i = 0; i < 24; i++) v[i] = p[(size_t)(384 + j0 + i) * TILE];
+#pragma unroll
+        for (int i = 0; i < 24; i += 4) {
+            s0 += v[i] * v[i]; s1 += v[i + 1] * v[i + 1]; s2 += v[i + 2] * v[i + 2]; s3 += v[i + 3] * v[i + 3];
+        }
+    }
+    const float xx = s0 + s1 + s2 + s3;
+    float *yo = NNN_TI(b.xx_yy, 386, tile, lane);
+    yo[0] = xx;
+    yo[TILE] = xx;  // yy_lookup[0]
+    float yy = xx;
+    for (int i0 = 1; i0 <= 384; i0 += 24) {
+        float a[24], c[24];
+#pragma unroll
+        for (int i = 0; i < 24; i++) {
+            a[i] = p[(size_t)(384 - (i0 + i)) * TILE];
+            c[i] = p[(size_t)(384 + 480 - (i0 + i)) * TILE];
+        }
+#pragma unroll
+        for (int i = 0; i < 24; i++) {
+            yy += a[i] * a[i] - c[i] * c[i];
+            yo[(size_t)(1 + i0 + i) * TILE] = fmaxf(yy, 0.0f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K5  xcorr_coarse: 147 lags x 240 taps on the 4x-decimated signal, every lag a strictly
 //     sequential sum in j (ref: src/pitch.rs:296-363, call site :82).  lane = stream, one wave per
 //     (tile, chunk of LC lags); LC accumulators + an LC-deep sliding window of y in registers, so a
@@ -350,6 +388,10 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
 template <int LC>
 __global__ void __launch_bounds__(64) k_xcorr(Buffers b)
 {
+    if (blockIdx.y == gridDim.y - 1) {   // the extra block row: xx / yy_lookup (same input, independent work)
+        yy_lookup(b, blockIdx.x, threadIdx.x);
+        return;
+    }
     const int lane = threadIdx.x, tile = blockIdx.x, L0 = blockIdx.y * LC;
     const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
 #define X4(j) p[(size_t)(384 + 2 * (j)) * TILE]
@@ -559,45 +601,6 @@ __global__ void __launch_bounds__(64) k_best2(Buffers b)
         else if (a - c > 0.7f * (bb - c)) offset = -1;
     }
     NNN_TI(b.psearch, 1, tile, lane)[0] = 2 * bp.best - offset;
-}
-
-// ---------------------------------------------------------------------------------------------
-// K7y yy: xx = |x|^2 over the analysis frame (4 interleaved partial sums) and the 384-step running
-//     energy yy_lookup of remove_doubling (ref: src/pitch.rs:133-142).  Depends only on pitch_buf, so
-//     it runs beside the pitch search.  lane = stream.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_yy(Buffers b)
-{
-    const int lane = threadIdx.x, tile = blockIdx.x;
-    const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    for (int j0 = 0; j0 < 480; j0 += 24) {
-        float v[24];
-#pragma unroll
-        for (int i = 0; i < 24; i++) v[i] = p[(size_t)(384 + j0 + i) * TILE];
-#pragma unroll
-        for (int i = 0; i < 24; i += 4) {
-            s0 += v[i] * v[i]; s1 += v[i + 1] * v[i + 1]; s2 += v[i + 2] * v[i + 2]; s3 += v[i + 3] * v[i + 3];
-        }
-    }
-    const float xx = s0 + s1 + s2 + s3;
-    float *yo = NNN_TI(b.xx_yy, 386, tile, lane);
-    yo[0] = xx;
-    yo[TILE] = xx;  // yy_lookup[0]
-    float yy = xx;
-    for (int i0 = 1; i0 <= 384; i0 += 24) {
-        float a[24], c[24];
-#pragma unroll
-        for (int i = 0; i < 24; i++) {
-            a[i] = p[(size_t)(384 - (i0 + i)) * TILE];
-            c[i] = p[(size_t)(384 + 480 - (i0 + i)) * TILE];
-        }
-#pragma unroll
-        for (int i = 0; i < 24; i++) {
-            yy += a[i] * a[i] - c[i] * c[i];
-            yo[(size_t)(1 + i0 + i) * TILE] = fmaxf(yy, 0.0f);
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1160,6 +1163,68 @@ __device__ __forceinline__ float spectral_variability(const float *dists, int la
 #pragma unroll
     for (int i = 0; i < CEPS_MEM; i++) sv += mind[i];
     return sv / (float)CEPS_MEM - 2.1f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K9b features, stand-alone: the same feature stage as the RNN kernel's prologue for callers that stop at the 42
+//     features (training-data generation, ref: src/training.rs:113-160).  One 64-stream tile per block, 8 waves.
+// ---------------------------------------------------------------------------------------------
+constexpr int FEAT_WAVES = 8;
+__global__ void __launch_bounds__(64 * FEAT_WAVES) k_features(Buffers b)
+{
+    __shared__ float crs[CEPS_MEM * NB * TILE];   // staged cepstral ring
+    __shared__ float dists[28 * TILE];            // new cepstrum / correlation DCT, then the pair distances
+    const int wave = (int)(threadIdx.x >> 6), lane = threadIdx.x & 63, tile = blockIdx.x;
+    FeatHead fh;
+    float fr[NFEAT];
+    if (wave == 0) {
+        features_head(b, tile, lane, lane, fh, dists);
+    } else {
+        const float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, lane);
+        for (int r = wave - 1; r < CEPS_MEM * NB; r += FEAT_WAVES - 1) crs[r * TILE + lane] = cm[(size_t)r * TILE];
+    }
+    __syncthreads();
+    if (wave == 0) features_deltas(b, tile, lane, lane, fh, crs, dists, fr);
+    __syncthreads();
+    for (int p = wave; p < 28; p += FEAT_WAVES) dists[p * TILE + lane] = pair_dist(crs, p, lane);
+    __syncthreads();
+    if (wave == 0) {
+        if (!fh.silent) fr[41] = spectral_variability(dists, lane);
+        float *f = NNN_TI(b.feat, NFEAT, tile, lane);
+#pragma unroll
+        for (int k = 0; k < NFEAT; k++) f[(size_t)k * TILE] = fr[k];
+    }
+}
+
+// One training row per stream (ref: src/training.rs:136-158): the combined signal's 42 features, 22 ideal band gains
+// sqrt((Ex_clean + 1e-3) / (Ex_combined + 1e-3)) capped at 1 (-1 where both energies are below 5e-2, and from the
+// band cutoff up; cutoff 0 on silent frames), 22 noise levels log10(Ex_noise + 1e-2), and the caller's VAD label.
+constexpr int TRAIN_COLS = NFEAT + 2 * NB + 1;
+__global__ void __launch_bounds__(64) k_train_rows(Buffers comb, Buffers clean, Buffers noise, const int *cutoff, const float *vad,
+                                                   float *rows)
+{
+    __shared__ float row[TILE][TRAIN_COLS + 1];
+    const int lane = threadIdx.x, tile = blockIdx.x, s = tile * TILE + lane;
+    if (s < comb.S) {
+        const bool silent = NNN_TI(comb.silence, 1, tile, lane)[0] != 0;
+        const int cut = silent ? 0 : cutoff[s];
+        const float *f = NNN_TI(comb.feat, NFEAT, tile, lane);
+        for (int k = 0; k < NFEAT; k++) row[lane][k] = f[(size_t)k * TILE];
+        const float *ec = NNN_TI(clean.ex, NB, tile, lane), *ex = NNN_TI(comb.ex, NB, tile, lane), *en = NNN_TI(noise.ex, NB, tile, lane);
+        for (int i = 0; i < NB; i++) {
+            const float c = ec[(size_t)i * TILE], x = ex[(size_t)i * TILE];
+            float g = -1.0f;
+            if (i < cut && !(c < 5e-2f && x < 5e-2f)) g = fminf(sqrtf((c + 1e-3f) / (x + 1e-3f)), 1.0f);
+            row[lane][NFEAT + i] = g;
+            row[lane][NFEAT + NB + i] = log10f(en[(size_t)i * TILE] + 1e-2f);
+        }
+        row[lane][NFEAT + 2 * NB] = vad[s];
+    }
+    __syncthreads();
+    // rows of the tile are contiguous in the output: write them coalesced
+    const int n = (comb.S - tile * TILE < TILE ? comb.S - tile * TILE : TILE) * TRAIN_COLS;
+    float *o = rows + (size_t)tile * TILE * TRAIN_COLS;
+    for (int i = lane; i < n; i += 64) o[i] = row[i / TRAIN_COLS][i % TRAIN_COLS];
 }
 
 // ---------------------------------------------------------------------------------------------

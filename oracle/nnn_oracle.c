@@ -922,6 +922,53 @@ int nnno_run_streams(const nnno_model *m, int n_streams, int n_frames, const flo
     return used;
 }
 
+/* ---- training-feature rows ------------------------------------------------------------------------ */
+
+/* shift_and_filter_input (src/features.rs:97-104) + compute_frame_features (:115-219) on one DenoiseFeatures */
+static int features_frame(nnno_state *st, const float *in)
+{
+    memmove(st->input_mem, st->input_mem + FRAME_SIZE, (PITCH_BUF_SIZE - FRAME_SIZE) * sizeof(float));
+    biquad_hp(st->input_mem + PITCH_BUF_SIZE - FRAME_SIZE, st->mem_hp_x, in, FRAME_SIZE);
+    return compute_frame_features(st);
+}
+
+/* ref: src/training.rs:113-160, the per-frame body: three DenoiseFeatures (clean, noise, mix) -> one 87-column row.
+ * The NoiseSimulator that produces the three signals, the band cutoff and the vad label (:263-422) is the caller's. */
+void nnno_training_rows(const nnno_model *m, int n_streams, int n_frames, const float *signal, const float *noise,
+                        const float *combined, const int32_t *cutoff, const float *vad, float *rows, int n_threads)
+{
+    init_tables();
+    int used = n_threads > 1 ? n_threads : 1;
+    (void)used;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(used)
+#endif
+    for (int s = 0; s < n_streams; s++) {
+        nnno_state *clean = nnno_create(m), *nz = nnno_create(m), *comb = nnno_create(m);
+        for (int t = 0; t < n_frames; t++) {
+            const size_t ft = ((size_t)s * n_frames + t) * FRAME_SIZE, ts = (size_t)t * n_streams + s;
+            float *row = rows + ts * (NB_FEATURES + 2 * NB_BANDS + 1);
+            features_frame(clean, signal + ft);                               /* :125,:131 */
+            features_frame(nz, noise + ft);                                   /* :126,:132 */
+            const int silence = features_frame(comb, combined + ft);          /* :127,:134 */
+            const int cut = silence ? 0 : cutoff[ts];                         /* :135 */
+            memcpy(row, comb->features, NB_FEATURES * sizeof(float));         /* :153 */
+            for (int i = 0; i < NB_BANDS; i++) {
+                float g = -1.0f;                                              /* :146-148 */
+                if (i < cut && !(clean->ex[i] < 5e-2f && comb->ex[i] < 5e-2f)) {   /* :136-145 */
+                    g = sqrtf((clean->ex[i] + 1e-3f) / (comb->ex[i] + 1e-3f));
+                    g = g < 1.0f ? g : 1.0f;
+                    if (g != g) g = 1.0f;                                     /* f32::min drops a NaN */
+                }
+                row[NB_FEATURES + i] = g;
+                row[NB_FEATURES + NB_BANDS + i] = log10f(nz->ex[i] + 1e-2f);  /* :150-152 */
+            }
+            row[NB_FEATURES + 2 * NB_BANDS] = vad[ts];                        /* :156 */
+        }
+        nnno_destroy(clean); nnno_destroy(nz); nnno_destroy(comb);
+    }
+}
+
 /* ---- the reference's multi-channel callers ------------------------------------------------------- */
 
 /* ref: src/nnnoiseless.rs:301-331 (frame loop: `break 'outer` on a short read drops the partial frame; `first`

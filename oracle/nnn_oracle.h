@@ -104,6 +104,14 @@ int nnno_run_streams(const nnno_model *m, int n_streams, int n_frames, const flo
 long nnno_cli_raw_i16(const nnno_model *m, const int16_t *in, long n, int channels, int16_t *out);
 long nnno_denoise_signal(const nnno_model *m, const float *in, long n, int channels, float *out);
 
+/*
+ * The per-frame body of the reference's training-data generator, src/training.rs:113-160: per stream three
+ * DenoiseFeatures states (clean, noise, mix), one row [42 features of the mix | 22 gains | 22 noise levels | vad].
+ *   signal / noise / combined [n_streams][n_frames][480];  cutoff, vad [n_frames][n_streams];  rows [n_frames][n_streams][87]
+ */
+void nnno_training_rows(const nnno_model *m, int n_streams, int n_frames, const float *signal, const float *noise,
+                        const float *combined, const int32_t *cutoff, const float *vad, float *rows, int n_threads);
+
 /* Stand-alone FFT entry points so tests can pin the restated FFT against a naive DFT. */
 void nnno_rfft960(const float *in960, float *out_re_im_481x2);   /* un-normalised forward  */
 void nnno_irfft960(const float *in_re_im_481x2, float *out960);  /* un-normalised inverse  */

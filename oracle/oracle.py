@@ -180,6 +180,20 @@ def denoise_signal(model: Model, x, channels=1):
     return out[:n]
 
 
+def training_rows(model: Model, signal, noise, combined, cutoff, vad, n_threads=1):
+    """src/training.rs:113-160 for [S][T][480] inputs and [T][S] cutoff / vad -> rows [T][S][87]."""
+    signal, noise, combined = (np.ascontiguousarray(a, dtype=np.float32) for a in (signal, noise, combined))
+    S, T, _ = signal.shape
+    cutoff = np.ascontiguousarray(cutoff, dtype=np.int32)
+    vad = np.ascontiguousarray(vad, dtype=np.float32)
+    rows = np.empty((T, S, 87), np.float32)
+    fn = model._L.nnno_training_rows
+    fn.restype = None
+    fn.argtypes = [C.c_void_p] + [C.c_int] * 2 + [C.c_void_p] * 6 + [C.c_int]
+    fn(model._h, S, T, _ptr(signal), _ptr(noise), _ptr(combined), _ptr(cutoff), _ptr(vad), _ptr(rows), int(n_threads))
+    return rows
+
+
 def rfft960(x, f32_fft=False):
     x = np.ascontiguousarray(x, dtype=np.float32)
     out = np.empty(962, np.float32)

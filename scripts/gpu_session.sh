@@ -16,3 +16,4 @@ cd "$GRAFT_REPO_ROOT"
 DB=$(find gpurun_out/prof -name '*_results.db' | head -1)
 [ -n "$DB" ] && python scripts/rocpd_kernel_stats.py "$DB" > gpurun_out/kernel_stats.md 2>&1 && head -20 gpurun_out/kernel_stats.md
 find gpurun_out/prof -name '*.db' -size +20M -delete
+for S in 4096 16384; do timeout 300 python bench.py --workload train --streams $S --steps 20 --warmup 3 > gpurun_out/bench_train_$S.json 2>gpurun_out/bench_train_$S.err; cut -c1-200 gpurun_out/bench_train_$S.json; done

@@ -373,3 +373,45 @@ def test_rnn_rows_per_block_variants(nn, oracle_mod, weights_bytes, rows, monkey
     monkeypatch.delenv("NNN_RNN_ROWS")
     base, vbase = nn.BatchDenoiser(200).process(x)
     assert np.array_equal(out, base) and np.array_equal(vad, vbase)
+
+
+# ---- batched training-feature rows -----------------------------------------------------------------
+
+def test_training_rows(nn, oracle_mod, weights_bytes):
+    """1000 (clean, noise, mix) triples x 30 frames, in two calls, against the oracle's src/training.rs:113-160."""
+    from nnnoiseless_amd.training import TrainingFeatures
+    from train_fixtures import check_rows, make_training_inputs
+    sig, noise, comb, cutoff, vad = make_training_inputs(9, 1000, 30)
+    ref = oracle_mod.training_rows(oracle_mod.Model(weights_bytes), sig, noise, comb, cutoff, vad, n_threads=os.cpu_count() or 1)
+    tf = TrainingFeatures(1000)
+    rows = np.concatenate([tf.process(sig[:, :11], noise[:, :11], comb[:, :11], cutoff[:11], vad[:11]),
+                           tf.process(sig[:, 11:], noise[:, 11:], comb[:, 11:], cutoff[11:], vad[11:])])
+    check_rows(rows, ref)
+
+
+def test_states_on_concurrent_threads(nn, golden_io):
+    """SURVEY 8(b) threading: rnnoise-style states are independent and may be driven from different threads at once
+    (the reference's DenoiseState is Send + Sync, src/denoise.rs:125); each thread's output equals a lone run."""
+    import threading
+    frames, _ = golden_io
+    frames = frames[:30]
+
+    def run(offset, out):
+        st = nn.DenoiseState.new()
+        buf = np.zeros(480, np.float32)
+        res = []
+        for f in np.roll(frames, offset, axis=0):
+            st.process_frame(buf, f)
+            res.append(buf.copy())
+        out[offset] = np.stack(res)
+
+    lone, conc = {}, {}
+    for off in range(4):
+        run(off, lone)
+    threads = [threading.Thread(target=run, args=(off, conc)) for off in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for off in range(4):
+        assert np.array_equal(lone[off], conc[off]), off

@@ -1,0 +1,38 @@
+"""Inputs for the training-row tests: a deterministic stand-in for the reference's NoiseSimulator outputs
+(src/training.rs:263-422) -- speech-like and noise-like streams with per-stream gains, silent stretches, the
+energy-based VAD label (:364-384) and a band cutoff."""
+import numpy as np
+
+
+def make_training_inputs(seed, n_streams, n_frames):
+    from nnnoiseless_amd.synthetic import make_streams
+    rng = np.random.default_rng(seed)
+    sig = make_streams(seed, n_streams, n_frames).astype(np.float32)
+    noise = (rng.standard_normal((n_streams, n_frames, 480)) * rng.uniform(5, 2000, (n_streams, 1, 1))).astype(np.float32)
+    sig[rng.random(n_streams) < 0.15] = 0.0                       # signal_gain = 0 (src/training.rs:345-347)
+    quiet = rng.random((n_streams, n_frames)) < 0.1
+    sig[quiet] = 0.0
+    noise[rng.random((n_streams, n_frames)) < 0.1] = 0.0          # silent mix frames when both are quiet
+    noise[quiet & (rng.random((n_streams, n_frames)) < 0.5)] = 0.0
+    comb = sig + noise
+    e = (sig.astype(np.float64) ** 2).sum(axis=2)                 # vad(): 0 / 0.5 / 1 from a counter; any label will do
+    vad = np.where(e > 1e9, 1.0, np.where(e > 1e7, 0.5, 0.0)).astype(np.float32).T.copy()
+    cutoff = rng.integers(0, 23, (n_frames, n_streams)).astype(np.int32)
+    return sig, noise, comb, cutoff, vad
+
+
+def check_rows(rows, ref):
+    """Cepstral / delta / variability features within 2e-4 absolute (values of order 1..20; the oracle's own f32-FFT and
+    f64-FFT builds differ by up to 4e-5 on them).  The six pitch-correlation features (columns 34..39: band correlation /
+    sqrt(.001 + Ex Ep)) are ill-conditioned on bands that hold only rounding noise -- the two oracle builds differ by up
+    to 1.1e-2 there, 8e-5 rms -- so they get 4e-2 worst case and 5e-4 rms.  Gains and log levels within 1e-4; the -1
+    markers, zeroed silent rows and the vad column exactly."""
+    assert rows.shape == ref.shape
+    assert np.array_equal(rows[..., 86], ref[..., 86])
+    assert np.array_equal(rows[..., 42:64] == -1.0, ref[..., 42:64] == -1.0)
+    assert np.array_equal((rows[..., :42] == 0).all(axis=-1), (ref[..., :42] == 0).all(axis=-1))
+    d = np.abs(rows[..., :42] - ref[..., :42]).max(axis=tuple(range(rows.ndim - 1)))
+    assert np.delete(d, slice(34, 40)).max() < 2e-4, d
+    assert d[34:40].max() < 4e-2, d
+    assert np.sqrt(((rows[..., 34:40] - ref[..., 34:40]) ** 2).mean()) < 5e-4
+    assert np.abs(rows[..., 42:86] - ref[..., 42:86]).max() < 1e-4
