@@ -38,6 +38,33 @@ extern "C" {
         frame_stride: usize,
         hip_stream: *mut c_void,
     ) -> c_int;
+    fn nnn_model_from_rnnoise_text(text: *const u8, len: usize) -> *mut RawModel;
+    fn nnn_batch_create_grouped(
+        models: *const *const RawModel,
+        group_streams: *const c_int,
+        n_groups: c_int,
+        device: c_int,
+    ) -> *mut RawBatch;
+    fn nnn_batch_process_pcm_host(
+        b: *mut RawBatch,
+        input: *const c_void,
+        output: *mut c_void,
+        vad: *mut c_float,
+        n_frames: c_int,
+        layout: *const PcmLayout,
+    ) -> c_int;
+}
+
+/// `struct nnn_pcm_layout` (include/nnn_batch.h): the sample formats and channel interleave of the reference's callers
+/// (src/nnnoiseless.rs:147-177,301-331, src/signal.rs:95-100,123-127), converted inside the first and last kernels.
+#[repr(C)]
+pub struct PcmLayout {
+    pub format: c_int,        // 0 = f32 in i16 range, 1 = i16, 2 = f32 in [-1, 1]
+    pub channels: c_int,
+    pub discard_first: c_int, // drop the first frame after new()/reset, as the CLI and DenoiseSignal do
+    pub reserved: c_int,
+    pub group_stride: usize,  // elements between groups of `channels` interleaved streams
+    pub frame_stride: usize,  // elements between frames of a group (>= 480 * channels)
 }
 
 /// Model parameters; `from_bytes` returns `None` exactly where the reference does (src/rnn.rs:196-222).
@@ -56,6 +83,15 @@ impl RnnModel {
     }
     pub fn from_static_bytes(bytes: &'static [u8]) -> Option<RnnModel> {
         Self::from_bytes(bytes)
+    }
+    /// An RNNoise text model (what train/convert_rnnoise.py converts first).
+    pub fn from_rnnoise_text(text: &str) -> Option<RnnModel> {
+        let p = unsafe { nnn_model_from_rnnoise_text(text.as_ptr(), text.len()) };
+        if p.is_null() {
+            None
+        } else {
+            Some(RnnModel(p))
+        }
     }
 }
 impl Default for RnnModel {

@@ -19,8 +19,11 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "nnn_batch.h"
+#include "nnn_train.h"
 
 namespace nnnoiseless {
 
@@ -29,6 +32,13 @@ class RnnModel {
     static std::optional<RnnModel> from_bytes(const uint8_t *bytes, size_t len)
     {
         RNNModel *m = nnn_model_from_bytes(bytes, len);
+        if (!m) return std::nullopt;
+        return RnnModel(m);
+    }
+    // an RNNoise / rnnoise-nu text model (train/convert_rnnoise.py + from_bytes in one step)
+    static std::optional<RnnModel> from_rnnoise_text(const std::string &text)
+    {
+        RNNModel *m = nnn_model_from_rnnoise_text(text.data(), text.size());
         if (!m) return std::nullopt;
         return RnnModel(m);
     }
@@ -48,7 +58,29 @@ class BatchDenoiser {
     {
         if (!b_) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
     }
+    // several models resident at once: streams [0, n0) run models[0], the next n1 models[1], ... (nullptr = built-in)
+    BatchDenoiser(const std::vector<std::pair<const RnnModel *, int>> &groups, int device = 0)
+    {
+        std::vector<const RNNModel *> ms;
+        std::vector<int> ns;
+        for (const auto &g : groups) {
+            ms.push_back(g.first ? g.first->raw() : nullptr);
+            ns.push_back(g.second);
+        }
+        b_.reset(nnn_batch_create_grouped(ms.data(), ns.data(), (int)ns.size(), device), nnn_batch_destroy);
+        if (!b_) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+    }
     int num_streams() const { return nnn_batch_num_streams(b_.get()); }
+    // packed PCM in the reference callers' formats (int16 / unit floats, interleaved channels, first frame dropped)
+    void process_pcm(const void *in, void *out, float *vad, int n_frames, const nnn_pcm_layout &layout)
+    {
+        check(nnn_batch_process_pcm_host(b_.get(), in, out, vad, n_frames, &layout));
+    }
+    void process_pcm_device(const void *d_in, void *d_out, float *d_vad, int n_frames, const nnn_pcm_layout &layout,
+                            void *hip_stream = nullptr)
+    {
+        check(nnn_batch_process_pcm_device(b_.get(), d_in, d_out, d_vad, n_frames, &layout, hip_stream));
+    }
     // host buffers: sample i of frame t of stream s at [s * stream_stride + t * frame_stride + i]; vad[t * n_streams + s]
     void process(const float *in, float *out, float *vad, int n_frames, size_t stream_stride, size_t frame_stride)
     {
@@ -70,6 +102,27 @@ class BatchDenoiser {
         if (rc) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
     }
     std::shared_ptr<nnn_batch> b_;
+};
+
+// the per-frame body of the reference's training-data generator (src/training.rs:113-160) for n_streams triples
+class TrainingFeatures {
+  public:
+    static constexpr int ROW_WIDTH = NNN_TRAIN_COLS;
+    explicit TrainingFeatures(int n_streams, int device = 0) : t_(nnn_train_create(n_streams, device), nnn_train_destroy)
+    {
+        if (!t_) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+    }
+    // host buffers: signal / noise / combined [n_streams][n_frames][480]; cutoff, vad [n_frames][n_streams]; rows [..][87]
+    void process(const float *signal, const float *noise, const float *combined, const int32_t *cutoff, const float *vad,
+                 float *rows, int n_frames)
+    {
+        if (nnn_train_process_host(t_.get(), signal, noise, combined, cutoff, vad, rows, n_frames))
+            throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+    }
+    void reset() { nnn_train_reset(t_.get()); }
+
+  private:
+    std::shared_ptr<nnn_train> t_;
 };
 
 class DenoiseState {

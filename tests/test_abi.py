@@ -102,3 +102,10 @@ def test_reference_demo_compiles_against_our_header(tmp_path):
     if not os.path.exists(demo):
         pytest.skip("reference tree not present")
     subprocess.check_call(["gcc", "-c", "-I", os.path.join(ROOT, "include"), demo, "-o", str(tmp_path / "demo.o")])
+
+
+def test_cpp_mirror_header_compiles(tmp_path):
+    """include/nnnoiseless.hpp (header-only C++ mirror of RnnModel / DenoiseState / BatchDenoiser / TrainingFeatures)."""
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "nnnoiseless.hpp"\nint main() { return 0; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"), str(src)])
