@@ -1,0 +1,20 @@
+#!/bin/bash
+# HBM traffic per kernel launch: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes (never with other trace domains).
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+S=${STREAMS:-4096}
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $O/pmct_$C
+  timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/pmct_$C -o pmc -- python $R/bench.py --streams $S --frames-per-step 1 --steps 8 --warmup 2 --no-cpu-baseline --no-roofline > $O/pmct_$C.json 2> $O/pmct_$C.err
+  tail -1 $O/pmct_$C.err | cut -c1-120
+done
+cd $R
+python scripts/rocpd_pmc_traffic.py $(find $O/pmct_FETCH_SIZE -name '*_results.db' | head -1) $(find $O/pmct_WRITE_SIZE -name '*_results.db' | head -1) $S > $O/pmc_traffic_${S}streams.json
+python -c "
+import json; d=json.load(open('$O/pmc_traffic_${S}streams.json'))
+print(d['calibration'])
+for k,v in d['kernels'].items(): print(k, round(v['hbm_bytes_per_launch']/$S))
+"
