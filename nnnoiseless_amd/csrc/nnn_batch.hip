@@ -480,7 +480,7 @@ static bool enqueue_frame(nnn_batch *h, int set, hipStream_t st, const StepParam
             chk(hipEventRecord(h->ev_fork[0], st));
             chk(hipStreamWaitEvent(s0, h->ev_fork[0], 0));
         }
-        L0.go(K_FFT_X, k_fft_x, dim3(Sp), dim3(64), 0, b, sp);
+        L0.go(K_FFT_X, k_fft_x, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp);
         if (br) chk(hipEventRecord(h->ev_join[0], s0));
         L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp);
         const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
@@ -495,13 +495,13 @@ static bool enqueue_frame(nnn_batch *h, int set, hipStream_t st, const StepParam
     L.go(K_DOUBLING, k_doubling, dim3(Sp / 4), dim3(256), 0, b);
     mark(CH_DBL);
     if (br) chk(hipStreamWaitEvent(st, h->ev_join[0], 0));
-    L.go(K_FFT_P, k_fft_p, dim3(Sp), dim3(64), 0, b, sp);
+    L.go(K_FFT_P, k_fft_p, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp);
     wait_prev(CH_RNN);
     for (const nnn_batch::ModelGroup &G : h->groups)   // one launch per resident model (a run of whole tiles)
         L.go(K_RNN, k_rnn, dim3((unsigned)(G.ntiles * (TILE / G.rows))), dim3(64 * RNN_WAVES), G.rnn_lds, b, G.plan, G.wq, G.fpar, G.tile0, G.rows);
     mark(CH_RNN);
     wait_prev(CH_SYN);
-    L.go(K_SYNTH, k_synth, dim3(Sp), dim3(64), 0, b, sp);
+    L.go(K_SYNTH, k_synth, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp);
     mark(CH_SYN);
     if (!chain) L.go(K_ADVANCE, k_advance, dim3(1), dim3(1), 0, h->sp + set, (int)NLANE);
     return ok;
@@ -514,7 +514,7 @@ static bool enqueue_front(nnn_batch *h, int set, hipStream_t st)
     const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad;
     const StepParams *sp = h->sp + set;
     Launcher L{h, st, false};
-    L.go(K_FFT_X, k_fft_x, dim3(Sp), dim3(64), 0, b, sp);
+    L.go(K_FFT_X, k_fft_x, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp);
     L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp);
     const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
     if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4 + 1), dim3(64), 0, b);
@@ -923,7 +923,7 @@ static void enqueue_feature_frame(nnn_batch *h, hipStream_t st, const float *in,
     StepParams *sp = h->sp;
     hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, sp, v);
     hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, sp, (StepParams *)nullptr);
-    hipLaunchKernelGGL(k_fft_x, dim3(Sp), dim3(64), 0, st, b, sp);
+    hipLaunchKernelGGL(k_fft_x, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, sp);
     if (full) {
         hipLaunchKernelGGL(k_lpc, dim3(NT), dim3(320), 0, st, b, sp);
         const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
@@ -934,7 +934,7 @@ static void enqueue_feature_frame(nnn_batch *h, hipStream_t st, const float *in,
         hipLaunchKernelGGL(k_refine, dim3(Sp / 4), dim3(256), 0, st, b);
         hipLaunchKernelGGL(k_best2, dim3(NT), dim3(64), 0, st, b);
         hipLaunchKernelGGL(k_doubling, dim3(Sp / 4), dim3(256), 0, st, b);
-        hipLaunchKernelGGL(k_fft_p, dim3(Sp), dim3(64), 0, st, b, sp);
+        hipLaunchKernelGGL(k_fft_p, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, sp);
         hipLaunchKernelGGL(k_features, dim3(NT), dim3(64 * FEAT_WAVES), 0, st, b);
     }
     h->frame_count += 1;

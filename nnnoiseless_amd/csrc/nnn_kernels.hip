@@ -800,9 +800,37 @@ template <int R> __device__ __forceinline__ void dftR(float2 *v)
     else dft10(v);
 }
 
+// The wave = stream transform kernels run FFT_SPB streams per block (one wave each) so that the block's waves share
+// one copy of the read-only tables in LDS: every table read sits on a wave's dependent chain, and from LDS it costs
+// ~100 cycles instead of a trip to L2.  After the tables are in place (one __syncthreads) the waves never meet again:
+// each synchronises only with itself (wave_lds_sync) on its own LDS region.
+constexpr int FFT_SPB = 4;
+struct FftLds {
+    float2 tw[NFFT];           // exp(-2 pi i k / 960), k < 480; the other half of the circle is the negation
+    float frac[400];           // triangular band weights (ref: src/lib.rs:65-82)
+    unsigned char band[400];   // band of each bin
+    short seg[192];            // band-sum segmentation (see band_sums_par)
+};
+// fills the block's tables; every thread of the block calls it, the caller synchronises
+__device__ __forceinline__ void fft_tables_load(FftLds &t, const Buffers &b, bool want_band)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < NFFT; i += nt) t.tw[i] = b.tw960[i];
+    for (int i = tid; i < 400; i += nt) {
+        t.frac[i] = b.bin_frac[i];
+        if (want_band) t.band[i] = (unsigned char)b.bin_band[i];
+    }
+    for (int i = tid; i < 192; i += nt) t.seg[i] = (short)b.seg[i];
+}
+__device__ __forceinline__ float2 tw960_at(const float2 *tw, int k)   // k in [0, 960)
+{
+    const float2 w = tw[k >= NFFT ? k - NFFT : k];
+    return k >= NFFT ? make_float2(-w.x, -w.y) : w;
+}
+
 // one Stockham pass of the 480-point transform, in place: every lane pulls its butterflies into registers,
 // the wave synchronises, then scatters the results (autosort order).  Radix R, NS = product of the radices
-// already applied; tw = exp(-2 pi i k / 960), k < 960.  One 3.8 KB buffer per transform keeps LDS small
+// already applied; tw = the LDS half-table of exp(-2 pi i k / 960).  One 3.8 KB buffer per transform keeps LDS small
 // enough for a full complement of waves per CU.
 template <int R, int NS>
 __device__ __forceinline__ void fft_pass(float2 *buf, const float2 *tw, int lane)
@@ -819,12 +847,12 @@ __device__ __forceinline__ void fft_pass(float2 *buf, const float2 *tw, int lane
             if (NS > 1) {
                 constexpr int step = 960 / (NS * R);
 #pragma unroll
-                for (int r = 1; r < R; r++) v[it][r] = cmulf(v[it][r], tw[(r * k * step) % 960]);
+                for (int r = 1; r < R; r++) v[it][r] = cmulf(v[it][r], tw960_at(tw, (r * k * step) % 960));
             }
             dftR<R>(v[it]);
         }
     }
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int it = 0; it < IT; it++) {
         const int j = lane + 64 * it;
@@ -834,7 +862,7 @@ __device__ __forceinline__ void fft_pass(float2 *buf, const float2 *tw, int lane
             for (int r = 0; r < R; r++) buf[base + r * NS] = v[it][r];
         }
     }
-    __syncthreads();
+    wave_lds_sync();
 }
 
 // forward 480-point FFT in place (natural order in, natural order out)
@@ -851,7 +879,7 @@ __device__ __forceinline__ float2 rfft_bin(const float2 *Z, const float2 *tw, in
     float2 zk = Z[k % NFFT], zn = Z[(NFFT - k) % NFFT];
     float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
     float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));   // (zk - conj zn) / (2i)
-    float2 wo = cmulf(o, tw[k]);
+    float2 wo = cmulf(o, tw960_at(tw, k));
     return cadd(e, wo);
 }
 
@@ -874,17 +902,17 @@ __device__ __forceinline__ float band_sum(const float *v, int bnd, const float *
 // segment; first segment and segment count per interval); lane = segment forms the two triangularly
 // weighted partial sums of up to NQ quantities, then lane = band adds its partials.
 template <int NQ>
-__device__ __forceinline__ void band_sums_par(const Buffers &b, const float *const (&v)[NQ], float *part /* [2 * NQ][64] */,
+__device__ __forceinline__ void band_sums_par(const FftLds &t, const float *const (&v)[NQ], float *part /* [2 * NQ][64] */,
                                               float (&out)[NQ], int lane)
 {
-    const int *seg = b.seg;
+    const short *seg = t.seg;
     if (lane < 54) {
         const int k0 = seg[lane], cnt = seg[64 + lane];
         float pa[NQ], pb[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) { pa[q] = 0.0f; pb[q] = 0.0f; }
         for (int k = k0; k < k0 + cnt; k++) {
-            const float fr = b.bin_frac[k];
+            const float fr = t.frac[k];
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
                 const float x = v[q][k];
@@ -895,7 +923,7 @@ __device__ __forceinline__ void band_sums_par(const Buffers &b, const float *con
 #pragma unroll
         for (int q = 0; q < NQ; q++) { part[(2 * q) * 64 + lane] = pa[q]; part[(2 * q + 1) * 64 + lane] = pb[q]; }
     }
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int q = 0; q < NQ; q++) out[q] = 0.0f;
     if (lane < NB) {
@@ -925,11 +953,11 @@ __device__ __forceinline__ void band_sums_par(const Buffers &b, const float *con
 //     fft_p also forms the band correlation of X and P (ref: src/features.rs:135).
 // ---------------------------------------------------------------------------------------------
 template <bool LAGGED>
-__device__ __forceinline__ void transform_input(Buffers b, const StepParams *sp, float2 *Z, float *vv, float *vc, float *part)
+__device__ __forceinline__ void transform_input(const Buffers &b, const StepParams *sp, FftLds &t, float2 *Z, float *part)
 {
-    const int lane = threadIdx.x, s = blockIdx.x, tile = s >> 6, sl = s & 63;
+    const int lane = threadIdx.x & 63, s = blockIdx.x * FFT_SPB + (int)(threadIdx.x >> 6), tile = s >> 6, sl = s & 63;
     const int rb = ring_base(sp->slot);
-    // loads that do not depend on the pitch go first
+    // loads that do not depend on the pitch go first, the block's tables among them
     float2 Xr[7];
     if (LAGGED) {
 #pragma unroll
@@ -945,6 +973,7 @@ __device__ __forceinline__ void transform_input(Buffers b, const StepParams *sp,
         w[u] = n < NFFT ? ((const float2 *)b.window)[n] : make_float2(0.0f, 0.0f);
     }
     const int lag = LAGGED ? NNN_TI(b.pitch, 1, tile, sl)[0] : 0;
+    fft_tables_load(t, b, false);
     const float *h = b.hist + (size_t)s * RING;
     int start = rb + (HIST - WINDOW) - lag;   // in (0, 2 RING)
     if (start >= RING) start -= RING;
@@ -958,29 +987,36 @@ __device__ __forceinline__ void transform_input(Buffers b, const StepParams *sp,
             Z[n] = make_float2(h[i0] * w[u].x, h[i1] * w[u].y);
         }
     }
-    __syncthreads();
-    fft480(Z, b.tw960, lane);
+    __syncthreads();   // tables in place; from here on every wave is on its own
+    fft480(Z, t.tw, lane);
     const float wn = b.wnorm;
     float2 *dst = (LAGGED ? b.P : b.X) + (size_t)s * FREQ;
+    float2 Y[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         const int k = lane + 64 * u;
         if (k < FREQ) {
-            float2 Y = rfft_bin(Z, b.tw960, k);
-            Y.x *= wn;
-            Y.y *= wn;
-            dst[k] = Y;
-            if (k < 400) {
-                vv[k] = Y.x * Y.x + Y.y * Y.y;
-                if (LAGGED) vc[k] = Xr[u < 7 ? u : 6].x * Y.x + Xr[u < 7 ? u : 6].y * Y.y;
-            }
+            Y[u] = rfft_bin(Z, t.tw, k);
+            Y[u].x *= wn;
+            Y[u].y *= wn;
+            dst[k] = Y[u];
         }
     }
-    __syncthreads();
+    wave_lds_sync();   // the transform has been read: its buffer now takes the per-bin products for the band sums
+    float *vv = (float *)Z, *vc = vv + 400;
+#pragma unroll
+    for (int u = 0; u < 7; u++) {
+        const int k = lane + 64 * u;
+        if (k < 400) {
+            vv[k] = Y[u].x * Y[u].x + Y[u].y * Y[u].y;
+            if (LAGGED) vc[k] = Xr[u].x * Y[u].x + Xr[u].y * Y[u].y;
+        }
+    }
+    wave_lds_sync();
     if (LAGGED) {
         const float *const v[2] = {vv, vc};
         float o[2];
-        band_sums_par<2>(b, v, part, o, lane);
+        band_sums_par<2>(t, v, part, o, lane);
         if (lane < NB) {
             NNN_TI(b.ep, NB, tile, sl)[(size_t)lane * TILE] = o[0];
             NNN_TI(b.exp_, NB, tile, sl)[(size_t)lane * TILE] = o[1];
@@ -988,25 +1024,27 @@ __device__ __forceinline__ void transform_input(Buffers b, const StepParams *sp,
     } else {
         const float *const v[1] = {vv};
         float o[1];
-        band_sums_par<1>(b, v, part, o, lane);
+        band_sums_par<1>(t, v, part, o, lane);
         if (lane < NB) NNN_TI(b.ex, NB, tile, sl)[(size_t)lane * TILE] = o[0];
     }
 }
 
-__global__ void __launch_bounds__(64) k_fft_x(Buffers b, const StepParams *sp)
+__global__ void __launch_bounds__(64 * FFT_SPB) k_fft_x(Buffers b, const StepParams *sp)
 {
-    __shared__ float2 Z[NFFT];
-    __shared__ float vv[400];
-    __shared__ float part[2 * 64];
-    transform_input<false>(b, sp, Z, vv, nullptr, part);
+    __shared__ FftLds t;
+    __shared__ float2 Z[FFT_SPB][NFFT];
+    __shared__ float part[FFT_SPB][2 * 64];
+    const int wave = threadIdx.x >> 6;
+    transform_input<false>(b, sp, t, Z[wave], part[wave]);
 }
 
-__global__ void __launch_bounds__(64) k_fft_p(Buffers b, const StepParams *sp)
+__global__ void __launch_bounds__(64 * FFT_SPB) k_fft_p(Buffers b, const StepParams *sp)
 {
-    __shared__ float2 Z[NFFT];
-    __shared__ float vv[400], vc[400];
-    __shared__ float part[4 * 64];
-    transform_input<true>(b, sp, Z, vv, vc, part);
+    __shared__ FftLds t;
+    __shared__ float2 Z[FFT_SPB][NFFT];
+    __shared__ float part[FFT_SPB][4 * 64];
+    const int wave = threadIdx.x >> 6;
+    transform_input<true>(b, sp, t, Z[wave], part[wave]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1633,7 +1671,7 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
 }
 
 // interpolated band gain at bin k (ref: src/lib.rs:84-97): zero for k >= 400
-__device__ __forceinline__ float interp_gain(const float *g, int k, const float *bin_frac, const int *bin_band)
+__device__ __forceinline__ float interp_gain(const float *g, int k, const float *bin_frac, const unsigned char *bin_band)
 {
     if (k >= 400) return 0.0f;
     int i = bin_band[k];
@@ -1645,15 +1683,19 @@ __device__ __forceinline__ float interp_gain(const float *g, int k, const float 
 // K11 synth: pitch filter, band renormalisation, gains, inverse FFT, window, overlap-add.
 //     ref: src/features.rs:223-275, src/denoise.rs:103-114.  One wave per stream.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
+__global__ void __launch_bounds__(64 * FFT_SPB, 5) k_synth(Buffers b, const StepParams *sp)
 {
     float *vad_out = sp->vad;
     const int fmt = sp->fmt;
-    __shared__ float2 A[FREQ + 3];
-    __shared__ float ebuf[400];
-    __shared__ float r[NB], r2[NB], gg[NB];
-    __shared__ float part[2 * 64];
-    const int lane = threadIdx.x, s = blockIdx.x, tile = s >> 6, sl = s & 63;
+    __shared__ FftLds t;
+    __shared__ float2 A_[FFT_SPB][FREQ + 3];   // also the per-bin energies of the band renormalisation (before A is filled)
+    __shared__ float r_[FFT_SPB][3 * NB];
+    __shared__ float part_[FFT_SPB][2 * 64];
+    const int wave = threadIdx.x >> 6;
+    float2 *A = A_[wave];
+    float *ebuf = (float *)A, *r = r_[wave], *r2 = r + NB, *gg = r + 2 * NB, *part = part_[wave];
+    const int lane = threadIdx.x & 63, s = blockIdx.x * FFT_SPB + wave, tile = s >> 6, sl = s & 63;
+    fft_tables_load(t, b, true);
     const float2 *Xg = b.X + (size_t)s * FREQ, *Pg = b.P + (size_t)s * FREQ;
     float *sm = b.synth_mem + (size_t)s * FRAME;
     // every global load of this block is independent of its own results: issue them all now
@@ -1688,6 +1730,7 @@ __global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
     char *o = sp->out + (long long)grp * sp->group_stride + (long long)(s - grp * ch) * elem;
     const bool store = s < b.S && !sp->discard;
     const bool pair_ok = ch == 1 && (((size_t)o) & (size_t)(2 * elem - 1)) == 0;
+    __syncthreads();   // tables in place; from here on every wave is on its own (a silent stream skips the filter)
     if (live) {
         if (lane < NB) {
             float v;
@@ -1701,34 +1744,34 @@ __global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
             r[lane] = v;
             gg[lane] = b_g;
         }
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int k = lane + 64 * u;
             if (k < FREQ) {
                 float2 X = Xr[u];
-                const float rf = interp_gain(r, k, b.bin_frac, b.bin_band);
+                const float rf = interp_gain(r, k, t.frac, t.band);
                 X.x = X.x + Pr[u].x * rf;
                 X.y = X.y + Pr[u].y * rf;
                 Xr[u] = X;
                 if (k < 400) ebuf[k] = X.x * X.x + X.y * X.y;
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         {
             const float *const v[1] = {ebuf};
             float ne[1];
-            band_sums_par<1>(b, v, part, ne, lane);
+            band_sums_par<1>(t, v, part, ne, lane);
             if (lane < NB) r2[lane] = sqrtf(b_ex / (1e-8f + ne[0]));
         }
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int k = lane + 64 * u;
             if (k < FREQ) {
-                const float rf = interp_gain(r2, k, b.bin_frac, b.bin_band);
+                const float rf = interp_gain(r2, k, t.frac, t.band);
                 Xr[u].x *= rf; Xr[u].y *= rf;
-                const float gf = interp_gain(gg, k, b.bin_frac, b.bin_band);
+                const float gf = interp_gain(gg, k, t.frac, t.band);
                 Xr[u].x *= gf; Xr[u].y *= gf;
             }
         }
@@ -1738,7 +1781,7 @@ __global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
         const int k = lane + 64 * u;
         if (k < FREQ) A[k] = Xr[u];
     }
-    __syncthreads();
+    wave_lds_sync();
     // complex-to-real 960-point inverse as a 480-point complex inverse: Zin[k] = (X[k] + conj X[480-k])
     // + i e^{+2 pi i k/960} (X[k] - conj X[480-k]); stored re/im-swapped so the forward FFT inverts.
     float2 zin[8];
@@ -1749,20 +1792,20 @@ __global__ void __launch_bounds__(64) k_synth(Buffers b, const StepParams *sp)
             float2 a = A[k], c = A[NFFT - k];
             float2 e2 = make_float2(a.x + c.x, a.y - c.y);
             float2 d = make_float2(a.x - c.x, a.y + c.y);
-            float2 w = b.tw960[k];
+            float2 w = t.tw[k];
             w.y = -w.y;
             float2 o2 = cmulf(d, w);
             zin[u] = make_float2(e2.y + o2.x, e2.x - o2.y);
         }
     }
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         const int k = lane + 64 * u;
         if (k < NFFT) A[k] = zin[u];
     }
-    __syncthreads();
-    fft480(A, b.tw960, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
+    wave_lds_sync();
+    fft480(A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
     if (lane == 0 && vad_out && s < b.S) vad_out[s] = vadv;
 #pragma unroll
     for (int u = 0; u < 4; u++) {

@@ -26,6 +26,16 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Orders one wave's LDS traffic: lanes of a wave may read what other lanes of the SAME wave wrote before this point.
+// The LDS unit executes a wave's instructions in issue order, so only the compiler has to be held back; no s_barrier,
+// and other waves of the block are not involved (each works on its own LDS region).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Loads/stores through pointers that reach a kernel inside a struct read from memory (the per-frame StepParams):
 // the compiler cannot prove them global and would emit flat_* instructions, which also occupy the LDS counter.
 template <class T> __device__ __forceinline__ T ld_global(const void *p)

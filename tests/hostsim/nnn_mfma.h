@@ -52,6 +52,8 @@ static inline f32x4 mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c)
 }
 
 static inline void lds_barrier() { __syncthreads(); }
+// the interpreter's lanes are fibers, not lock-step: a wave-level rendezvous (the shuffle machinery) stands in
+static inline void wave_lds_sync() { (void)__shfl(0, 0); }
 template <class T> static inline T ld_global(const void *p) { T v; memcpy(&v, p, sizeof(T)); return v; }
 static inline uint4 ld_global_u4(const void *p) { return ld_global<uint4>(p); }
 template <class T> static inline void st_global(void *p, T v) { memcpy(p, &v, sizeof(T)); }

@@ -415,3 +415,25 @@ def test_states_on_concurrent_threads(nn, golden_io):
         t.join()
     for off in range(4):
         assert np.array_equal(lone[off], conc[off]), off
+
+
+def test_nonfinite_inputs_stay_contained(nn, oracle_mod, weights_bytes):
+    """NaN / Inf / 1e30 samples in some streams: no crash, neighbours bit-identical to a clean run, pitch indices and
+    the extent of NaN propagation as in the oracle (the reference has no input validation either, src/denoise.rs:95)."""
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(3, 8, 6)
+    bad = x.copy()
+    bad[1, 2, 100] = np.nan
+    bad[3, 1, :] = np.inf
+    bad[5, :, :] = 1e30
+    bad[6, 3, 7] = -np.inf
+    clean, _ = nn.BatchDenoiser(8).process(x)
+    bd = nn.BatchDenoiser(8)
+    out, _ = bd.process(bad)
+    for s in (0, 2, 4, 7):
+        assert np.array_equal(out[s], clean[s]), s
+    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), bad)
+    assert np.array_equal(bd.tap("pitch")[:, 0], ref["pitch"][:, -1])
+    assert np.array_equal(np.isnan(out), np.isnan(ref["out"]))
+    ok = np.isfinite(out) & np.isfinite(ref["out"])
+    assert np.allclose(out[ok], ref["out"][ok], rtol=1e-4, atol=1e-2)

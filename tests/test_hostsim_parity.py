@@ -146,3 +146,26 @@ def test_long_run_ring_wrap(hostsim_lib, oracle_mod, weights_bytes):
     out = np.concatenate(outs, axis=1)
     assert np.array_equal(bd.tap("pitch")[:, 0], ref["pitch"][:, -1])
     assert rel_rms(out[:, 1:], ref["out"][:, 1:]) < 1e-5
+
+
+def test_nonfinite_inputs_stay_contained(hostsim_lib, oracle_mod, weights_bytes):
+    """NaN / Inf / 1e30 samples in some streams: no crash, neighbours bit-identical to a clean run, pitch indices and
+    the extent of NaN propagation as in the oracle (the reference has no input validation either, src/denoise.rs:95)."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(3, 8, 6)
+    bad = x.copy()
+    bad[1, 2, 100] = np.nan
+    bad[3, 1, :] = np.inf
+    bad[5, :, :] = 1e30
+    bad[6, 3, 7] = -np.inf
+    clean, _ = nn.BatchDenoiser(8, lib=hostsim_lib).process(x)
+    bd = nn.BatchDenoiser(8, lib=hostsim_lib)
+    out, _ = bd.process(bad)
+    for s in (0, 2, 4, 7):
+        assert np.array_equal(out[s], clean[s]), s
+    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), bad)
+    assert np.array_equal(bd.tap("pitch")[:, 0], ref["pitch"][:, -1])
+    assert np.array_equal(np.isnan(out), np.isnan(ref["out"]))
+    ok = np.isfinite(out) & np.isfinite(ref["out"])
+    assert np.allclose(out[ok], ref["out"][ok], rtol=1e-4, atol=1e-2)
