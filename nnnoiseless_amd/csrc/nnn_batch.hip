@@ -186,10 +186,10 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
 }
 
 // dynamic LDS of k_rnn: tanh table (256 floats) + live flags (64 ints) + 3 bf16 planes of both operand matrices for
-// `rows` streams + the feature stage's staged cepstral ring and pair distances ((8 x 22 + 28) rows of 64 floats)
+// `rows` streams + the feature stage's staged cepstral ring and pair distances ((8 x 22 + 28) x `rows` floats)
 static size_t rnn_lds_bytes(const RnnPlan &pl, int rows)
 {
-    return 256 * 4 + 64 * 4 + (size_t)3 * rows * (pl.in_w + pl.rec_w) * 2 + (size_t)(CEPS_MEM * NB + 28) * TILE * 4;
+    return 256 * 4 + 64 * 4 + (size_t)3 * rows * (pl.in_w + pl.rec_w) * 2 + (size_t)(CEPS_MEM * NB + 28) * rows * 4;
 }
 // below this many RNN blocks a launch leaves compute units idle and the per-block chain dominates
 static int rnn_small_batch_blocks()

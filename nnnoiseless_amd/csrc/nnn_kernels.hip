@@ -1070,8 +1070,9 @@ struct FeatHead {
 
 // The two DCTs are rolled loops over the output index (their fully unrolled form needs ~500 live table values);
 // the new cepstrum (rows 0..21) and the pitch-correlation DCT (rows 22..27) are parked in LDS (`cn`).
-// `lane` = the stream's row in its 64-stream tile (global layouts), `ll` = its column in the block's LDS staging.
-__device__ __forceinline__ void features_head(const Buffers &b, int tile, int lane, int ll, FeatHead &h, float *cn)
+// `lane` = the stream's row in its 64-stream tile (global layouts), `ll` = its column in the block's LDS staging,
+// `ls` = the staging's row stride (columns per block).
+__device__ __forceinline__ void features_head(const Buffers &b, int tile, int lane, int ll, int ls, FeatHead &h, float *cn)
 {
     float ex[NB], ep[NB], ly[NB], tmp[NB];
     const float *exg = NNN_TI(b.ex, NB, tile, lane), *epg = NNN_TI(b.ep, NB, tile, lane);
@@ -1093,7 +1094,7 @@ __device__ __forceinline__ void features_head(const Buffers &b, int tile, int la
     for (int i = 0; i < 6; i++) {
         float v = dct_out(tmp, b.dct, i);
         v -= i == 0 ? 1.3f : (i == 1 ? 0.9f : 0.0f);
-        cn[(NB + i) * TILE + ll] = v;
+        cn[(NB + i) * ls + ll] = v;
     }
     h.fpitch = 0.01f * ((float)pitch - 300.0f);
     float log_max = -2.0f, follow = -2.0f, e = 0.0f;
@@ -1111,12 +1112,12 @@ __device__ __forceinline__ void features_head(const Buffers &b, int tile, int la
     for (int i = 0; i < NB; i++) {
         float v = dct_out(ly, b.dct, i);
         v -= i == 0 ? 12.0f : (i == 1 ? 4.0f : 0.0f);
-        cn[i * TILE + ll] = v;
+        cn[i * ls + ll] = v;
     }
 }
 
 // ring update + delta features (wave 0, after the ring has been staged in crs)
-__device__ __forceinline__ void features_deltas(const Buffers &b, int tile, int lane, int ll, const FeatHead &h, float *crs,
+__device__ __forceinline__ void features_deltas(const Buffers &b, int tile, int lane, int ll, int ls, const FeatHead &h, float *crs,
                                                 const float *cn, float (&fr)[NFEAT])
 {
     if (h.silent) {   // "if there's no audio, avoid messing up the state" (ref: src/features.rs:160-166)
@@ -1132,9 +1133,9 @@ __device__ __forceinline__ void features_deltas(const Buffers &b, int tile, int 
     float c[NB];
 #pragma unroll
     for (int k = 0; k < NB; k++) {
-        c[k] = cn[k * TILE + ll];
+        c[k] = cn[k * ls + ll];
         cm[(size_t)(c0 * NB + k) * TILE] = c[k];
-        crs[(c0 * NB + k) * TILE + ll] = c[k];
+        crs[(c0 * NB + k) * ls + ll] = c[k];
     }
     mem_id += 1;
     if (mem_id == CEPS_MEM) mem_id = 0;
@@ -1143,12 +1144,12 @@ __device__ __forceinline__ void features_deltas(const Buffers &b, int tile, int 
     for (int i = 0; i < NB; i++) fr[i] = c[i];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        const float v1 = crs[(c1 * NB + i) * TILE + ll], v2 = crs[(c2 * NB + i) * TILE + ll];
+        const float v1 = crs[(c1 * NB + i) * ls + ll], v2 = crs[(c2 * NB + i) * ls + ll];
         const float v0 = c[i];
         fr[i] = v0 + v1 + v2;
         fr[NB + i] = v0 - v2;
         fr[NB + 6 + i] = v0 - 2.0f * v1 + v2;
-        fr[NB + 12 + i] = cn[(NB + i) * TILE + ll];
+        fr[NB + 12 + i] = cn[(NB + i) * ls + ll];
     }
     fr[40] = h.fpitch;
     fr[41] = 0.0f;
@@ -1168,21 +1169,21 @@ __device__ __forceinline__ void pair_of(int p, int &i, int &j)
 }
 
 // squared cepstral distance of one pair, summed over the 22 bands in order (ref: src/features.rs:203-208)
-__device__ __forceinline__ float pair_dist(const float *crs, int p, int lane)
+__device__ __forceinline__ float pair_dist(const float *crs, int p, int lane, int ls)
 {
     int i, j;
     pair_of(p, i, j);
     float dist = 0.0f;
 #pragma unroll
     for (int k = 0; k < NB; k++) {
-        float d = crs[(i * NB + k) * TILE + lane] - crs[(j * NB + k) * TILE + lane];
+        float d = crs[(i * NB + k) * ls + lane] - crs[(j * NB + k) * ls + lane];
         dist += d * d;
     }
     return dist;
 }
 
 // spectral variability = mean_i min_{j != i} dist(i, j) - 2.1 from the 28 staged pair distances
-__device__ __forceinline__ float spectral_variability(const float *dists, int lane)
+__device__ __forceinline__ float spectral_variability(const float *dists, int lane, int ls)
 {
     float mind[CEPS_MEM];
 #pragma unroll
@@ -1192,7 +1193,7 @@ __device__ __forceinline__ float spectral_variability(const float *dists, int la
     for (int i = 0; i < CEPS_MEM; i++)
 #pragma unroll
         for (int j = i + 1; j < CEPS_MEM; j++) {
-            const float d = dists[p * TILE + lane];
+            const float d = dists[p * ls + lane];
             mind[i] = fminf(mind[i], d);
             mind[j] = fminf(mind[j], d);
             p++;
@@ -1216,18 +1217,18 @@ __global__ void __launch_bounds__(64 * FEAT_WAVES) k_features(Buffers b)
     FeatHead fh;
     float fr[NFEAT];
     if (wave == 0) {
-        features_head(b, tile, lane, lane, fh, dists);
+        features_head(b, tile, lane, lane, TILE, fh, dists);
     } else {
         const float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, lane);
         for (int r = wave - 1; r < CEPS_MEM * NB; r += FEAT_WAVES - 1) crs[r * TILE + lane] = cm[(size_t)r * TILE];
     }
     __syncthreads();
-    if (wave == 0) features_deltas(b, tile, lane, lane, fh, crs, dists, fr);
+    if (wave == 0) features_deltas(b, tile, lane, lane, TILE, fh, crs, dists, fr);
     __syncthreads();
-    for (int p = wave; p < 28; p += FEAT_WAVES) dists[p * TILE + lane] = pair_dist(crs, p, lane);
+    for (int p = wave; p < 28; p += FEAT_WAVES) dists[p * TILE + lane] = pair_dist(crs, p, lane, TILE);
     __syncthreads();
     if (wave == 0) {
-        if (!fh.silent) fr[41] = spectral_variability(dists, lane);
+        if (!fh.silent) fr[41] = spectral_variability(dists, lane, TILE);
         float *f = NNN_TI(b.feat, NFEAT, tile, lane);
 #pragma unroll
         for (int k = 0; k < NFEAT; k++) f[(size_t)k * TILE] = fr[k];
@@ -1563,14 +1564,14 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
           *sn = b.gru_n + ((size_t)tile * TILE * b.gru_n_w + (size_t)r0 * pl.noise.n),
           *sdn = b.gru_dn + ((size_t)tile * TILE * b.gru_dn_w + (size_t)r0 * pl.dn.n);
     NNN_STAMP(b, 8);
-    float *crs = (float *)(REC + 3 * rec_ps);          // staged cepstral ring [8 * 22][64] (columns >= rm unused)
-    float *dists = crs + CEPS_MEM * NB * TILE;         // pair distances [28][64]
+    float *crs = (float *)(REC + 3 * rec_ps);          // staged cepstral ring [8 * 22][rm]
+    float *dists = crs + CEPS_MEM * NB * rm;           // pair distances [28][rm]
     FeatHead fh;
     fh.silent = true;
     fh.fpitch = 0.0f;
     float fr[NFEAT];
     if (wave == 0) {
-        if (rowl) features_head(b, tile, trow, lane, fh, dists);
+        if (rowl) features_head(b, tile, trow, lane, rm, fh, dists);
     } else {
         // waves 1..7: stage the cepstral ring, zero both operand matrices (padding columns must read as 0),
         // fetch the activation table
@@ -1589,16 +1590,17 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             const int r = (wave - 1) + i * (RNN_WAVES - 1);
-            if (r < CEPS_MEM * NB) crs[r * TILE + lane] = st[i];
+            if (rowl && r < CEPS_MEM * NB) crs[r * rm + lane] = st[i];
         }
     }
     lds_barrier();
     if (wave == 0) {
-        if (rowl) features_deltas(b, tile, trow, lane, fh, crs, dists, fr);
+        if (rowl) features_deltas(b, tile, trow, lane, rm, fh, crs, dists, fr);
         live[lane] = fh.silent ? 0 : 1;
     }
     lds_barrier();
-    for (int p = wave; p < 28; p += RNN_WAVES) dists[p * TILE + lane] = pair_dist(crs, p, lane);
+    if (rowl)
+        for (int p = wave; p < 28; p += RNN_WAVES) dists[p * rm + lane] = pair_dist(crs, p, lane, rm);
     // the dense layers' weights and biases travel during the rest of the prologue
     Frags<1> f_dense, f_out;
     load_frags<1, 0>(f_dense, pl.dense.in, dense_frags(pl.dense, Wq, wave, mbt), lane);
@@ -1607,7 +1609,7 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     lds_barrier();
     NNN_STAMP(b, 9);
     if (wave == 0 && rowl) {
-        if (!fh.silent) fr[41] = spectral_variability(dists, lane);
+        if (!fh.silent) fr[41] = spectral_variability(dists, lane, rm);
         float *f = NNN_TI(b.feat, NFEAT, tile, trow);
 #pragma unroll
         for (int k = 0; k < NFEAT; k++) {
