@@ -79,10 +79,11 @@ def cpu_baseline(budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--streams", type=int, default=4096, help="concurrent streams PER GPU")
-    ap.add_argument("--frames-per-step", type=int, default=16)
+    ap.add_argument("--frames-per-step", type=int, default=48,
+                    help="frames per stream per call (0.48 s of audio by default); the same JSON line also reports the one-frame-per-call rate (`tick`)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--workload", choices=["denoise", "train"], default="denoise",
                     help="denoise = process_frame (the headline); train = 87-column training rows (SURVEY 8(f) #3)")
@@ -233,7 +234,7 @@ def main():
                        "boundary_format": {"f32": "f32 planar (process_frame's own)", "i16": "packed int16",
                                            "unit": "unit-range f32"}[args.pcm] + (f", {Cc} interleaved channels" if Cc > 1 else ""),
                        "streams_per_gpu": S, "streams_total": S * world, "frames_per_step": fps,
-                       "launch": ("up to 3 frames in flight on 3 HIP streams, pitch-front segment replayed as a hipGraph"
+                       "launch": ("groups of 4 frames per launch for the kernels without cross-frame state, three groups in flight on three HIP streams, each group's pitch-front segment replayed as a hipGraph"
                                   if fps > 1 else ("eager" if args.no_graph else "one hipGraph replay per frame")),
                        "parallelism": f"streams sharded x{world}"},
             "tick": tick,

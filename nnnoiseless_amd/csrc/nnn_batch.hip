@@ -49,7 +49,8 @@ static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_xcorr", "k_best1
 
 
 struct nnn_batch {
-    Buffers b[NLANE];              // same state, NLANE scratch sets: frame f works in set f % NLANE
+    Buffers b[NSET];               // same state, NSET scratch sets (views into one allocation per scratch array: set s lies
+                                   // s * S_pad * LEN after set 0, see frame_view); a group of frames takes consecutive sets
     ModelDims md;                  // state widths: the maxima over the resident models
     struct ModelGroup {            // a run of whole tiles sharing one model
         RnnPlan plan;
@@ -64,22 +65,24 @@ struct nnn_batch {
     int device = 0;
     int S = 0, S_pad = 0, NT = 0;
     uint64_t frame_count = 0;
-    int n_lanes = 3;   // frames in flight in pipelined calls; measured 2: 20.4, 3: 23.4, 4: 19.7 M frames/s at 4096 streams
+    uint64_t group_count = 0;      // groups launched so far: group_count % LANES picks the block of GROUP scratch sets
+    int last_set = 0;              // scratch set of the most recent frame (parity taps)
     std::vector<void *> allocs;     // everything hipMalloc'ed
     std::vector<std::pair<void *, size_t>> state_bufs;  // zeroed by reset
-    StepParams *sp = nullptr;       // device, [NLANE]: launch parameters of the next frame of each scratch set (graph mode)
+    StepParams *sp = nullptr;       // device, [NSET]: launch parameters per scratch set (stand-alone frames: stepped on the
+                                    // device; pipelined groups: republished by each frame's high-pass for the front graph)
     StepParams *sp_tab = nullptr;   // device, per-frame parameter table of a pipelined call
     int sp_tab_cap = 0;
     hipStream_t stream = nullptr;   // default launch stream
-    hipStream_t lanes[NLANE] = {};  // frame lanes 1.. of a pipelined call (lane 0 is the caller's stream)
+    hipStream_t lanes[LANES] = {};  // group lanes 1.. of a pipelined call (lane 0 is the caller's stream)
     hipStream_t side[2] = {nullptr, nullptr};   // branches of a stand-alone frame: fft_x, yy
     hipEvent_t ev_fork[2] = {}, ev_join[2] = {};
-    hipEvent_t ev_chain[NLANE][4] = {};  // per lane: hp, doubling, rnn, synth done (the cross-frame recurrences)
-    hipEvent_t ev_lane = nullptr, ev_lane_done[NLANE] = {};
+    hipEvent_t ev_chain[LANES][4] = {};  // per lane: hp, doubling, rnn, synth done (the cross-frame recurrences)
+    hipEvent_t ev_lane = nullptr, ev_lane_done[LANES] = {};
 
     bool use_graph = true, use_pipeline = true;
-    hipGraphExec_t g_single[NLANE] = {};
-    hipGraphExec_t g_front[NLANE] = {};   // per scratch set: fft_x, lpc, yy, xcorr, best1, refine, best2 (pipelined calls)
+    hipGraphExec_t g_single[LANES] = {};   // per set block: one stand-alone frame
+    hipGraphExec_t g_front[LANES] = {};    // per set block: fft_x, lpc, xcorr+yy, best1, refine, best2 of a full group
     bool front_failed = false;
     hipStream_t graph_stream = nullptr;  // stream the graphs were captured on
     bool use_branches = true;
@@ -162,7 +165,7 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
     NNN_RT_LOCK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    for (int i = 0; i < NLANE; i++) {
+    for (int i = 0; i < LANES; i++) {
         if (h->g_single[i]) hipGraphExecDestroy(h->g_single[i]);
         if (h->g_front[i]) hipGraphExecDestroy(h->g_front[i]);
     }
@@ -171,7 +174,7 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
         if (h->ev_fork[i]) hipEventDestroy(h->ev_fork[i]);
         if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
     }
-    for (int l = 0; l < NLANE; l++) {
+    for (int l = 0; l < LANES; l++) {
         for (int i = 0; i < 4; i++)
             if (h->ev_chain[l][i]) hipEventDestroy(h->ev_chain[l][i]);
         if (h->ev_lane_done[l]) hipEventDestroy(h->ev_lane_done[l]);
@@ -222,16 +225,12 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
     }
-    for (int l = 0; l < NLANE; l++) {
+    for (int l = 0; l < LANES; l++) {
         if (l > 0) HIPCHK(hipStreamCreateWithFlags(&h->lanes[l], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&h->ev_lane_done[l], hipEventDisableTiming));
         for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_chain[l][i], hipEventDisableTiming));
     }
     if (const char *e = getenv("NNN_PIPELINE")) h->use_pipeline = atoi(e) != 0;
-    if (const char *e = getenv("NNN_LANES")) {   // lane streams used by pipelined calls (<= NLANE scratch sets)
-        const int n = atoi(e);
-        if (n >= 2 && n <= NLANE) h->n_lanes = n;
-    }
     if (const char *e = getenv("NNN_RNN_ROWS")) {
         const int v = atoi(e);
         if (v == 16 || v == 32 || v == 64) h->rnn_rows = v;
@@ -302,7 +301,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     HIPCHK(dalloc(h, &b.gru_v, Sp * md.nv, true));
     HIPCHK(dalloc(h, &b.gru_n, Sp * md.nn, true));
     HIPCHK(dalloc(h, &b.gru_dn, Sp * md.ndn, true));
-    HIPCHK(dalloc(h, &h->sp, NLANE, false));
+    HIPCHK(dalloc(h, &h->sp, NSET, false));
     HIPCHK(dalloc(h, &b.stamps, 64, false));
     // tables
     std::vector<float> window, dct, tansig, bin_frac;
@@ -340,31 +339,12 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
         h->groups[g].wq = (const uint4 *)dq;
         HIPCHK(upload(h, &h->groups[g].fpar, fpars[g]));
     }
-    for (int set = 1; set < NLANE; set++) h->b[set] = h->b[0];
-    for (int set = 0; set < NLANE; set++) {   // per-frame scratch (doubles as parity taps), one set per frame in flight
-        Buffers &q = h->b[set];
-        HIPCHK(dalloc(h, &q.xlp0, Sp, false));
-        HIPCHK(dalloc(h, &q.lpc, Sp * 10, false));
-        HIPCHK(dalloc(h, &q.xlp_ti, Sp * XLP, false));
-        HIPCHK(dalloc(h, &q.xlp_sm, Sp * XLP, false));
-        HIPCHK(dalloc(h, &q.xc1, Sp * NLAG1, false));
-        HIPCHK(dalloc(h, &q.best1, Sp * 2, false));
-        HIPCHK(dalloc(h, &q.xc2, Sp * 10, false));
-        HIPCHK(dalloc(h, &q.ysq2, Sp * NLAG2, false));
-        HIPCHK(dalloc(h, &q.psearch, Sp, false));
-        HIPCHK(dalloc(h, &q.xx_yy, Sp * 386, false));
-        HIPCHK(dalloc(h, &q.pitch, Sp, false));
-        HIPCHK(dalloc(h, &q.pgain, Sp, false));
-        HIPCHK(dalloc(h, &q.X, Sp * FREQ, false));
-        HIPCHK(dalloc(h, &q.P, Sp * FREQ, false));
-        HIPCHK(dalloc(h, &q.ex, Sp * NB, false));
-        HIPCHK(dalloc(h, &q.ep, Sp * NB, false));
-        HIPCHK(dalloc(h, &q.exp_, Sp * NB, false));
-        HIPCHK(dalloc(h, &q.feat, Sp * NFEAT, false));
-        HIPCHK(dalloc(h, &q.silence, Sp, false));
-        HIPCHK(dalloc(h, &q.g_raw, Sp * NB, false));
-        HIPCHK(dalloc(h, &q.g, Sp * NB, false));
-        HIPCHK(dalloc(h, &q.vad, Sp, false));
+    {   // per-frame scratch (doubles as parity taps): every array holds NSET sets back to back
+        Buffers &q = h->b[0];
+#define NNN_F(name, len) HIPCHK(dalloc(h, &q.name, Sp * (size_t)(len) * NSET, false));
+        NNN_SCRATCH_FIELDS(NNN_F)
+#undef NNN_F
+        for (int set = 1; set < NSET; set++) h->b[set] = frame_view(h->b[0], set);
     }
     if (lds_max > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
@@ -415,6 +395,8 @@ extern "C" int nnn_batch_reset(nnn_batch *h)
     for (auto &sb : h->state_bufs) HIPCHK(hipMemset(sb.first, 0, sb.second));
     HIPCHK(hipDeviceSynchronize());
     h->frame_count = 0;
+    h->group_count = 0;
+    h->last_set = 0;
     return 0;
 }
 
@@ -441,21 +423,44 @@ struct Launcher {
     }
 };
 
-// Per-frame DAG.  Critical path: hp -> lpc -> xcorr -> best1 -> refine -> best2 -> doubling -> fft_p -> rnn -> synth.
-// Two branches run beside it: fft_x (needs only the filtered history) and yy (needs only pitch_buf).
-// `lane` selects the side streams / events; with `chain` the frame waits for the previous frame (other lane) only
-// at its true recurrences -- biquad state, last pitch, RNN state + cepstral ring + last gains, overlap memory --
-// so that frame f+1's front half overlaps frame f's back half.  With branches off (profiling) everything is
-// serial on `st`.
+// Per-frame DAG: hp -> lpc -> xcorr(+yy) -> best1 -> refine -> best2 -> doubling -> fft_p -> rnn -> synth, with fft_x
+// (needs only the filtered history) beside the pitch search.  Four kernels carry state from frame to frame -- the
+// biquad (hp), the last pitch (doubling), GRU / cepstral / last-gain state (rnn), the overlap memory (synth); the
+// others depend only on their own frame, so ONE launch of each covers a whole group of up to GROUP consecutive
+// frames (block index = frame * blocks_per_frame + block; scratch set of frame f = set0 + f, see frame_view): with
+// 4096 streams a one-frame launch of a lane = stream kernel has 64 waves for 256 compute units, a group launch 256.
+// LANES groups are in flight, one per lane stream; a group waits for its predecessor (another lane) only in front of its
+// recurrent kernels.
 enum { CH_HP, CH_DBL, CH_RNN, CH_SYN };
-// One frame.  Stand-alone (`lane` < 0): on `st` with fft_x and yy on side branches, parameters in h->sp[set].
-// Pipelined (`lane` >= 0): frame on lane stream `st`, serial inside the frame (the other frames in flight provide
-// the overlap, and every event call costs host time), waits for the previous frame (lane `prev`) only at the true
-// recurrences -- biquad state, last pitch, RNN state + cepstral ring + last gains, overlap memory.
-// Returns false if a stream/event call failed.
-static bool enqueue_frame(nnn_batch *h, int set, hipStream_t st, const StepParams *sp, int lane, int prev, bool prof)
+
+static void launch_xcorr(Launcher &L, nnn_batch *h, const Buffers &b, unsigned nblk)
 {
-    const Buffers &b = h->b[set];
+    const unsigned NT = (unsigned)h->NT;
+    const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
+    if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(nblk, (NLAG1 + 3) / 4 + 1), dim3(64), 0, b);
+    else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(nblk, (NLAG1 + 7) / 8 + 1), dim3(64), 0, b);
+    else L.go(K_XCORR, k_xcorr<16>, dim3(nblk, (NLAG1 + 15) / 16 + 1), dim3(64), 0, b);
+}
+
+// the kernels of a group between its high-passes and its remove_doubling, parameters at sp0[0..g)
+static void enqueue_front(nnn_batch *h, int set0, int g, const StepParams *sp0, Launcher &L, Launcher &Lx)
+{
+    const Buffers &b = h->b[set0];
+    const unsigned NT = (unsigned)h->NT * g, Sp = (unsigned)h->S_pad * g;
+    Lx.go(K_FFT_X, k_fft_x, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0);
+    L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp0);
+    launch_xcorr(L, h, b, NT);
+    L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
+    L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
+    L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
+}
+
+// One group of g <= GROUP consecutive frames in scratch sets set0 .. set0 + g - 1, parameters at sp0[0..g).
+// Stand-alone (`lane` < 0): everything on `st`, fft_x on a side branch.  Pipelined (`lane` >= 0): on lane stream `st`,
+// waiting for the previous group (lane `prev`) in front of each recurrent kernel.  Returns false if a stream / event
+// call failed.
+static bool enqueue_group(nnn_batch *h, int set0, int g, hipStream_t st, const StepParams *sp0, int lane, int prev, bool prof)
+{
     const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad;
     const bool chain = lane >= 0;
     const bool br = h->use_branches && !prof && !chain;
@@ -469,61 +474,38 @@ static bool enqueue_frame(nnn_batch *h, int set, hipStream_t st, const StepParam
     auto mark = [&](int which) {
         if (chain) chk(hipEventRecord(h->ev_chain[lane][which], st));
     };
+    const int blk = set0 / GROUP;
+    const bool replay_front = chain && g == GROUP && h->g_front[blk] != nullptr;
     wait_prev(CH_HP);
-    const bool replay_front = chain && h->g_front[set] != nullptr;
-    L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp, replay_front ? h->sp + set : (StepParams *)nullptr);
+    for (int f = 0; f < g; f++)
+        L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, h->b[set0 + f], sp0 + f, replay_front ? h->sp + set0 + f : (StepParams *)nullptr);
     mark(CH_HP);
     if (replay_front) {
-        chk(hipGraphLaunch(h->g_front[set], st));   // the seven kernels below as one replayed single-stream graph
+        chk(hipGraphLaunch(h->g_front[blk], st));   // the six kernels of enqueue_front as one replayed single-stream graph
     } else {
         if (br) {
             chk(hipEventRecord(h->ev_fork[0], st));
             chk(hipStreamWaitEvent(s0, h->ev_fork[0], 0));
         }
-        L0.go(K_FFT_X, k_fft_x, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp);
+        enqueue_front(h, set0, g, sp0, L, L0);
         if (br) chk(hipEventRecord(h->ev_join[0], s0));
-        L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp);
-        const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
-        if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4 + 1), dim3(64), 0, b);
-        else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8 + 1), dim3(64), 0, b);
-        else L.go(K_XCORR, k_xcorr<16>, dim3(NT, (NLAG1 + 15) / 16 + 1), dim3(64), 0, b);
-        L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
-        L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
-        L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
     }
     wait_prev(CH_DBL);
-    L.go(K_DOUBLING, k_doubling, dim3(Sp / 4), dim3(256), 0, b);
+    for (int f = 0; f < g; f++) L.go(K_DOUBLING, k_doubling, dim3(Sp / 4), dim3(256), 0, h->b[set0 + f]);
     mark(CH_DBL);
     if (br) chk(hipStreamWaitEvent(st, h->ev_join[0], 0));
-    L.go(K_FFT_P, k_fft_p, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp);
+    L.go(K_FFT_P, k_fft_p, dim3(Sp * g / FFT_SPB), dim3(64 * FFT_SPB), 0, h->b[set0], sp0);
     wait_prev(CH_RNN);
-    for (const nnn_batch::ModelGroup &G : h->groups)   // one launch per resident model (a run of whole tiles)
-        L.go(K_RNN, k_rnn, dim3((unsigned)(G.ntiles * (TILE / G.rows))), dim3(64 * RNN_WAVES), G.rnn_lds, b, G.plan, G.wq, G.fpar, G.tile0, G.rows);
+    for (int f = 0; f < g; f++)
+        for (const nnn_batch::ModelGroup &G : h->groups)   // one launch per resident model (a run of whole tiles)
+            L.go(K_RNN, k_rnn, dim3((unsigned)(G.ntiles * (TILE / G.rows))), dim3(64 * RNN_WAVES), G.rnn_lds, h->b[set0 + f], G.plan, G.wq,
+                 G.fpar, G.tile0, G.rows);
     mark(CH_RNN);
     wait_prev(CH_SYN);
-    L.go(K_SYNTH, k_synth, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp);
+    for (int f = 0; f < g; f++) L.go(K_SYNTH, k_synth, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, h->b[set0 + f], sp0 + f);
     mark(CH_SYN);
-    if (!chain) L.go(K_ADVANCE, k_advance, dim3(1), dim3(1), 0, h->sp + set, (int)NLANE);
+    if (!chain) L.go(K_ADVANCE, k_advance, dim3(1), dim3(1), 0, h->sp + set0, (int)LANES);   // this set block's next stand-alone frame
     return ok;
-}
-
-// the pitch-front segment of a pipelined frame (serial, single stream), parameters read from h->sp[set]
-static bool enqueue_front(nnn_batch *h, int set, hipStream_t st)
-{
-    const Buffers &b = h->b[set];
-    const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad;
-    const StepParams *sp = h->sp + set;
-    Launcher L{h, st, false};
-    L.go(K_FFT_X, k_fft_x, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp);
-    L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp);
-    const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
-    if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4 + 1), dim3(64), 0, b);
-    else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8 + 1), dim3(64), 0, b);
-    else L.go(K_XCORR, k_xcorr<16>, dim3(NT, (NLAG1 + 15) / 16 + 1), dim3(64), 0, b);
-    L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
-    L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
-    L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
-    return true;
 }
 
 // captures body() on `st` and instantiates an executable graph from it
@@ -576,7 +558,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     const bool graph = h->use_graph && !h->profiling;
     const bool pipe = h->use_pipeline && h->use_branches && !h->profiling && n_frames >= 2;
     if (pipe) {
-        // Up to NLANE frames in flight: frame t of the call on lane t % NLANE (lane 0 = `st`), cross-lane waits only at
+        // Groups of up to GROUP frames, round-robin over LANES lane streams (lane 0 = `st`), cross-lane waits only at
         // the recurrences.  Launched eagerly (replaying this shape as a captured multi-stream graph back to back crashes
         // the ROCm 7.2 runtime); the per-frame parameters come from a table filled by one small kernel.
         if (n_frames > h->sp_tab_cap) {
@@ -590,59 +572,71 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
         }
         if (h->use_graph && !h->g_front[0] && !h->front_failed) {   // built on first use
             bool all = true;
-            for (int i = 0; i < NLANE && all; i++) {
-                h->g_front[i] = capture(st, [&] { return enqueue_front(h, i, st); });
-                all = h->g_front[i] != nullptr;
+            for (int p = 0; p < LANES && all; p++) {
+                h->g_front[p] = capture(st, [&] {
+                    Launcher L{h, st, false};
+                    enqueue_front(h, p * GROUP, GROUP, h->sp + p * GROUP, L, L);
+                    return true;
+                });
+                all = h->g_front[p] != nullptr;
             }
             if (!all) {
-                for (int i = 0; i < NLANE; i++)
-                    if (h->g_front[i]) { hipGraphExecDestroy(h->g_front[i]); h->g_front[i] = nullptr; }
+                for (int p = 0; p < LANES; p++)
+                    if (h->g_front[p]) { hipGraphExecDestroy(h->g_front[p]); h->g_front[p] = nullptr; }
                 h->front_failed = true;
             }
             (void)hipGetLastError();
         }
         hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, st, h->sp_tab, v0, n_frames);
-        const int NL = h->n_lanes;
-        const int nl = n_frames < NL ? n_frames : NL;
+        const int n_groups = (n_frames + GROUP - 1) / GROUP;
+        const int nl = n_groups < LANES ? n_groups : LANES;
         bool ok = hipEventRecord(h->ev_lane, st) == hipSuccess;
         for (int l = 1; l < nl && ok; l++) ok = hipStreamWaitEvent(h->lanes[l], h->ev_lane, 0) == hipSuccess;
-        for (int t = 0; t < n_frames && ok; t++) {
-            // frame t - NLANE (same scratch set) precedes frame t - 1 on t - 1's lane whenever NL <= NLANE, and every
-            // frame waits for its predecessor's high-pass first: the set is free when this frame starts
-            const int lane = t % NL, set = (int)(h->frame_count % NLANE);
-            ok = enqueue_frame(h, set, lane ? h->lanes[lane] : st, h->sp_tab + t, lane, t > 0 ? (t - 1) % NL : -1, false);
-            h->frame_count += 1;
+        for (int k = 0, t = 0; k < n_groups && ok; k++) {
+            // group k - LANES (same lane, same scratch sets when the call started on a fresh block rotation; otherwise
+            // the sets' previous user is an earlier group still, which its lane has long completed) precedes this one
+            // in its stream
+            const int g = n_frames - t < GROUP ? n_frames - t : GROUP, lane = k % LANES;
+            const int set0 = (int)(h->group_count % LANES) * GROUP;
+            ok = enqueue_group(h, set0, g, lane ? h->lanes[lane] : st, h->sp_tab + t, lane, k > 0 ? (k - 1) % LANES : -1, false);
+            h->group_count += 1;
+            h->frame_count += g;
+            h->last_set = set0 + g - 1;
+            t += g;
         }
         for (int l = 1; l < nl && ok; l++)
             ok = hipEventRecord(h->ev_lane_done[l], h->lanes[l]) == hipSuccess && hipStreamWaitEvent(st, h->ev_lane_done[l], 0) == hipSuccess;
         if (!ok) return fail("stream/event call failed while enqueueing pipelined frames: %s", hipGetErrorString(hipGetLastError()));
     } else {
-        // parameters of the next frame of each scratch set, stepped on the device after every frame
-        for (int i = 0; i < NLANE; i++) {
+        // one frame at a time on `st`; consecutive frames rotate through the LANES set blocks, each block's
+        // parameters live on the device and are stepped by LANES frames after every use
+        for (int i = 0; i < LANES; i++) {
             StepParams v = v0;
             v.in = v0.in + (long long)i * frame_stride;
             v.out = (char *)((intptr_t)v0.out + (long long)(i - drop) * frame_stride);
             v.discard = i < drop;
             v.vad = d_vad ? d_vad + (size_t)i * h->S : nullptr;
             v.slot = (int)((h->frame_count + i) % NSLOT);
-            hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, h->sp + (int)((h->frame_count + i) % NLANE), v);
+            hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, h->sp + (int)((h->group_count + i) % LANES) * GROUP, v);
         }
         if (graph && (!h->g_single[0] || h->graph_stream != st)) {
             bool all = true;
-            for (int i = 0; i < NLANE; i++) {
-                if (h->g_single[i]) { hipGraphExecDestroy(h->g_single[i]); h->g_single[i] = nullptr; }
-                h->g_single[i] = capture(st, [&] { return enqueue_frame(h, i, st, h->sp + i, -1, -1, false); });
-                all = all && h->g_single[i];
+            for (int p = 0; p < LANES; p++) {
+                if (h->g_single[p]) { hipGraphExecDestroy(h->g_single[p]); h->g_single[p] = nullptr; }
+                h->g_single[p] = capture(st, [&] { return enqueue_group(h, p * GROUP, 1, st, h->sp + p * GROUP, -1, -1, false); });
+                all = all && h->g_single[p];
             }
             if (all) h->graph_stream = st;
             else h->use_graph = false;  // capture unsupported here: stay eager
             (void)hipGetLastError();
         }
         for (int f = 0; f < n_frames; f++) {
-            const int set = (int)(h->frame_count % NLANE);
-            if (graph && h->use_graph && h->g_single[set]) HIPCHK(hipGraphLaunch(h->g_single[set], st));
-            else enqueue_frame(h, set, st, h->sp + set, -1, -1, h->profiling);
+            const int p = (int)(h->group_count % LANES), set0 = p * GROUP;
+            if (graph && h->use_graph && h->g_single[p]) HIPCHK(hipGraphLaunch(h->g_single[p], st));
+            else enqueue_group(h, set0, 1, st, h->sp + set0, -1, -1, h->profiling);
+            h->group_count += 1;
             h->frame_count += 1;
+            h->last_set = set0;
         }
     }
     HIPCHK(hipGetLastError());
@@ -752,7 +746,7 @@ extern "C" int nnn_batch_process_pcm_host(nnn_batch *h, const void *in, void *ou
 struct TapDesc { int len; int is_int; int layout; /* 0 TI, 1 SM float, 2 SM float2, 3 hist ring */ int sub_ofs; int sub_len; };
 static bool tap_desc(const nnn_batch *h, int tap, TapDesc &d, const void **ptr)
 {
-    const Buffers *b = h ? &h->b[(h->frame_count + NLANE - 1) % NLANE] : nullptr;   // scratch set of the most recent frame
+    const Buffers *b = h ? &h->b[h->last_set] : nullptr;   // scratch set of the most recent frame
 #define TP(field) (b ? (const void *)b->field : nullptr)
     switch (tap) {
     case NNN_TAP_FILTERED: d = {FRAME, 0, 3, 0, FRAME}; *ptr = TP(hist); return true;

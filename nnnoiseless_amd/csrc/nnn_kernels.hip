@@ -19,6 +19,13 @@ namespace nnn {
 
 #define NNN_TI(ptr, len, tile, lane) ((ptr) + ((size_t)(tile) * (len)) * TILE + (lane))
 
+// A launch of a kernel without cross-frame recurrence covers several consecutive frames: block index = frame * PER +
+// block-of-frame.  Re-bases the (by-value) Buffers `b` on that frame's scratch set; `frame` and `bx` are left in scope.
+#define NNN_FRAME_SPLIT(PER)                              \
+    const int frame = (int)blockIdx.x / (int)(PER);      \
+    const int bx = (int)blockIdx.x - frame * (int)(PER); \
+    b = frame_view(b, frame);
+
 // Optional phase stamps (developer instrumentation, off in the shipped build): block 0 / thread 0 records the
 // shader clock at labelled points so a phase breakdown can be read back through nnn_batch_read_stamps.
 #ifdef NNN_STAMPS
@@ -203,11 +210,13 @@ constexpr int LPC_PER_WAVE = LPC_ROWS / 5;  // 44 row loads in flight per wave
 
 __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
 {
+    NNN_FRAME_SPLIT(b.NT)
+    sp += frame;
     __shared__ float buf[2][LPC_ROWS][64];   // double-buffered window chunks; reused as the FIR transpose tiles
     __shared__ float acs[5][64];
     __shared__ float coef[5][64];
     float (*tl)[64][33] = (float (*)[64][33])buf;
-    const int lane = threadIdx.x & 63, tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, tile = bx;
     const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // this wave's lag
     NNN_STAMP(b, 0);
     const float *xw = NNN_TI(b.dec, 2 * DEC_RING, tile, lane) + (size_t)dec_base(sp->slot) * TILE;   // x_lp[0..863]
@@ -388,11 +397,12 @@ __device__ __forceinline__ void yy_lookup(const Buffers &b, int tile, int lane)
 template <int LC>
 __global__ void __launch_bounds__(64) k_xcorr(Buffers b)
 {
+    NNN_FRAME_SPLIT(b.NT)
     if (blockIdx.y == gridDim.y - 1) {   // the extra block row: xx / yy_lookup (same input, independent work)
-        yy_lookup(b, blockIdx.x, threadIdx.x);
+        yy_lookup(b, bx, threadIdx.x);
         return;
     }
-    const int lane = threadIdx.x, tile = blockIdx.x, L0 = blockIdx.y * LC;
+    const int lane = threadIdx.x, tile = bx, L0 = blockIdx.y * LC;
     const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
 #define X4(j) p[(size_t)(384 + 2 * (j)) * TILE]
 #define Y4(m) p[(size_t)(2 * (m)) * TILE]
@@ -448,7 +458,8 @@ struct BestPitch {
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_best1(Buffers b)
 {
-    const int lane = threadIdx.x, tile = blockIdx.x;
+    NNN_FRAME_SPLIT(b.NT)
+    const int lane = threadIdx.x, tile = bx;
     const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
     const float *xc = NNN_TI(b.xc1, NLAG1, tile, lane);
     float ysq = 1.0f;
@@ -505,8 +516,9 @@ __global__ void __launch_bounds__(256) k_refine(Buffers b)
 {
     __shared__ float sh[4][XLP];
     __shared__ float part[4][64];
+    NNN_FRAME_SPLIT(b.S_pad / 4)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + wave, tile = s >> 6, sl = s & 63;
+    const int s = bx * 4 + wave, tile = s >> 6, sl = s & 63;
     for (int i = lane; i < XLP; i += 64) sh[wave][i] = b.xlp_sm[(size_t)s * XLP + i];
     const int *b1 = NNN_TI(b.best1, 2, tile, sl);
     const int best = b1[0], second = b1[TILE];
@@ -550,7 +562,8 @@ struct Xc2 {   // xcorr[] of the fine search: zero except within 2 of 2*best / 2
 
 __global__ void __launch_bounds__(64) k_best2(Buffers b)
 {
-    const int lane = threadIdx.x, tile = blockIdx.x;
+    NNN_FRAME_SPLIT(b.NT)
+    const int lane = threadIdx.x, tile = bx;
     const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
     const float *xc2 = NNN_TI(b.xc2, 10, tile, lane);
     const int *b1 = NNN_TI(b.best1, 2, tile, lane);
@@ -953,9 +966,9 @@ __device__ __forceinline__ void band_sums_par(const FftLds &t, const float *cons
 //     fft_p also forms the band correlation of X and P (ref: src/features.rs:135).
 // ---------------------------------------------------------------------------------------------
 template <bool LAGGED>
-__device__ __forceinline__ void transform_input(const Buffers &b, const StepParams *sp, FftLds &t, float2 *Z, float *part)
+__device__ __forceinline__ void transform_input(const Buffers &b, const StepParams *sp, int bx, FftLds &t, float2 *Z, float *part)
 {
-    const int lane = threadIdx.x & 63, s = blockIdx.x * FFT_SPB + (int)(threadIdx.x >> 6), tile = s >> 6, sl = s & 63;
+    const int lane = threadIdx.x & 63, s = bx * FFT_SPB + (int)(threadIdx.x >> 6), tile = s >> 6, sl = s & 63;
     const int rb = ring_base(sp->slot);
     // loads that do not depend on the pitch go first, the block's tables among them
     float2 Xr[7];
@@ -1034,8 +1047,9 @@ __global__ void __launch_bounds__(64 * FFT_SPB) k_fft_x(Buffers b, const StepPar
     __shared__ FftLds t;
     __shared__ float2 Z[FFT_SPB][NFFT];
     __shared__ float part[FFT_SPB][2 * 64];
+    NNN_FRAME_SPLIT(b.S_pad / FFT_SPB)
     const int wave = threadIdx.x >> 6;
-    transform_input<false>(b, sp, t, Z[wave], part[wave]);
+    transform_input<false>(b, sp + frame, bx, t, Z[wave], part[wave]);
 }
 
 __global__ void __launch_bounds__(64 * FFT_SPB) k_fft_p(Buffers b, const StepParams *sp)
@@ -1043,8 +1057,9 @@ __global__ void __launch_bounds__(64 * FFT_SPB) k_fft_p(Buffers b, const StepPar
     __shared__ FftLds t;
     __shared__ float2 Z[FFT_SPB][NFFT];
     __shared__ float part[FFT_SPB][4 * 64];
+    NNN_FRAME_SPLIT(b.S_pad / FFT_SPB)
     const int wave = threadIdx.x >> 6;
-    transform_input<true>(b, sp, t, Z[wave], part[wave]);
+    transform_input<true>(b, sp + frame, bx, t, Z[wave], part[wave]);
 }
 
 // ---------------------------------------------------------------------------------------------

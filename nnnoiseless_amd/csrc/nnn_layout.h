@@ -22,9 +22,11 @@ constexpr int NB = 22;            // src/lib.rs:49
 constexpr int NFEAT = 42;         // src/lib.rs:53
 constexpr int CEPS_MEM = 8;       // src/lib.rs:50
 constexpr int HIST = 1728;        // PITCH_BUF_SIZE, src/lib.rs:46
-constexpr int NLANE = 4;          // frames in flight in a multi-frame call (frame lanes / scratch sets)
-constexpr int NSLOT = 3 + NLANE;  // ring slots: 4 cover the 1728-sample history of a frame, one more per extra frame in
-                                  // flight so that a later frame's high-pass never overwrites what an earlier one reads
+constexpr int GROUP = 4;          // frames handled by one launch of every kernel without a cross-frame recurrence
+constexpr int LANES = 3;          // groups in flight, one lane stream each (a fourth HIP stream would share a hardware queue)
+constexpr int NSET = LANES * GROUP;   // per-frame scratch sets
+constexpr int NSLOT = 4 * GROUP;  // history ring slots: the high-pass of group j may run while groups j-2 and j-1 still read
+                                  // their 1728-sample histories (3 slots behind their first frame): 3 GROUP + 3 <= NSLOT
 constexpr int RING = NSLOT * 480; // history ring instead of the reference's memmove
 constexpr int XLP = 864;          // HIST / 2
 constexpr int PITCH_MIN = 60, PITCH_MAX = 768;
@@ -116,6 +118,21 @@ struct Buffers {
     float wnorm;
     int S, S_pad, NT;
 };
+
+// Per-frame scratch of set f lies f * S_pad * LEN elements after set 0 in every scratch array, so a launch that covers
+// several consecutive frames (block index = frame * blocks_per_frame + block) reaches its frame's set by offsetting.
+#define NNN_SCRATCH_FIELDS(F)                                                                                        \
+    F(lpc, 10) F(xlp0, 1) F(xlp_ti, XLP) F(xlp_sm, XLP) F(xc1, NLAG1) F(best1, 2) F(xc2, 10) F(ysq2, NLAG2) F(psearch, 1)  \
+    F(xx_yy, 386) F(pitch, 1) F(pgain, 1) F(X, FREQ) F(P, FREQ) F(ex, NB) F(ep, NB) F(exp_, NB) F(feat, NFEAT)      \
+    F(silence, 1) F(g_raw, NB) F(g, NB) F(vad, 1)
+__host__ __device__ inline Buffers frame_view(Buffers b, int f)
+{
+    const size_t sp = (size_t)b.S_pad * (size_t)f;
+#define NNN_F(name, len) b.name += sp * (size_t)(len);
+    NNN_SCRATCH_FIELDS(NNN_F)
+#undef NNN_F
+    return b;
+}
 
 // Per-frame launch parameters, resident in device memory so that one captured hipGraph can be
 // replayed for every frame: k_advance steps it at the end of each frame.

@@ -27,13 +27,14 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // Orders one wave's LDS traffic: lanes of a wave may read what other lanes of the SAME wave wrote before this point.
-// The LDS unit executes a wave's instructions in issue order, so only the compiler has to be held back; no s_barrier,
-// and other waves of the block are not involved (each works on its own LDS region).
+// s_waitcnt lgkmcnt(0) (every LDS access this wave has issued is complete) and a compiler barrier; no s_barrier, and
+// no vmcnt drain: the other waves of the block are not involved (each works on its own LDS region).  Relying on the
+// LDS unit's in-order execution alone (no wait at all) produced rare single-stream glitches on some runs.
 __device__ __forceinline__ void wave_lds_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // Loads/stores through pointers that reach a kernel inside a struct read from memory (the per-frame StepParams):

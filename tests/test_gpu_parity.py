@@ -437,3 +437,24 @@ def test_nonfinite_inputs_stay_contained(nn, oracle_mod, weights_bytes):
     assert np.array_equal(np.isnan(out), np.isnan(ref["out"]))
     ok = np.isfinite(out) & np.isfinite(ref["out"])
     assert np.allclose(out[ok], ref["out"][ok], rtol=1e-4, atol=1e-2)
+
+
+def test_pipelined_runs_repeat_bit_identically(nn):
+    """Race probe: the same 454-stream, 20-frame input through eight fresh batches in pipelined mode (frame groups in
+    flight on two streams) must reproduce one sequential run bit for bit, every time."""
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(41, 454, 20)
+
+    def run(pipe):
+        bd = nn.BatchDenoiser(454)
+        bd.set_pipeline(pipe)
+        out, vad = bd.process(x)
+        bd.close()
+        return out, vad
+
+    ref, vref = run(False)
+    for it in range(8):
+        out, vad = run(True)
+        bad = np.argwhere(np.abs(out - ref).max(axis=2) > 0)
+        assert not len(bad), (it, bad[:8])
+        assert np.array_equal(vad, vref)
