@@ -4,8 +4,8 @@
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
 A "step" is one pass of the hot path over one batch: every stream of this rank's shard advances by
-`--frames-per-step` frames (default 16 = 160 ms of audio per stream per call; the library then keeps up to
-four frames in flight).  The single-frame tick (`--frames-per-step 1`, what a live 10 ms cadence would
+`--frames-per-step` frames (default 48 = 0.48 s of audio per stream per call; the library runs them as groups
+of 4 frames per launch, three groups in flight).  The single-frame tick (`--frames-per-step 1`, what a live 10 ms cadence would
 use) is measured as well and reported in `tick`.  The workload is BASELINE.json configs[1]: 4096 concurrent
 mono streams per GPU, built-in model, synthetic 48 kHz sine + noise, inputs resident
 in HBM before the timed region.  Streams are
