@@ -138,8 +138,9 @@ int nnn_batch_read_stamps(nnn_batch *b, long long *dst64);
 
 /* 1 = replay each frame step from a captured hipGraph (default), 0 = eager launches. */
 int nnn_batch_set_graph(nnn_batch *b, int on);
-/* 1 = multi-frame calls keep two frames in flight (frame t+1's high-pass / pitch search / X transform overlap
- * frame t's RNN and synthesis; default), 0 = one frame at a time.  Results are bit-identical either way. */
+/* 1 = multi-frame calls run as groups of 4 frames (one launch per group for every kernel without cross-frame state)
+ * with three groups in flight on separate HIP streams (default), 0 = one frame at a time on the caller's stream.
+ * Results are bit-identical either way. */
 int nnn_batch_set_pipeline(nnn_batch *b, int on);
 
 const char *nnn_last_error(void);
