@@ -588,15 +588,32 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
             (void)hipGetLastError();
         }
         hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, st, h->sp_tab, v0, n_frames);
-        const int n_groups = (n_frames + GROUP - 1) / GROUP;
+        // Group sizes ramp up 1, 2, 3 at the start of a call and down 3, 2, 1 at its end: a lane can only start its
+        // first group after the previous lane's high-passes, and the caller's stream waits for every lane at the end,
+        // so short first and last groups shorten the fill and drain of the three-lane pipeline (the asynchronous-on-
+        // one-stream contract orders consecutive calls, it cannot be overlapped away).
+        int sizes[64], n_groups = 0;
+        std::vector<int> big;
+        {
+            int rem = n_frames;
+            while (rem > 0) {
+                int g = GROUP < n_groups + 1 ? GROUP : n_groups + 1;
+                const int half = (rem + 1) / 2 > 1 ? (rem + 1) / 2 : 1;
+                if (g > half) g = half;
+                if (n_groups < 64) sizes[n_groups] = g;
+                else big.push_back(g);
+                n_groups++;
+                rem -= g;
+            }
+        }
+        auto size_of = [&](int k) { return k < 64 ? sizes[k] : big[k - 64]; };
         const int nl = n_groups < LANES ? n_groups : LANES;
         bool ok = hipEventRecord(h->ev_lane, st) == hipSuccess;
         for (int l = 1; l < nl && ok; l++) ok = hipStreamWaitEvent(h->lanes[l], h->ev_lane, 0) == hipSuccess;
         for (int k = 0, t = 0; k < n_groups && ok; k++) {
-            // group k - LANES (same lane, same scratch sets when the call started on a fresh block rotation; otherwise
-            // the sets' previous user is an earlier group still, which its lane has long completed) precedes this one
-            // in its stream
-            const int g = n_frames - t < GROUP ? n_frames - t : GROUP, lane = k % LANES;
+            // group k - LANES (same lane, and the previous user of this block of scratch sets or an earlier one)
+            // precedes this group in its stream
+            const int g = size_of(k), lane = k % LANES;
             const int set0 = (int)(h->group_count % LANES) * GROUP;
             ok = enqueue_group(h, set0, g, lane ? h->lanes[lane] : st, h->sp_tab + t, lane, k > 0 ? (k - 1) % LANES : -1, false);
             h->group_count += 1;

@@ -17,3 +17,11 @@ DB=$(find gpurun_out/prof -name '*_results.db' | head -1)
 [ -n "$DB" ] && python scripts/rocpd_kernel_stats.py "$DB" > gpurun_out/kernel_stats.md 2>&1 && head -20 gpurun_out/kernel_stats.md
 find gpurun_out/prof -name '*.db' -size +20M -delete
 for S in 4096 16384; do timeout 300 python bench.py --workload train --streams $S --steps 20 --warmup 3 > gpurun_out/bench_train_$S.json 2>gpurun_out/bench_train_$S.err; cut -c1-200 gpurun_out/bench_train_$S.json; done
+for S in 16384 65536; do
+  timeout 300 python bench.py --streams $S --steps 12 --warmup 2 --no-cpu-baseline > gpurun_out/bench_$S.json 2>gpurun_out/bench_$S.err
+  python -c "
+import json; d=json.load(open('gpurun_out/bench_$S.json'))
+print('S=$S: %.2f M, tick %.2f M' % (d['value']/1e6, d['tick']['value']/1e6), {k[2:]: round(v['avg_us']) for k,v in d['kernels'].items()})"
+done
+bash scripts/gpu_pmc_traffic.sh 2>&1 | tail -3
+bash scripts/gpu_trace.sh 2>&1 | tail -8

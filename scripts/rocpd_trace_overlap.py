@@ -8,7 +8,7 @@ import statistics
 import sys
 
 con = sqlite3.connect(sys.argv[1])
-fps = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+fps = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 rows = con.execute("select name, start, end, queue_id, stream_id from kernels order by start").fetchall()
 fills = [i for i, r in enumerate(rows) if "k_fill_params" in r[0]]
 if len(fills) < 8:
@@ -38,3 +38,14 @@ for k, v in bys.items():
     busy = sum(e - s for s, e in v) / 1e3
     gaps = [(v[i + 1][0] - v[i][1]) / 1e3 for i in range(len(v) - 1)]
     print("stream/queue", k, "kernels", len(v), "busy %.0f%%" % (100 * busy / wall), "median gap %.1f us" % statistics.median(gaps))
+
+# idle time in front of each kernel type (a lane waiting for its predecessor group, or for the host)
+bk = collections.defaultdict(list)
+for n, s, e, q, st in sel:
+    bk[(st, q)].append((s, e, n.split("(")[0].replace("nnn::", "").replace("void ", "")))
+g = collections.defaultdict(list)
+for k, v in bk.items():
+    v.sort()
+    for i in range(len(v) - 1):
+        g[v[i + 1][2]].append((v[i + 1][0] - v[i][1]) / 1e3)
+print("idle in front of (mean us, total us per frame):", {k: (round(sum(x) / len(x), 1), round(sum(x) / (nsteps * fps), 1)) for k, x in g.items()})
