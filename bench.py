@@ -161,6 +161,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(W, W + K):
         step(i)
+    t_enq = time.perf_counter() - t0          # host time to enqueue everything (the calls are asynchronous)
     barrier()
     elapsed = time.perf_counter() - t0
     frames_done, elapsed_max = aggregate(dist if world > 1 else None, S * fps * K, elapsed, dev)
@@ -238,6 +239,7 @@ def main():
                                   if fps > 1 else ("eager" if args.no_graph else "one hipGraph replay per frame")),
                        "parallelism": f"streams sharded x{world}"},
             "tick": tick,
+            "host_enqueue_ms_per_step": t_enq * 1e3 / K,
             "outputs_finite": finite,
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
         }

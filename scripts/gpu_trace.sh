@@ -8,6 +8,6 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline ${BENCH_ARGS:-} > $O/trace_bench.json 2> $O/trace.err
 cd $R
 DB=$(find $O/trace -name '*_results.db' | head -1)
-python scripts/rocpd_trace_overlap.py $DB ${FPS:-48} | tee $O/trace_overlap.txt
+python scripts/rocpd_trace_overlap.py $DB ${FPS:-48} ${TIMELINE:-} | tee $O/trace_overlap.txt
 python scripts/rocpd_kernel_stats.py $DB > $O/trace_kernel_stats.md
 find $O/trace -name '*.db' -size +20M -delete

@@ -49,3 +49,12 @@ for k, v in bk.items():
     for i in range(len(v) - 1):
         g[v[i + 1][2]].append((v[i + 1][0] - v[i][1]) / 1e3)
 print("idle in front of (mean us, total us per frame):", {k: (round(sum(x) / len(x), 1), round(sum(x) / (nsteps * fps), 1)) for k, x in g.items()})
+
+# textual timeline of ~100 consecutive kernels from the middle of the run (us relative to the first one)
+if len(sys.argv) > 3:
+    mid = len(sel) // 2
+    t0 = sel[mid][1]
+    sid = {k: i for i, k in enumerate(sorted(bys))}
+    for n, s, e, q, st in sel[mid:mid + int(sys.argv[3])]:
+        name = n.split("(")[0].replace("nnn::", "").replace("void ", "")
+        print("%8.1f %8.1f  %s%-12s" % ((s - t0) / 1e3, (e - t0) / 1e3, "              " * sid[(st, q)], name))
