@@ -31,7 +31,8 @@ def library():
     """The hipcc-built gfx950 library (loaded on first use)."""
     global _lib
     if _lib is None:
-        _lib = _ffi.Library(LIB_PATH)
+        import os
+        _lib = _ffi.Library(os.environ.get("NNN_LIBRARY", LIB_PATH))   # developer override: an experimental build
     return _lib
 
 

@@ -22,11 +22,18 @@ constexpr int NB = 22;            // src/lib.rs:49
 constexpr int NFEAT = 42;         // src/lib.rs:53
 constexpr int CEPS_MEM = 8;       // src/lib.rs:50
 constexpr int HIST = 1728;        // PITCH_BUF_SIZE, src/lib.rs:46
-constexpr int GROUP = 4;          // frames handled by one launch of every kernel without a cross-frame recurrence
-constexpr int LANES = 3;          // groups in flight, one lane stream each (a fourth HIP stream would share a hardware queue)
+#ifndef NNN_GROUP
+#define NNN_GROUP 4
+#endif
+#ifndef NNN_LANES
+#define NNN_LANES 3
+#endif
+constexpr int GROUP = NNN_GROUP;  // frames handled by one launch of every kernel without a cross-frame recurrence
+constexpr int LANES = NNN_LANES;  // groups in flight, one lane stream each (a fourth HIP stream would share a hardware queue)
 constexpr int NSET = LANES * GROUP;   // per-frame scratch sets
-constexpr int NSLOT = 4 * GROUP;  // history ring slots: the high-pass of group j may run while groups j-2 and j-1 still read
-                                  // their 1728-sample histories (3 slots behind their first frame): 3 GROUP + 3 <= NSLOT
+constexpr int NSLOT = LANES * GROUP + 4;   // history ring slots: the high-pass of group j may run while groups j-LANES+1 .. j-1
+                                  // still read their 1728-sample histories (3 slots behind their first frame):
+                                  // LANES GROUP + 3 <= NSLOT
 constexpr int RING = NSLOT * 480; // history ring instead of the reference's memmove
 constexpr int XLP = 864;          // HIST / 2
 constexpr int PITCH_MIN = 60, PITCH_MAX = 768;
