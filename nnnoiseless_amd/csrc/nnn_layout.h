@@ -81,10 +81,10 @@ struct RnnPlan {
 
 struct Buffers {
     // ---- persistent per-stream state (src/denoise.rs:37-42, features.rs:18-46, pitch.rs:4-17, rnn.rs:65-70)
-    float *hist;         // SM [RING]   high-passed input history, ring of 5 frame slots
+    float *hist;         // SM [RING]   high-passed input history, ring of NSLOT frame slots
     float *hp_mem;       // TI [2]      biquad state
     float *hp_last;      // TI [1]      last filtered sample of the previous frame
-    float *dec;          // TI [2400]   2:1 decimated history: ring of 5 x 240 stored twice (p and p + 1200) so that the
+    float *dec;          // TI [2 DEC_RING]  2:1 decimated history: ring of NSLOT x 240 stored twice (p and p + DEC_RING) so that the
                          //             864-value window of any frame is one contiguous run (240 values are new per frame)
     float *ceps_mem;     // TI [8*22]
     int *mem_id;         // TI [1]

@@ -148,9 +148,9 @@ def test_full_size_properties(nn, oracle_mod, weights_bytes, S):
 
 
 def test_two_frames_in_flight_is_bit_identical(nn):
-    """Multi-frame calls replay a graph that keeps two frames in flight (frame t+1's high-pass, pitch search and
-    X transform overlap frame t's RNN and synthesis).  Same bits as one frame at a time, for odd/even starts,
-    lengths that are not a multiple of the graph size, and in place."""
+    """Multi-frame calls run as frame groups (one launch per group for the kernels without cross-frame state, three
+    groups in flight on three streams).  Same bits as one frame at a time, for every start offset within the
+    group rotation, lengths that are not a multiple of the group size, and in place."""
     from nnnoiseless_amd.synthetic import make_streams
     S, T = 512, 37
     x = make_streams(50, S, T)
@@ -167,6 +167,18 @@ def test_two_frames_in_flight_is_bit_identical(nn):
     assert np.array_equal(np.concatenate([va, vb], axis=0), want_vad)
     for k in ("pitch", "g", "features"):
         assert np.array_equal(bd.tap(k), ref.tap(k)), k
+    # call lengths that leave the group rotation (3 set blocks) and the ramped group sizes in every phase
+    for cuts in ((1, 2, 5, 7, 11, 4, 7), (2, 2, 2, 13, 1, 1, 16), (9, 9, 9, 10), (37,)):
+        bd.reset()
+        outs, vads, pos = [], [], 0
+        for n in cuts:
+            o, v = bd.process(x[:, pos:pos + n])
+            outs.append(o)
+            vads.append(v)
+            pos += n
+        assert pos == T
+        assert np.array_equal(np.concatenate(outs, axis=1), want), cuts
+        assert np.array_equal(np.concatenate(vads, axis=0), want_vad), cuts
 
 
 def test_edge_case_inputs(nn, oracle_mod, weights_bytes):
@@ -193,7 +205,7 @@ def test_edge_case_inputs(nn, oracle_mod, weights_bytes):
 
 
 def test_long_run_ring_wrap(nn, oracle_mod, weights_bytes):
-    """1000 frames (the 7-slot rings wrap 142 times) in uneven multi-frame calls, frames in flight."""
+    """1000 frames (the 16-slot rings wrap 62 times) in uneven multi-frame calls, frame groups in flight."""
     from nnnoiseless_amd.synthetic import make_streams
     x = make_streams(300, 70, 1000)
     ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x, n_threads=os.cpu_count() or 1)

@@ -133,7 +133,7 @@ def test_edge_case_inputs(hostsim_lib, oracle_mod, weights_bytes):
 
 
 def test_long_run_ring_wrap(hostsim_lib, oracle_mod, weights_bytes):
-    """150 frames (the 7-slot rings wrap 21 times) in uneven multi-frame calls."""
+    """150 frames (the 16-slot rings wrap 9 times) in uneven multi-frame calls."""
     import nnnoiseless_amd as nn
     from nnnoiseless_amd.synthetic import make_streams
     x = make_streams(200, 3, 150)
