@@ -169,3 +169,22 @@ def test_nonfinite_inputs_stay_contained(hostsim_lib, oracle_mod, weights_bytes)
     assert np.array_equal(np.isnan(out), np.isnan(ref["out"]))
     ok = np.isfinite(out) & np.isfinite(ref["out"])
     assert np.allclose(out[ok], ref["out"][ok], rtol=1e-4, atol=1e-2)
+
+
+def test_call_length_patterns(hostsim_lib):
+    """Group rotation and ramped group sizes: any way of cutting 37 frames into calls gives the same bits."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(60, 3, 37)
+    bd = nn.BatchDenoiser(3, lib=hostsim_lib)
+    want, want_vad = bd.process(x)
+    for cuts in ((1, 2, 5, 7, 11, 4, 7), (2, 2, 2, 13, 1, 1, 16), (9, 9, 9, 10)):
+        bd.reset()
+        outs, vads, pos = [], [], 0
+        for n in cuts:
+            o, v = bd.process(x[:, pos:pos + n])
+            outs.append(o)
+            vads.append(v)
+            pos += n
+        assert np.array_equal(np.concatenate(outs, axis=1), want), cuts
+        assert np.array_equal(np.concatenate(vads, axis=0), want_vad), cuts
