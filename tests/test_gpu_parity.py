@@ -114,6 +114,26 @@ def test_pitch_every_frame_and_audio_1024x40(nn, oracle_mod, weights_bytes):
     assert np.array_equal(out2, out) and np.array_equal(vad2, np.concatenate(vads, axis=0))
 
 
+def test_parity_subset_1024x200(nn, oracle_mod, weights_bytes):
+    """SURVEY 8(d)'s parity subset: 1024 streams x 200 frames (2 s: GRU and cepstral state warm) against the oracle, in
+    20-frame calls; pitch index checked bit for bit at the end of every call, audio over all 200 frames."""
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T, C = 1024, 200, 20
+    x = make_streams(7000, S, T)
+    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x, n_threads=os.cpu_count() or 1)
+    bd = nn.BatchDenoiser(S)
+    outs = []
+    for t in range(0, T, C):
+        o, _ = bd.process(x[:, t:t + C])
+        outs.append(o)
+        assert np.array_equal(bd.tap("pitch")[:, 0], ref["pitch"][:, t + C - 1]), t
+    out = np.concatenate(outs, axis=1)
+    r = rel_rms(out[:, 1:], ref["out"][:, 1:])
+    assert r <= 1e-4, r                                           # measured ~1e-6
+    per_stream = np.sqrt(((out[:, 1:] - ref["out"][:, 1:]) ** 2).sum(axis=(1, 2)) / np.maximum((ref["out"][:, 1:] ** 2).sum(axis=(1, 2)), 1e-9))
+    assert np.median(per_stream) <= 1e-5
+
+
 @pytest.mark.parametrize("S", [4096, 65536])
 def test_full_size_properties(nn, oracle_mod, weights_bytes, S):
     """BASELINE sizes (configs 2 and 3): size-independent properties instead of a full oracle run.
