@@ -896,8 +896,25 @@ float nnno_process_frame(nnno_state *st, float *out, const float *in)
     return vad;
 }
 
-int nnno_run_streams(const nnno_model *m, int n_streams, int n_frames, const float *in, float *out,
-                     float *vad, int32_t *pitch, float *gains, float *feats, int n_threads)
+/* Conditioning of the most recent frame: pitch_filter (src/features.rs:223-257) picks r = 1 when exp > g and a closed
+ * form otherwise; where the closed form is far from 1 at exp == g (both near 1, or g near 0) the branch is a jump, and
+ * rounding noise in the FFT decides the frame's output.  Returns the smallest |exp - g| over the bands whose jump exceeds
+ * 0.01 (a large number if none, or if the frame is silent): parity tests excuse frames where this is tiny. */
+float nnno_frame_condition(const nnno_state *st)
+{
+    float best = 1e30f;
+    if (st->taps.silence) return best;
+    for (int i = 0; i < NB_BANDS; i++) {
+        double e = st->taps.exp_[i], g = st->taps.g_raw[i];
+        double jump = 1.0 - e * e * (1.0 - g * g) / (0.001 + g * g * (1.0 - e * e));
+        float d = (float)fabs(e - g);
+        if (jump > 0.01 && d < best) best = d;
+    }
+    return best;
+}
+
+int nnno_run_streams_cond(const nnno_model *m, int n_streams, int n_frames, const float *in, float *out,
+                          float *vad, int32_t *pitch, float *gains, float *feats, float *cond, int n_threads)
 {
     init_tables();
     int used = 1;
@@ -916,10 +933,17 @@ int nnno_run_streams(const nnno_model *m, int n_streams, int n_frames, const flo
             if (pitch) pitch[ft] = st->taps.pitch_idx;
             if (gains) memcpy(gains + ft * NB_BANDS, st->taps.g, NB_BANDS * sizeof(float));
             if (feats) memcpy(feats + ft * NB_FEATURES, st->features, NB_FEATURES * sizeof(float));
+            if (cond) cond[ft] = nnno_frame_condition(st);
         }
         nnno_destroy(st);
     }
     return used;
+}
+
+int nnno_run_streams(const nnno_model *m, int n_streams, int n_frames, const float *in, float *out,
+                     float *vad, int32_t *pitch, float *gains, float *feats, int n_threads)
+{
+    return nnno_run_streams_cond(m, n_streams, n_frames, in, out, vad, pitch, gains, feats, NULL, n_threads);
 }
 
 /* ---- training-feature rows ------------------------------------------------------------------------ */

@@ -89,6 +89,13 @@ int nnno_run_streams(const nnno_model *m, int n_streams, int n_frames, const flo
                      float *out, float *vad, int32_t *pitch, float *gains, float *feats,
                      int n_threads);
 
+/* The same, plus cond[n_streams][n_frames] = nnno_frame_condition of every frame (may be NULL). */
+int nnno_run_streams_cond(const nnno_model *m, int n_streams, int n_frames, const float *in, float *out,
+                          float *vad, int32_t *pitch, float *gains, float *feats, float *cond, int n_threads);
+/* Smallest |exp - g| over the bands where pitch_filter's branch (src/features.rs:229-236) is a jump discontinuity
+ * (large if none): frames where it is tiny are decided by FFT rounding noise in the REFERENCE itself. */
+float nnno_frame_condition(const nnno_state *st);
+
 /*
  * The reference's two multi-channel callers of process_frame, restated around the oracle state.
  * Both return the number of sample frames (one sample per channel) written to `out`.

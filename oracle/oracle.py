@@ -139,8 +139,9 @@ class State:
             self._h = None
 
 
-def run_streams(model: Model, x, n_threads=1, want=("out", "vad", "pitch", "gains", "feats")):
-    """x: [S][T][480] float32.  Returns dict of arrays (fresh state per stream)."""
+def run_streams(model: Model, x, n_threads=1, want=("out", "vad", "pitch", "gains", "feats", "cond")):
+    """x: [S][T][480] float32.  Returns dict of arrays (fresh state per stream).  "cond" = per-frame conditioning of the
+    reference's pitch-filter branch (nnno_frame_condition): tiny values mark frames the reference itself cannot pin."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     S, Tn, F = x.shape
     assert F == FRAME_SIZE
@@ -150,10 +151,13 @@ def run_streams(model: Model, x, n_threads=1, want=("out", "vad", "pitch", "gain
         "pitch": np.empty((S, Tn), np.int32) if "pitch" in want else None,
         "gains": np.empty((S, Tn, 22), np.float32) if "gains" in want else None,
         "feats": np.empty((S, Tn, 42), np.float32) if "feats" in want else None,
+        "cond": np.empty((S, Tn), np.float32) if "cond" in want else None,
     }
-    used = model._L.nnno_run_streams(model._h, S, Tn, _ptr(x), _ptr(res["out"]), _ptr(res["vad"]),
-                                     _ptr(res["pitch"]), _ptr(res["gains"]), _ptr(res["feats"]),
-                                     int(n_threads))
+    fn = model._L.nnno_run_streams_cond
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int]
+    used = fn(model._h, S, Tn, _ptr(x), _ptr(res["out"]), _ptr(res["vad"]), _ptr(res["pitch"]), _ptr(res["gains"]),
+              _ptr(res["feats"]), _ptr(res["cond"]), int(n_threads))
     res["threads"] = used
     return res
 

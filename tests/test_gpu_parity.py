@@ -128,10 +128,21 @@ def test_parity_subset_1024x200(nn, oracle_mod, weights_bytes):
         outs.append(o)
         assert np.array_equal(bd.tap("pitch")[:, 0], ref["pitch"][:, t + C - 1]), t
     out = np.concatenate(outs, axis=1)
-    r = rel_rms(out[:, 1:], ref["out"][:, 1:])
+    # Frames where the reference's own pitch-filter branch (exp > g, src/features.rs:229-236) is decided by FFT rounding
+    # noise are excused from the AUDIO comparison, together with the next frame (overlap-add): on this input the
+    # oracle's f32-FFT and f64-FFT builds differ by 1.0e-4 rel rms overall, all of it from one such frame of one stream,
+    # and by 6e-7 on the rest.  |exp - g| < 1e-4 on a band where the branch is a jump marks them (oracle "cond").
+    ill = ref["cond"] < 1e-4
+    ill[:, 1:] |= ill[:, :-1].copy()
+    ok = ~ill[:, 1:]
+    assert ill.mean() < 0.08
+    d = (out[:, 1:] - ref["out"][:, 1:]).astype(np.float64)
+    rr = ref["out"][:, 1:].astype(np.float64)
+    r = np.sqrt((d[ok] ** 2).sum() / (rr[ok] ** 2).sum())
     assert r <= 1e-4, r                                           # measured ~1e-6
-    per_stream = np.sqrt(((out[:, 1:] - ref["out"][:, 1:]) ** 2).sum(axis=(1, 2)) / np.maximum((ref["out"][:, 1:] ** 2).sum(axis=(1, 2)), 1e-9))
-    assert np.median(per_stream) <= 1e-5
+    assert np.abs(d).max() <= 0.05 * np.abs(rr).max()             # excused frames stay sane
+    per_stream = np.sqrt((d ** 2).sum(axis=(1, 2)) / np.maximum((rr ** 2).sum(axis=(1, 2)), 1e-9))
+    assert np.median(per_stream) <= 1e-5 and np.percentile(per_stream, 99) <= 1e-4
 
 
 @pytest.mark.parametrize("S", [4096, 65536])
