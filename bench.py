@@ -131,7 +131,8 @@ def main():
     del x_host
     esz = x.element_size()
     bd = nn.BatchDenoiser(S, device=local_rank)
-    bd.set_graph(not args.no_graph)
+    if args.no_graph:
+        bd.set_graph(False)
     stream = torch.cuda.current_stream().cuda_stream
 
     def run(f0, n):   # n frames of every stream starting at frame f0 of the pool
@@ -236,7 +237,7 @@ def main():
                                            "unit": "unit-range f32"}[args.pcm] + (f", {Cc} interleaved channels" if Cc > 1 else ""),
                        "streams_per_gpu": S, "streams_total": S * world, "frames_per_step": fps,
                        "launch": ("groups of 4 frames per launch for the kernels without cross-frame state, three groups in flight on three HIP streams, each group's pitch-front segment replayed as a hipGraph"
-                                  if fps > 1 else ("eager" if args.no_graph else "one hipGraph replay per frame")),
+                                  if fps > 1 else "eager launches, one frame per call"),
                        "parallelism": f"streams sharded x{world}"},
             "tick": tick,
             "host_enqueue_ms_per_step": t_enq * 1e3 / K,

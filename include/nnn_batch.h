@@ -136,7 +136,9 @@ int nnn_batch_read_kernel_times(nnn_batch *b, double *total_ms, int64_t *launche
  * -DNNN_STAMPS). */
 int nnn_batch_read_stamps(nnn_batch *b, long long *dst64);
 
-/* 1 = replay each frame step from a captured hipGraph (default), 0 = eager launches. */
+/* hipGraph replay.  Default: a full frame group's six front kernels are replayed as one captured graph, one-frame
+ * calls are launched eagerly (measured faster on the MI355X host).  1 = one-frame calls replay a captured graph too
+ * (one API call per frame instead of 13: for hosts short of CPU), 0 = no graphs at all. */
 int nnn_batch_set_graph(nnn_batch *b, int on);
 /* 1 = multi-frame calls run as groups of 4 frames (one launch per group for every kernel without cross-frame state)
  * with three groups in flight on separate HIP streams (default), 0 = one frame at a time on the caller's stream.

@@ -81,6 +81,8 @@ struct nnn_batch {
     hipEvent_t ev_lane = nullptr, ev_lane_done[LANES] = {};
 
     bool use_graph = true, use_pipeline = true;
+    bool graph_single = false;      // replay one-frame calls from a graph too (measured 6 % slower than eager launches on the
+                                    // MI355X host, 14.2 vs 15.0 M frames/s at 4096 streams; saves host CPU; nnn_batch_set_graph(1))
     hipGraphExec_t g_single[LANES] = {};   // per set block: one stand-alone frame
     hipGraphExec_t g_front[LANES] = {};    // per set block: fft_x, lpc, xcorr+yy, best1, refine, best2 of a full group
     bool front_failed = false;
@@ -231,6 +233,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
         for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_chain[l][i], hipEventDisableTiming));
     }
     if (const char *e = getenv("NNN_PIPELINE")) h->use_pipeline = atoi(e) != 0;
+    if (const char *e = getenv("NNN_GRAPH_SINGLE")) h->graph_single = atoi(e) != 0;
     if (const char *e = getenv("NNN_RNN_ROWS")) {
         const int v = atoi(e);
         if (v == 16 || v == 32 || v == 64) h->rnn_rows = v;
@@ -555,7 +558,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     v0.discard = drop;
     v0.slot = (int)(h->frame_count % NSLOT);
     v0.n_streams = h->S;
-    const bool graph = h->use_graph && !h->profiling;
+    const bool graph = h->use_graph && h->graph_single && !h->profiling;
     const bool pipe = h->use_pipeline && h->use_branches && !h->profiling && n_frames >= 2;
     if (pipe) {
         // Groups of up to GROUP frames, round-robin over LANES lane streams (lane 0 = `st`), cross-lane waits only at
@@ -867,6 +870,7 @@ extern "C" int nnn_batch_set_graph(nnn_batch *h, int on)
 {
     if (!h) return fail("null batch");
     h->use_graph = on != 0;
+    h->graph_single = on != 0;
     return 0;
 }
 extern "C" int nnn_batch_set_pipeline(nnn_batch *h, int on)

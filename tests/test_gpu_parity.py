@@ -210,6 +210,12 @@ def test_two_frames_in_flight_is_bit_identical(nn):
         assert pos == T
         assert np.array_equal(np.concatenate(outs, axis=1), want), cuts
         assert np.array_equal(np.concatenate(vads, axis=0), want_vad), cuts
+    # one-frame calls replayed from captured graphs (opt-in) give the same bits as eager launches
+    bd.reset()
+    bd.set_graph(True)
+    for t in range(14):
+        o, v = bd.process(x[:, t:t + 1])
+        assert np.array_equal(o[:, 0], want[:, t]) and np.array_equal(v[0], want_vad[t]), t
 
 
 def test_edge_case_inputs(nn, oracle_mod, weights_bytes):
