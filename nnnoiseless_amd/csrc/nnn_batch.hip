@@ -71,6 +71,10 @@ struct nnn_batch {
     std::vector<std::pair<void *, size_t>> state_bufs;  // zeroed by reset
     StepParams *sp = nullptr;       // device, [NSET]: launch parameters per scratch set (stand-alone frames: stepped on the
                                     // device; pipelined groups: republished by each frame's high-pass for the front graph)
+    char *stage = nullptr;          // device staging of the host-buffer entry points (grow-only)
+    float *stage_vad = nullptr;
+    size_t stage_cap = 0, stage_vad_cap = 0;
+    std::vector<char> stage_host;   // host side of the copy back
     StepParams *sp_tab = nullptr;   // device, per-frame parameter table of a pipelined call
     int sp_tab_cap = 0;
     hipStream_t stream = nullptr;   // default launch stream
@@ -186,6 +190,8 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
     if (h->sp_tab) hipFree(h->sp_tab);
+    if (h->stage) hipFree(h->stage);
+    if (h->stage_vad) hipFree(h->stage_vad);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -706,23 +712,39 @@ static int process_host_span(nnn_batch *h, const void *in, void *out, float *vad
     const size_t e = (size_t)pcm_elem_bytes(L->format), groups = (size_t)(h->S / L->channels), fr = (size_t)FRAME * L->channels * e;
     const size_t span = (groups - 1) * L->group_stride * e + (size_t)(n_frames - 1) * L->frame_stride * e + fr;
     const int drop = (L->discard_first && h->frame_count == 0) ? 1 : 0;
-    char *d = nullptr;
-    float *dv = nullptr;
-    hipError_t err;
-    {
+    // device staging grows as needed and is kept for the next call (per-call hipMalloc / hipFree cost more than a frame)
+    const size_t vbytes = vad ? (size_t)n_frames * h->S * sizeof(float) : 0;
+    if (span > h->stage_cap || vbytes > h->stage_vad_cap) {
         NNN_RT_LOCK;
-        HIPCHK(hipMalloc((void **)&d, span));
-        err = vad ? hipMalloc((void **)&dv, (size_t)n_frames * h->S * sizeof(float)) : hipSuccess;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (span > h->stage_cap) {
+            if (h->stage) HIPCHK(hipFree(h->stage));
+            h->stage = nullptr;
+            h->stage_cap = 0;
+            const size_t want = span + span / 2;
+            HIPCHK(hipMalloc((void **)&h->stage, want));
+            h->stage_cap = want;
+        }
+        if (vbytes > h->stage_vad_cap) {
+            if (h->stage_vad) HIPCHK(hipFree(h->stage_vad));
+            h->stage_vad = nullptr;
+            h->stage_vad_cap = 0;
+            HIPCHK(hipMalloc((void **)&h->stage_vad, vbytes * 2));
+            h->stage_vad_cap = vbytes * 2;
+        }
     }
-    if (err == hipSuccess) err = hipMemcpyAsync(d, in, span, hipMemcpyHostToDevice, h->stream);
+    char *d = h->stage;
+    float *dv = vad ? h->stage_vad : nullptr;
+    hipError_t err = hipMemcpyAsync(d, in, span, hipMemcpyHostToDevice, h->stream);
     int rc = 0;
     if (err != hipSuccess) rc = fail("host staging failed: %s", hipGetErrorString(err));
     if (!rc) rc = nnn_batch_process_pcm_device(h, d, d, dv, n_frames, L, h->stream);
     if (!rc) {
         // `out` may alias `in` and may be strided: bring the span back and copy only real frames
-        std::vector<char> tmp(span);
+        std::vector<char> &tmp = h->stage_host;
+        if (tmp.size() < span) tmp.resize(span);
         err = hipMemcpyAsync(tmp.data(), d, span, hipMemcpyDeviceToHost, h->stream);
-        if (err == hipSuccess && vad) err = hipMemcpyAsync(vad, dv, (size_t)n_frames * h->S * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+        if (err == hipSuccess && vad) err = hipMemcpyAsync(vad, dv, vbytes, hipMemcpyDeviceToHost, h->stream);
         if (err == hipSuccess) err = hipStreamSynchronize(h->stream);
         if (err == hipSuccess)
             for (size_t g = 0; g < groups; g++)
@@ -733,11 +755,6 @@ static int process_host_span(nnn_batch *h, const void *in, void *out, float *vad
         if (err != hipSuccess) rc = fail("copy back failed: %s", hipGetErrorString(err));
     } else {
         hipStreamSynchronize(h->stream);
-    }
-    {
-        NNN_RT_LOCK;
-        hipFree(d);
-        if (dv) hipFree(dv);
     }
     return rc;
 }
