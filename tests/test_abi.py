@@ -109,3 +109,15 @@ def test_cpp_mirror_header_compiles(tmp_path):
     src = tmp_path / "t.cpp"
     src.write_text('#include "nnnoiseless.hpp"\nint main() { return 0; }\n')
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+def test_bench_knows_every_kernel(lib):
+    """bench.py's roofline table must have an entry for every kernel the library times (a missing key would only show
+    up on the GPU box)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    lib.L.nnn_batch_kernel_name.restype = C.c_char_p
+    names = {lib.L.nnn_batch_kernel_name(k).decode() for k in range(lib.L.nnn_batch_num_kernels())}
+    assert names and names <= set(bench.KERNEL_BYTES), names - set(bench.KERNEL_BYTES)
