@@ -965,6 +965,15 @@ __device__ __forceinline__ void band_sums_par(const FftLds &t, const float *cons
 //     fft_x depends only on the filtered history, so it runs beside the whole pitch search;
 //     fft_p also forms the band correlation of X and P (ref: src/features.rs:135).
 // ---------------------------------------------------------------------------------------------
+// one DCT output (ref: src/lib.rs:139-148): sequential sum over the 22 inputs, scaled in double
+__device__ __forceinline__ float dct_out(const float *x, const float *dct, int i)
+{
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NB; j++) sum += x[j] * dct[j * NB + i];
+    return (float)((double)sum * 0.30151134457776363 /* sqrt(2/22) */);
+}
+
 template <bool LAGGED>
 __device__ __forceinline__ void transform_input(const Buffers &b, const StepParams *sp, int bx, FftLds &t, float2 *Z, float *part)
 {
@@ -1030,9 +1039,44 @@ __device__ __forceinline__ void transform_input(const Buffers &b, const StepPara
         const float *const v[2] = {vv, vc};
         float o[2];
         band_sums_par<2>(t, v, part, o, lane);
+        // Head of the feature stage (ref: src/features.rs:135-170), here because everything it needs is at hand and this
+        // launch covers a whole frame group: the correlation normalised by the band energies, the floored log energies,
+        // the silence test, and the two DCTs -- lane = band.  The RNN kernel's prologue, which sits on the frame-to-frame
+        // chain, only keeps the cepstral-ring part.  Same operations in the same order as when one lane did it all.
+        wave_lds_sync();
+        float *xc = part, *ly = part + 64, *exl = part + 128;
         if (lane < NB) {
+            const float exv = NNN_TI(b.ex, NB, tile, sl)[(size_t)lane * TILE];
+            const float xn = o[1] / sqrtf(0.001f + exv * o[0]);
             NNN_TI(b.ep, NB, tile, sl)[(size_t)lane * TILE] = o[0];
-            NNN_TI(b.exp_, NB, tile, sl)[(size_t)lane * TILE] = o[1];
+            NNN_TI(b.exp_, NB, tile, sl)[(size_t)lane * TILE] = xn;
+            xc[lane] = xn;
+            exl[lane] = exv;
+            ly[lane] = log10f(1e-2f + exv);
+        }
+        wave_lds_sync();
+        if (lane == 0) {
+            float log_max = -2.0f, follow = -2.0f, e = 0.0f;
+            for (int i = 0; i < NB; i++) {
+                const float l = fmaxf(fmaxf(ly[i], log_max - 7.0f), follow - 1.5f);
+                ly[i] = l;
+                log_max = fmaxf(log_max, l);
+                follow = fmaxf(follow - 1.5f, l);
+                e += exl[i];
+            }
+            NNN_TI(b.silence, 1, tile, sl)[0] = e < 0.04f ? 1 : 0;
+        }
+        wave_lds_sync();
+        if (lane < NB) {
+            float *cn = NNN_TI(b.cn, 28, tile, sl);
+            float c = dct_out(ly, b.dct, lane);
+            c -= lane == 0 ? 12.0f : (lane == 1 ? 4.0f : 0.0f);
+            cn[(size_t)lane * TILE] = c;
+            if (lane < 6) {
+                float d = dct_out(xc, b.dct, lane);
+                d -= lane == 0 ? 1.3f : (lane == 1 ? 0.9f : 0.0f);
+                cn[(size_t)(NB + lane) * TILE] = d;
+            }
         }
     } else {
         const float *const v[1] = {vv};
@@ -1066,13 +1110,6 @@ __global__ void __launch_bounds__(64 * FFT_SPB) k_fft_p(Buffers b, const StepPar
 // K9  features: the 42 RNN inputs from band energies, pitch and the cepstral history.
 //     ref: src/features.rs:135-219, src/lib.rs:139-148.  lane = stream; runs on wave 0 of the RNN kernel.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dct_out(const float *x, const float *dct, int i)
-{
-    float sum = 0.0f;
-#pragma unroll
-    for (int j = 0; j < NB; j++) sum += x[j] * dct[j * NB + i];
-    return (float)((double)sum * 0.30151134457776363 /* sqrt(2/22) */);
-}
 
 // The feature stage runs inside the RNN kernel, lane = stream, in three steps so that only the truly serial part
 // sits on one wave: (1) wave 0: band energies -> correlation DCT, log-energy DCT (the new cepstrum), silence
@@ -1083,52 +1120,21 @@ struct FeatHead {
     bool silent;
 };
 
-// The two DCTs are rolled loops over the output index (their fully unrolled form needs ~500 live table values);
-// the new cepstrum (rows 0..21) and the pitch-correlation DCT (rows 22..27) are parked in LDS (`cn`).
-// `lane` = the stream's row in its 64-stream tile (global layouts), `ll` = its column in the block's LDS staging,
-// `ls` = the staging's row stride (columns per block).
-__device__ __forceinline__ void features_head(const Buffers &b, int tile, int lane, int ll, int ls, FeatHead &h, float *cn)
+// The head of the feature stage (correlation normalisation, log energies, silence test, both DCTs) is done by
+// k_fft_p; this picks its results up: the new cepstrum (rows 0..21) and the pitch-correlation DCT (rows 22..27) go to
+// the block's LDS staging (`cn`).  `lane` = the stream's row in its 64-stream tile (global layouts), `ll` = its column
+// in the staging, `ls` = the staging's row stride (columns per block).
+__device__ __forceinline__ void features_load(const Buffers &b, int tile, int lane, int ll, int ls, FeatHead &h, float *cn)
 {
-    float ex[NB], ep[NB], ly[NB], tmp[NB];
-    const float *exg = NNN_TI(b.ex, NB, tile, lane), *epg = NNN_TI(b.ep, NB, tile, lane);
-    float *xpg = NNN_TI(b.exp_, NB, tile, lane);
+    const float *cg = NNN_TI(b.cn, 28, tile, lane);
+    float v[28];
 #pragma unroll
-    for (int i = 0; i < NB; i++) {
-        ex[i] = exg[(size_t)i * TILE];
-        ep[i] = epg[(size_t)i * TILE];
-        tmp[i] = xpg[(size_t)i * TILE];
-    }
+    for (int i = 0; i < 28; i++) v[i] = cg[(size_t)i * TILE];
     const int pitch = NNN_TI(b.pitch, 1, tile, lane)[0];
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        float v = tmp[i] / sqrtf(0.001f + ex[i] * ep[i]);
-        tmp[i] = v;
-        xpg[(size_t)i * TILE] = v;
-    }
-#pragma unroll 1
-    for (int i = 0; i < 6; i++) {
-        float v = dct_out(tmp, b.dct, i);
-        v -= i == 0 ? 1.3f : (i == 1 ? 0.9f : 0.0f);
-        cn[(NB + i) * ls + ll] = v;
-    }
+    h.silent = NNN_TI(b.silence, 1, tile, lane)[0] != 0;
     h.fpitch = 0.01f * ((float)pitch - 300.0f);
-    float log_max = -2.0f, follow = -2.0f, e = 0.0f;
 #pragma unroll
-    for (int i = 0; i < NB; i++) {
-        float l = fmaxf(fmaxf(log10f(1e-2f + ex[i]), log_max - 7.0f), follow - 1.5f);
-        ly[i] = l;
-        log_max = fmaxf(log_max, l);
-        follow = fmaxf(follow - 1.5f, l);
-        e += ex[i];
-    }
-    h.silent = e < 0.04f;
-    NNN_TI(b.silence, 1, tile, lane)[0] = h.silent ? 1 : 0;
-#pragma unroll 1
-    for (int i = 0; i < NB; i++) {
-        float v = dct_out(ly, b.dct, i);
-        v -= i == 0 ? 12.0f : (i == 1 ? 4.0f : 0.0f);
-        cn[i * ls + ll] = v;
-    }
+    for (int i = 0; i < 28; i++) cn[i * ls + ll] = v[i];
 }
 
 // ring update + delta features (wave 0, after the ring has been staged in crs)
@@ -1232,7 +1238,7 @@ __global__ void __launch_bounds__(64 * FEAT_WAVES) k_features(Buffers b)
     FeatHead fh;
     float fr[NFEAT];
     if (wave == 0) {
-        features_head(b, tile, lane, lane, TILE, fh, dists);
+        features_load(b, tile, lane, lane, TILE, fh, dists);
     } else {
         const float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, lane);
         for (int r = wave - 1; r < CEPS_MEM * NB; r += FEAT_WAVES - 1) crs[r * TILE + lane] = cm[(size_t)r * TILE];
@@ -1586,7 +1592,7 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     fh.fpitch = 0.0f;
     float fr[NFEAT];
     if (wave == 0) {
-        if (rowl) features_head(b, tile, trow, lane, rm, fh, dists);
+        if (rowl) features_load(b, tile, trow, lane, rm, fh, dists);
     } else {
         // waves 1..7: stage the cepstral ring, zero both operand matrices (padding columns must read as 0),
         // fetch the activation table

@@ -109,6 +109,7 @@ struct Buffers {
     float *pgain;        // TI [1]
     float2 *X, *P;       // SM [481]
     float *ex, *ep, *exp_;  // TI [22]
+    float *cn;           // TI [28]     the frame's own cepstrum (22) and pitch-correlation DCT (6), made at the end of k_fft_p
     float *feat;         // TI [42]
     int *silence;        // TI [1]
     float *g_raw, *g;    // TI [22]
@@ -130,7 +131,7 @@ struct Buffers {
 // several consecutive frames (block index = frame * blocks_per_frame + block) reaches its frame's set by offsetting.
 #define NNN_SCRATCH_FIELDS(F)                                                                                        \
     F(lpc, 10) F(xlp0, 1) F(xlp_ti, XLP) F(xlp_sm, XLP) F(xc1, NLAG1) F(best1, 2) F(xc2, 10) F(ysq2, NLAG2) F(psearch, 1)  \
-    F(xx_yy, 386) F(pitch, 1) F(pgain, 1) F(X, FREQ) F(P, FREQ) F(ex, NB) F(ep, NB) F(exp_, NB) F(feat, NFEAT)      \
+    F(xx_yy, 386) F(pitch, 1) F(pgain, 1) F(X, FREQ) F(P, FREQ) F(ex, NB) F(ep, NB) F(exp_, NB) F(cn, 28) F(feat, NFEAT)      \
     F(silence, 1) F(g_raw, NB) F(g, NB) F(vad, 1)
 __host__ __device__ inline Buffers frame_view(Buffers b, int f)
 {
