@@ -188,3 +188,24 @@ def test_call_length_patterns(hostsim_lib):
             pos += n
         assert np.array_equal(np.concatenate(outs, axis=1), want), cuts
         assert np.array_equal(np.concatenate(vads, axis=0), want_vad), cuts
+
+
+def test_rnnoise_c_abi_through_the_kernels(hostsim_lib, oracle_mod, weights_bytes):
+    """The RNNoise-compatible C ABI (include/rnnoise.h, ref: src/capi.rs:16-113) end to end on the interpreter build:
+    create with the built-in model, in-place process_frame (out aliases in, as test_data/rnnoise_demo.c:52 does), destroy."""
+    import ctypes as C
+    L = hostsim_lib.L
+    assert L.rnnoise_get_frame_size() == 480
+    st = L.rnnoise_create(None)
+    assert st
+    pcm = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "testing.raw"), dtype="<i2").astype(np.float32)
+    frames = pcm[:12 * 480].reshape(12, 480)
+    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), frames[None])
+    buf = np.empty(480, np.float32)
+    for t in range(12):
+        buf[:] = frames[t]
+        vad = L.rnnoise_process_frame(st, buf.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p))
+        assert abs(vad - ref["vad"][0, t]) < 1e-4
+        if t:
+            assert rel_rms(buf, ref["out"][0, t]) < 1e-5
+    L.rnnoise_destroy(st)
