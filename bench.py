@@ -1,31 +1,43 @@
 #!/usr/bin/env python
 """bench.py -- 480-sample frames/sec of the batched process_frame path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C]
 
-A "step" is one pass of the hot path over one batch: every stream of this rank's shard advances by
-`--frames-per-step` frames (default 48 = 0.48 s of audio per stream per call; the library runs them as groups
-of 4 frames per launch, three groups in flight).  The single-frame tick (`--frames-per-step 1`, what a live 10 ms cadence would
-use) is measured as well and reported in `tick`.  The workload is BASELINE.json configs[1]: 4096 concurrent
-mono streams per GPU, built-in model, synthetic 48 kHz sine + noise, inputs resident
-in HBM before the timed region.  Streams are
-independent, so ranks shard them with no data-path collective (weak scaling: 4096 streams per GPU);
-the only collective is the aggregation of the result.
+`--gpus N` with N > 1 may be started either way: under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment, what the driver does) or as a plain `python bench.py --gpus N`, in which case this script re-executes itself
+under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`.  One rank per GPU, rank r
+on device LOCAL_RANK; the line is refused (exit 2) when the ranks actually seen (an all-reduce of ones over RCCL) differ
+from --gpus.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel: algorithmic bytes per launch / its average duration measured live
-                with HIP events on the launch stream (a second, event-instrumented pass over the same
-                workload: the timed pass replays a hipGraph, which cannot carry per-kernel events)
-  cpu_baseline  the CPU oracle (scalar C port of the reference, f32 FFT) on the host's cores, bounded
-                sample; the genuine Rust reference cannot be built here (no cargo), hence kind "port"
+A "step" is one pass of the hot path over one batch: every stream of this rank's shard advances by `--frames-per-step`
+frames (default 48 = 0.48 s of audio per stream per call).  Workloads are BASELINE.json's configs (0-based index):
+
+  --config 1  (default)  4096 concurrent mono streams per GPU, built-in model          (configs[1], the headline)
+  --config 2             65536 concurrent streams on one GPU, built-in model            (configs[2])
+  --config 3             262144 streams sharded over the node = 32768 per GPU at 8 GPUs (configs[3]; per-GPU share fixed)
+  --config 4             65536 streams, custom model (--model, default tests/golden/sh.rnn: GregorR's rnnoise-models
+                         "sh" converted to .rnn)                                        (configs[4])
+  --config 0             the reference's CPU-runnable case (testing.raw through the CPU oracle; no GPU, plumbing only)
+
+Synthetic 48 kHz sine + noise per stream, inputs resident in HBM before the timed region.  Streams are
+independent, so ranks shard them with no data-path collective (weak scaling); the only collective aggregates the result.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline      dominant kernel: algorithmic bytes per launch / its average duration measured live with HIP events on
+                the launch stream (a second, event-instrumented pass over the same workload)
+  cpu_baseline  the CPU oracle (scalar C port of the reference, f32 FFT) on the host's cores: the synthetic mix at
+                several thread counts (best reported, scaling table alongside) and the reference's own bench shape
+                (benches/sin.rs: 100 frames of a 440 Hz sine, fresh state per iteration, one thread).  The genuine Rust
+                reference cannot be built here (no cargo), hence kind "port".
+  also          (default N=1 run only) the same measurement on configs[2] and configs[4], so the driver's line carries them
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -52,36 +64,92 @@ KERNEL_BYTES = {
     "k_advance": 0,
 }
 
+CONFIGS = {
+    1: {"streams": 4096, "model": None, "name": "configs[1]: 4096 concurrent mono streams per GPU, built-in weights.rnn"},
+    2: {"streams": 65536, "model": None, "name": "configs[2]: 65536 concurrent streams on one GPU, built-in weights.rnn, GRU as batched MFMA GEMM"},
+    3: {"streams": 32768, "model": None, "name": "configs[3]: 262144 streams sharded over 8 GPUs = 32768 per GPU, built-in weights.rnn"},
+    4: {"streams": 65536, "model": os.path.join(ROOT, "tests", "golden", "sh.rnn"),
+        "name": "configs[4]: custom model (GregorR rnnoise-models 'sh' converted to .rnn), 65536 streams"},
+}
 
-def cpu_baseline(budget_s=12.0):
-    """Time the CPU oracle (f32-FFT build) on all host cores over a bounded sample of the same workload."""
+
+def host_info():
+    """What the CPU baseline ran on: logical CPUs, affinity, cgroup quota, model name, load."""
+    info = {"nproc": os.cpu_count()}
+    if hasattr(os, "sched_getaffinity"):
+        info["affinity"] = len(os.sched_getaffinity(0))
+    for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            info["cgroup_" + os.path.basename(p)] = open(p).read().strip()
+        except OSError:
+            pass
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                info["cpu_model"] = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        info["loadavg"] = open("/proc/loadavg").read().split()[:3]
+    except OSError:
+        pass
+    return info
+
+
+def cpu_baseline(budget_s=16.0):
+    """Time the CPU oracle (f32-FFT build) on the host's cores: nothing but process_frame in the timed region (one
+    state and one input buffer per thread, made before the clock starts; oracle/nnn_oracle.c nnno_bench)."""
     from oracle import oracle as O
-    from nnnoiseless_amd.synthetic import make_streams_fast
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     model = O.Model(open(os.path.join(ROOT, "nnnoiseless_amd", "data", "weights.rnn"), "rb").read(), f32_fft=True)
-    frames = 100
-    x = make_streams_fast(cores, frames, seed=99)
-    t0 = time.perf_counter()
-    O.run_streams(model, x[:1], n_threads=1, want=("out",))
-    per_frame = (time.perf_counter() - t0) / frames
-    per_thread = max(1, min(64, int(budget_s / (per_frame * frames))))
-    x = make_streams_fast(cores * per_thread, frames, seed=99)
-    t0 = time.perf_counter()
-    used = O.run_streams(model, x, n_threads=cores, want=("out",))["threads"]
-    dt = time.perf_counter() - t0
-    total = x.shape[0] * frames
-    return {"value": total / dt, "unit": "frames/s", "cores": used, "kind": "port",
-            "sample": f"{x.shape[0]} synthetic streams x {frames} frames, {used} threads, "
-                      f"oracle/nnn_oracle.c -O3 f32 FFT; single-thread {1.0 / per_frame:.0f} frames/s",
-            "note": "genuine Rust reference not buildable here (no cargo/rustc)"}
+    info = host_info()
+    cores = info.get("affinity") or info.get("nproc") or 1
+    w1, _ = O.bench(model, 1, 10, 0)
+    one = 1000.0 / w1                                  # frames/s, one thread, synthetic mix, continuing state
+    ws, _ = O.bench(model, 1, 10, 1)
+    sin440 = 1000.0 / ws                              # frames/s, the reference's benches/sin.rs shape
+    counts = sorted({c for c in (2, 4, 8, 16, 32, 64, 128, cores // 2, cores) if 1 < c <= cores})
+    per = max(1.0, (budget_s - 2.0) / max(1, len(counts)))
+    table = {"1": one}
+    best_n, best = 1, one
+    for n in counts:
+        wall, _ = O.bench(model, n, 2, 0)                        # pilot: how fast do n threads really go here
+        iters = max(2, min(400, int(per / (wall / 2.0))))        # then ~`per` seconds at that rate
+        wall, secs = O.bench(model, n, iters, 0)
+        v = n * iters * 100.0 / wall
+        table[str(n)] = v
+        if v > best:
+            best_n, best = n, v
+    eff = best / (best_n * one)
+    note = "genuine Rust reference not buildable here (no cargo/rustc)"
+    if eff < 0.7:
+        note += (f"; threads scale {eff:.2f}x of linear at the best count ({best_n}): the timed region holds only process_frame "
+                 "(private state and input per thread, no allocation, no shared writes), so the loss is the host's -- a CPU quota / "
+                 "shared cores of the container (see host), not the port")
+    return {"value": best, "unit": "frames/s", "cores": best_n, "kind": "port",
+            "sample": f"synthetic sine+noise, one continuing state per thread, {best_n} threads; oracle/nnn_oracle.c -O3 -march=x86-64-v3, f32 FFT",
+            "single_thread": one, "scaling_frames_per_s_by_threads": table, "thread_efficiency": eff,
+            "sin_440": {"value": sin440, "unit": "frames/s", "cores": 1,
+                        "sample": "benches/sin.rs shape: 100 frames of a 440 Hz sine at amplitude 32767, fresh state per iteration, 10 iterations"},
+            "host": info, "note": note}
 
 
-def main():
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--streams", type=int, default=4096, help="concurrent streams PER GPU")
+    ap.add_argument("--config", type=int, default=1, choices=[0, 1, 2, 3, 4], help="BASELINE.json configs[i] (see the module docstring)")
+    ap.add_argument("--streams", type=int, default=None, help="concurrent streams PER GPU (overrides the config's)")
+    ap.add_argument("--model", default=None, help=".rnn model file (configs[4]; default for --config 4: tests/golden/sh.rnn)")
     ap.add_argument("--frames-per-step", type=int, default=48,
                     help="frames per stream per call (0.48 s of audio by default); the same JSON line also reports the one-frame-per-call rate (`tick`)")
     ap.add_argument("--no-graph", action="store_true")
@@ -93,49 +161,45 @@ def main():
     ap.add_argument("--channels", type=int, default=1, help="interleaved channels per group (with --pcm i16/unit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-also", action="store_true", help="skip the extra configs[2] / configs[4] measurements of the default run")
+    ap.add_argument("--pool-bytes", type=float, default=6e9, help="HBM budget for the resident input pool (and as much again for the output)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing check without a GPU: gloo backend, CPU tensors, the library named by NNN_LIBRARY (the tests "
+                         "point it at the SIMT-interpreter build), a few streams; the numbers mean nothing")
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
+def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want_tick=True, want_roofline=True):
+    """One workload on this rank's device: returns the dict of measured quantities (aggregated over ranks)."""
     import nnnoiseless_amd as nn
-    from nnnoiseless_amd.synthetic import make_streams_fast
     from nnnoiseless_amd.shard import aggregate
-
-    if args.workload == "train":
-        return bench_train(args, rank, world, dev, local_rank, dist)
-    S, fps, K, W = args.streams, args.frames_per_step, args.steps, args.warmup
+    from nnnoiseless_amd.synthetic import make_streams_device
+    fps, K, W = args.frames_per_step, args.steps, args.warmup
     total_frames = (K + W) * fps
-    # distinct audio for every step while it fits ~6 GB per GPU, else cycle through a pool of frames
-    pool = total_frames
-    while S * pool * 480 * 4 > 6e9 and pool > 8:
-        pool //= 2
-    x_host = make_streams_fast(S, pool, seed=rank)
     fmt = {"f32": 0, "i16": 1, "unit": 2}[args.pcm]
     Cc = args.channels
     assert S % Cc == 0
+    esz = 2 if fmt == 1 else 4
+    # distinct audio for every step while it fits the pool budget, else cycle through a pool of frames
+    pool = max(1, min(total_frames, int(args.pool_bytes // (S * 480 * esz))))
+    x = make_streams_device(torch, dev, S, pool, seed=rank)               # [S, pool, 480] f32, resident
     if fmt or Cc > 1:   # packed PCM: [groups][pool * 480][channels], channel-interleaved
-        x_host = x_host.reshape(S // Cc, Cc, pool * 480).transpose(0, 2, 1)
-        x_host = np.ascontiguousarray(x_host.astype(np.int16) if fmt == 1 else (x_host / 32768.0 if fmt == 2 else x_host))
-    x = torch.from_numpy(x_host).to(dev)              # resident in HBM
+        x = x.reshape(S // Cc, Cc, pool * 480).permute(0, 2, 1)
+        x = (x.to(torch.int16) if fmt == 1 else (x / 32768.0 if fmt == 2 else x)).contiguous()
     y = torch.empty_like(x)
     vad = torch.empty((pool, S), dtype=torch.float32, device=dev)
-    del x_host
-    esz = x.element_size()
-    bd = nn.BatchDenoiser(S, device=local_rank)
+    model = None
+    if model_path:
+        model = nn.RnnModel.from_bytes(open(model_path, "rb").read())
+        if model is None:
+            raise SystemExit(f"bench: {model_path} is not a valid .rnn model")
+    bd = nn.BatchDenoiser(S, model=model, device=0 if args.dry_run else local_rank)   # the interpreter build has one device
     if args.no_graph:
         bd.set_graph(False)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = torch.cuda.current_stream().cuda_stream if dev.type == "cuda" else 0
 
-    def run(f0, n):   # n frames of every stream starting at frame f0 of the pool
+    def run(f0, n):   # n frames of every stream starting at frame f0 of the pool: never past its end
+        assert 0 <= f0 and n > 0 and f0 + n <= pool, (f0, n, pool)
         off = f0 * 480 * Cc * esz
         if fmt or Cc > 1:
             bd.process_pcm_device(x.data_ptr() + off, y.data_ptr() + off, vad.data_ptr() + f0 * S * 4, n, fmt, Cc,
@@ -143,107 +207,223 @@ def main():
         else:
             bd.process_device(x.data_ptr() + off, y.data_ptr() + off, vad.data_ptr() + f0 * S * 4, n, pool * 480, 480, stream)
 
-    def step(i):
-        f0 = (i * fps) % pool
-        n = min(fps, pool - f0)  # a step never wraps inside the pool unless fps does not divide it
-        run(f0, n)
-        if n < fps:
-            run(0, fps - n)
+    def run_span(pos, n):   # n frames starting at absolute frame `pos`, wrapping around the pool as often as needed
+        while n > 0:
+            f0 = pos % pool
+            m = min(n, pool - f0)
+            run(f0, m)
+            pos += m
+            n -= m
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        else:
+            bd.synchronize()
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     for i in range(W):
-        step(i)
+        run_span(i * fps, fps)
     barrier()
     t0 = time.perf_counter()
     for i in range(W, W + K):
-        step(i)
+        run_span(i * fps, fps)
     t_enq = time.perf_counter() - t0          # host time to enqueue everything (the calls are asynchronous)
     barrier()
     elapsed = time.perf_counter() - t0
-    frames_done, elapsed_max = aggregate(dist if world > 1 else None, S * fps * K, elapsed, dev)
-    ms_per_step = elapsed_max * 1e3 / K
-    value = frames_done / elapsed_max
-    finite = bool(torch.isfinite(y.float()).all().item())
+    d = dist if world > 1 else None
+    frames_done, elapsed_max = aggregate(d, S * fps * K, elapsed, dev)
+    res = {"value": frames_done / elapsed_max, "ms_per_step": elapsed_max * 1e3 / K, "timed_s": elapsed_max,
+           "host_enqueue_ms_per_step": t_enq * 1e3 / K, "pool_frames": pool,
+           "outputs_finite": bool(torch.isfinite(y.float()).all().item())}
 
-    # the same workload at one frame per call (live 10 ms tick): no frames in flight, one graph replay per frame
-    tick = None
-    if fps != 1:
+    # the same workload at one frame per call (live 10 ms tick)
+    if want_tick and fps != 1:
         kt = min(200, max(20, K * fps // 4))
         pos = (W + K) * fps
-        def tick_step(j):
-            run((pos + j) % pool, 1)
         for j in range(10):
-            tick_step(j)
+            run_span(pos + j, 1)
         barrier()
         t1 = time.perf_counter()
         for j in range(10, 10 + kt):
-            tick_step(j)
+            run_span(pos + j, 1)
         barrier()
         tt = time.perf_counter() - t1
-        tf, tmax = aggregate(dist if world > 1 else None, S * kt, tt, dev)
-        tick = {"frames_per_step": 1, "value": tf / tmax, "unit": "frames/s", "ms_per_step": tmax * 1e3 / kt, "steps": kt}
+        tf, tmax = aggregate(d, S * kt, tt, dev)
+        res["tick"] = {"frames_per_step": 1, "value": tf / tmax, "unit": "frames/s", "ms_per_step": tmax * 1e3 / kt, "steps": kt}
 
-    roofline = None
-    kern = {}
-    if rank == 0 and not args.no_roofline:
-        # second pass over the same workload with HIP events around every launch (eager launches)
+    if want_roofline and rank == 0 and dev.type == "cuda":
+        # second pass over the same workload with HIP events around every launch, on the stream they are launched on
         bd.set_profiling(True)
-        kp = min(K, 50)
-        t1 = time.perf_counter()
-        for i in range(W + K, W + K + kp):
-            run((i * fps) % pool, 1)
-        torch.cuda.synchronize()
-        prof_ms_per_step = (time.perf_counter() - t1) * 1e3 / kp   # per FRAME: the instrumented pass runs single frames
+        kp = min(K, 12)
+        for i in range(kp):
+            run_span((W + K + i) * fps, fps)
+        sync()
         times = bd.kernel_times()
         bd.set_profiling(False)
-        kern = {k: {"avg_us": 1e3 * ms / max(n, 1), "launches": n} for k, (ms, n) in times.items()}
-        dom = max(times, key=lambda k: times[k][0])
-        avg_s = times[dom][0] / times[dom][1] * 1e-3
-        achieved = KERNEL_BYTES[dom] * S / avg_s / 1e9
-        sum_us = sum(v["avg_us"] for v in kern.values())
+        frames_prof = kp * fps
+        kern = {k: {"avg_us": 1e3 * ms / max(n, 1), "launches": n, "us_per_frame": 1e3 * ms / frames_prof}
+                for k, (ms, n) in times.items() if n}
+        dom = max(kern, key=lambda k: kern[k]["us_per_frame"])
+        # one launch of the dominant kernel covers frames_prof / launches frames of every stream
+        frames_per_launch = frames_prof / kern[dom]["launches"]
+        avg_s = kern[dom]["avg_us"] * 1e-6
+        bytes_per_launch = KERNEL_BYTES.get(dom, 0) * S * frames_per_launch
+        achieved = bytes_per_launch / avg_s / 1e9
         traffic = None
         try:   # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes (same workload only)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_4096streams.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", f"pmc_traffic_{S}streams.json")))
             if pm.get("streams") == S and dom in pm["kernels"]:
                 traffic = pm["kernels"][dom]["hbm_bytes_per_launch"]
         except Exception:
             pass
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "avg_kernel_us": avg_s * 1e6, "bytes_per_launch": KERNEL_BYTES[dom] * S,
-                    "sum_kernel_us_per_frame": sum_us, "profiled_ms_per_frame": prof_ms_per_step,
-                    "pipeline_fused_bytes_GBs": value / args.gpus * BYTES_PER_FRAME_FUSED / 1e9,
-                    "pipeline_hbm_frac": value / args.gpus * BYTES_PER_FRAME_FUSED / 1e9 / HBM_PEAK_GBS,
-                    "pipeline_fp32_frac": value / args.gpus * FLOPS_PER_FRAME / 1e12 / FP32_PEAK_TFLOPS,
-                    "note": "path is FP32-VALU/latency bound (23-100 FLOP/B, SURVEY 8d); HBM fraction reported as north_star asks"}
+        per_gpu = res["value"] / world
+        res["kernels"] = kern
+        res["roofline"] = {
+            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "avg_kernel_us": avg_s * 1e6, "frames_per_launch": frames_per_launch, "bytes_per_launch": bytes_per_launch,
+            "sum_kernel_us_per_frame": sum(v["us_per_frame"] for v in kern.values()),
+            "pipeline_fused_bytes_GBs": per_gpu * BYTES_PER_FRAME_FUSED / 1e9,
+            "pipeline_hbm_frac": per_gpu * BYTES_PER_FRAME_FUSED / 1e9 / HBM_PEAK_GBS,
+            "pipeline_fp32_frac": per_gpu * FLOPS_PER_FRAME / 1e12 / FP32_PEAK_TFLOPS,
+            "note": "path is FP32-VALU/latency bound (23-100 FLOP/B, SURVEY 8d); HBM fraction reported as north_star asks"}
+    bd.close()
+    del x, y, vad
+    if dev.type == "cuda":
+        torch.cuda.empty_cache()
+    return res
+
+
+def config0():
+    """configs[0]: the reference's own CPU-runnable case, on the CPU oracle (plumbing; no GPU involved)."""
+    import numpy as np
+    from oracle import oracle as O
+    g = os.path.join(ROOT, "tests", "golden")
+    inp = np.fromfile(os.path.join(g, "testing.raw"), dtype="<i2").astype(np.float32)
+    ref = np.fromfile(os.path.join(g, "reference_output.raw"), dtype="<i2")
+    n = len(inp) // 480
+    model = O.Model(open(os.path.join(ROOT, "nnnoiseless_amd", "data", "weights.rnn"), "rb").read(), f32_fft=True)
+    t0 = time.perf_counter()
+    out = O.run_streams(model, inp[: n * 480].reshape(1, n, 480), want=("out",))["out"][0, 1:].reshape(-1)
+    dt = time.perf_counter() - t0
+    o16 = np.clip(np.trunc(out), -32768, 32767)
+    err = float(((ref - o16) ** 2).sum() / (o16 ** 2).sum())
+    print(json.dumps({"metric": "480-sample frames/sec (whole node) at N concurrent streams", "value": n / dt, "unit": "frames/s",
+                      "n_gpus": 0, "steps": 1, "warmup": 0, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "f32", "data": "test_data/testing.raw (reference golden input)",
+                      "config": {"workload": "configs[0]: 1 stream, built-in weights.rnn, testing.raw on the CPU oracle (port of the reference; plumbing, no GPU)"},
+                      "golden_metric": err}), flush=True)
+
+
+def main():
+    args = parse_args()
+    if args.config == 0:
+        return config0()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        # not under a launcher: start one rank per GPU ourselves
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line whose n_gpus is not the number of ranks", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    if args.dry_run:
+        dev = torch.device("cpu")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo")
+    else:
+        if torch.cuda.device_count() <= local_rank:
+            print(f"bench: rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} visible", file=sys.stderr)
+            sys.exit(2)
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        if ranks_seen != args.gpus:
+            if rank == 0:
+                print(f"bench: all-reduce saw {ranks_seen} ranks, --gpus says {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+
+    if args.workload == "train":
+        return bench_train(args, rank, world, dev, local_rank, dist)
+    cfg = CONFIGS[args.config]
+    S = args.streams or cfg["streams"]
+    if args.dry_run:
+        S = args.streams or 6
+        args.frames_per_step = min(args.frames_per_step, 3)
+        args.steps, args.warmup = min(args.steps, 2), min(args.warmup, 1)
+    model_path = args.model or cfg["model"]
+    res = measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want_roofline=not args.no_roofline)
+
+    also = None
+    default_run = (args.config == 1 and args.streams is None and args.model is None and world == 1 and args.pcm == "f32"
+                   and args.channels == 1 and not args.dry_run and not args.no_also)
+    if default_run:
+        # the other single-GPU configurations of BASELINE.json, measured the same way, so the driver's line carries them
+        also = {}
+        for c in (2, 4):
+            a = argparse.Namespace(**vars(args))
+            a.steps, a.warmup = min(args.steps, 12), min(args.warmup, 2)
+            r = measure(a, CONFIGS[c]["streams"], CONFIGS[c]["model"], rank, world, dev, local_rank, dist, torch, want_tick=False,
+                        want_roofline=not args.no_roofline)
+            also[f"configs[{c}]"] = {
+                "workload": CONFIGS[c]["name"], "value": r["value"], "unit": "frames/s", "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": r["ms_per_step"], "timed_s": r["timed_s"], "frames_per_step": args.frames_per_step,
+                "outputs_finite": r["outputs_finite"], "pool_frames": r["pool_frames"],
+                "pipeline_hbm_frac": r["value"] * BYTES_PER_FRAME_FUSED / 1e9 / HBM_PEAK_GBS,
+                "kernels_us_per_frame": {k: round(v["us_per_frame"], 2) for k, v in r.get("kernels", {}).items()},
+                "roofline": r.get("roofline")}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and not args.dry_run:
         cpu = cpu_baseline()
 
     if rank == 0:
+        fps = args.frames_per_step
         line = {
-            "metric": "480-sample frames/sec (whole node) at N concurrent streams", "value": value, "unit": "frames/s",
-            "n_gpus": args.gpus, "steps": K, "warmup": W, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "metric": "480-sample frames/sec (whole node) at N concurrent streams", "value": res["value"], "unit": "frames/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{S} concurrent mono streams per GPU, built-in weights.rnn, synthetic 48 kHz sine+noise "
-                                   f"(BASELINE.json configs[1]), {fps} frame(s) per stream per step",
+            "config": {"workload": f"{cfg['name'] if S == cfg['streams'] else f'{S} concurrent mono streams per GPU (custom --streams)'}"
+                                   f"{'' if model_path == cfg['model'] else ', model ' + os.path.basename(model_path or 'built-in')}, "
+                                   f"synthetic 48 kHz sine+noise, {fps} frame(s) per stream per step",
+                       "baseline_config_index": args.config,
+                       "model": os.path.basename(model_path) if model_path else "built-in weights.rnn",
                        "boundary_format": {"f32": "f32 planar (process_frame's own)", "i16": "packed int16",
-                                           "unit": "unit-range f32"}[args.pcm] + (f", {Cc} interleaved channels" if Cc > 1 else ""),
+                                           "unit": "unit-range f32"}[args.pcm] + (f", {args.channels} interleaved channels" if args.channels > 1 else ""),
                        "streams_per_gpu": S, "streams_total": S * world, "frames_per_step": fps,
-                       "launch": ("groups of 4 frames per launch for the kernels without cross-frame state, three groups in flight on three HIP streams, each group's pitch-front segment replayed as a hipGraph"
-                                  if fps > 1 else "eager launches, one frame per call"),
-                       "parallelism": f"streams sharded x{world}"},
-            "tick": tick,
-            "host_enqueue_ms_per_step": t_enq * 1e3 / K,
-            "outputs_finite": finite,
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
+                       "parallelism": f"streams sharded x{world}, one process per GPU, no data-path collective"},
+            "ranks_seen": ranks_seen, "timed_s": res["timed_s"], "pool_frames": res["pool_frames"],
+            "tick": res.get("tick"),
+            "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
+            "outputs_finite": res["outputs_finite"],
+            "roofline": res.get("roofline"), "cpu_baseline": cpu, "kernels": res.get("kernels", {}), "also": also,
         }
+        if args.dry_run:
+            line["dry_run"] = "gloo + CPU tensors + NNN_LIBRARY build: plumbing only, numbers meaningless"
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -254,12 +434,12 @@ def bench_train(args, rank, world, dev, local_rank, dist):
     """Training-feature rows per second: three feature states per stream, no RNN, no synthesis."""
     import torch
     from nnnoiseless_amd.shard import aggregate
-    from nnnoiseless_amd.synthetic import make_streams_fast
+    from nnnoiseless_amd.synthetic import make_streams_device
     from nnnoiseless_amd.training import ROW_WIDTH, TrainingFeatures
-    S, fps, K, W = args.streams, args.frames_per_step, args.steps, args.warmup
+    S, fps, K, W = args.streams or 4096, args.frames_per_step, args.steps, args.warmup
     pool = max(fps, 16)
-    sig = torch.from_numpy(make_streams_fast(S, pool, seed=rank)).to(dev)
-    noise = torch.from_numpy(make_streams_fast(S, pool, seed=1000 + rank) * 0.3).to(dev)
+    sig = make_streams_device(torch, dev, S, pool, seed=rank)
+    noise = make_streams_device(torch, dev, S, pool, seed=1000 + rank) * 0.3
     comb = sig + noise
     cutoff = torch.full((pool, S), 20, dtype=torch.int32, device=dev)
     vad = torch.ones((pool, S), dtype=torch.float32, device=dev)

@@ -48,3 +48,28 @@ def make_streams_fast(count, n_frames, seed=0):
     x += sigma * rng.standard_normal(x.shape, dtype=np.float32)
     x[idx == 7] = 0.0
     return np.clip(np.round(x), -32768, 32767).astype(np.float32).reshape(count, n_frames, 480)
+
+
+def make_streams_device(torch, dev, count, n_frames, seed=0):
+    """Same distribution as make_streams_fast, generated on `dev` with torch (bench-sized inputs: 65 536 streams x tens of
+    frames would take minutes in numpy).  Returns a float32 tensor [count, n_frames, 480] resident on the device."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED0 ^ (seed + 1))
+    u = torch.rand((4, count, 1), generator=g, device=dev, dtype=torch.float32)
+    f = 80.0 + 920.0 * u[0]
+    a = 500.0 + 11500.0 * u[1]
+    sigma = 50.0 + 2950.0 * u[2]
+    phi = 2.0 * np.pi * u[3]
+    idx = torch.arange(count, device=dev) % 16
+    a[idx == 11] = 0.0
+    n = n_frames * 480
+    x = torch.empty((count, n), dtype=torch.float32, device=dev)
+    chunk = max(1, int(2 ** 27 // max(n, 1)))           # bound the temporaries (~0.5 GB each)
+    t = torch.arange(n, device=dev, dtype=torch.float32)[None, :]
+    for lo in range(0, count, chunk):
+        hi = min(count, lo + chunk)
+        v = a[lo:hi] * torch.sin((2.0 * np.pi / 48000.0) * f[lo:hi] * t + phi[lo:hi])
+        v += sigma[lo:hi] * torch.randn((hi - lo, n), generator=g, device=dev, dtype=torch.float32)
+        x[lo:hi] = torch.clamp(torch.round(v), -32768.0, 32767.0)
+    x[idx == 7] = 0.0
+    return x.reshape(count, n_frames, 480)

@@ -913,8 +913,25 @@ float nnno_frame_condition(const nnno_state *st)
     return best;
 }
 
-int nnno_run_streams_cond(const nnno_model *m, int n_streams, int n_frames, const float *in, float *out,
-                          float *vad, int32_t *pitch, float *gains, float *feats, float *cond, int n_threads)
+/* Discrete decisions of the most recent frame: bit i (< 22) = pitch_filter took its `exp > g` branch in band i
+ * (src/features.rs:227), bit 22 = the frame was silent (src/features.rs:160-166, src/denoise.rs:100).  Parity tests
+ * excuse the audio comparison only on frames where the device's mask differs from this one. */
+int32_t nnno_frame_branch(const nnno_state *st)
+{
+    int32_t m = 0;
+    if (st->taps.silence) return 1 << NB_BANDS;
+    for (int i = 0; i < NB_BANDS; i++)
+        if (st->taps.exp_[i] > st->taps.g_raw[i]) m |= 1 << i;
+    return m;
+}
+
+/* the activation functions on their own (src/util.rs:29-53), for a direct known-answer sweep against the device's */
+float nnno_tansig(float x) { init_tables(); return tansig_approx(x); }
+float nnno_sigmoid(float x) { init_tables(); return sigmoid_approx(x); }
+
+int nnno_run_streams_full(const nnno_model *m, int n_streams, int n_frames, const float *in, float *out, float *vad,
+                          int32_t *pitch, float *gains, float *feats, float *cond, int32_t *branch, float *g_raw,
+                          float *exp_, int n_threads)
 {
     init_tables();
     int used = 1;
@@ -934,10 +951,81 @@ int nnno_run_streams_cond(const nnno_model *m, int n_streams, int n_frames, cons
             if (gains) memcpy(gains + ft * NB_BANDS, st->taps.g, NB_BANDS * sizeof(float));
             if (feats) memcpy(feats + ft * NB_FEATURES, st->features, NB_FEATURES * sizeof(float));
             if (cond) cond[ft] = nnno_frame_condition(st);
+            if (branch) branch[ft] = nnno_frame_branch(st);
+            if (g_raw) memcpy(g_raw + ft * NB_BANDS, st->taps.g_raw, NB_BANDS * sizeof(float));
+            if (exp_) memcpy(exp_ + ft * NB_BANDS, st->taps.exp_, NB_BANDS * sizeof(float));
         }
         nnno_destroy(st);
     }
     return used;
+}
+
+int nnno_run_streams_cond(const nnno_model *m, int n_streams, int n_frames, const float *in, float *out,
+                          float *vad, int32_t *pitch, float *gains, float *feats, float *cond, int n_threads)
+{
+    return nnno_run_streams_full(m, n_streams, n_frames, in, out, vad, pitch, gains, feats, cond, NULL, NULL, NULL, n_threads);
+}
+
+/* ---- CPU baseline timing (bench.py cpu_baseline) ---------------------------------------------------
+ * Times process_frame on `n_threads` host threads with nothing but process_frame in the timed region: every thread
+ * owns one state and one 100-frame input buffer made before the clock starts (no allocation, no shared output).
+ *   kind 0: SURVEY 8(d) synthetic mix -- per thread a sine (80..1000 Hz) plus uniform noise, `iters` x 100 frames
+ *           on ONE continuing state per thread;
+ *   kind 1: the reference's own bench shape, benches/sin.rs:9-20 -- 100 frames of a 440 Hz sine at amplitude
+ *           i16::MAX, FRESH state every iteration (the state reset is inside the timed region there too).
+ * secs[t] = wall seconds of thread t; returns the wall seconds of the whole parallel region. */
+double nnno_bench(const nnno_model *m, int n_threads, int iters, int kind, double *secs)
+{
+    init_tables();
+    if (n_threads < 1) n_threads = 1;
+    double wall = 0.0;
+#ifdef _OPENMP
+    double t_begin = 0.0;
+#pragma omp parallel num_threads(n_threads)
+    {
+        const int tid = omp_get_thread_num();
+#else
+    {
+        const int tid = 0;
+#endif
+        float *buf = (float *)malloc(sizeof(float) * 100 * FRAME_SIZE);
+        float o[FRAME_SIZE];
+        unsigned rng = 0x9E3779B9u * (unsigned)(tid + 1);
+        const double f = kind ? 440.0 : 80.0 + 920.0 * ((double)(tid % 97) / 97.0);
+        const double amp = kind ? 32767.0 : 3000.0 + 50.0 * (tid % 64);
+        for (int i = 0; i < 100 * FRAME_SIZE; i++) {
+            double v = amp * sin(2.0 * 3.14159265358979323846 * f * (double)i / 48000.0);
+            if (!kind) {
+                rng = rng * 1664525u + 1013904223u;
+                v += 600.0 * ((double)(rng >> 8) / 8388608.0 - 1.0);
+            }
+            buf[i] = (float)floor(v + 0.5);
+        }
+        nnno_state *st = nnno_create(m);
+        for (int t = 0; t < 4; t++) nnno_process_frame(st, o, buf + t * FRAME_SIZE);   /* warm the caches */
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp master
+        t_begin = omp_get_wtime();
+#pragma omp barrier
+        const double t0 = omp_get_wtime();
+#else
+        const double t0 = 0.0;
+#endif
+        for (int it = 0; it < iters; it++) {
+            if (kind) { const nnno_model *mm = st->model; memset(st, 0, sizeof(*st)); st->model = mm; }   /* DenoiseState::new() */
+            for (int t = 0; t < 100; t++) nnno_process_frame(st, o, buf + t * FRAME_SIZE);
+        }
+#ifdef _OPENMP
+        if (secs) secs[tid] = omp_get_wtime() - t0;
+#pragma omp barrier
+#pragma omp master
+        wall = omp_get_wtime() - t_begin;
+#endif
+        nnno_destroy(st);
+        free(buf);
+    }
+    return wall;
 }
 
 int nnno_run_streams(const nnno_model *m, int n_streams, int n_frames, const float *in, float *out,

@@ -92,6 +92,18 @@ int nnno_run_streams(const nnno_model *m, int n_streams, int n_frames, const flo
 /* The same, plus cond[n_streams][n_frames] = nnno_frame_condition of every frame (may be NULL). */
 int nnno_run_streams_cond(const nnno_model *m, int n_streams, int n_frames, const float *in, float *out,
                           float *vad, int32_t *pitch, float *gains, float *feats, float *cond, int n_threads);
+/* Everything run_streams_cond returns plus, per frame: branch = nnno_frame_branch, g_raw[22] (RNN gains before
+ * smoothing), exp_[22] (normalised pitch correlation).  Any output pointer may be NULL. */
+int nnno_run_streams_full(const nnno_model *m, int n_streams, int n_frames, const float *in, float *out, float *vad,
+                          int32_t *pitch, float *gains, float *feats, float *cond, int32_t *branch, float *g_raw,
+                          float *exp_, int n_threads);
+/* bit i < 22: pitch_filter's `exp > g` branch taken in band i (src/features.rs:227); bit 22: silent frame. */
+int32_t nnno_frame_branch(const nnno_state *st);
+/* tansig_approx / sigmoid_approx on their own (src/util.rs:29-53) */
+float nnno_tansig(float x);
+float nnno_sigmoid(float x);
+/* CPU baseline timing: see nnn_oracle.c */
+double nnno_bench(const nnno_model *m, int n_threads, int iters, int kind, double *secs);
 /* Smallest |exp - g| over the bands where pitch_filter's branch (src/features.rs:229-236) is a jump discontinuity
  * (large if none): frames where it is tiny are decided by FFT rounding noise in the REFERENCE itself. */
 float nnno_frame_condition(const nnno_state *st);

@@ -141,7 +141,8 @@ class State:
 
 def run_streams(model: Model, x, n_threads=1, want=("out", "vad", "pitch", "gains", "feats", "cond")):
     """x: [S][T][480] float32.  Returns dict of arrays (fresh state per stream).  "cond" = per-frame conditioning of the
-    reference's pitch-filter branch (nnno_frame_condition): tiny values mark frames the reference itself cannot pin."""
+    reference's pitch-filter branch (nnno_frame_condition): tiny values mark frames the reference itself cannot pin;
+    "branch" = nnno_frame_branch (22 `exp > g` bits + silence bit), "g_raw" / "exp" = the two sides of that comparison."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     S, Tn, F = x.shape
     assert F == FRAME_SIZE
@@ -152,14 +153,38 @@ def run_streams(model: Model, x, n_threads=1, want=("out", "vad", "pitch", "gain
         "gains": np.empty((S, Tn, 22), np.float32) if "gains" in want else None,
         "feats": np.empty((S, Tn, 42), np.float32) if "feats" in want else None,
         "cond": np.empty((S, Tn), np.float32) if "cond" in want else None,
+        "branch": np.empty((S, Tn), np.int32) if "branch" in want else None,
+        "g_raw": np.empty((S, Tn, 22), np.float32) if "g_raw" in want else None,
+        "exp": np.empty((S, Tn, 22), np.float32) if "exp" in want else None,
     }
-    fn = model._L.nnno_run_streams_cond
+    fn = model._L.nnno_run_streams_full
     fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int]
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int]
     used = fn(model._h, S, Tn, _ptr(x), _ptr(res["out"]), _ptr(res["vad"]), _ptr(res["pitch"]), _ptr(res["gains"]),
-              _ptr(res["feats"]), _ptr(res["cond"]), int(n_threads))
+              _ptr(res["feats"]), _ptr(res["cond"]), _ptr(res["branch"]), _ptr(res["g_raw"]), _ptr(res["exp"]), int(n_threads))
     res["threads"] = used
     return res
+
+
+def activation(x, kind):
+    """tansig_approx (kind 0) / sigmoid_approx (kind 1) of src/util.rs:29-53, elementwise."""
+    L = lib()
+    fn = L.nnno_sigmoid if kind else L.nnno_tansig
+    fn.restype = C.c_float
+    fn.argtypes = [C.c_float]
+    x = np.asarray(x, np.float32)
+    return np.array([fn(float(v)) for v in x.ravel()], np.float32).reshape(x.shape)
+
+
+def bench(model: Model, n_threads, iters, kind):
+    """nnno_bench: (wall seconds, per-thread seconds) for n_threads x iters x 100 frames; kind 0 synthetic mix on a
+    continuing state, kind 1 the reference's benches/sin.rs shape (fresh state per 100-frame iteration)."""
+    fn = model._L.nnno_bench
+    fn.restype = C.c_double
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    secs = np.zeros(max(1, n_threads), np.float64)
+    wall = fn(model._h, int(n_threads), int(iters), int(kind), _ptr(secs))
+    return float(wall), secs
 
 
 def cli_raw_i16(model: Model, pcm, channels=1):

@@ -91,3 +91,47 @@ def test_sharded_streams_match_unsharded_world2():
     assert [(lo, hi) for lo, hi, _, _ in got] == [(0, 4), (4, 7)]
     assert np.array_equal(np.concatenate([g[2] for g in got]), out)
     assert np.array_equal(np.concatenate([g[3] for g in got], axis=1), vad)
+
+
+def _run_bench(extra, env_extra=None):
+    """bench.py on CPU: gloo, CPU tensors, the SIMT-interpreter build of the product sources (plumbing only)."""
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "hostsim"))
+    import build_hostsim
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NNN_LIBRARY=build_hostsim.build())
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run"] + extra, env=env, capture_output=True, text=True,
+                       timeout=900)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, [json.loads(l) for l in lines], p.stderr
+
+
+def test_bench_self_spawns_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself, counts them with an all-reduce and
+    reports the whole-job aggregate (it used to start ONE rank and print n_gpus 2)."""
+    rc, lines, err = _run_bench(["--gpus", "2"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1                               # rank 0 only
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
+    assert d["config"]["streams_total"] == 2 * d["config"]["streams_per_gpu"]
+    assert d["outputs_finite"] and d["value"] > 0
+
+
+def test_bench_refuses_wrong_world():
+    rc, lines, err = _run_bench(["--gpus", "2"], {"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc == 2 and not lines and "refusing" in err
+
+
+def test_bench_pool_wrap_stays_in_bounds():
+    """A step longer than the resident pool wraps as often as needed and never runs past the pool's end (VERDICT r1:
+    the old wrap ran 7 frames past x / y / vad at 65 536 streams)."""
+    rc, lines, err = _run_bench(["--streams", "3", "--frames-per-step", "3", "--steps", "2", "--warmup", "1",
+                                 "--pool-bytes", str(3 * 480 * 4 * 2)])          # room for 2 frames: every step wraps
+    assert rc == 0, err[-2000:]
+    assert lines[0]["pool_frames"] == 2 and lines[0]["outputs_finite"]
