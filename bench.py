@@ -47,21 +47,17 @@ FP32_PEAK_TFLOPS = 157.3
 BYTES_PER_FRAME_FUSED = 16948  # I/O + resident-state touch of one process_frame
 FLOPS_PER_FRAME = 0.42e6
 
-# Algorithmic HBM bytes per stream-frame of each kernel (its own inputs + outputs, each counted once;
-# derivation in DESIGN.md "Kernels")
+# Algorithmic HBM bytes per stream-frame of each kernel (its own inputs + outputs, each counted once; per-group state traffic
+# divided by the 4 frames of a full group; derivation in DESIGN.md "Kernels")
+G = 4
 KERNEL_BYTES = {
-    "k_hp": 1920 + 1920 + 16 + 2 * 960 + 8,          # input, history slot, biquad state, 240 decimated values (stored twice)
-    "k_lpc": 3456 + 40 + 2 * 3456,                    # decimated window in; taps + pitch_buf (TI + SM) out
-    "k_xcorr": 3456 + 588 + 1544,                     # pitch_buf in; 147 coarse lags + xx / yy_lookup (386) out
-    "k_best1": 1548 + 588 + 8,
-    "k_refine": 3456 + 8 + 40,
-    "k_best2": 3456 + 40 + 8 + 4 + 2 * 1176,
-    "k_doubling": 3456 + 116 + 24,
-    "k_fft_x": 3840 + 3848 + 88,
-    "k_fft_p": 3840 + 4 + 3848 + 3848 + 176,
-    "k_rnn": 264 + 88 + 704 + 88 + 168 + 16 + 2 * 672 + 2 * 88 + 180,   # features stage + RNN state/gains (weights amortised)
-    "k_synth": 7696 + 440 + 3840 + 1920 + 4,
-    "k_advance": 0,
+    "k_hp": 1920 + 1920 + 960 + 960 // 5 + 4 + (16 + 8) // G,     # input, history slot, 240 decimated values (+ mirrored share), x_lp[0]; biquad state per group
+    "k_lpc": 3456 + 4 + 40 + 3456,                                 # decimated window in; taps + pitch_buf (tile-interleaved only) out
+    "k_pitch1": 3456 + 8 + 1176 + 1544,                            # pitch_buf in; best / second lag, fine-lag energies, xx / yy_lookup out
+    "k_pitch2": 3456 + 8 + 40 + 120 + 12 + 16 // G,                # pitch_buf in (16-stream slices through LDS), lags / energies looked up; pitch out
+    "k_fft_xp": 3840 + 1200 + 4 + 3848 + 3200 + 264 + 112 + 4,     # 960 + (mean lag 300) history samples; X (481 bins), P (400 bins), band energies, cepstrum head out
+    "k_rnn": 120 + 88 + 4 + 2 * 88 + 2 * 88 + (704 + 2 * 672 + 8) // G,   # features head in; ring row, vad, gains, last gains; ring + GRU states per group
+    "k_synth": 3848 + 3200 + 440 + 8 + 1920 + 8 + 3840 // G,       # X, P, band quantities in; audio, vad, branch out; overlap memory per group
 }
 
 CONFIGS = {

@@ -56,6 +56,17 @@ int nnn_batch_num_streams(const nnn_batch *b);
 /* Back to freshly-created state (all zeros, src/features.rs:58-74). */
 int nnn_batch_reset(nnn_batch *b);
 
+/* DenoiseState is Clone (src/denoise.rs:36): a second batch with the same models and a copy of every stream's state as of
+ * the calls made so far (device-to-device copy; waits for them).  NULL on failure.  The two continue independently and, fed
+ * the same input, bit-identically. */
+nnn_batch *nnn_batch_clone(nnn_batch *b);
+/* The same state as host bytes: nnn_batch_state_bytes() of them.  A snapshot only loads into a batch of the same stream
+ * count and models made by the same build of the library (it is a raw image of the state slab, not an interchange
+ * format). */
+size_t nnn_batch_state_bytes(const nnn_batch *b);
+int nnn_batch_save_state(nnn_batch *b, void *host_dst, size_t dst_bytes);
+int nnn_batch_load_state(nnn_batch *b, const void *host_src, size_t src_bytes);
+
 /*
  * n_frames x process_frame for every stream, buffers resident in device memory.
  *   sample i of frame t of stream s:  d_in [s * stream_stride + t * frame_stride + i]   (floats)
@@ -100,7 +111,9 @@ int nnn_batch_process_pcm_host(nnn_batch *b, const void *in, void *out, float *v
 int nnn_batch_synchronize(nnn_batch *b);
 
 /* Parity taps: intermediate quantities of the most recent frame, copied to the host as
- * [n_streams][len] (float32 or int32, see nnn_tap_info).  Test/diagnostic interface. */
+ * [n_streams][len] (float32 or int32, see nnn_tap_info).  Test/diagnostic interface.  Four of them (XCORR1, XCORR2C, P
+ * beyond bin 399, FEATURES) are quantities the kernels keep on chip: they are stored to device memory only after
+ * nnn_batch_set_taps(batch, 1), and reading them without it is an error. */
 enum nnn_tap {
     NNN_TAP_FILTERED = 0, /* [480] f32  high-passed input (features.rs:97-104)           */
     NNN_TAP_XLP,          /* [864] f32  pitch_buf after pitch_downsample (pitch.rs:448)   */
@@ -120,9 +133,11 @@ enum nnn_tap {
     NNN_TAP_G_RAW,        /* [22]  f32  RNN gains                                         */
     NNN_TAP_G,            /* [22]  f32  smoothed gains                                    */
     NNN_TAP_VAD,          /* [1]   f32                                                    */
+    NNN_TAP_BRANCH,       /* [1]   i32  bit i < 22: pitch_filter took `exp > g` in band i (src/features.rs:227); bit 22: silent frame */
     NNN_TAP_COUNT
 };
 int nnn_tap_info(int tap, int *len, int *is_int);
+int nnn_batch_set_taps(nnn_batch *b, int on);
 int nnn_batch_read_tap(nnn_batch *b, int tap, void *host_dst, size_t dst_bytes);
 
 /* Per-kernel timing with HIP events on the launch stream (off by default: it adds two event
@@ -136,14 +151,20 @@ int nnn_batch_read_kernel_times(nnn_batch *b, double *total_ms, int64_t *launche
  * -DNNN_STAMPS). */
 int nnn_batch_read_stamps(nnn_batch *b, long long *dst64);
 
-/* hipGraph replay.  Default: a full frame group's six front kernels are replayed as one captured graph, one-frame
- * calls are launched eagerly (measured faster on the MI355X host).  1 = one-frame calls replay a captured graph too
- * (one API call per frame instead of 13: for hosts short of CPU), 0 = no graphs at all. */
+/* Retained from the round-1 ABI, no effect: a frame group is seven kernel launches now and they are always eager. */
 int nnn_batch_set_graph(nnn_batch *b, int on);
-/* 1 = multi-frame calls run as groups of 4 frames (one launch per group for every kernel without cross-frame state)
- * with three groups in flight on separate HIP streams (default), 0 = one frame at a time on the caller's stream.
- * Results are bit-identical either way. */
+/* 1 = calls of 8 frames or more spread their frame groups over the batch's internal HIP streams so that independent stages
+ * overlap (default), 0 = every call runs its groups back to back on the caller's stream.  Results are bit-identical. */
 int nnn_batch_set_pipeline(nnn_batch *b, int on);
+/* How a pipelined call uses the internal streams: mode 0 = not at all (as set_pipeline(0)); 1 = "lanes": the high-pass
+ * chain on its own stream, the other six stages of group k on lane stream k mod `lanes` (1..4; default 3);
+ * 2 = "stages": one stream per stage pair, every stream a chain of groups.  Environment: NNN_SCHED=seq|lanes|stages,
+ * NNN_LANES=n. */
+int nnn_batch_set_schedule(nnn_batch *b, int mode, int lanes);
+
+/* Diagnostic: the device's activation functions on their own, y[i] = act(x[i]) for n host floats; act 0 = tansig_approx,
+ * 1 = sigmoid_approx, 2 = relu (src/util.rs:29-53). */
+int nnn_debug_activations(int device, int act, const float *x, float *y, int n);
 
 const char *nnn_last_error(void);
 

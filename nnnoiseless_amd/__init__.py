@@ -79,12 +79,17 @@ class RnnModel:
 class BatchDenoiser:
     """n_streams DenoiseStates in lock-step on one GPU."""
 
-    def __init__(self, n_streams, model=None, device=0, lib=None, groups=None):
+    def __init__(self, n_streams, model=None, device=0, lib=None, groups=None, taps=False, _handle=None):
         """groups: [(model_or_None, n_streams), ...] keeps several models resident, one per run of streams (every run
-        but the last a multiple of 64); it replaces `model` and must add up to n_streams."""
+        but the last a multiple of 64); it replaces `model` and must add up to n_streams.  taps=True also stores the
+        intermediate quantities the kernels otherwise keep on chip (parity tests: tap("xcorr1"), "xcorr2c", "P", "features")."""
         self._lib = lib or library()
         self._model = model
         self.n_streams = int(n_streams)
+        self.frames_done = 0
+        if _handle is not None:   # clone()
+            self._h = _handle
+            return
         if groups:
             if sum(n for _, n in groups) != self.n_streams:
                 raise ValueError("group sizes must add up to n_streams")
@@ -96,7 +101,34 @@ class BatchDenoiser:
             self._h = self._lib.L.nnn_batch_create(model._h if model is not None else None, self.n_streams, device)
         if not self._h:
             raise RuntimeError("nnnoiseless_amd: " + self._lib.error())
-        self.frames_done = 0
+        if taps:
+            self.set_taps(True)
+
+    def clone(self):
+        """A second batch with the same models and a copy of every stream's state (DenoiseState: Clone, src/denoise.rs:36)."""
+        h = self._lib.L.nnn_batch_clone(self._h)
+        if not h:
+            raise RuntimeError("nnnoiseless_amd: " + self._lib.error())
+        c = BatchDenoiser(self.n_streams, model=self._model, lib=self._lib, _handle=h)
+        c.frames_done = self.frames_done
+        return c
+
+    def save_state(self):
+        """The streams' state as bytes (a raw image: loads only into a batch of the same shape made by the same build)."""
+        buf = np.empty(self._lib.L.nnn_batch_state_bytes(self._h), np.uint8)
+        self._lib.check(self._lib.L.nnn_batch_save_state(self._h, _ffi.ptr(buf), buf.nbytes))
+        return buf.tobytes()
+
+    def load_state(self, data):
+        buf = np.frombuffer(data, np.uint8)
+        self._lib.check(self._lib.L.nnn_batch_load_state(self._h, _ffi.ptr(buf), buf.nbytes))
+
+    def set_taps(self, on):
+        self._lib.check(self._lib.L.nnn_batch_set_taps(self._h, int(on)))
+
+    def set_schedule(self, mode, lanes=0):
+        """mode: "seq" | "lanes" | "stages" (include/nnn_batch.h nnn_batch_set_schedule)."""
+        self._lib.check(self._lib.L.nnn_batch_set_schedule(self._h, {"seq": 0, "lanes": 1, "stages": 2}[mode], int(lanes)))
 
     def process(self, x):
         """x: float32 [n_streams, n_frames, 480] on the host -> (out same shape, vad [n_frames, n_streams])."""
@@ -186,8 +218,12 @@ class DenoiseState:
 
     FRAME_SIZE = FRAME_SIZE
 
-    def __init__(self, model=None, device=0, lib=None):
-        self._b = BatchDenoiser(1, model, device, lib)
+    def __init__(self, model=None, device=0, lib=None, _batch=None):
+        self._b = _batch if _batch is not None else BatchDenoiser(1, model, device, lib)
+
+    def clone(self):
+        """`impl Clone for DenoiseState` (src/denoise.rs:36)."""
+        return DenoiseState(_batch=self._b.clone())
 
     @classmethod
     def new(cls, **kw):

@@ -7,7 +7,7 @@ import numpy as np
 FRAME_SIZE = 480
 
 TAPS = ["filtered", "xlp", "ac", "lpc2", "xcorr1", "best1", "xcorr2c", "pitch_search", "pitch", "pitch_gain",
-        "X", "P", "ex", "ep", "exp", "features", "silence", "g_raw", "g", "vad"]
+        "X", "P", "ex", "ep", "exp", "features", "silence", "g_raw", "g", "vad", "branch"]
 
 # every symbol the two headers declare (tests check that the built library exports all of them)
 BATCH_SYMBOLS = [
@@ -15,7 +15,8 @@ BATCH_SYMBOLS = [
     "nnn_convert_rnnoise_text", "nnn_model_from_rnnoise_text",
     "nnn_batch_create", "nnn_batch_create_grouped", "nnn_batch_destroy", "nnn_batch_num_streams", "nnn_batch_reset",
     "nnn_batch_process_device", "nnn_batch_process_host", "nnn_batch_process_pcm_device", "nnn_batch_process_pcm_host",
-    "nnn_batch_synchronize",
+    "nnn_batch_synchronize", "nnn_batch_clone", "nnn_batch_state_bytes", "nnn_batch_save_state", "nnn_batch_load_state",
+    "nnn_batch_set_taps", "nnn_batch_set_schedule", "nnn_debug_activations",
     "nnn_tap_info", "nnn_batch_read_tap", "nnn_batch_set_profiling", "nnn_batch_num_kernels",
     "nnn_batch_kernel_name", "nnn_batch_read_kernel_times", "nnn_batch_set_graph", "nnn_batch_set_pipeline", "nnn_batch_read_stamps",
     "nnn_last_error",
@@ -78,6 +79,15 @@ class Library:
         L.nnn_batch_kernel_name.argtypes = [i32]
         L.nnn_batch_read_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
         L.nnn_batch_set_graph.argtypes = [vp, i32]
+        L.nnn_batch_clone.restype = vp
+        L.nnn_batch_clone.argtypes = [vp]
+        L.nnn_batch_state_bytes.restype = sz
+        L.nnn_batch_state_bytes.argtypes = [vp]
+        L.nnn_batch_save_state.argtypes = [vp, vp, sz]
+        L.nnn_batch_load_state.argtypes = [vp, vp, sz]
+        L.nnn_batch_set_taps.argtypes = [vp, i32]
+        L.nnn_batch_set_schedule.argtypes = [vp, i32, i32]
+        L.nnn_debug_activations.argtypes = [i32, i32, vp, vp, i32]
         L.nnn_batch_set_pipeline.argtypes = [vp, i32]
         L.nnn_train_create.restype = vp
         L.nnn_train_create.argtypes = [i32, i32]

@@ -43,10 +43,16 @@ static int fail(const char *fmt, ...)
         if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));  \
     } while (0)
 
-enum KernelId { K_HP, K_LPC, K_XCORR, K_BEST1, K_REFINE, K_BEST2, K_DOUBLING, K_FFT_X, K_FFT_P, K_RNN, K_SYNTH, K_ADVANCE, K_COUNT };
-static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_xcorr", "k_best1", "k_refine", "k_best2",
-                                            "k_doubling", "k_fft_x", "k_fft_p", "k_rnn", "k_synth", "k_advance"};
+enum KernelId { K_HP, K_LPC, K_PITCH1, K_PITCH2, K_FFT_XP, K_RNN, K_SYNTH, K_COUNT };
+static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_pitch1", "k_pitch2", "k_fft_xp", "k_rnn", "k_synth"};
 
+// The seven stages of a frame group, one kernel launch each (k_rnn: one per resident model).  hp, pitch2, rnn and synth carry
+// state from frame to frame and loop over the group's frames inside the launch; the others cover all frames of the group
+// side by side (block index = frame * blocks_per_frame + block).
+enum Stage { ST_HP, ST_LPC, ST_P1, ST_P2, ST_FFT, ST_RNN, ST_SYN, ST_COUNT };
+constexpr int NSTREAMS = 5;    // internal streams of a pipelined call
+constexpr int EVR = 16;        // event ring: groups of one call that may still be referred to
+enum SchedMode { SCHED_SEQ = 0, SCHED_LANES = 1, SCHED_STAGES = 2 };
 
 struct nnn_batch {
     Buffers b[NSET];               // same state, NSET scratch sets (views into one allocation per scratch array: set s lies
@@ -57,45 +63,41 @@ struct nnn_batch {
         const uint4 *wq = nullptr;     // packed bf16 weights (device)
         const float *fpar = nullptr;   // biases + vad output layer (device)
         size_t rnn_lds = 0;            // dynamic LDS bytes at `rows`
-        int rows = TILE;               // stream rows per RNN block: 64, 32 or 16
+        int rows = 32;                 // stream rows per RNN block: 32 or 16
         int tile0 = 0, ntiles = 0;
     };
     int rnn_rows = 0;              // forced rows per RNN block (env NNN_RNN_ROWS), 0 = by model size and batch size
     std::vector<ModelGroup> groups;
+    std::vector<RNNModel> models;  // host copies of the resident models (clone)
+    std::vector<int> group_streams;
     int device = 0;
     int S = 0, S_pad = 0, NT = 0;
     uint64_t frame_count = 0;
-    uint64_t group_count = 0;      // groups launched so far: group_count % LANES picks the block of GROUP scratch sets
+    uint64_t group_count = 0;      // groups launched so far: group_count % DEPTH picks the block of GROUP scratch sets
     int last_set = 0;              // scratch set of the most recent frame (parity taps)
     std::vector<void *> allocs;     // everything hipMalloc'ed
-    std::vector<std::pair<void *, size_t>> state_bufs;  // zeroed by reset
-    StepParams *sp = nullptr;       // device, [NSET]: launch parameters per scratch set (stand-alone frames: stepped on the
-                                    // device; pipelined groups: republished by each frame's high-pass for the front graph)
+    std::vector<std::pair<void *, size_t>> state_bufs;  // zeroed by reset, copied by clone / save / load
     char *stage = nullptr;          // device staging of the host-buffer entry points (grow-only)
     float *stage_vad = nullptr;
     size_t stage_cap = 0, stage_vad_cap = 0;
     std::vector<char> stage_host;   // host side of the copy back
-    StepParams *sp_tab = nullptr;   // device, per-frame parameter table of a pipelined call
+    StepParams *sp_tab = nullptr;   // device, per-frame parameter table of a call
     int sp_tab_cap = 0;
     hipStream_t stream = nullptr;   // default launch stream
-    hipStream_t lanes[LANES] = {};  // group lanes 1.. of a pipelined call (lane 0 is the caller's stream)
-    hipStream_t side[2] = {nullptr, nullptr};   // branches of a stand-alone frame: fft_x, yy
-    hipEvent_t ev_fork[2] = {}, ev_join[2] = {};
-    hipEvent_t ev_chain[LANES][4] = {};  // per lane: hp, doubling, rnn, synth done (the cross-frame recurrences)
-    hipEvent_t ev_lane = nullptr, ev_lane_done[LANES] = {};
-
-    bool use_graph = true, use_pipeline = true;
-    bool graph_single = false;      // replay one-frame calls from a graph too (measured 6 % slower than eager launches on the
-                                    // MI355X host, 14.2 vs 15.0 M frames/s at 4096 streams; saves host CPU; nnn_batch_set_graph(1))
-    hipGraphExec_t g_single[LANES] = {};   // per set block: one stand-alone frame
-    hipGraphExec_t g_front[LANES] = {};    // per set block: fft_x, lpc, xcorr+yy, best1, refine, best2 of a full group
-    bool front_failed = false;
-    hipStream_t graph_stream = nullptr;  // stream the graphs were captured on
-    bool use_branches = true;
-    int xcorr_chunk = 0;            // lags per k_xcorr wave: 4, 8 or 16 (0 = by batch size); env NNN_XCORR_CHUNK
+    hipStream_t pool[NSTREAMS] = {};   // internal streams of pipelined calls
+    uint64_t pool_call[NSTREAMS] = {}; // call in which each last waited for the caller's stream
+    hipEvent_t ev[ST_COUNT][EVR] = {}; // stage s of group (k mod EVR) of the current call done
+    hipEvent_t ev_in = nullptr;     // the caller's stream at the start of a pipelined call
+    hipEvent_t ev_last = nullptr;   // end of the most recent call, on the stream it was made on
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+    uint64_t call_count = 0;
+    int sched = SCHED_LANES;        // how a multi-frame call spreads over streams (env NNN_SCHED: seq | lanes | stages)
+    int n_lanes = 3;                // SCHED_LANES: lane streams besides the high-pass stream (env NNN_LANES, 1..4)
+    bool use_pipeline = true;
     bool profiling = false;
-    std::vector<hipEvent_t> ev;     // pairs per launch while profiling
-    std::vector<int> ev_kernel;
+    std::vector<hipEvent_t> evp;    // pairs per launch while profiling
+    std::vector<int> evp_kernel;
     double k_ms[K_COUNT] = {0};
     int64_t k_launches[K_COUNT] = {0};
 };
@@ -170,38 +172,33 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
     if (!h) return;
     NNN_RT_LOCK;
     hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
-    for (int i = 0; i < LANES; i++) {
-        if (h->g_single[i]) hipGraphExecDestroy(h->g_single[i]);
-        if (h->g_front[i]) hipGraphExecDestroy(h->g_front[i]);
-    }
-    for (int i = 0; i < 2; i++) {
-        if (h->side[i]) hipStreamDestroy(h->side[i]);
-        if (h->ev_fork[i]) hipEventDestroy(h->ev_fork[i]);
-        if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
-    }
-    for (int l = 0; l < LANES; l++) {
-        for (int i = 0; i < 4; i++)
-            if (h->ev_chain[l][i]) hipEventDestroy(h->ev_chain[l][i]);
-        if (h->ev_lane_done[l]) hipEventDestroy(h->ev_lane_done[l]);
-        if (h->lanes[l]) hipStreamDestroy(h->lanes[l]);
-    }
-    if (h->ev_lane) hipEventDestroy(h->ev_lane);
-    for (hipEvent_t e : h->ev) hipEventDestroy(e);
+    hipDeviceSynchronize();
+    for (int s = 0; s < ST_COUNT; s++)
+        for (int i = 0; i < EVR; i++)
+            if (h->ev[s][i]) hipEventDestroy(h->ev[s][i]);
+    if (h->ev_in) hipEventDestroy(h->ev_in);
+    if (h->ev_last) hipEventDestroy(h->ev_last);
+    for (hipEvent_t e : h->evp) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
     if (h->sp_tab) hipFree(h->sp_tab);
     if (h->stage) hipFree(h->stage);
     if (h->stage_vad) hipFree(h->stage_vad);
+    for (int i = 0; i < NSTREAMS; i++)
+        if (h->pool[i]) hipStreamDestroy(h->pool[i]);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
 
-// dynamic LDS of k_rnn: tanh table (256 floats) + live flags (64 ints) + 3 bf16 planes of both operand matrices for
-// `rows` streams + the feature stage's staged cepstral ring and pair distances ((8 x 22 + 28) x `rows` floats)
+// dynamic LDS of k_rnn (mirrors its carve-up): tanh table (256 floats) + live flags (2 x 64 ints), 3 bf16 planes of the
+// input matrix, the r * state matrix, the three state matrices and the feature staging for `rows` streams, the cepstral
+// ring and its pair distances ((8 x 22 + 28) x `rows` floats)
 static size_t rnn_lds_bytes(const RnnPlan &pl, int rows)
 {
-    return 256 * 4 + 64 * 4 + (size_t)3 * rows * (pl.in_w + pl.rec_w) * 2 + (size_t)(CEPS_MEM * NB + 28) * rows * 4;
+    auto sw = [](const LayerDesc &L) { return (size_t)(32 * L.rec.ksteps + 8); };
+    const size_t cols = (size_t)pl.in_w + pl.rec_w + sw(pl.vad) + sw(pl.noise) + sw(pl.dn) + FS_W;
+    return (256 + 128) * 4 + (size_t)3 * rows * cols * 2 + (size_t)(CEPS_MEM * NB + 28) * rows * 4;
 }
+constexpr size_t kLdsMax = 160 * 1024;
 // below this many RNN blocks a launch leaves compute units idle and the per-block chain dominates
 static int rnn_small_batch_blocks()
 {
@@ -227,26 +224,24 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     HIPCHK(hipSetDevice(device));
     h->device = device;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_lane, hipEventDisableTiming));
-    for (int i = 0; i < 2; i++) {
-        HIPCHK(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_fork[i], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
-    }
-    for (int l = 0; l < LANES; l++) {
-        if (l > 0) HIPCHK(hipStreamCreateWithFlags(&h->lanes[l], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_lane_done[l], hipEventDisableTiming));
-        for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_chain[l][i], hipEventDisableTiming));
-    }
+    HIPCHK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming));
+    for (int i = 0; i < NSTREAMS; i++) HIPCHK(hipStreamCreateWithFlags(&h->pool[i], hipStreamNonBlocking));
+    for (int s = 0; s < ST_COUNT; s++)
+        for (int i = 0; i < EVR; i++) HIPCHK(hipEventCreateWithFlags(&h->ev[s][i], hipEventDisableTiming));
     if (const char *e = getenv("NNN_PIPELINE")) h->use_pipeline = atoi(e) != 0;
-    if (const char *e = getenv("NNN_GRAPH_SINGLE")) h->graph_single = atoi(e) != 0;
+    if (const char *e = getenv("NNN_SCHED")) {
+        if (!strcmp(e, "seq")) h->sched = SCHED_SEQ;
+        else if (!strcmp(e, "lanes")) h->sched = SCHED_LANES;
+        else if (!strcmp(e, "stages")) h->sched = SCHED_STAGES;
+    }
+    if (const char *e = getenv("NNN_LANES")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= NSTREAMS - 1) h->n_lanes = v;
+    }
     if (const char *e = getenv("NNN_RNN_ROWS")) {
         const int v = atoi(e);
-        if (v == 16 || v == 32 || v == 64) h->rnn_rows = v;
-    }
-    if (const char *e = getenv("NNN_XCORR_CHUNK")) {
-        int v = atoi(e);
-        if (v == 4 || v == 8 || v == 16) h->xcorr_chunk = v;
+        if (v == 16 || v == 32) h->rnn_rows = v;
     }
     h->S = n_streams;
     h->S_pad = (n_streams + TILE - 1) / TILE * TILE;
@@ -257,8 +252,8 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     std::vector<std::vector<uint16_t>> wqs(n_groups);
     std::vector<std::vector<float>> fpars(n_groups);
     h->groups.resize(n_groups);
+    h->group_streams.assign(group_streams, group_streams + n_groups);
     memset(&h->md, 0, sizeof(h->md));
-    size_t lds_max = 0;
     for (int g = 0, tile0 = 0; g < n_groups; g++) {
         const RNNModel *model = models ? models[g] : nullptr;
         RNNModel *own = nullptr;
@@ -269,6 +264,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
             if (!own) return fail("built-in weights failed to parse");
             model = own;
         }
+        h->models.push_back(*model);
         nnn_batch::ModelGroup &G = h->groups[g];
         ModelDims md;
         nnn_model_pack(*model, wqs[g], fpars[g], G.plan, md);
@@ -277,18 +273,17 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
         G.ntiles = (group_streams[g] + TILE - 1) / TILE;
         // rows per block: the most that fit the LDS; fewer (more, shorter blocks) while the launch cannot fill the GPU
         G.rows = 0;
-        for (int rows = TILE; rows >= 16 && !G.rows; rows /= 2)
-            if (rnn_lds_bytes(G.plan, rows) <= 160 * 1024) G.rows = rows;
+        for (int rows = 32; rows >= 16 && !G.rows; rows /= 2)   // (64 rows never fit: the states stay in LDS for a whole group)
+            if (rnn_lds_bytes(G.plan, rows) <= kLdsMax) G.rows = rows;
         if (!G.rows) return fail("model too large for the RNN kernel's LDS operand matrices");
         while (G.rows > 16 && G.ntiles * (TILE / G.rows) < rnn_small_batch_blocks()) G.rows /= 2;
-        if (h->rnn_rows && rnn_lds_bytes(G.plan, h->rnn_rows) <= 160 * 1024) G.rows = h->rnn_rows;
+        if (h->rnn_rows && rnn_lds_bytes(G.plan, h->rnn_rows) <= kLdsMax) G.rows = h->rnn_rows;
         G.rnn_lds = rnn_lds_bytes(G.plan, G.rows);
         tile0 += G.ntiles;
         h->md.nd = md.nd > h->md.nd ? md.nd : h->md.nd;
         h->md.nv = md.nv > h->md.nv ? md.nv : h->md.nv;
         h->md.nn = md.nn > h->md.nn ? md.nn : h->md.nn;
         h->md.ndn = md.ndn > h->md.ndn ? md.ndn : h->md.ndn;
-        lds_max = G.rnn_lds > lds_max ? G.rnn_lds : lds_max;
     }
     const ModelDims &md = h->md;
 
@@ -300,7 +295,8 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     HIPCHK(dalloc(h, &b.hist, Sp * RING, true));
     HIPCHK(dalloc(h, &b.hp_mem, Sp * 2, true));
     HIPCHK(dalloc(h, &b.hp_last, Sp, true));
-    HIPCHK(dalloc(h, &b.dec, Sp * 2 * DEC_RING, true));
+    HIPCHK(dalloc(h, &b.dec, Sp * DEC_LEN, true));
+    HIPCHK(dalloc(h, &b.xlp0, Sp * NSLOT, true));
     HIPCHK(dalloc(h, &b.ceps_mem, Sp * CEPS_MEM * NB, true));
     HIPCHK(dalloc(h, &b.mem_id, Sp, true));
     HIPCHK(dalloc(h, &b.synth_mem, Sp * FRAME, true));
@@ -310,8 +306,9 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     HIPCHK(dalloc(h, &b.gru_v, Sp * md.nv, true));
     HIPCHK(dalloc(h, &b.gru_n, Sp * md.nn, true));
     HIPCHK(dalloc(h, &b.gru_dn, Sp * md.ndn, true));
-    HIPCHK(dalloc(h, &h->sp, NSET, false));
     HIPCHK(dalloc(h, &b.stamps, 64, false));
+    HIPCHK(hipMalloc((void **)&h->sp_tab, 64 * sizeof(StepParams)));
+    h->sp_tab_cap = 64;
     // tables
     std::vector<float> window, dct, tansig, bin_frac;
     std::vector<float2> tw;
@@ -355,8 +352,8 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
 #undef NNN_F
         for (int set = 1; set < NSET; set++) h->b[set] = frame_view(h->b[0], set);
     }
-    if (lds_max > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void *)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    // the RNN kernel's dynamic LDS limit is a per-device function attribute: raise it to the hardware's 160 KB once
+    HIPCHK(hipFuncSetAttribute((const void *)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     HIPCHK(hipDeviceSynchronize());
     return 0;
 }
@@ -391,16 +388,28 @@ extern "C" int nnn_batch_num_streams(const nnn_batch *h) { return h ? h->S : 0; 
 
 extern "C" int nnn_batch_synchronize(nnn_batch *h)
 {
+    if (!h) return fail("null batch");
     HIPCHK(hipSetDevice(h->device));
+    if (h->have_last) HIPCHK(hipEventSynchronize(h->ev_last));   // the most recent call, whatever stream it was made on
     HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// everything this batch has enqueued anywhere is complete
+static int quiesce(nnn_batch *h)
+{
+    HIPCHK(hipSetDevice(h->device));
+    if (h->have_last) HIPCHK(hipEventSynchronize(h->ev_last));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < NSTREAMS; i++) HIPCHK(hipStreamSynchronize(h->pool[i]));
     return 0;
 }
 
 extern "C" int nnn_batch_reset(nnn_batch *h)
 {
     NNN_RT_LOCK;
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!h) return fail("null batch");
+    if (int rc = quiesce(h)) return rc;
     for (auto &sb : h->state_bufs) HIPCHK(hipMemset(sb.first, 0, sb.second));
     HIPCHK(hipDeviceSynchronize());
     h->frame_count = 0;
@@ -409,7 +418,87 @@ extern "C" int nnn_batch_reset(nnn_batch *h)
     return 0;
 }
 
-// ---- one frame of the pipeline -----------------------------------------------------------------
+// ---- state snapshots: DenoiseState is Clone in the reference (src/denoise.rs:36) ------------------------------------
+struct SnapHeader { uint64_t magic, frame_count, group_count, n_bufs, total, streams; };
+constexpr uint64_t kSnapMagic = 0x6e6e6e5f73743032ull;   // "nnn_st02"
+
+extern "C" size_t nnn_batch_state_bytes(const nnn_batch *h)
+{
+    if (!h) return 0;
+    size_t n = sizeof(SnapHeader);
+    for (auto &sb : h->state_bufs) n += sb.second;
+    return n;
+}
+
+extern "C" int nnn_batch_save_state(nnn_batch *h, void *host_dst, size_t dst_bytes)
+{
+    NNN_RT_LOCK;
+    if (!h || !host_dst) return fail("null argument");
+    const size_t need = nnn_batch_state_bytes(h);
+    if (dst_bytes < need) return fail("state buffer too small: %zu bytes needed", need);
+    if (int rc = quiesce(h)) return rc;
+    SnapHeader hd{kSnapMagic, h->frame_count, h->group_count, (uint64_t)h->state_bufs.size(), (uint64_t)need, (uint64_t)h->S};
+    char *p = (char *)host_dst;
+    memcpy(p, &hd, sizeof(hd));
+    p += sizeof(hd);
+    for (auto &sb : h->state_bufs) {
+        HIPCHK(hipMemcpy(p, sb.first, sb.second, hipMemcpyDeviceToHost));
+        p += sb.second;
+    }
+    return 0;
+}
+
+extern "C" int nnn_batch_load_state(nnn_batch *h, const void *host_src, size_t src_bytes)
+{
+    NNN_RT_LOCK;
+    if (!h || !host_src) return fail("null argument");
+    const size_t need = nnn_batch_state_bytes(h);
+    SnapHeader hd;
+    if (src_bytes < sizeof(hd)) return fail("not a state snapshot");
+    memcpy(&hd, host_src, sizeof(hd));
+    if (hd.magic != kSnapMagic || hd.n_bufs != h->state_bufs.size() || hd.total != need || hd.streams != (uint64_t)h->S || src_bytes < need)
+        return fail("state snapshot does not match this batch (streams / models / library build)");
+    if (int rc = quiesce(h)) return rc;
+    const char *p = (const char *)host_src + sizeof(hd);
+    for (auto &sb : h->state_bufs) {
+        HIPCHK(hipMemcpy(sb.first, p, sb.second, hipMemcpyHostToDevice));
+        p += sb.second;
+    }
+    HIPCHK(hipDeviceSynchronize());
+    h->frame_count = hd.frame_count;
+    h->group_count = hd.group_count;
+    return 0;
+}
+
+extern "C" nnn_batch *nnn_batch_clone(nnn_batch *h)
+{
+    NNN_RT_LOCK;
+    if (!h) { fail("null batch"); return nullptr; }
+    if (quiesce(h)) return nullptr;
+    std::vector<const RNNModel *> mp;
+    for (const RNNModel &m : h->models) mp.push_back(&m);
+    nnn_batch *c = nnn_batch_create_grouped(mp.data(), h->group_streams.data(), (int)h->group_streams.size(), h->device);
+    if (!c) return nullptr;
+    bool ok = c->state_bufs.size() == h->state_bufs.size();
+    for (size_t i = 0; ok && i < h->state_bufs.size(); i++)
+        ok = c->state_bufs[i].second == h->state_bufs[i].second &&
+             hipMemcpy(c->state_bufs[i].first, h->state_bufs[i].first, h->state_bufs[i].second, hipMemcpyDeviceToDevice) == hipSuccess;
+    if (!ok || hipDeviceSynchronize() != hipSuccess) {
+        nnn_batch_destroy(c);
+        fail("state copy failed");
+        return nullptr;
+    }
+    c->frame_count = h->frame_count;
+    c->group_count = h->group_count;
+    c->sched = h->sched;
+    c->n_lanes = h->n_lanes;
+    c->use_pipeline = h->use_pipeline;
+    c->b[0].taps = h->b[0].taps;
+    for (int set = 1; set < NSET; set++) c->b[set].taps = h->b[0].taps;
+    return c;
+}
+
+// ---- one group of frames ------------------------------------------------------------------------
 struct Launcher {
     nnn_batch *h;
     hipStream_t st;
@@ -425,134 +514,72 @@ struct Launcher {
         hipLaunchKernelGGL(kern, grid, block, lds, st, args...);
         if (prof) {
             hipEventRecord(e1, st);
-            h->ev.push_back(e0);
-            h->ev.push_back(e1);
-            h->ev_kernel.push_back(id);
+            h->evp.push_back(e0);
+            h->evp.push_back(e1);
+            h->evp_kernel.push_back(id);
         }
     }
 };
 
-// Per-frame DAG: hp -> lpc -> xcorr(+yy) -> best1 -> refine -> best2 -> doubling -> fft_p -> rnn -> synth, with fft_x
-// (needs only the filtered history) beside the pitch search.  Four kernels carry state from frame to frame -- the
-// biquad (hp), the last pitch (doubling), GRU / cepstral / last-gain state (rnn), the overlap memory (synth); the
-// others depend only on their own frame, so ONE launch of each covers a whole group of up to GROUP consecutive
-// frames (block index = frame * blocks_per_frame + block; scratch set of frame f = set0 + f, see frame_view): with
-// 4096 streams a one-frame launch of a lane = stream kernel has 64 waves for 256 compute units, a group launch 256.
-// LANES groups are in flight, one per lane stream; a group waits for its predecessor (another lane) only in front of its
-// recurrent kernels.
-enum { CH_HP, CH_DBL, CH_RNN, CH_SYN };
-
-static void launch_xcorr(Launcher &L, nnn_batch *h, const Buffers &b, unsigned nblk)
+// Per-group DAG: hp -> lpc -> pitch1 -> pitch2 -> fft_xp -> rnn -> synth.  Four stages carry state from group to group -- the
+// biquad (hp), the last pitch (pitch2), GRU / cepstral / last-gain state (rnn), the overlap memory (synth).
+// stage `s` of the group of `g` frames in scratch sets set0 .. set0 + g - 1, parameters at sp0[0..g), on stream `st`
+static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams *sp0, hipStream_t st, bool prof)
 {
-    const unsigned NT = (unsigned)h->NT;
-    const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
-    if (lc == 4) L.go(K_XCORR, k_xcorr<4>, dim3(nblk, (NLAG1 + 3) / 4 + 1), dim3(64), 0, b);
-    else if (lc == 8) L.go(K_XCORR, k_xcorr<8>, dim3(nblk, (NLAG1 + 7) / 8 + 1), dim3(64), 0, b);
-    else L.go(K_XCORR, k_xcorr<16>, dim3(nblk, (NLAG1 + 15) / 16 + 1), dim3(64), 0, b);
-}
-
-// the kernels of a group between its high-passes and its remove_doubling, parameters at sp0[0..g)
-static void enqueue_front(nnn_batch *h, int set0, int g, const StepParams *sp0, Launcher &L, Launcher &Lx)
-{
+    const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad, ug = (unsigned)g;
     const Buffers &b = h->b[set0];
-    const unsigned NT = (unsigned)h->NT * g, Sp = (unsigned)h->S_pad * g;
-    Lx.go(K_FFT_X, k_fft_x, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0);
-    L.go(K_LPC, k_lpc, dim3(NT), dim3(320), 0, b, sp0);
-    launch_xcorr(L, h, b, NT);
-    L.go(K_BEST1, k_best1, dim3(NT), dim3(64), 0, b);
-    L.go(K_REFINE, k_refine, dim3(Sp / 4), dim3(256), 0, b);
-    L.go(K_BEST2, k_best2, dim3(NT), dim3(64), 0, b);
-}
-
-// One group of g <= GROUP consecutive frames in scratch sets set0 .. set0 + g - 1, parameters at sp0[0..g).
-// Stand-alone (`lane` < 0): everything on `st`, fft_x on a side branch.  Pipelined (`lane` >= 0): on lane stream `st`,
-// waiting for the previous group (lane `prev`) in front of each recurrent kernel.  Returns false if a stream / event
-// call failed.
-static bool enqueue_group(nnn_batch *h, int set0, int g, hipStream_t st, const StepParams *sp0, int lane, int prev, bool prof)
-{
-    const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad;
-    const bool chain = lane >= 0;
-    const bool br = h->use_branches && !prof && !chain;
-    hipStream_t s0 = br ? h->side[0] : st;
-    Launcher L{h, st, prof}, L0{h, s0, prof};
-    bool ok = true;
-    auto chk = [&](hipError_t e) { ok = ok && e == hipSuccess; };
-    auto wait_prev = [&](int which) {
-        if (chain && prev >= 0) chk(hipStreamWaitEvent(st, h->ev_chain[prev][which], 0));
-    };
-    auto mark = [&](int which) {
-        if (chain) chk(hipEventRecord(h->ev_chain[lane][which], st));
-    };
-    const int blk = set0 / GROUP;
-    const bool replay_front = chain && g == GROUP && h->g_front[blk] != nullptr;
-    wait_prev(CH_HP);
-    for (int f = 0; f < g; f++)
-        L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, h->b[set0 + f], sp0 + f, replay_front ? h->sp + set0 + f : (StepParams *)nullptr);
-    mark(CH_HP);
-    if (replay_front) {
-        chk(hipGraphLaunch(h->g_front[blk], st));   // the six kernels of enqueue_front as one replayed single-stream graph
-    } else {
-        if (br) {
-            chk(hipEventRecord(h->ev_fork[0], st));
-            chk(hipStreamWaitEvent(s0, h->ev_fork[0], 0));
-        }
-        enqueue_front(h, set0, g, sp0, L, L0);
-        if (br) chk(hipEventRecord(h->ev_join[0], s0));
-    }
-    wait_prev(CH_DBL);
-    for (int f = 0; f < g; f++) L.go(K_DOUBLING, k_doubling, dim3(Sp / 4), dim3(256), 0, h->b[set0 + f]);
-    mark(CH_DBL);
-    if (br) chk(hipStreamWaitEvent(st, h->ev_join[0], 0));
-    L.go(K_FFT_P, k_fft_p, dim3(Sp * g / FFT_SPB), dim3(64 * FFT_SPB), 0, h->b[set0], sp0);
-    wait_prev(CH_RNN);
-    for (int f = 0; f < g; f++)
+    Launcher L{h, st, prof};
+    switch (s) {
+    case ST_HP: L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g); break;
+    case ST_LPC: L.go(K_LPC, k_lpc, dim3(NT * ug), dim3(320), 0, b, sp0); break;
+    case ST_P1: L.go(K_PITCH1, k_pitch1, dim3(NT * ug), dim3(64 * P1_WAVES), 0, b); break;
+    case ST_P2: L.go(K_PITCH2, k_pitch2, dim3(Sp / P2_SPB), dim3(64 * P2_SPB), 0, b, g); break;
+    case ST_FFT: L.go(K_FFT_XP, k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0); break;
+    case ST_RNN:
         for (const nnn_batch::ModelGroup &G : h->groups)   // one launch per resident model (a run of whole tiles)
-            L.go(K_RNN, k_rnn, dim3((unsigned)(G.ntiles * (TILE / G.rows))), dim3(64 * RNN_WAVES), G.rnn_lds, h->b[set0 + f], G.plan, G.wq,
-                 G.fpar, G.tile0, G.rows);
-    mark(CH_RNN);
-    wait_prev(CH_SYN);
-    for (int f = 0; f < g; f++) L.go(K_SYNTH, k_synth, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, h->b[set0 + f], sp0 + f);
-    mark(CH_SYN);
-    if (!chain) L.go(K_ADVANCE, k_advance, dim3(1), dim3(1), 0, h->sp + set0, (int)LANES);   // this set block's next stand-alone frame
-    return ok;
-}
-
-// captures body() on `st` and instantiates an executable graph from it
-template <class F> static hipGraphExec_t capture(hipStream_t st, F &&body)
-{
-    NNN_RT_LOCK;
-    hipGraph_t g = nullptr;
-    hipGraphExec_t ex = nullptr;
-    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
-    const bool ok = body();
-    if (hipStreamEndCapture(st, &g) != hipSuccess || !g) return nullptr;
-    if (ok && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) ex = nullptr;
-    hipGraphDestroy(g);
-    return ex;
+            L.go(K_RNN, k_rnn, dim3((unsigned)(G.ntiles * (TILE / G.rows))), dim3(64 * RNN_WAVES), G.rnn_lds, b, G.plan, G.wq, G.fpar,
+                 G.tile0, G.rows, g);
+        break;
+    case ST_SYN: L.go(K_SYNTH, k_synth, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0, g); break;
+    }
 }
 
 static int drain_profile(nnn_batch *h)
 {
-    for (size_t i = 0; i < h->ev_kernel.size(); i++) {
+    for (size_t i = 0; i < h->evp_kernel.size(); i++) {
         float ms = 0.0f;
-        HIPCHK(hipEventSynchronize(h->ev[2 * i + 1]));
-        HIPCHK(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
-        h->k_ms[h->ev_kernel[i]] += ms;
-        h->k_launches[h->ev_kernel[i]] += 1;
-        hipEventDestroy(h->ev[2 * i]);
-        hipEventDestroy(h->ev[2 * i + 1]);
+        HIPCHK(hipEventSynchronize(h->evp[2 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&ms, h->evp[2 * i], h->evp[2 * i + 1]));
+        h->k_ms[h->evp_kernel[i]] += ms;
+        h->k_launches[h->evp_kernel[i]] += 1;
+        hipEventDestroy(h->evp[2 * i]);
+        hipEventDestroy(h->evp[2 * i + 1]);
     }
-    h->ev.clear();
-    h->ev_kernel.clear();
+    h->evp.clear();
+    h->evp_kernel.clear();
     return 0;
 }
 
 // Common body of the process entry points: strides in BYTES, `drop` leading frames of the call produce no audio.
+//
+// A call is cut into groups of up to GROUP frames; group k uses scratch-set block (group_count mod DEPTH).  Short calls
+// (and profiling) run the groups' stages back to back on the caller's stream.  Longer calls spread over the batch's
+// internal streams so that independent stages overlap (at 4096 streams a lone stage cannot fill the GPU):
+//   lanes   the high-pass chain on its own stream, running ahead as far as the history rings allow; stages lpc .. synth of
+//           group k on lane stream k mod n_lanes
+//   stages  one stream per stage pair: hp | lpc, pitch1 | pitch2, fft_xp | rnn | synth; every stream is a chain of groups
+// An edge of the DAG whose ends share a stream needs nothing (streams are in-order); the others are an event record + wait.
+// Edges: previous stage of the same group; the same stage of the previous group for the four stateful stages; the scratch-set
+// block's previous user (synth of group k - DEPTH, before lpc of group k); the history rings (synth of the group holding the
+// newest frame whose history slots group k's high-pass overwrites).  Everything before this call is ordered by the caller's
+// stream, which every internal stream waits for at its first use and which waits for the last synth at the end.
 static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_vad, int n_frames, int fmt, int channels,
                           long long group_stride, long long frame_stride, int drop, void *hip_stream)
 {
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    // calls are ordered even when consecutive ones arrive on different streams
+    if (h->have_last && h->last_stream != st) HIPCHK(hipStreamWaitEvent(st, h->ev_last, 0));
     StepParams v0;
     v0.in = (const char *)d_in;
     v0.out = (char *)d_out;
@@ -564,107 +591,99 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     v0.discard = drop;
     v0.slot = (int)(h->frame_count % NSLOT);
     v0.n_streams = h->S;
-    const bool graph = h->use_graph && h->graph_single && !h->profiling;
-    const bool pipe = h->use_pipeline && h->use_branches && !h->profiling && n_frames >= 2;
-    if (pipe) {
-        // Groups of up to GROUP frames, round-robin over LANES lane streams (lane 0 = `st`), cross-lane waits only at
-        // the recurrences.  Launched eagerly (replaying this shape as a captured multi-stream graph back to back crashes
-        // the ROCm 7.2 runtime); the per-frame parameters come from a table filled by one small kernel.
-        if (n_frames > h->sp_tab_cap) {
-            NNN_RT_LOCK;
-            HIPCHK(hipStreamSynchronize(st));
-            if (h->sp_tab) HIPCHK(hipFree(h->sp_tab));
-            h->sp_tab = nullptr;
-            h->sp_tab_cap = 0;
-            HIPCHK(hipMalloc((void **)&h->sp_tab, (size_t)n_frames * sizeof(StepParams)));
-            h->sp_tab_cap = n_frames;
+    if (n_frames > h->sp_tab_cap) {
+        NNN_RT_LOCK;
+        if (int rc = quiesce(h)) return rc;
+        if (h->sp_tab) HIPCHK(hipFree(h->sp_tab));
+        h->sp_tab = nullptr;
+        h->sp_tab_cap = 0;
+        const int cap = n_frames < 64 ? 64 : n_frames;
+        HIPCHK(hipMalloc((void **)&h->sp_tab, (size_t)cap * sizeof(StepParams)));
+        h->sp_tab_cap = cap;
+    }
+    hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, st, h->sp_tab, v0, n_frames);
+    // group sizes: in pipelined calls they ramp up 1, 2, 3 at the start and down 3, 2, 1 at the end (shorter fill and
+    // drain of the pipeline: the caller's stream waits for the last stage of the last group)
+    const bool pipe = h->use_pipeline && h->sched != SCHED_SEQ && !h->profiling && n_frames >= 2 * GROUP;
+    std::vector<int> sizes;
+    for (int rem = n_frames, k = 0; rem > 0; k++) {
+        int g = GROUP;
+        if (pipe) {
+            g = GROUP < k + 1 ? GROUP : k + 1;
+            const int half = (rem + 1) / 2 > 1 ? (rem + 1) / 2 : 1;
+            if (g > half) g = half;
         }
-        if (h->use_graph && !h->g_front[0] && !h->front_failed) {   // built on first use
-            bool all = true;
-            for (int p = 0; p < LANES && all; p++) {
-                h->g_front[p] = capture(st, [&] {
-                    Launcher L{h, st, false};
-                    enqueue_front(h, p * GROUP, GROUP, h->sp + p * GROUP, L, L);
-                    return true;
-                });
-                all = h->g_front[p] != nullptr;
-            }
-            if (!all) {
-                for (int p = 0; p < LANES; p++)
-                    if (h->g_front[p]) { hipGraphExecDestroy(h->g_front[p]); h->g_front[p] = nullptr; }
-                h->front_failed = true;
-            }
-            (void)hipGetLastError();
-        }
-        hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, st, h->sp_tab, v0, n_frames);
-        // Group sizes ramp up 1, 2, 3 at the start of a call and down 3, 2, 1 at its end: a lane can only start its
-        // first group after the previous lane's high-passes, and the caller's stream waits for every lane at the end,
-        // so short first and last groups shorten the fill and drain of the three-lane pipeline (the asynchronous-on-
-        // one-stream contract orders consecutive calls, it cannot be overlapped away).
-        int sizes[64], n_groups = 0;
-        std::vector<int> big;
-        {
-            int rem = n_frames;
-            while (rem > 0) {
-                int g = GROUP < n_groups + 1 ? GROUP : n_groups + 1;
-                const int half = (rem + 1) / 2 > 1 ? (rem + 1) / 2 : 1;
-                if (g > half) g = half;
-                if (n_groups < 64) sizes[n_groups] = g;
-                else big.push_back(g);
-                n_groups++;
-                rem -= g;
-            }
-        }
-        auto size_of = [&](int k) { return k < 64 ? sizes[k] : big[k - 64]; };
-        const int nl = n_groups < LANES ? n_groups : LANES;
-        bool ok = hipEventRecord(h->ev_lane, st) == hipSuccess;
-        for (int l = 1; l < nl && ok; l++) ok = hipStreamWaitEvent(h->lanes[l], h->ev_lane, 0) == hipSuccess;
-        for (int k = 0, t = 0; k < n_groups && ok; k++) {
-            // group k - LANES (same lane, and the previous user of this block of scratch sets or an earlier one)
-            // precedes this group in its stream
-            const int g = size_of(k), lane = k % LANES;
-            const int set0 = (int)(h->group_count % LANES) * GROUP;
-            ok = enqueue_group(h, set0, g, lane ? h->lanes[lane] : st, h->sp_tab + t, lane, k > 0 ? (k - 1) % LANES : -1, false);
+        if (g > rem) g = rem;
+        sizes.push_back(g);
+        rem -= g;
+    }
+    const int n_groups = (int)sizes.size();
+    h->call_count += 1;
+    bool ok = true;
+    auto chk = [&](hipError_t e) { ok = ok && e == hipSuccess; };
+    if (!pipe) {
+        for (int k = 0, t = 0; k < n_groups; k++) {
+            const int g = sizes[k], set0 = (int)(h->group_count % DEPTH) * GROUP;
+            for (int s = 0; s < ST_COUNT; s++) launch_stage(h, s, set0, g, h->sp_tab + t, st, h->profiling);
             h->group_count += 1;
             h->frame_count += g;
             h->last_set = set0 + g - 1;
             t += g;
         }
-        for (int l = 1; l < nl && ok; l++)
-            ok = hipEventRecord(h->ev_lane_done[l], h->lanes[l]) == hipSuccess && hipStreamWaitEvent(st, h->ev_lane_done[l], 0) == hipSuccess;
-        if (!ok) return fail("stream/event call failed while enqueueing pipelined frames: %s", hipGetErrorString(hipGetLastError()));
     } else {
-        // one frame at a time on `st`; consecutive frames rotate through the LANES set blocks, each block's
-        // parameters live on the device and are stepped by LANES frames after every use
-        for (int i = 0; i < LANES; i++) {
-            StepParams v = v0;
-            v.in = v0.in + (long long)i * frame_stride;
-            v.out = (char *)((intptr_t)v0.out + (long long)(i - drop) * frame_stride);
-            v.discard = i < drop;
-            v.vad = d_vad ? d_vad + (size_t)i * h->S : nullptr;
-            v.slot = (int)((h->frame_count + i) % NSLOT);
-            hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, h->sp + (int)((h->group_count + i) % LANES) * GROUP, v);
-        }
-        if (graph && (!h->g_single[0] || h->graph_stream != st)) {
-            bool all = true;
-            for (int p = 0; p < LANES; p++) {
-                if (h->g_single[p]) { hipGraphExecDestroy(h->g_single[p]); h->g_single[p] = nullptr; }
-                h->g_single[p] = capture(st, [&] { return enqueue_group(h, p * GROUP, 1, st, h->sp + p * GROUP, -1, -1, false); });
-                all = all && h->g_single[p];
+        chk(hipEventRecord(h->ev_in, st));
+        auto stream_of = [&](int s, int k) -> int {   // index into h->pool
+            if (h->sched == SCHED_STAGES) return s == ST_HP ? 0 : (s <= ST_P1 ? 1 : (s <= ST_FFT ? 2 : (s == ST_RNN ? 3 : 4)));
+            return s == ST_HP ? 0 : 1 + k % h->n_lanes;
+        };
+        std::vector<int> first(n_groups);   // first frame (within the call) of every group
+        for (int k = 0, t = 0; k < n_groups; k++) { first[k] = t; t += sizes[k]; }
+        // which (stage, group) nodes have a consumer on another stream: only those record an event
+        auto consumers_elsewhere = [&](int s, int k) {
+            const int me = stream_of(s, k);
+            if (s + 1 < ST_COUNT && stream_of(s + 1, k) != me) return true;
+            if ((s == ST_HP || s == ST_P2 || s == ST_RNN || s == ST_SYN) && k + 1 < n_groups && stream_of(s, k + 1) != me) return true;
+            if (s == ST_SYN) return true;   // scratch-set / ring edges and the end of the call
+            return false;
+        };
+        for (int k = 0; k < n_groups; k++) {
+            const int g = sizes[k], set0 = (int)(h->group_count % DEPTH) * GROUP;
+            for (int s = 0; s < ST_COUNT; s++) {
+                const int si = stream_of(s, k);
+                hipStream_t ss = h->pool[si];
+                if (h->pool_call[si] != h->call_count) {   // first use in this call: everything before the call comes first
+                    chk(hipStreamWaitEvent(ss, h->ev_in, 0));
+                    h->pool_call[si] = h->call_count;
+                }
+                auto wait_for = [&](int ds, int dk) {
+                    if (dk < 0 || dk < k - EVR + 1) return;   // before this call (ordered by ev_in) or long retired
+                    if (stream_of(ds, dk) != si) chk(hipStreamWaitEvent(ss, h->ev[ds][dk % EVR], 0));
+                };
+                if (s > 0) wait_for(s - 1, k);
+                if (s == ST_HP || s == ST_P2 || s == ST_RNN || s == ST_SYN) wait_for(s, k - 1);
+                if (s == ST_LPC) wait_for(ST_SYN, k - DEPTH);
+                if (s == ST_HP) {
+                    // slots written now held frames (newest of this group) - NSLOT and older; their last readers are the
+                    // frames up to 3 later
+                    const int need = first[k] + g - 1 + 3 - NSLOT;
+                    int dk = -1;   // the group of this call that holds frame `need` (none: it precedes the call)
+                    for (int j = 0; j < k; j++)
+                        if (first[j] <= need) dk = j;
+                    wait_for(ST_SYN, dk);
+                }
+                launch_stage(h, s, set0, g, h->sp_tab + first[k], ss, false);
+                if (consumers_elsewhere(s, k)) chk(hipEventRecord(h->ev[s][k % EVR], ss));
             }
-            if (all) h->graph_stream = st;
-            else h->use_graph = false;  // capture unsupported here: stay eager
-            (void)hipGetLastError();
-        }
-        for (int f = 0; f < n_frames; f++) {
-            const int p = (int)(h->group_count % LANES), set0 = p * GROUP;
-            if (graph && h->use_graph && h->g_single[p]) HIPCHK(hipGraphLaunch(h->g_single[p], st));
-            else enqueue_group(h, set0, 1, st, h->sp + set0, -1, -1, h->profiling);
             h->group_count += 1;
-            h->frame_count += 1;
-            h->last_set = set0;
+            h->frame_count += g;
+            h->last_set = set0 + g - 1;
         }
+        chk(hipStreamWaitEvent(st, h->ev[ST_SYN][(n_groups - 1) % EVR], 0));
     }
+    chk(hipEventRecord(h->ev_last, st));
+    h->last_stream = st;
+    h->have_last = true;
+    if (!ok) return fail("stream/event call failed while enqueueing frames: %s", hipGetErrorString(hipGetLastError()));
     HIPCHK(hipGetLastError());
     if (h->profiling) {
         HIPCHK(hipStreamSynchronize(st));
@@ -688,6 +707,7 @@ extern "C" int nnn_batch_process_device(nnn_batch *h, const float *d_in, float *
     if (!h) return fail("null batch");
     if (n_frames <= 0) return 0;
     if (!d_in || !d_out) return fail("null buffer");
+    if (n_frames > 1 && frame_stride < (size_t)FRAME) return fail("frame_stride smaller than one frame");
     return process_frames(h, d_in, d_out, d_vad, n_frames, PCM_F32, 1, (long long)stream_stride * 4, (long long)frame_stride * 4, 0,
                           hip_stream);
 }
@@ -716,7 +736,7 @@ static int process_host_span(nnn_batch *h, const void *in, void *out, float *vad
     const size_t vbytes = vad ? (size_t)n_frames * h->S * sizeof(float) : 0;
     if (span > h->stage_cap || vbytes > h->stage_vad_cap) {
         NNN_RT_LOCK;
-        HIPCHK(hipStreamSynchronize(h->stream));
+        if (int rc = quiesce(h)) return rc;
         if (span > h->stage_cap) {
             if (h->stage) HIPCHK(hipFree(h->stage));
             h->stage = nullptr;
@@ -765,6 +785,7 @@ extern "C" int nnn_batch_process_host(nnn_batch *h, const float *in, float *out,
     if (!h) return fail("null batch");
     if (n_frames <= 0) return 0;
     if (!in || !out) return fail("null buffer");
+    if (n_frames > 1 && frame_stride < (size_t)FRAME) return fail("frame_stride smaller than one frame");
     nnn_pcm_layout L = {NNN_PCM_F32, 1, 0, 0, stream_stride, frame_stride};
     return process_host_span(h, in, out, vad, n_frames, &L);
 }
@@ -780,32 +801,33 @@ extern "C" int nnn_batch_process_pcm_host(nnn_batch *h, const void *in, void *ou
 }
 
 // ---- taps ---------------------------------------------------------------------------------------
-struct TapDesc { int len; int is_int; int layout; /* 0 TI, 1 SM float, 2 SM float2, 3 hist ring */ int sub_ofs; int sub_len; };
+struct TapDesc { int len; int is_int; int layout; /* 0 TI, 2 SM float2 rows of FSTR, 3 hist ring */ int sub_ofs; int sub_len; int needs_taps; };
 static bool tap_desc(const nnn_batch *h, int tap, TapDesc &d, const void **ptr)
 {
     const Buffers *b = h ? &h->b[h->last_set] : nullptr;   // scratch set of the most recent frame
 #define TP(field) (b ? (const void *)b->field : nullptr)
     switch (tap) {
-    case NNN_TAP_FILTERED: d = {FRAME, 0, 3, 0, FRAME}; *ptr = TP(hist); return true;
-    case NNN_TAP_XLP: d = {XLP, 0, 0, 0, XLP}; *ptr = TP(xlp_ti); return true;
-    case NNN_TAP_AC: d = {5, 0, 0, 0, 10}; *ptr = TP(lpc); return true;
-    case NNN_TAP_LPC2: d = {5, 0, 0, 5, 10}; *ptr = TP(lpc); return true;
-    case NNN_TAP_XCORR1: d = {NLAG1, 0, 0, 0, NLAG1}; *ptr = TP(xc1); return true;
-    case NNN_TAP_BEST1: d = {2, 1, 0, 0, 2}; *ptr = TP(best1); return true;
-    case NNN_TAP_XCORR2C: d = {10, 0, 0, 0, 10}; *ptr = TP(xc2); return true;
-    case NNN_TAP_PITCH_SEARCH: d = {1, 1, 0, 0, 1}; *ptr = TP(psearch); return true;
-    case NNN_TAP_PITCH: d = {1, 1, 0, 0, 1}; *ptr = TP(pitch); return true;
-    case NNN_TAP_PITCH_GAIN: d = {1, 0, 0, 0, 1}; *ptr = TP(pgain); return true;
-    case NNN_TAP_X: d = {2 * FREQ, 0, 2, 0, 2 * FREQ}; *ptr = TP(X); return true;
-    case NNN_TAP_P: d = {2 * FREQ, 0, 2, 0, 2 * FREQ}; *ptr = TP(P); return true;
-    case NNN_TAP_EX: d = {NB, 0, 0, 0, NB}; *ptr = TP(ex); return true;
-    case NNN_TAP_EP: d = {NB, 0, 0, 0, NB}; *ptr = TP(ep); return true;
-    case NNN_TAP_EXP: d = {NB, 0, 0, 0, NB}; *ptr = TP(exp_); return true;
-    case NNN_TAP_FEATURES: d = {NFEAT, 0, 0, 0, NFEAT}; *ptr = TP(feat); return true;
-    case NNN_TAP_SILENCE: d = {1, 1, 0, 0, 1}; *ptr = TP(silence); return true;
-    case NNN_TAP_G_RAW: d = {NB, 0, 0, 0, NB}; *ptr = TP(g_raw); return true;
-    case NNN_TAP_G: d = {NB, 0, 0, 0, NB}; *ptr = TP(g); return true;
-    case NNN_TAP_VAD: d = {1, 0, 0, 0, 1}; *ptr = TP(vad); return true;
+    case NNN_TAP_FILTERED: d = {FRAME, 0, 3, 0, FRAME, 0}; *ptr = TP(hist); return true;
+    case NNN_TAP_XLP: d = {XLP, 0, 0, 0, XLP, 0}; *ptr = TP(xlp_ti); return true;
+    case NNN_TAP_AC: d = {5, 0, 0, 0, 10, 0}; *ptr = TP(lpc); return true;
+    case NNN_TAP_LPC2: d = {5, 0, 0, 5, 10, 0}; *ptr = TP(lpc); return true;
+    case NNN_TAP_XCORR1: d = {NLAG1, 0, 0, 0, NLAG1, 1}; *ptr = TP(xc1); return true;
+    case NNN_TAP_BEST1: d = {2, 1, 0, 0, 2, 0}; *ptr = TP(best1); return true;
+    case NNN_TAP_XCORR2C: d = {10, 0, 0, 0, 10, 1}; *ptr = TP(xc2); return true;
+    case NNN_TAP_PITCH_SEARCH: d = {1, 1, 0, 0, 1, 0}; *ptr = TP(psearch); return true;
+    case NNN_TAP_PITCH: d = {1, 1, 0, 0, 1, 0}; *ptr = TP(pitch); return true;
+    case NNN_TAP_PITCH_GAIN: d = {1, 0, 0, 0, 1, 0}; *ptr = TP(pgain); return true;
+    case NNN_TAP_X: d = {2 * FREQ, 0, 2, 0, 2 * FREQ, 0}; *ptr = TP(X); return true;
+    case NNN_TAP_P: d = {2 * FREQ, 0, 2, 0, 2 * FREQ, 1}; *ptr = TP(P); return true;
+    case NNN_TAP_EX: d = {NB, 0, 0, 0, NB, 0}; *ptr = TP(ex); return true;
+    case NNN_TAP_EP: d = {NB, 0, 0, 0, NB, 0}; *ptr = TP(ep); return true;
+    case NNN_TAP_EXP: d = {NB, 0, 0, 0, NB, 0}; *ptr = TP(exp_); return true;
+    case NNN_TAP_FEATURES: d = {NFEAT, 0, 0, 0, NFEAT, 1}; *ptr = TP(feat); return true;
+    case NNN_TAP_SILENCE: d = {1, 1, 0, 0, 1, 0}; *ptr = TP(silence); return true;
+    case NNN_TAP_G_RAW: d = {NB, 0, 0, 0, NB, 0}; *ptr = TP(g_raw); return true;
+    case NNN_TAP_G: d = {NB, 0, 0, 0, NB, 0}; *ptr = TP(g); return true;
+    case NNN_TAP_VAD: d = {1, 0, 0, 0, 1, 0}; *ptr = TP(vad); return true;
+    case NNN_TAP_BRANCH: d = {1, 1, 0, 0, 1, 0}; *ptr = TP(branch); return true;
     default: return false;
     }
 #undef TP
@@ -821,6 +843,13 @@ extern "C" int nnn_tap_info(int tap, int *len, int *is_int)
     return 0;
 }
 
+extern "C" int nnn_batch_set_taps(nnn_batch *h, int on)
+{
+    if (!h) return fail("null batch");
+    for (int set = 0; set < NSET; set++) h->b[set].taps = on != 0;
+    return 0;
+}
+
 extern "C" int nnn_batch_read_tap(nnn_batch *h, int tap, void *host_dst, size_t dst_bytes)
 {
     NNN_RT_LOCK;
@@ -828,9 +857,9 @@ extern "C" int nnn_batch_read_tap(nnn_batch *h, int tap, void *host_dst, size_t 
     TapDesc d;
     const void *p;
     if (!tap_desc(h, tap, d, &p)) return fail("unknown tap %d", tap);
+    if (d.needs_taps && !h->b[0].taps) return fail("tap %d is only stored after nnn_batch_set_taps(batch, 1)", tap);
     if (dst_bytes < (size_t)h->S * d.len * 4) return fail("tap buffer too small");
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (int rc = quiesce(h)) return rc;
     HIPCHK(hipDeviceSynchronize());
     uint32_t *dst = (uint32_t *)host_dst;
     const size_t Sp = (size_t)h->S_pad;
@@ -841,9 +870,9 @@ extern "C" int nnn_batch_read_tap(nnn_batch *h, int tap, void *host_dst, size_t 
             for (int i = 0; i < d.len; i++)
                 dst[(size_t)s * d.len + i] = tmp[((size_t)(s / TILE) * d.sub_len + d.sub_ofs + i) * TILE + s % TILE];
     } else if (d.layout == 2) {
-        std::vector<uint32_t> tmp(Sp * d.len);
+        std::vector<uint32_t> tmp(Sp * 2 * FSTR);
         HIPCHK(hipMemcpy(tmp.data(), p, tmp.size() * 4, hipMemcpyDeviceToHost));
-        memcpy(dst, tmp.data(), (size_t)h->S * d.len * 4);
+        for (int s = 0; s < h->S; s++) memcpy(dst + (size_t)s * d.len, tmp.data() + (size_t)s * 2 * FSTR, (size_t)d.len * 4);
     } else {  // newest frame in the history ring
         std::vector<uint32_t> tmp(Sp * RING);
         HIPCHK(hipMemcpy(tmp.data(), p, tmp.size() * 4, hipMemcpyDeviceToHost));
@@ -863,7 +892,34 @@ extern "C" int nnn_batch_read_stamps(nnn_batch *h, long long *dst64)
     return 0;
 }
 
-// ---- profiling / graph switches ---------------------------------------------------------------
+// The device's activation functions on their own: y[i] = act(x[i]) with act 0 = tansig_approx, 1 = sigmoid_approx,
+// 2 = relu (ref: src/util.rs:29-53) -- a direct known-answer check for the parity tests.
+extern "C" int nnn_debug_activations(int device, int act, const float *x, float *y, int n)
+{
+    NNN_RT_LOCK;
+    if (!x || !y || n < 0 || act < 0 || act > 2) return fail("bad argument");
+    HIPCHK(hipSetDevice(device));
+    std::vector<float> window, dct, tansig, bin_frac;
+    std::vector<float2> tw;
+    std::vector<int> bin_band;
+    float wnorm;
+    make_tables(window, dct, tw, tansig, bin_frac, bin_band, wnorm);
+    float *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, (size_t)(2 * n + 256) * sizeof(float)));
+    float *dx = d + 256, *dy = dx + n;
+    hipError_t e = hipMemcpy(d, tansig.data(), 201 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dx, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) {
+        hipLaunchKernelGGL(k_activation_kat, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t) nullptr, (const float *)d, (const float *)dx, dy, act, n);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipMemcpy(y, dy, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return fail("activation sweep failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// ---- profiling / scheduling switches -------------------------------------------------------------
 extern "C" int nnn_batch_set_profiling(nnn_batch *h, int on)
 {
     if (!h) return fail("null batch");
@@ -885,15 +941,22 @@ extern "C" int nnn_batch_read_kernel_times(nnn_batch *h, double *total_ms, int64
 }
 extern "C" int nnn_batch_set_graph(nnn_batch *h, int on)
 {
+    (void)on;
     if (!h) return fail("null batch");
-    h->use_graph = on != 0;
-    h->graph_single = on != 0;
-    return 0;
+    return 0;   // kept for callers of the round-1 ABI: a group is seven launches now and they are always eager
 }
 extern "C" int nnn_batch_set_pipeline(nnn_batch *h, int on)
 {
     if (!h) return fail("null batch");
     h->use_pipeline = on != 0;
+    return 0;
+}
+extern "C" int nnn_batch_set_schedule(nnn_batch *h, int mode, int lanes)
+{
+    if (!h) return fail("null batch");
+    if (mode < SCHED_SEQ || mode > SCHED_STAGES) return fail("unknown schedule %d", mode);
+    h->sched = mode;
+    if (lanes >= 1 && lanes <= NSTREAMS - 1) h->n_lanes = lanes;
     return 0;
 }
 
@@ -937,7 +1000,7 @@ extern "C" int nnn_train_reset(nnn_train *t)
 // shift_and_filter_input + the part of compute_frame_features the row needs: everything up to the 42 features for the
 // mix, only the band energies of X for the clean and noise states (src/training.rs:129-131 computes their full
 // features and says itself that only the transform and band energies are needed; nothing else of them is read).
-static void enqueue_feature_frame(nnn_batch *h, hipStream_t st, const float *in, size_t stream_stride, bool full)
+static void enqueue_feature_frame(nnn_batch *h, hipStream_t st, StepParams *sp, const float *in, size_t stream_stride, bool full)
 {
     const Buffers &b = h->b[0];
     const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad;
@@ -949,25 +1012,19 @@ static void enqueue_feature_frame(nnn_batch *h, hipStream_t st, const float *in,
     v.frame_stride = 0;
     v.fmt = PCM_F32;
     v.channels = 1;
-    v.discard = 1;
+    v.discard = 0;
     v.slot = (int)(h->frame_count % NSLOT);
     v.n_streams = h->S;
-    StepParams *sp = h->sp;
-    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, sp, v);
-    hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, sp, (StepParams *)nullptr);
-    hipLaunchKernelGGL(k_fft_x, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, sp);
+    hipLaunchKernelGGL(k_fill_params, dim3(1), dim3(64), 0, st, sp, v, 1);
+    hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, (const StepParams *)sp, 1);
     if (full) {
-        hipLaunchKernelGGL(k_lpc, dim3(NT), dim3(320), 0, st, b, sp);
-        const int lc = h->xcorr_chunk ? h->xcorr_chunk : (NT <= 128 ? 4 : (NT <= 512 ? 8 : 16));
-        if (lc == 4) hipLaunchKernelGGL(k_xcorr<4>, dim3(NT, (NLAG1 + 3) / 4 + 1), dim3(64), 0, st, b);
-        else if (lc == 8) hipLaunchKernelGGL(k_xcorr<8>, dim3(NT, (NLAG1 + 7) / 8 + 1), dim3(64), 0, st, b);
-        else hipLaunchKernelGGL(k_xcorr<16>, dim3(NT, (NLAG1 + 15) / 16 + 1), dim3(64), 0, st, b);
-        hipLaunchKernelGGL(k_best1, dim3(NT), dim3(64), 0, st, b);
-        hipLaunchKernelGGL(k_refine, dim3(Sp / 4), dim3(256), 0, st, b);
-        hipLaunchKernelGGL(k_best2, dim3(NT), dim3(64), 0, st, b);
-        hipLaunchKernelGGL(k_doubling, dim3(Sp / 4), dim3(256), 0, st, b);
-        hipLaunchKernelGGL(k_fft_p, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, sp);
+        hipLaunchKernelGGL(k_lpc, dim3(NT), dim3(320), 0, st, b, (const StepParams *)sp);
+        hipLaunchKernelGGL(k_pitch1, dim3(NT), dim3(64 * P1_WAVES), 0, st, b);
+        hipLaunchKernelGGL(k_pitch2, dim3(Sp / P2_SPB), dim3(64 * P2_SPB), 0, st, b, 1);
+        hipLaunchKernelGGL(k_fft_xp, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp);
         hipLaunchKernelGGL(k_features, dim3(NT), dim3(64 * FEAT_WAVES), 0, st, b);
+    } else {
+        hipLaunchKernelGGL(k_fft_x, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp);
     }
     h->frame_count += 1;
 }
@@ -985,9 +1042,9 @@ extern "C" int nnn_train_process_device(nnn_train *t, const float *d_signal, con
     const size_t S = (size_t)h->S;
     for (int f = 0; f < n_frames; f++) {
         const size_t off = (size_t)f * frame_stride;
-        enqueue_feature_frame(t->comb, st, d_combined + off, stream_stride, true);
-        enqueue_feature_frame(t->clean, st, d_signal + off, stream_stride, false);
-        enqueue_feature_frame(t->noise, st, d_noise + off, stream_stride, false);
+        enqueue_feature_frame(t->comb, st, t->comb->sp_tab, d_combined + off, stream_stride, true);
+        enqueue_feature_frame(t->clean, st, t->clean->sp_tab, d_signal + off, stream_stride, false);
+        enqueue_feature_frame(t->noise, st, t->noise->sp_tab, d_noise + off, stream_stride, false);
         hipLaunchKernelGGL(k_train_rows, dim3((unsigned)h->NT), dim3(64), 0, st, t->comb->b[0], t->clean->b[0], t->noise->b[0],
                            (const int *)d_cutoff + f * S, d_vad + f * S, d_rows + f * S * TRAIN_COLS);
     }

@@ -18,6 +18,9 @@
 namespace nnn {
 
 #define NNN_TI(ptr, len, tile, lane) ((ptr) + ((size_t)(tile) * (len)) * TILE + (lane))
+// the same for a per-frame scratch array of frame `f` of a group (set f lies f * S_pad * len after set 0, see frame_view):
+// kernels that loop over a group's frames address single fields this way instead of re-basing the whole argument block
+#define NNN_TIF(b, field, len, f, tile, lane) ((b).field + ((size_t)(b).S_pad * (size_t)(f) + (size_t)(tile) * TILE) * (size_t)(len) + (lane))
 
 // A launch of a kernel without cross-frame recurrence covers several consecutive frames: block index = frame * PER +
 // block-of-frame.  Re-bases the (by-value) Buffers `b` on that frame's scratch set; `frame` and `bx` are left in scope.
@@ -114,14 +117,17 @@ template <int FMT, bool VEC> struct HpChunk {
 //     (ref: src/features.rs:97-104, src/util.rs:95-107), and the 2:1 decimation of pitch_downsample
 //     (ref: src/pitch.rs:455-458) done incrementally: decimated sample d = ((s[2d-1] + s[2d+1])/2 + s[2d])/2
 //     depends only on absolute samples, so each frame adds 240 values to a persistent ring instead of
-//     recomputing all 864; only the reference's special first element is per frame.  The ring is stored
-//     twice (p, p + 960): every frame's 864-value window is then one contiguous run for its readers.
+//     recomputing all 864; only the reference's special first element is per frame.  The first 960 values of the
+//     ring are mirrored behind its end: every frame's 864-value window is then one contiguous run for its reader.
 //     lane = stream; the 480-step recurrence is inherently serial per stream and a lone wave is bound by
 //     instruction issue, so each lane moves its own stream's samples with 16-byte accesses (a full 128-byte
-//     line per 32 samples) instead of transposing tiles through LDS for coalescing.
+//     line per 32 samples) instead of transposing tiles through LDS for coalescing.  One launch covers the `g`
+//     consecutive frames of a group: the biquad state stays in registers from frame to frame.
 // ---------------------------------------------------------------------------------------------
+struct HpState { float m0, m1, prev; };
+
 template <int FMT, bool VEC>
-__device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp, int tile, int lane)
+__device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp, int tile, int lane, HpState &st)
 {
     const int slot = sp->slot;
     const int elem = pcm_elem_bytes(FMT), ch = sp->channels, sstride = ch * elem;
@@ -131,20 +137,18 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp,
     const char *in = sp->in + (long long)grp * sp->group_stride + (long long)(sc - grp * ch) * elem;
     HpChunk<FMT, VEC> nxt;
     nxt.load(in, sstride);
-    float *hp = NNN_TI(b.hp_mem, 2, tile, lane);
-    float m0 = hp[0], m1 = hp[TILE];
-    float prev = NNN_TI(b.hp_last, 1, tile, lane)[0];
+    float m0 = st.m0, m1 = st.m1, prev = st.prev;
     NNN_STAMP(b, 24);
-    float *ring = NNN_TI(b.dec, 2 * DEC_RING, tile, lane);
+    float *ring = NNN_TI(b.dec, DEC_LEN, tile, lane);
     float *h = b.hist + (size_t)s * RING;
-    {   // x_lp[0] = (x[1] / 2 + x[0]) / 2 on the oldest two samples of this frame's 1728-sample history: kept in
-        // per-frame scratch (the ring position it replaces is still a regular value for the previous frame,
-        // which may be in flight)
+    {   // x_lp[0] = (x[1] / 2 + x[0]) / 2 on the oldest two samples of this frame's 1728-sample history: kept beside
+        // the ring, per slot (the ring position it replaces is still a regular value for the previous frame)
         const int rb = ring_base(slot);
         const float x0 = h[rb], x1 = h[(rb + 1) % RING];
-        NNN_TI(b.xlp0, 1, tile, lane)[0] = (x1 / 2.0f + x0) / 2.0f;
+        NNN_TI(b.xlp0, NSLOT, tile, lane)[(size_t)slot * TILE] = (x1 / 2.0f + x0) / 2.0f;
     }
     float *dec = ring + (size_t)(240 * slot) * TILE;
+    const bool mirror = slot < DEC_MIRROR;
     float4 *hw = (float4 *)(h + slot * FRAME);   // RING * 4 and FRAME * 4 are multiples of 16
     const double a0 = (double)-1.99599f, a1 = (double)0.99600f, b0 = (double)-2.0f, b1 = (double)1.0f;
     // Software pipeline over 32-sample chunks.  Loads and stores share one in-order counter (vmcnt), so waiting for
@@ -156,9 +160,10 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp,
         if (c < FRAME / 32) nxt.get(xs);
         if (c > 0) {
 #pragma unroll
-            for (int t = 0; t < 16; t++) {
-                dec[(size_t)(16 * (c - 1) + t) * TILE] = dvs[t];
-                dec[(size_t)(DEC_RING + 16 * (c - 1) + t) * TILE] = dvs[t];
+            for (int t = 0; t < 16; t++) dec[(size_t)(16 * (c - 1) + t) * TILE] = dvs[t];
+            if (mirror) {
+#pragma unroll
+                for (int t = 0; t < 16; t++) dec[(size_t)(DEC_RING + 16 * (c - 1) + t) * TILE] = dvs[t];
             }
 #pragma unroll
             for (int q = 0; q < 8; q++) hw[8 * (c - 1) + q] = make_float4(ys[4 * q], ys[4 * q + 1], ys[4 * q + 2], ys[4 * q + 3]);
@@ -180,21 +185,29 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp,
         }
         prev = ys[31];
     }
-    hp[0] = m0;
-    hp[TILE] = m1;
-    NNN_TI(b.hp_last, 1, tile, lane)[0] = prev;
+    st.m0 = m0; st.m1 = m1; st.prev = prev;
     NNN_STAMP(b, 25);
 }
 
-__global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp, StepParams *publish)
+template <int FMT, bool VEC>
+__device__ __forceinline__ void hp_group(const Buffers &b, const StepParams *sp, int g, int tile, int lane)
 {
-    // pipelined calls: the frame's parameters are republished where this frame's replayed graph segment reads them
-    if (publish && blockIdx.x == 0 && threadIdx.x == 0) *publish = *sp;
+    float *hp = NNN_TI(b.hp_mem, 2, tile, lane);
+    float *hl = NNN_TI(b.hp_last, 1, tile, lane);
+    HpState st{hp[0], hp[TILE], hl[0]};
+    for (int f = 0; f < g; f++) hp_frame<FMT, VEC>(b, sp + f, tile, lane, st);
+    hp[0] = st.m0;
+    hp[TILE] = st.m1;
+    hl[0] = st.prev;
+}
+
+__global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp, int g)
+{
     const int lane = threadIdx.x, tile = blockIdx.x, fmt = sp->fmt;
-    const bool vec = sp->channels == 1 && ((((size_t)sp->in) | (size_t)sp->group_stride) & 15) == 0;
-    if (fmt == PCM_F32) { if (vec) hp_frame<PCM_F32, true>(b, sp, tile, lane); else hp_frame<PCM_F32, false>(b, sp, tile, lane); }
-    else if (fmt == PCM_I16) { if (vec) hp_frame<PCM_I16, true>(b, sp, tile, lane); else hp_frame<PCM_I16, false>(b, sp, tile, lane); }
-    else { if (vec) hp_frame<PCM_F32_UNIT, true>(b, sp, tile, lane); else hp_frame<PCM_F32_UNIT, false>(b, sp, tile, lane); }
+    const bool vec = sp->channels == 1 && ((((size_t)sp->in) | (size_t)sp->group_stride | (size_t)sp->frame_stride) & 15) == 0;
+    if (fmt == PCM_F32) { if (vec) hp_group<PCM_F32, true>(b, sp, g, tile, lane); else hp_group<PCM_F32, false>(b, sp, g, tile, lane); }
+    else if (fmt == PCM_I16) { if (vec) hp_group<PCM_I16, true>(b, sp, g, tile, lane); else hp_group<PCM_I16, false>(b, sp, g, tile, lane); }
+    else { if (vec) hp_group<PCM_F32_UNIT, true>(b, sp, g, tile, lane); else hp_group<PCM_F32_UNIT, false>(b, sp, g, tile, lane); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -212,16 +225,16 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
 {
     NNN_FRAME_SPLIT(b.NT)
     sp += frame;
-    __shared__ float buf[2][LPC_ROWS][64];   // double-buffered window chunks; reused as the FIR transpose tiles
+    __shared__ float buf[2][LPC_ROWS][64];   // double-buffered window chunks
     __shared__ float acs[5][64];
     __shared__ float coef[5][64];
-    float (*tl)[64][33] = (float (*)[64][33])buf;
     const int lane = threadIdx.x & 63, tile = bx;
     const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // this wave's lag
     NNN_STAMP(b, 0);
-    const float *xw = NNN_TI(b.dec, 2 * DEC_RING, tile, lane) + (size_t)dec_base(sp->slot) * TILE;   // x_lp[0..863]
+    const int slot = sp->slot;
+    const float *xw = NNN_TI(b.dec, DEC_LEN, tile, lane) + (size_t)dec_base(slot) * TILE;   // x_lp[0..863]
 #define x(j) xw[(size_t)(j) * TILE]
-    const float x_first = NNN_TI(b.xlp0, 1, tile, lane)[0];   // x_lp[0] is special (ref: src/pitch.rs:458)
+    const float x_first = NNN_TI(b.xlp0, NSLOT, tile, lane)[(size_t)slot * TILE];   // x_lp[0] is special (ref: src/pitch.rs:458)
     const int fast_n = XLP - 4;
     {
         // Every row of the window is fetched once per block (wave w takes rows w, w+5, ...), parked in LDS, and
@@ -314,45 +327,38 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
     }
     __syncthreads();
     NNN_STAMP(b, 2);
-    // FIR5 over 27 chunks of 32 outputs, 5 waves round-robin (every wave runs 6 rounds so barriers match)
+    // FIR5 over 27 chunks of 32 outputs, 5 waves round-robin; pitch_buf goes out tile-interleaved only (the wave = stream
+    // consumer stages 16-stream slices of it through LDS)
     const float n0 = coef[0][lane], n1 = coef[1][lane], n2 = coef[2][lane], n3 = coef[3][lane], n4 = coef[4][lane];
     float *o = NNN_TI(b.xlp_ti, XLP, tile, lane);
-    const int sub = lane >> 5, col = lane & 31;
-    for (int round = 0; round < 6; round++) {
-        const int c = round * 5 + k;
-        const bool on = c < XLP / 32;
-        if (on) {
-            const int i0 = 32 * c;
-            float v[37];
+    for (int c = k; c < XLP / 32; c += 5) {
+        const int i0 = 32 * c;
+        float v[37];
 #pragma unroll
-            for (int u = 0; u < 37; u++) v[u] = (i0 + u - 5 >= 0) ? x(i0 + u - 5) : 0.0f;
-            if (c == 0) v[5] = x_first;
+        for (int u = 0; u < 37; u++) v[u] = (i0 + u - 5 >= 0) ? x(i0 + u - 5) : 0.0f;
+        if (c == 0) v[5] = x_first;
 #pragma unroll
-            for (int u = 0; u < 32; u++) {
-                // out = x + n0 m0 + n1 m1 + n2 m2 + n3 m3 + n4 m4, left to right (m0 = previous input, ...)
-                float out = v[u + 5] + n0 * v[u + 4] + n1 * v[u + 3] + n2 * v[u + 2] + n3 * v[u + 1] + n4 * v[u];
-                o[(size_t)(i0 + u) * TILE] = out;
-                tl[k][lane][u] = out;
-            }
+        for (int u = 0; u < 32; u++) {
+            // out = x + n0 m0 + n1 m1 + n2 m2 + n3 m3 + n4 m4, left to right (m0 = previous input, ...)
+            o[(size_t)(i0 + u) * TILE] = v[u + 5] + n0 * v[u + 4] + n1 * v[u + 3] + n2 * v[u + 2] + n3 * v[u + 1] + n4 * v[u];
         }
-        __syncthreads();
-        if (on) {
-#pragma unroll
-            for (int r = 0; r < 32; r++) {
-                int row = r * 2 + sub;
-                b.xlp_sm[(size_t)(tile * TILE + row) * XLP + 32 * c + col] = tl[k][row][col];
-            }
-        }
-        __syncthreads();
     }
 #undef x
     NNN_STAMP(b, 3);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K7y yy: xx = |x|^2 over the analysis frame (4 interleaved partial sums) and the 384-step running
-//     energy yy_lookup of remove_doubling (ref: src/pitch.rs:133-142).  Depends only on pitch_buf, so
-//     it rides in the coarse cross-correlation's launch as one more block row.  lane = stream.
+// K5  pitch1: everything of the pitch search that is a strictly sequential sum per stream, lane = stream on the
+//     tile-interleaved pitch_buf, one block per (tile, frame), the independent chains spread over its 12 waves:
+//       waves 0..9   coarse cross-correlation, 147 lags x 240 taps on the 4x-decimated signal, every lag a sequential
+//                    sum in j (ref: src/pitch.rs:296-363, call site :82); 16 lags per wave: 16 accumulators and a
+//                    16-deep sliding window of y in registers, 2 coalesced row loads per 16 multiply-adds
+//       wave 10      xx = |x|^2 over the analysis frame and the 384-step running energy yy_lookup of
+//                    remove_doubling (ref: src/pitch.rs:133-142)
+//       wave 11      the running energy every fine lag sees in find_best_pitch (ref: src/pitch.rs:97, :401-402)
+//                    and the coarse search's start energy
+//     then wave 0 runs find_best_pitch over the coarse lags (ref: src/pitch.rs:372-405, call site :83-84) on the
+//     block's cross-correlation, which never leaves LDS (stored to HBM only for the parity taps).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void yy_lookup(const Buffers &b, int tile, int lane)
 {
@@ -387,22 +393,14 @@ __device__ __forceinline__ void yy_lookup(const Buffers &b, int tile, int lane)
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// K5  xcorr_coarse: 147 lags x 240 taps on the 4x-decimated signal, every lag a strictly
-//     sequential sum in j (ref: src/pitch.rs:296-363, call site :82).  lane = stream, one wave per
-//     (tile, chunk of LC lags); LC accumulators + an LC-deep sliding window of y in registers, so a
-//     step costs 2 coalesced row loads for LC multiply-adds.  Small batches use short chunks (more waves,
-//     shorter serial chain), large batches long chunks (fewer L2 reads per multiply-add).
-// ---------------------------------------------------------------------------------------------
-template <int LC>
-__global__ void __launch_bounds__(64) k_xcorr(Buffers b)
+constexpr int P1_LC = 16;                                   // lags per cross-correlation wave
+constexpr int P1_CHUNKS = (NLAG1 + P1_LC - 1) / P1_LC;      // 10
+constexpr int P1_WAVES = P1_CHUNKS + 2;
+
+// lags L0 .. L0 + 15 of the coarse cross-correlation -> xc[lag][lane]
+__device__ __forceinline__ void xcorr_chunk(const Buffers &b, int tile, int lane, int L0, float (*xc)[TILE])
 {
-    NNN_FRAME_SPLIT(b.NT)
-    if (blockIdx.y == gridDim.y - 1) {   // the extra block row: xx / yy_lookup (same input, independent work)
-        yy_lookup(b, bx, threadIdx.x);
-        return;
-    }
-    const int lane = threadIdx.x, tile = bx, L0 = blockIdx.y * LC;
+    constexpr int LC = P1_LC;
     const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
 #define X4(j) p[(size_t)(384 + 2 * (j)) * TILE]
 #define Y4(m) p[(size_t)(2 * (m)) * TILE]
@@ -426,10 +424,44 @@ __global__ void __launch_bounds__(64) k_xcorr(Buffers b)
     }
 #undef X4
 #undef Y4
-    float *o = NNN_TI(b.xc1, NLAG1, tile, lane);
 #pragma unroll
-    for (int q = 0; q < LC; q++)
-        if (L0 + q < NLAG1) o[(size_t)(L0 + q) * TILE] = acc[q];
+    for (int q = 0; q < LC; q++) xc[L0 + q][lane] = acc[q];
+    if (b.taps) {
+        float *o = NNN_TI(b.xc1, NLAG1, tile, lane);
+#pragma unroll
+        for (int q = 0; q < LC; q++)
+            if (L0 + q < NLAG1) o[(size_t)(L0 + q) * TILE] = acc[q];
+    }
+}
+
+// the running energy y_sq_norm seen by every fine lag (ref: src/pitch.rs:97 -> :380-402), kept per lag: only <= 10
+// lags can update the best pitch there, and they are replayed by pitch2 with the energy each of them saw
+__device__ __forceinline__ void fine_energy(const Buffers &b, int tile, int lane)
+{
+    const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
+    float *yq = NNN_TI(b.ysq2, NLAG2, tile, lane);
+    float ysq = 1.0f;
+    for (int j0 = 0; j0 < 480; j0 += 24) {
+        float v[24];
+#pragma unroll
+        for (int i = 0; i < 24; i++) v[i] = p[(size_t)(j0 + i) * TILE];
+#pragma unroll
+        for (int i = 0; i < 24; i++) ysq += v[i] * v[i];
+    }
+    for (int i0 = 0; i0 < NLAG2; i0 += 21) {   // 294 = 14 x 21
+        float a[21], d[21];
+#pragma unroll
+        for (int i = 0; i < 21; i++) {
+            a[i] = p[(size_t)(i0 + i + 480) * TILE];
+            d[i] = p[(size_t)(i0 + i) * TILE];
+        }
+#pragma unroll
+        for (int i = 0; i < 21; i++) {
+            yq[(size_t)(i0 + i) * TILE] = ysq;
+            ysq += a[i] * a[i] - d[i] * d[i];
+            ysq = fmaxf(ysq, 1.0f);
+        }
+    }
 }
 
 // running best / second-best update of find_best_pitch, ref: src/pitch.rs:383-400
@@ -452,16 +484,18 @@ struct BestPitch {
     }
 };
 
-// ---------------------------------------------------------------------------------------------
-// K6  best1: find_best_pitch over the coarse lags (running energy with its >= 1 clamp is a serial
-//     scan).  ref: src/pitch.rs:372-405, call site :83-84.  lane = stream.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_best1(Buffers b)
+__global__ void __launch_bounds__(64 * P1_WAVES) k_pitch1(Buffers b)
 {
+    __shared__ float xc[P1_CHUNKS * P1_LC][TILE];
     NNN_FRAME_SPLIT(b.NT)
-    const int lane = threadIdx.x, tile = bx;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, tile = bx;
+    if (wave < P1_CHUNKS) xcorr_chunk(b, tile, lane, wave * P1_LC, xc);
+    else if (wave == P1_CHUNKS) yy_lookup(b, tile, lane);
+    else fine_energy(b, tile, lane);
+    __syncthreads();
+    if (wave != 0) return;
+    // find_best_pitch over the coarse lags: the running energy with its >= 1 clamp is a serial scan
     const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
-    const float *xc = NNN_TI(b.xc1, NLAG1, tile, lane);
     float ysq = 1.0f;
     for (int j0 = 0; j0 < 240; j0 += 24) {
         float v[24];
@@ -476,7 +510,7 @@ __global__ void __launch_bounds__(64) k_best1(Buffers b)
         float c[21], a[21], d[21];
 #pragma unroll
         for (int i = 0; i < 21; i++) {
-            c[i] = xc[(size_t)(i0 + i) * TILE];
+            c[i] = xc[i0 + i][lane];
             a[i] = p[(size_t)(2 * (i0 + i + 240)) * TILE];
             d[i] = p[(size_t)(2 * (i0 + i)) * TILE];
         }
@@ -507,42 +541,6 @@ __device__ __forceinline__ float ip480_partial(const float *xs, const float *ys,
     return s;
 }
 
-// ---------------------------------------------------------------------------------------------
-// K7a refine: fine cross-correlation at the <= 10 lags within +-2 of 2*best / 2*second
-//     (ref: src/pitch.rs:88-96).  Lags are data dependent, so wave = stream with pitch_buf in LDS;
-//     lane (candidate, partial) keeps the reference's 4 interleaved partial sums.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_refine(Buffers b)
-{
-    __shared__ float sh[4][XLP];
-    __shared__ float part[4][64];
-    NNN_FRAME_SPLIT(b.S_pad / 4)
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = bx * 4 + wave, tile = s >> 6, sl = s & 63;
-    for (int i = lane; i < XLP; i += 64) sh[wave][i] = b.xlp_sm[(size_t)s * XLP + i];
-    const int *b1 = NNN_TI(b.best1, 2, tile, sl);
-    const int best = b1[0], second = b1[TILE];
-    __syncthreads();
-    const int c = lane >> 2, q = lane & 3;
-    int lag = (c < 5) ? 2 * best - 2 + c : 2 * second - 2 + (c - 5);
-    const bool valid = c < 10 && lag >= 0 && lag < NLAG2;
-    part[wave][lane] = valid ? ip480_partial(&sh[wave][384], &sh[wave][lag], q) : 0.0f;
-    __syncthreads();
-    if (q == 0 && c < 10) {
-        float v = 0.0f;
-        if (valid) {
-            v = part[wave][lane] + part[wave][lane + 1] + part[wave][lane + 2] + part[wave][lane + 3];
-            v = fmaxf(v, -1.0f);
-        }
-        NNN_TI(b.xc2, 10, tile, sl)[(size_t)c * TILE] = v;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K7b best2: find_best_pitch over the 294 fine lags + pseudo-interpolation (ref: src/pitch.rs:97-114)
-//     and, for remove_doubling, xx and the 384-step running energy yy_lookup (ref: :133-142).
-//     All serial scans -> lane = stream.
-// ---------------------------------------------------------------------------------------------
 struct Xc2 {   // xcorr[] of the fine search: zero except within 2 of 2*best / 2*second (ref: src/pitch.rs:88-96)
     float v[10];
     int lo1, lo2;
@@ -560,162 +558,192 @@ struct Xc2 {   // xcorr[] of the fine search: zero except within 2 of 2*best / 2
     }
 };
 
-__global__ void __launch_bounds__(64) k_best2(Buffers b)
-{
-    NNN_FRAME_SPLIT(b.NT)
-    const int lane = threadIdx.x, tile = bx;
-    const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
-    const float *xc2 = NNN_TI(b.xc2, 10, tile, lane);
-    const int *b1 = NNN_TI(b.best1, 2, tile, lane);
-    float *yq = NNN_TI(b.ysq2, NLAG2, tile, lane);
-    Xc2 xc;
-    xc.lo1 = 2 * b1[0] - 2;
-    xc.lo2 = 2 * b1[TILE] - 2;
-#pragma unroll
-    for (int u = 0; u < 10; u++) xc.v[u] = xc2[(size_t)u * TILE];
-    float ysq = 1.0f;
-    for (int j0 = 0; j0 < 480; j0 += 24) {
-        float v[24];
-#pragma unroll
-        for (int i = 0; i < 24; i++) v[i] = p[(size_t)(j0 + i) * TILE];
-#pragma unroll
-        for (int i = 0; i < 24; i++) ysq += v[i] * v[i];
-    }
-    // Serial part: the running energy y_sq_norm for every lag (ref: src/pitch.rs:401-402), kept per step.
-    // xcorr is zero outside two 5-lag windows, so only <= 10 lags can update the best pitch; they are
-    // replayed below in increasing lag order with the energy each of them saw.
-    for (int i0 = 0; i0 < NLAG2; i0 += 21) {   // 294 = 14 x 21
-        float a[21], d[21];
-#pragma unroll
-        for (int i = 0; i < 21; i++) {
-            a[i] = p[(size_t)(i0 + i + 480) * TILE];
-            d[i] = p[(size_t)(i0 + i) * TILE];
-        }
-#pragma unroll
-        for (int i = 0; i < 21; i++) {
-            yq[(size_t)(i0 + i) * TILE] = ysq;
-            ysq += a[i] * a[i] - d[i] * d[i];
-            ysq = fmaxf(ysq, 1.0f);
-        }
-    }
-    BestPitch bp;
-    bp.init();
-    const int loA = min(xc.lo1, xc.lo2), loB = max(xc.lo1, xc.lo2);
-#pragma unroll
-    for (int u = 0; u < 10; u++) {
-        const int i = u < 5 ? loA + u : loB + (u - 5);
-        const bool on = i >= 0 && i < NLAG2 && (u < 5 || i > loA + 4);
-        if (on) bp.update(i, xc.at(i), yq[(size_t)i * TILE]);
-    }
-    int offset = 0;
-    if (bp.best > 0 && bp.best < NLAG2 - 1) {
-        float a = xc.at(bp.best - 1), bb = xc.at(bp.best), c = xc.at(bp.best + 1);
-        if (c - a > 0.7f * (bb - a)) offset = 1;
-        else if (a - c > 0.7f * (bb - c)) offset = -1;
-    }
-    NNN_TI(b.psearch, 1, tile, lane)[0] = 2 * bp.best - offset;
-}
-
-// ---------------------------------------------------------------------------------------------
-// K7c doubling: remove_doubling (ref: src/pitch.rs:118-221).  The 29 candidate periods depend only
-//     on t0, so all their inner products are computed up front, lane (candidate, partial); the
-//     k = 2..15 decision loop then runs on scalars.  wave = stream, pitch_buf in LDS.
-// ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1.0f + xx * yy); }
 
-__global__ void __launch_bounds__(256) k_doubling(Buffers b)
+// ---------------------------------------------------------------------------------------------
+// K7  pitch2: the data-dependent-lag part of the pitch search, wave = stream with the stream's pitch_buf in LDS:
+//       fine cross-correlation at the <= 10 lags within +-2 of 2*best / 2*second (ref: src/pitch.rs:88-96), lane
+//       (candidate, partial) keeping the reference's 4 interleaved partial sums; find_best_pitch over the fine lags
+//       replayed on those <= 10 lags with the running energies of pitch1, pseudo-interpolation (ref: :97-114);
+//       remove_doubling (ref: :118-221): the 29 candidate periods depend only on t0, so their inner products are
+//       computed up front, lane (candidate, partial), and the k = 2..15 decision loop runs on scalars.
+//     A block takes 16 consecutive streams (a quarter tile, one wave each): the tile-interleaved pitch_buf reaches LDS
+//     as 864 coalesced 64-byte segments, so no stream-major copy of it exists.  remove_doubling carries
+//     last_period / last_gain from frame to frame: the launch loops over the `g` frames of its group.
+// ---------------------------------------------------------------------------------------------
+constexpr int P2_SPB = 16;
+constexpr int P2_ROW = XLP + 1;   // odd row length: the transposing LDS writes of the staging spread over the banks
+
+__global__ void __launch_bounds__(64 * P2_SPB) k_pitch2(Buffers b, int g)
 {
-    __shared__ float sh[4][XLP];
-    __shared__ float part[4][64];
-    __shared__ float ipv[4][32], yyc[4][32];
-    __shared__ int cand[4][32];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + wave, tile = s >> 6, sl = s & 63;
-    for (int i = lane; i < XLP; i += 64) sh[wave][i] = b.xlp_sm[(size_t)s * XLP + i];
-    const int ps = NNN_TI(b.psearch, 1, tile, sl)[0];
-    const int last_period = NNN_TI(b.last_period, 1, tile, sl)[0];
-    const float last_gain = NNN_TI(b.last_gain, 1, tile, sl)[0];
-    const float *xy_tab = NNN_TI(b.xx_yy, 386, tile, sl);
-    const float xx = xy_tab[0];
+    __shared__ float sh[P2_SPB][P2_ROW];
+    __shared__ float part[P2_SPB][64];
+    __shared__ float ipv[P2_SPB][32], yyc[P2_SPB][32];
+    __shared__ int cand[P2_SPB][32];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int s = blockIdx.x * P2_SPB + wave, tile = s >> 6, sl = s & 63;
+    const int q0 = (blockIdx.x * P2_SPB) & 63;            // first stream of this block within its tile
     const int min_period = PITCH_MIN / 2, max_period = PITCH_MAX / 2;
-    int t0 = (PITCH_MAX - ps) / 2;
-    if (t0 > max_period - 1) t0 = max_period - 1;
-    const int prev_period = last_period / 2;
-    if (lane < 29) {
-        int t;
-        if (lane == 0) t = t0;
-        else {
-            int k = 2 + (lane - 1) / 2;
-            int t1 = (2 * t0 + k) / (2 * k);
-            if ((lane - 1) & 1) {
-                const int sc = kSecondCheck[k];
-                t = (k == 2) ? ((t1 + t0 > max_period) ? t0 : t0 + t1) : (2 * sc * t0 + k) / (2 * k);
-            } else t = t1;
-        }
-        cand[wave][lane] = t;
-        yyc[wave][lane] = xy_tab[(size_t)(1 + t) * TILE];
-    }
-    __syncthreads();
-    for (int pass = 0; pass < 2; pass++) {
-        int e = pass * 16 + (lane >> 2), q = lane & 3;
-        float v = 0.0f;
-        if (e < 29) v = ip480_partial(&sh[wave][max_period], &sh[wave][max_period - cand[wave][e]], q);
-        part[wave][lane] = v;
-        __syncthreads();
-        if ((lane & 3) == 0 && e < 29)
-            ipv[wave][e] = part[wave][lane] + part[wave][lane + 1] + part[wave][lane + 2] + part[wave][lane + 3];
-        __syncthreads();
-    }
-    // decision loop on scalars (every lane computes the same thing)
-    int t = t0;
-    float xy = ipv[wave][0], yy = yyc[wave][0];
-    float best_xy = xy, best_yy = yy;
-    const float g0 = pitch_gain(xy, xx, yy);
-    float g = g0;
-    for (int k = 2; k <= 15; k++) {
-        int t1 = cand[wave][1 + 2 * (k - 2)];
-        if (t1 < min_period) break;
-        int e1 = 1 + 2 * (k - 2), e2 = e1 + 1;
-        xy = (ipv[wave][e1] + ipv[wave][e2]) / 2.0f;
-        yy = (yyc[wave][e1] + yyc[wave][e2]) / 2.0f;
-        float g1 = pitch_gain(xy, xx, yy);
-        int d = t1 - prev_period;
-        if (d < 0) d = -d;
-        float cont;
-        if (d <= 1) cont = last_gain;
-        else if (d <= 2 && 5 * k * k < t0) cont = last_gain / 2.0f;
-        else cont = 0.0f;
-        float thresh;
-        if (t1 < 3 * min_period) thresh = fmaxf(0.85f * g0 - cont, 0.4f);
-        else if (t1 < 2 * min_period) thresh = fmaxf(0.9f * g0 - cont, 0.5f);
-        else thresh = fmaxf(0.7f * g0 - cont, 0.3f);
-        if (g1 > thresh) { best_xy = xy; best_yy = yy; t = t1; g = g1; }
-    }
-    best_xy = fmaxf(best_xy, 0.0f);
-    float pg = (best_yy <= best_xy) ? 1.0f : best_xy / (best_yy + 1.0f);
-    // final +-1 refinement: three inner products around t
-    {
-        int e = lane >> 2, q = lane & 3;
-        float v = 0.0f;
-        if (e < 3) v = ip480_partial(&sh[wave][max_period], &sh[wave][max_period - (t + e - 1)], q);
-        part[wave][lane] = v;
-    }
-    __syncthreads();
-    float xc[3];
+    int last_period = NNN_TI(b.last_period, 1, tile, sl)[0];
+    float last_gain = NNN_TI(b.last_gain, 1, tile, sl)[0];
+    for (int f = 0; f < g; f++) {
+        {   // stage the 16 streams' pitch_buf: thread -> (row, stream), 16 lanes share a 64-byte segment
+            const float *src = NNN_TIF(b, xlp_ti, XLP, f, tile, q0);
+            const int col = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+            float v[(XLP + 63) / 64];
 #pragma unroll
-    for (int e = 0; e < 3; e++)
-        xc[e] = part[wave][4 * e] + part[wave][4 * e + 1] + part[wave][4 * e + 2] + part[wave][4 * e + 3];
-    int offset = 0;
-    if (xc[2] - xc[0] > 0.7f * (xc[1] - xc[0])) offset = 1;
-    else if (xc[0] - xc[2] > 0.7f * (xc[1] - xc[2])) offset = -1;
-    pg = fminf(pg, g);
-    int res = 2 * t + offset;
-    if (res < PITCH_MIN) res = PITCH_MIN;
+            for (int i = 0; i < (XLP + 63) / 64; i++) {
+                const int r = r0 + 64 * i;
+                v[i] = r < XLP ? src[(size_t)r * TILE + col] : 0.0f;
+            }
+            if (f) __syncthreads();   // every wave is done with the previous frame's rows
+#pragma unroll
+            for (int i = 0; i < (XLP + 63) / 64; i++) {
+                const int r = r0 + 64 * i;
+                if (r < XLP) sh[col][r] = v[i];
+            }
+        }
+        const int *b1 = NNN_TIF(b, best1, 2, f, tile, sl);
+        const int best = b1[0], second = b1[TILE];
+        const float *yq = NNN_TIF(b, ysq2, NLAG2, f, tile, sl);
+        const float *xy_tab = NNN_TIF(b, xx_yy, 386, f, tile, sl);
+        const float xx = xy_tab[0];
+        __syncthreads();
+        // ---- fine cross-correlation
+        Xc2 xc;
+        xc.lo1 = 2 * best - 2;
+        xc.lo2 = 2 * second - 2;
+        {
+            const int c = lane >> 2, q = lane & 3;
+            const int lag = (c < 5) ? xc.lo1 + c : xc.lo2 + (c - 5);
+            const bool valid = c < 10 && lag >= 0 && lag < NLAG2;
+            part[wave][lane] = valid ? ip480_partial(&sh[wave][384], &sh[wave][lag], q) : 0.0f;
+            wave_lds_sync();
+            float v = 0.0f;
+            if (q == 0 && valid) {
+                v = part[wave][lane] + part[wave][lane + 1] + part[wave][lane + 2] + part[wave][lane + 3];
+                v = fmaxf(v, -1.0f);
+            }
+            wave_lds_sync();
+            if (q == 0 && c < 10) {
+                ipv[wave][c] = v;
+                // the energy this lag saw in the serial scan (pitch1), for the replay below
+                yyc[wave][c] = valid ? yq[(size_t)lag * TILE] : 0.0f;
+                if (b.taps) NNN_TIF(b, xc2, 10, f, tile, sl)[(size_t)c * TILE] = v;
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int u = 0; u < 10; u++) xc.v[u] = ipv[wave][u];
+        }
+        // ---- find_best_pitch over the fine lags: xcorr is zero outside the two 5-lag windows, so only they can
+        //      update the best pitch; replayed in increasing lag order (every lane computes the same thing)
+        int ps;
+        {
+            BestPitch bp;
+            bp.init();
+            const int loA = min(xc.lo1, xc.lo2), loB = max(xc.lo1, xc.lo2);
+            const int baseA = xc.lo1 <= xc.lo2 ? 0 : 5, baseB = 5 - baseA;
+#pragma unroll
+            for (int u = 0; u < 10; u++) {
+                const int i = u < 5 ? loA + u : loB + (u - 5);
+                const bool on = i >= 0 && i < NLAG2 && (u < 5 || i > loA + 4);
+                if (on) bp.update(i, xc.at(i), yyc[wave][(u < 5 ? baseA + u : baseB + (u - 5))]);
+            }
+            int offset = 0;
+            if (bp.best > 0 && bp.best < NLAG2 - 1) {
+                float a = xc.at(bp.best - 1), bb = xc.at(bp.best), c = xc.at(bp.best + 1);
+                if (c - a > 0.7f * (bb - a)) offset = 1;
+                else if (a - c > 0.7f * (bb - c)) offset = -1;
+            }
+            ps = 2 * bp.best - offset;
+            if (lane == 0) NNN_TIF(b, psearch, 1, f, tile, sl)[0] = ps;
+        }
+        wave_lds_sync();   // ipv / yyc are reused below
+        // ---- remove_doubling
+        int t0 = (PITCH_MAX - ps) / 2;
+        if (t0 > max_period - 1) t0 = max_period - 1;
+        const int prev_period = last_period / 2;
+        if (lane < 29) {
+            int t;
+            if (lane == 0) t = t0;
+            else {
+                int k = 2 + (lane - 1) / 2;
+                int t1 = (2 * t0 + k) / (2 * k);
+                if ((lane - 1) & 1) {
+                    const int sc = kSecondCheck[k];
+                    t = (k == 2) ? ((t1 + t0 > max_period) ? t0 : t0 + t1) : (2 * sc * t0 + k) / (2 * k);
+                } else t = t1;
+            }
+            cand[wave][lane] = t;
+            yyc[wave][lane] = xy_tab[(size_t)(1 + t) * TILE];
+        }
+        wave_lds_sync();
+        for (int pass = 0; pass < 2; pass++) {
+            int e = pass * 16 + (lane >> 2), q = lane & 3;
+            float v = 0.0f;
+            if (e < 29) v = ip480_partial(&sh[wave][max_period], &sh[wave][max_period - cand[wave][e]], q);
+            part[wave][lane] = v;
+            wave_lds_sync();
+            if ((lane & 3) == 0 && e < 29)
+                ipv[wave][e] = part[wave][lane] + part[wave][lane + 1] + part[wave][lane + 2] + part[wave][lane + 3];
+            wave_lds_sync();
+        }
+        // decision loop on scalars (every lane computes the same thing)
+        int t = t0;
+        float xy = ipv[wave][0], yy = yyc[wave][0];
+        float best_xy = xy, best_yy = yy;
+        const float g0 = pitch_gain(xy, xx, yy);
+        float gg = g0;
+        for (int k = 2; k <= 15; k++) {
+            int t1 = cand[wave][1 + 2 * (k - 2)];
+            if (t1 < min_period) break;
+            int e1 = 1 + 2 * (k - 2), e2 = e1 + 1;
+            xy = (ipv[wave][e1] + ipv[wave][e2]) / 2.0f;
+            yy = (yyc[wave][e1] + yyc[wave][e2]) / 2.0f;
+            float g1 = pitch_gain(xy, xx, yy);
+            int d = t1 - prev_period;
+            if (d < 0) d = -d;
+            float cont;
+            if (d <= 1) cont = last_gain;
+            else if (d <= 2 && 5 * k * k < t0) cont = last_gain / 2.0f;
+            else cont = 0.0f;
+            float thresh;
+            if (t1 < 3 * min_period) thresh = fmaxf(0.85f * g0 - cont, 0.4f);
+            else if (t1 < 2 * min_period) thresh = fmaxf(0.9f * g0 - cont, 0.5f);
+            else thresh = fmaxf(0.7f * g0 - cont, 0.3f);
+            if (g1 > thresh) { best_xy = xy; best_yy = yy; t = t1; gg = g1; }
+        }
+        best_xy = fmaxf(best_xy, 0.0f);
+        float pg = (best_yy <= best_xy) ? 1.0f : best_xy / (best_yy + 1.0f);
+        // final +-1 refinement: three inner products around t
+        {
+            int e = lane >> 2, q = lane & 3;
+            float v = 0.0f;
+            if (e < 3) v = ip480_partial(&sh[wave][max_period], &sh[wave][max_period - (t + e - 1)], q);
+            part[wave][lane] = v;
+        }
+        wave_lds_sync();
+        float x3[3];
+#pragma unroll
+        for (int e = 0; e < 3; e++)
+            x3[e] = part[wave][4 * e] + part[wave][4 * e + 1] + part[wave][4 * e + 2] + part[wave][4 * e + 3];
+        int offset = 0;
+        if (x3[2] - x3[0] > 0.7f * (x3[1] - x3[0])) offset = 1;
+        else if (x3[0] - x3[2] > 0.7f * (x3[1] - x3[2])) offset = -1;
+        pg = fminf(pg, gg);
+        int res = 2 * t + offset;
+        if (res < PITCH_MIN) res = PITCH_MIN;
+        if (lane == 0) {
+            NNN_TIF(b, pitch, 1, f, tile, sl)[0] = res;
+            NNN_TIF(b, pgain, 1, f, tile, sl)[0] = pg;
+        }
+        last_period = res;
+        last_gain = pg;
+        wave_lds_sync();   // part / ipv / yyc / cand are rewritten by the next frame
+    }
     if (lane == 0) {
-        NNN_TI(b.pitch, 1, tile, sl)[0] = res;
-        NNN_TI(b.pgain, 1, tile, sl)[0] = pg;
-        NNN_TI(b.last_period, 1, tile, sl)[0] = res;
-        NNN_TI(b.last_gain, 1, tile, sl)[0] = pg;
+        NNN_TI(b.last_period, 1, tile, sl)[0] = last_period;
+        NNN_TI(b.last_gain, 1, tile, sl)[0] = last_gain;
     }
 }
 
@@ -960,10 +988,11 @@ __device__ __forceinline__ void band_sums_par(const FftLds &t, const float *cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// K8x / K8p  fft_x, fft_p: transform_input (window, real FFT, normalise, band energy) at lag 0 and at
-//     lag = pitch.  ref: src/features.rs:281-298, src/lib.rs:65-82, 150-155.  One wave per stream.
-//     fft_x depends only on the filtered history, so it runs beside the whole pitch search;
-//     fft_p also forms the band correlation of X and P (ref: src/features.rs:135).
+// K8  fft_xp: transform_input (window, real FFT, normalise, band energy) at lag 0 and at lag = pitch, one after the
+//     other in the same wave: X never leaves the registers between its own transform and the band correlation with P
+//     (ref: src/features.rs:119-135, 281-298, src/lib.rs:65-82, 150-155).  One wave per stream, one launch per frame
+//     group.  Ends with the head of the feature stage (ref: src/features.rs:135-170).  WITH_P = false: the lag-0
+//     transform and its band energies only (the clean / noise states of the training rows).
 // ---------------------------------------------------------------------------------------------
 // one DCT output (ref: src/lib.rs:139-148): sequential sum over the 22 inputs, scaled in double
 __device__ __forceinline__ float dct_out(const float *x, const float *dct, int i)
@@ -974,29 +1003,11 @@ __device__ __forceinline__ float dct_out(const float *x, const float *dct, int i
     return (float)((double)sum * 0.30151134457776363 /* sqrt(2/22) */);
 }
 
-template <bool LAGGED>
-__device__ __forceinline__ void transform_input(const Buffers &b, const StepParams *sp, int bx, FftLds &t, float2 *Z, float *part)
+// windowed 960 samples ending `lag` samples before the newest one -> Z (packed as 480 complex), transform in place,
+// spectrum bins into Y (lane owns bins lane + 64 u), scaled by wnorm
+__device__ __forceinline__ void window_rfft(const Buffers &b, const float *h, int rb, int lag, const float2 (&w)[8], const FftLds &t,
+                                            float2 *Z, float2 (&Y)[8], int lane, bool first)
 {
-    const int lane = threadIdx.x & 63, s = bx * FFT_SPB + (int)(threadIdx.x >> 6), tile = s >> 6, sl = s & 63;
-    const int rb = ring_base(sp->slot);
-    // loads that do not depend on the pitch go first, the block's tables among them
-    float2 Xr[7];
-    if (LAGGED) {
-#pragma unroll
-        for (int u = 0; u < 7; u++) {
-            const int k = lane + 64 * u;
-            Xr[u] = k < 400 ? b.X[(size_t)s * FREQ + k] : make_float2(0.0f, 0.0f);
-        }
-    }
-    float2 w[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const int n = lane + 64 * u;
-        w[u] = n < NFFT ? ((const float2 *)b.window)[n] : make_float2(0.0f, 0.0f);
-    }
-    const int lag = LAGGED ? NNN_TI(b.pitch, 1, tile, sl)[0] : 0;
-    fft_tables_load(t, b, false);
-    const float *h = b.hist + (size_t)s * RING;
     int start = rb + (HIST - WINDOW) - lag;   // in (0, 2 RING)
     if (start >= RING) start -= RING;
 #pragma unroll
@@ -1009,11 +1020,10 @@ __device__ __forceinline__ void transform_input(const Buffers &b, const StepPara
             Z[n] = make_float2(h[i0] * w[u].x, h[i1] * w[u].y);
         }
     }
-    __syncthreads();   // tables in place; from here on every wave is on its own
+    if (first) __syncthreads();   // tables in place; from here on every wave is on its own
+    else wave_lds_sync();
     fft480(Z, t.tw, lane);
     const float wn = b.wnorm;
-    float2 *dst = (LAGGED ? b.P : b.X) + (size_t)s * FREQ;
-    float2 Y[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         const int k = lane + 64 * u;
@@ -1021,71 +1031,121 @@ __device__ __forceinline__ void transform_input(const Buffers &b, const StepPara
             Y[u] = rfft_bin(Z, t.tw, k);
             Y[u].x *= wn;
             Y[u].y *= wn;
-            dst[k] = Y[u];
         }
     }
     wave_lds_sync();   // the transform has been read: its buffer now takes the per-bin products for the band sums
+}
+
+template <bool WITH_P>
+__device__ __forceinline__ void transform_inputs(const Buffers &b, const StepParams *sp, int bx, FftLds &t, float2 *Z, float *part)
+{
+    const int lane = threadIdx.x & 63, s = bx * FFT_SPB + (int)(threadIdx.x >> 6), tile = s >> 6, sl = s & 63;
+    const int rb = ring_base(sp->slot);
+    float2 w[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int n = lane + 64 * u;
+        w[u] = n < NFFT ? ((const float2 *)b.window)[n] : make_float2(0.0f, 0.0f);
+    }
+    const int lag = WITH_P ? NNN_TI(b.pitch, 1, tile, sl)[0] : 0;
+    fft_tables_load(t, b, false);
+    const float *h = b.hist + (size_t)s * RING;
+    float2 X[8];
+    window_rfft(b, h, rb, 0, w, t, Z, X, lane, true);
+    float2 *dx = b.X + (size_t)s * FSTR;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = lane + 64 * u;
+        if (k < FREQ) dx[k] = X[u];
+    }
     float *vv = (float *)Z, *vc = vv + 400;
+#pragma unroll
+    for (int u = 0; u < 7; u++) {
+        const int k = lane + 64 * u;
+        if (k < 400) vv[k] = X[u].x * X[u].x + X[u].y * X[u].y;
+    }
+    wave_lds_sync();
+    float exv;
+    {
+        const float *const v[1] = {vv};
+        float o[1];
+        band_sums_par<1>(t, v, part, o, lane);
+        exv = o[0];
+        if (lane < NB) NNN_TI(b.ex, NB, tile, sl)[(size_t)lane * TILE] = exv;
+    }
+    if (!WITH_P) return;
+    wave_lds_sync();
+    float2 Y[8];
+    window_rfft(b, h, rb, lag, w, t, Z, Y, lane, false);
+    float2 *dp = b.P + (size_t)s * FSTR;
+    const int np = b.taps ? FREQ : 400;   // the pitch filter reads bins 0..399 only
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = lane + 64 * u;
+        if (k < np) dp[k] = Y[u];
+    }
 #pragma unroll
     for (int u = 0; u < 7; u++) {
         const int k = lane + 64 * u;
         if (k < 400) {
             vv[k] = Y[u].x * Y[u].x + Y[u].y * Y[u].y;
-            if (LAGGED) vc[k] = Xr[u].x * Y[u].x + Xr[u].y * Y[u].y;
+            vc[k] = X[u].x * Y[u].x + X[u].y * Y[u].y;
         }
     }
     wave_lds_sync();
-    if (LAGGED) {
-        const float *const v[2] = {vv, vc};
-        float o[2];
-        band_sums_par<2>(t, v, part, o, lane);
-        // Head of the feature stage (ref: src/features.rs:135-170), here because everything it needs is at hand and this
-        // launch covers a whole frame group: the correlation normalised by the band energies, the floored log energies,
-        // the silence test, and the two DCTs -- lane = band.  The RNN kernel's prologue, which sits on the frame-to-frame
-        // chain, only keeps the cepstral-ring part.  Same operations in the same order as when one lane did it all.
-        wave_lds_sync();
-        float *xc = part, *ly = part + 64, *exl = part + 128;
-        if (lane < NB) {
-            const float exv = NNN_TI(b.ex, NB, tile, sl)[(size_t)lane * TILE];
-            const float xn = o[1] / sqrtf(0.001f + exv * o[0]);
-            NNN_TI(b.ep, NB, tile, sl)[(size_t)lane * TILE] = o[0];
-            NNN_TI(b.exp_, NB, tile, sl)[(size_t)lane * TILE] = xn;
-            xc[lane] = xn;
-            exl[lane] = exv;
-            ly[lane] = log10f(1e-2f + exv);
+    const float *const v[2] = {vv, vc};
+    float o[2];
+    band_sums_par<2>(t, v, part, o, lane);
+    // Head of the feature stage (ref: src/features.rs:135-170), here because everything it needs is at hand and this
+    // launch covers a whole frame group: the correlation normalised by the band energies, the floored log energies,
+    // the silence test, and the two DCTs -- lane = band.  Same operations in the same order as when one lane did it all.
+    wave_lds_sync();
+    float *xc = part, *ly = part + 64, *exl = part + 128;
+    if (lane < NB) {
+        const float xn = o[1] / sqrtf(0.001f + exv * o[0]);
+        NNN_TI(b.ep, NB, tile, sl)[(size_t)lane * TILE] = o[0];
+        NNN_TI(b.exp_, NB, tile, sl)[(size_t)lane * TILE] = xn;
+        xc[lane] = xn;
+        exl[lane] = exv;
+        ly[lane] = log10f(1e-2f + exv);
+    }
+    wave_lds_sync();
+    if (lane == 0) {
+        float log_max = -2.0f, follow = -2.0f, e = 0.0f;
+        for (int i = 0; i < NB; i++) {
+            const float l = fmaxf(fmaxf(ly[i], log_max - 7.0f), follow - 1.5f);
+            ly[i] = l;
+            log_max = fmaxf(log_max, l);
+            follow = fmaxf(follow - 1.5f, l);
+            e += exl[i];
         }
-        wave_lds_sync();
-        if (lane == 0) {
-            float log_max = -2.0f, follow = -2.0f, e = 0.0f;
-            for (int i = 0; i < NB; i++) {
-                const float l = fmaxf(fmaxf(ly[i], log_max - 7.0f), follow - 1.5f);
-                ly[i] = l;
-                log_max = fmaxf(log_max, l);
-                follow = fmaxf(follow - 1.5f, l);
-                e += exl[i];
-            }
-            NNN_TI(b.silence, 1, tile, sl)[0] = e < 0.04f ? 1 : 0;
+        NNN_TI(b.silence, 1, tile, sl)[0] = e < 0.04f ? 1 : 0;
+    }
+    wave_lds_sync();
+    if (lane < NB) {
+        float *cn = NNN_TI(b.cn, 28, tile, sl);
+        float c = dct_out(ly, b.dct, lane);
+        c -= lane == 0 ? 12.0f : (lane == 1 ? 4.0f : 0.0f);
+        cn[(size_t)lane * TILE] = c;
+        if (lane < 6) {
+            float d = dct_out(xc, b.dct, lane);
+            d -= lane == 0 ? 1.3f : (lane == 1 ? 0.9f : 0.0f);
+            cn[(size_t)(NB + lane) * TILE] = d;
         }
-        wave_lds_sync();
-        if (lane < NB) {
-            float *cn = NNN_TI(b.cn, 28, tile, sl);
-            float c = dct_out(ly, b.dct, lane);
-            c -= lane == 0 ? 12.0f : (lane == 1 ? 4.0f : 0.0f);
-            cn[(size_t)lane * TILE] = c;
-            if (lane < 6) {
-                float d = dct_out(xc, b.dct, lane);
-                d -= lane == 0 ? 1.3f : (lane == 1 ? 0.9f : 0.0f);
-                cn[(size_t)(NB + lane) * TILE] = d;
-            }
-        }
-    } else {
-        const float *const v[1] = {vv};
-        float o[1];
-        band_sums_par<1>(t, v, part, o, lane);
-        if (lane < NB) NNN_TI(b.ex, NB, tile, sl)[(size_t)lane * TILE] = o[0];
     }
 }
 
+__global__ void __launch_bounds__(64 * FFT_SPB) k_fft_xp(Buffers b, const StepParams *sp)
+{
+    __shared__ FftLds t;
+    __shared__ float2 Z[FFT_SPB][NFFT];
+    __shared__ float part[FFT_SPB][4 * 64];
+    NNN_FRAME_SPLIT(b.S_pad / FFT_SPB)
+    const int wave = threadIdx.x >> 6;
+    transform_inputs<true>(b, sp + frame, bx, t, Z[wave], part[wave]);
+}
+
+// lag-0 transform and band energies only (training rows: clean and noise states)
 __global__ void __launch_bounds__(64 * FFT_SPB) k_fft_x(Buffers b, const StepParams *sp)
 {
     __shared__ FftLds t;
@@ -1093,17 +1153,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB) k_fft_x(Buffers b, const StepPar
     __shared__ float part[FFT_SPB][2 * 64];
     NNN_FRAME_SPLIT(b.S_pad / FFT_SPB)
     const int wave = threadIdx.x >> 6;
-    transform_input<false>(b, sp + frame, bx, t, Z[wave], part[wave]);
-}
-
-__global__ void __launch_bounds__(64 * FFT_SPB) k_fft_p(Buffers b, const StepParams *sp)
-{
-    __shared__ FftLds t;
-    __shared__ float2 Z[FFT_SPB][NFFT];
-    __shared__ float part[FFT_SPB][4 * 64];
-    NNN_FRAME_SPLIT(b.S_pad / FFT_SPB)
-    const int wave = threadIdx.x >> 6;
-    transform_input<true>(b, sp + frame, bx, t, Z[wave], part[wave]);
+    transform_inputs<false>(b, sp + frame, bx, t, Z[wave], part[wave]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1327,16 +1377,18 @@ __device__ __forceinline__ unsigned short bf16_rn(float x)   // round to nearest
 }
 __device__ __forceinline__ float bf16_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
-// x = hi + mid + lo exactly (8 + 8 + 8 significand bits), one bf16 plane each
+// x = hi + mid + lo exactly (8 + 8 + 8 significand bits), one bf16 plane each.  Truncation, not rounding: hi is the top
+// half of x's word, the remainder x - hi is exact and has <= 16 significant bits, its top half is mid, and what is left
+// has <= 8 bits and is a bf16 as it stands.
 __device__ __forceinline__ void store_split(unsigned short *P, int plane_stride, int idx, float x)
 {
-    unsigned short h = bf16_rn(x);
-    float r1 = x - bf16_f32(h);
-    unsigned short m = bf16_rn(r1);
-    float r2 = r1 - bf16_f32(m);
-    P[idx] = h;
-    P[idx + plane_stride] = m;
-    P[idx + 2 * plane_stride] = bf16_rn(r2);
+    const unsigned uh = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(uh);
+    const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(um);
+    P[idx] = (unsigned short)(uh >> 16);
+    P[idx + plane_stride] = (unsigned short)(um >> 16);
+    P[idx + 2 * plane_stride] = (unsigned short)(__float_as_uint(r2) >> 16);
 }
 __device__ __forceinline__ float load_split(const unsigned short *P, int plane_stride, int idx)
 {
@@ -1361,7 +1413,7 @@ __device__ __forceinline__ void load_frags(Frags<NG> &fr, const GemmDesc &g, con
 // acc[G0 + g][mb] += A[16 (mb0 + mb) .. +15][kbase ..] * B(gate G0 + g), g < NG, mb < MB, over all k-steps and
 // the three activation planes.  Bnb points at this neuron block's fragments ([gate][k-step][lane]).
 template <int NG, int MB, int G0>
-__device__ __forceinline__ void gemm_acc(f32x4 (&acc)[3][4], const unsigned short *A, int plane_stride, int row_w, int mb0,
+__device__ __forceinline__ void gemm_acc(f32x4 (&acc)[3][2], const unsigned short *A, int plane_stride, int row_w, int mb0,
                                          const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane, const Frags<NG> &fr)
 {
     const unsigned short *a0 = A + (size_t)(mb0 * 16 + (lane & 15)) * row_w + g.kbase + 8 * (lane >> 4);
@@ -1408,31 +1460,24 @@ __device__ __forceinline__ void gemm_acc(f32x4 (&acc)[3][4], const unsigned shor
 
 struct RnnLds {
     const float *tab;
-    const int *live;
-    unsigned short *IN, *REC;
-    int in_ps, rec_ps;   // plane strides (elements)
-    int rm;              // stream rows of this block: 64, 32 or 16
+    int *live;            // rows whose frame is not silent (this frame)
+    unsigned short *IN;   // input operand matrix [rm][in_w], 3 planes
+    unsigned short *RS;   // r * state of the layer in progress [rm][rec_w], 3 planes
+    int in_ps, rs_ps;     // plane strides (elements)
+    int rm;               // stream rows of this block: 32 or 16
 };
 
 // One GRU layer (ref: src/rnn.rs:292-327) as three GEMM groups on the matrix cores.  A wave owns one
 // (neuron block, MB stream blocks) unit: z, r and the input part of the candidate accumulate together,
-// r * state goes back through LDS (every candidate needs all of it), then the recurrent part of the
-// candidate and the state update.  z and the old state stay in registers in the C-fragment layout.
-constexpr int RNN_LOADERS = 64 * (RNN_WAVES - 1);   // waves 1..7 set up the block while wave 0 computes the features
-constexpr int RNN_PRE = (TILE * MAXN + 64 * RNN_WAVES - 1) / (64 * RNN_WAVES);   // state values per thread (<= 16)
-
-__device__ __forceinline__ void preload_state(float (&pre)[RNN_PRE], const float *state, int n, int rm)
-{
-#pragma unroll
-    for (int i = 0; i < RNN_PRE; i++) {
-        const int e = (int)threadIdx.x + i * 64 * RNN_WAVES;
-        pre[i] = e < rm * n ? state[e] : 0.0f;
-    }
-}
-
-template <int MB>
-__device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, const RnnPlan &pl, const RnnLds &lds, float *state,
-                                          const uint4 *__restrict__ Wq, const float *__restrict__ fpar, int wave, int lane)
+// r * state goes through LDS (every candidate needs all of it), then the recurrent part of the candidate and the state
+// update.  The state itself lives in the layer's own LDS planes `SP` (row stride `sw`; three bf16 planes hold an f32
+// exactly) for all frames of the launch: recurrent operand of the GEMMs, read back by the owning wave for the update, and
+// rewritten by it -- a layer costs two barriers, and no state travels to HBM and back between frames.
+// `idle` runs on waves without a unit while the others are in the first GEMM phase (the next frame's features).
+template <int MB, class Idle>
+__device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, const RnnPlan &pl, const RnnLds &lds, unsigned short *SP,
+                                          int sw, const uint4 *__restrict__ Wq, const float *__restrict__ fpar,
+                                          int wave, int lane, Idle &&idle)
 {
     const float scale = 1.0f / 256.0f;
     const int groups = (lds.rm >> 4) / MB, units = L.nb * groups;
@@ -1440,6 +1485,7 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
     const int nbi = mine ? wave / groups : 0, mb0 = (wave % groups) * MB;
     const int neuron = nbi * 16 + (lane & 15);
     const bool nvalid = mine && neuron < L.n;
+    const int sp_ps = lds.rm * sw;
     const uint4 *Bin = Wq + L.in.wofs + (size_t)nbi * 3 * L.in.ksteps * 64;
     const uint4 *Brec = Wq + L.rec.wofs + (size_t)nbi * 3 * L.rec.ksteps * 64;
     // all weight fragments of this layer start travelling now
@@ -1452,63 +1498,39 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
     float bias[3];
 #pragma unroll
     for (int g = 0; g < 3; g++) bias[g] = (neuron < L.n) ? fpar[L.bias + g * L.n + neuron] : 0.0f;
-    // old state -> recurrent operand planes (columns >= n stay zero); these loads share the latency window of
-    // the weight fragments requested above
-    {
-        float pre[RNN_PRE];
-        preload_state(pre, state, L.n, lds.rm);
-#pragma unroll
-        for (int i = 0; i < RNN_PRE; i++) {
-            const int e = (int)threadIdx.x + i * 64 * RNN_WAVES;
-            if (e < lds.rm * L.n) {
-                int row = e / L.n, col = e - row * L.n;
-                store_split(lds.REC, lds.rec_ps, row * pl.rec_w + col, pre[i]);
-            }
-        }
-    }
-    lds_barrier();
     NNN_STAMP(b, 16);
-    f32x4 acc[3][4];
-    float sold[4][4], zz[4][4], rs[4][4];
+    f32x4 acc[3][2];
+    float zz[2][4], sold[2][4];
     if (mine) {
 #pragma unroll
         for (int g = 0; g < 3; g++) {
 #pragma unroll
             for (int mb = 0; mb < MB; mb++) acc[g][mb] = f32x4{bias[g], bias[g], bias[g], bias[g]};
         }
-        NNN_STAMP(b, 19);
         gemm_acc<3, MB, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, Bin, lane, f_in);
-        NNN_STAMP(b, 20);
-        gemm_acc<2, MB, 0>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Brec, lane, f_zr);
-        NNN_STAMP(b, 21);
+        gemm_acc<2, MB, 0>(acc, SP, sp_ps, sw, mb0, L.rec, Brec, lane, f_zr);
+        // r * state: the columns of this neuron block, plus (last block) the padding up to the GEMM's k range, as zeros
+        const int kcols = 32 * L.rec.ksteps;
 #pragma unroll
         for (int mb = 0; mb < MB; mb++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int row = (mb0 + mb) * 16 + 4 * (lane >> 4) + q;
-                // the three planes hold the old state exactly
-                const float so = nvalid ? load_split(lds.REC, lds.rec_ps, row * pl.rec_w + neuron) : 0.0f;
+                const float so = nvalid ? load_split(SP, sp_ps, row * sw + neuron) : 0.0f;   // the three planes hold the state exactly
                 sold[mb][q] = so;
                 zz[mb][q] = sigmoid_approx(scale * acc[0][mb][q], lds.tab);
-                rs[mb][q] = so * sigmoid_approx(scale * acc[1][mb][q], lds.tab);
+                const float rs = so * sigmoid_approx(scale * acc[1][mb][q], lds.tab);
+                if (neuron < kcols) store_split(lds.RS, lds.rs_ps, row * pl.rec_w + neuron, rs);
+                if (nbi == L.nb - 1 && neuron + 16 < kcols) store_split(lds.RS, lds.rs_ps, row * pl.rec_w + neuron + 16, 0.0f);
             }
         NNN_STAMP(b, 22);
+    } else {
+        idle();
     }
-    lds_barrier();   // every wave is done reading the old state planes
-    NNN_STAMP(b, 17);
-    if (nvalid) {
-#pragma unroll
-        for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int row = (mb0 + mb) * 16 + 4 * (lane >> 4) + q;
-                store_split(lds.REC, lds.rec_ps, row * pl.rec_w + neuron, rs[mb][q]);
-            }
-    }
-    lds_barrier();
+    lds_barrier();   // r * state complete; every wave is done reading the old state planes
     NNN_STAMP(b, 18);
     if (mine) {
-        gemm_acc<1, MB, 2>(acc, lds.REC, lds.rec_ps, pl.rec_w, mb0, L.rec, Brec, lane, f_h);
+        gemm_acc<1, MB, 2>(acc, lds.RS, lds.rs_ps, pl.rec_w, mb0, L.rec, Brec, lane, f_h);
         NNN_STAMP(b, 23);
         if (nvalid) {
 #pragma unroll
@@ -1517,10 +1539,11 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
                 for (int q = 0; q < 4; q++) {
                     const int row = (mb0 + mb) * 16 + 4 * (lane >> 4) + q;
                     const float hh = activate(L.act, scale * acc[2][mb][q], lds.tab);
-                    const float z = zz[mb][q];
-                    const float snew = z * sold[mb][q] + (1.0f - z) * hh;
+                    const float z = zz[mb][q], so = sold[mb][q];
+                    float snew = z * so + (1.0f - z) * hh;
+                    snew = lds.live[row] ? snew : so;   // silent frames leave the state alone (ref: src/denoise.rs:100)
                     store_split(lds.IN, lds.in_ps, row * pl.in_w + L.out_col + neuron, snew);
-                    if (lds.live[row]) state[(size_t)row * L.n + neuron] = snew;   // silent frames leave the state alone
+                    store_split(SP, sp_ps, row * sw + neuron, snew);
                 }
         }
         NNN_STAMP(b, 26);
@@ -1528,169 +1551,255 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
     lds_barrier();
 }
 
-// dense layer on the matrix cores: returns act(W x + b) for this wave's (neuron block, stream block) unit
-// (dense layers: a wave owns one (neuron block, 16-stream block) unit; mbt = 16-stream blocks of this thread block)
-__device__ __forceinline__ float dense_bias(const LayerDesc &L, const float *__restrict__ fpar, int wave, int lane, int mbt)
+// a layer's state: its stream-major array in HBM (the rows of this block) <-> its LDS planes, all threads of the block
+__device__ __forceinline__ void gru_state_io(const LayerDesc &L, int rm, float *state, unsigned short *SP, int sw, bool load)
 {
-    const int neuron = (wave / mbt) * 16 + (lane & 15);
-    return (wave < L.nb * mbt && neuron < L.n) ? fpar[L.bias + neuron] : 0.0f;
+    const int n = rm * L.n;
+    for (int e = (int)threadIdx.x; e < n; e += 64 * RNN_WAVES) {
+        const int row = e / L.n, col = e - row * L.n;
+        if (load) store_split(SP, rm * sw, row * sw + col, state[e]);
+        else state[e] = load_split(SP, rm * sw, row * sw + col);
+    }
 }
 
-__device__ __forceinline__ const uint4 *dense_frags(const LayerDesc &L, const uint4 *__restrict__ Wq, int wave, int mbt)
-{
-    const int nbi = wave < L.nb * mbt ? wave / mbt : 0;
-    return Wq + L.in.wofs + (size_t)nbi * L.in.ksteps * 64;
-}
-
-__device__ __forceinline__ bool dense_unit(const LayerDesc &L, const RnnPlan &pl, const RnnLds &lds, const uint4 *__restrict__ Wq,
-                                           float bv, int wave, int lane, const Frags<1> &first,
-                                           f32x4 &out, int &neuron, int &mb0)
+// dense layer on the matrix cores: act(W x + b) for every (neuron block, 16-stream block) unit, units dealt round-robin to
+// the block's waves (a layer wider than the waves are many takes several rounds); `sink(row, neuron, value)` per output
+template <class Sink>
+__device__ __forceinline__ void dense_layer(const LayerDesc &L, const RnnPlan &pl, const RnnLds &lds, const uint4 *__restrict__ Wq,
+                                            const float *__restrict__ fpar, int wave, int lane, Sink &&sink)
 {
     const int mbt = lds.rm >> 4, units = L.nb * mbt;
-    const int nbi = wave / mbt;
-    mb0 = wave % mbt;
-    neuron = nbi * 16 + (lane & 15);
-    if (wave >= units) return false;
-    f32x4 acc[3][4];
-    acc[0][0] = f32x4{bv, bv, bv, bv};
-    gemm_acc<1, 1, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, dense_frags(L, Wq, wave, mbt), lane, first);
+    for (int unit = wave; unit < units; unit += RNN_WAVES) {
+        const int nbi = unit / mbt, mb0 = unit % mbt;
+        const int neuron = nbi * 16 + (lane & 15);
+        const uint4 *Bnb = Wq + L.in.wofs + (size_t)nbi * L.in.ksteps * 64;
+        Frags<1> fr;
+        load_frags<1, 0>(fr, L.in, Bnb, lane);
+        const float bv = neuron < L.n ? fpar[L.bias + neuron] : 0.0f;
+        f32x4 acc[3][2];
+        acc[0][0] = f32x4{bv, bv, bv, bv};
+        gemm_acc<1, 1, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, Bnb, lane, fr);
+        if (neuron < L.n) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) out[q] = activate(L.act, acc[0][0][q] * (1.0f / 256.0f), lds.tab);
-    return neuron < L.n;
+            for (int q = 0; q < 4; q++)
+                sink(mb0 * 16 + 4 * (lane >> 4) + q, neuron, activate(L.act, acc[0][0][q] * (1.0f / 256.0f), lds.tab));
+        }
+    }
+}
+
+// pair index of rows i < j among the 8 ring rows, in spectral_variability's order
+__device__ __forceinline__ int pair_index(int i, int j) { return i * (15 - i) / 2 + (j - i - 1); }
+
+// The feature stage of one frame for one row (lane = stream), start to finish without leaving the lane: cepstral-ring
+// update, delta features, spectral variability (ref: src/features.rs:170-219).  The ring (`crs`) and the 28 pairwise
+// cepstral distances (`dc`) stay in LDS for all frames of the launch: a new cepstrum changes only the 7 distances it
+// takes part in, the other 21 are the same sums over the same rows as the reference recomputes.  Writes the 42 features as
+// three bf16 planes into the staging `FS` (row stride FS_W) and the row's live flag for that frame.
+constexpr int FS_W = 56;   // 48 feature columns + 8: 16-byte rows, odd multiple of 16 bytes
+__device__ __forceinline__ void features_row(const Buffers &b, int f, int tile, int trow, int ll, int rm, float *crs, float *dc,
+                                             unsigned short *FS, int *live_next, int &mem_id)
+{
+    const float *cg = NNN_TIF(b, cn, 28, f, tile, trow);
+    float cn[28];
+#pragma unroll
+    for (int i = 0; i < 28; i++) cn[i] = cg[(size_t)i * TILE];
+    const int pitch = NNN_TIF(b, pitch, 1, f, tile, trow)[0];
+    const bool silent = NNN_TIF(b, silence, 1, f, tile, trow)[0] != 0;
+    float fr[NFEAT];
+    if (silent) {   // "if there's no audio, avoid messing up the state" (ref: src/features.rs:160-166)
+#pragma unroll
+        for (int i = 0; i < NFEAT; i++) fr[i] = 0.0f;
+    } else {
+        float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, trow);
+        const int c0 = mem_id, c1 = mem_id < 1 ? CEPS_MEM + mem_id - 1 : mem_id - 1;
+        const int c2 = mem_id < 2 ? CEPS_MEM + mem_id - 2 : mem_id - 2;
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            cm[(size_t)(c0 * NB + k) * TILE] = cn[k];
+            crs[(c0 * NB + k) * rm + ll] = cn[k];
+        }
+        mem_id = mem_id + 1 == CEPS_MEM ? 0 : mem_id + 1;
+#pragma unroll
+        for (int i = 0; i < NB; i++) fr[i] = cn[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const float v1 = crs[(c1 * NB + i) * rm + ll], v2 = crs[(c2 * NB + i) * rm + ll];
+            const float v0 = cn[i];
+            fr[i] = v0 + v1 + v2;
+            fr[NB + i] = v0 - v2;
+            fr[NB + 6 + i] = v0 - 2.0f * v1 + v2;
+            fr[NB + 12 + i] = cn[NB + i];
+        }
+        fr[40] = 0.01f * ((float)pitch - 300.0f);
+        // the 7 distances the new row takes part in, each summed over the 22 bands in order (ref: src/features.rs:203-208)
+        for (int j = 0; j < CEPS_MEM; j++) {
+            if (j == c0) continue;
+            float dist = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const float d = cn[k] - crs[(j * NB + k) * rm + ll];
+                dist += d * d;
+            }
+            dc[pair_index(j < c0 ? j : c0, j < c0 ? c0 : j) * rm + ll] = dist;
+        }
+        fr[41] = spectral_variability(dc, ll, rm);
+    }
+    live_next[ll] = silent ? 0 : 1;
+    if (b.taps) {
+        float *fo = NNN_TIF(b, feat, NFEAT, f, tile, trow);
+#pragma unroll
+        for (int k = 0; k < NFEAT; k++) fo[(size_t)k * TILE] = fr[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NFEAT; k++) store_split(FS, rm * FS_W, ll * FS_W + k, fr[k]);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K10 rnn: `rm` stream rows (64, 32 or 16 of a 64-stream tile) per block, 8 waves.  Fewer rows per block = more
-//     blocks and a shorter chain per block (small batches), and operand matrices that still fit the LDS for the
-//     widest models the format allows (127 neurons per layer).
+// K10 rnn: the feature stage's recurrent part and the network (ref: src/rnn.rs:343-379) for the `g` frames of a group in
+//     one launch.  `rm` stream rows (32 or 16 of a 64-stream tile) per block, 8 waves; GEMMs on the matrix cores with
+//     exact products (bf16 weights, activations as three bf16 planes).  Across the frames of the launch the GRU states stay in
+//     registers and LDS, the cepstral ring and its pair distances in LDS; the last wave prepares frame f + 1's features
+//     while the others are inside frame f's GRU GEMMs (when the layer shapes leave it without a unit).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int rnn_state_w(const LayerDesc &L) { return 32 * L.rec.ksteps + 8; }
+
 __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, const uint4 *__restrict__ Wq,
-                                                          const float *__restrict__ fpar, int tile0, int rm)
+                                                          const float *__restrict__ fpar, int tile0, int rm, int g)
 {
     HIP_DYNAMIC_SHARED(float, lds_raw)
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane0 = threadIdx.x & 63;
+    int wave = wave0, lane = lane0, tid = threadIdx.x;
     const int per = TILE / rm, mbt = rm >> 4;
     const int tile = tile0 + (int)blockIdx.x / per;        // tile0: first tile of this model's run
     const int r0 = ((int)blockIdx.x % per) * rm;           // first row of the tile handled here
     const bool rowl = lane < rm;                           // lane = stream phases: this lane has a row
     const int trow = r0 + (rowl ? lane : 0);               // its row in the tile
+    // ---- LDS carve-up (rnn_lds_bytes on the host mirrors it)
     float *tab = lds_raw;
-    int *live = (int *)(lds_raw + 256);
-    unsigned short *IN = (unsigned short *)(lds_raw + 256 + 64);
-    const int in_ps = rm * pl.in_w, rec_ps = rm * pl.rec_w;
-    unsigned short *REC = IN + 3 * in_ps;
-    RnnLds lds{tab, live, IN, REC, in_ps, rec_ps, rm};
+    int *live = (int *)(lds_raw + 256), *live_next = live + 64;
+    unsigned short *IN = (unsigned short *)(lds_raw + 256 + 128);
+    const int in_ps = rm * pl.in_w, rs_ps = rm * pl.rec_w;
+    unsigned short *RS = IN + 3 * in_ps;
+    const int sw_v = rnn_state_w(pl.vad), sw_n = rnn_state_w(pl.noise), sw_dn = rnn_state_w(pl.dn);
+    unsigned short *SPv = RS + 3 * rs_ps, *SPn = SPv + 3 * rm * sw_v, *SPdn = SPn + 3 * rm * sw_n;
+    unsigned short *FS = SPdn + 3 * rm * sw_dn;
+    float *crs = (float *)(FS + 3 * rm * FS_W);        // cepstral ring [8 * 22][rm]
+    float *dc = crs + CEPS_MEM * NB * rm;              // pair distances [28][rm]
+    RnnLds lds{tab, live, IN, RS, in_ps, rs_ps, rm};
     float *sv = b.gru_v + ((size_t)tile * TILE * b.gru_v_w + (size_t)r0 * pl.vad.n),
           *sn = b.gru_n + ((size_t)tile * TILE * b.gru_n_w + (size_t)r0 * pl.noise.n),
           *sdn = b.gru_dn + ((size_t)tile * TILE * b.gru_dn_w + (size_t)r0 * pl.dn.n);
     NNN_STAMP(b, 8);
-    float *crs = (float *)(REC + 3 * rec_ps);          // staged cepstral ring [8 * 22][rm]
-    float *dists = crs + CEPS_MEM * NB * rm;           // pair distances [28][rm]
-    FeatHead fh;
-    fh.silent = true;
-    fh.fpitch = 0.0f;
-    float fr[NFEAT];
-    if (wave == 0) {
-        if (rowl) features_load(b, tile, trow, lane, rm, fh, dists);
-    } else {
-        // waves 1..7: stage the cepstral ring, zero both operand matrices (padding columns must read as 0),
-        // fetch the activation table
-        const float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, trow);
-        constexpr int PER = (CEPS_MEM * NB + RNN_WAVES - 2) / (RNN_WAVES - 1);   // 26 rows per wave, all in flight
-        float st[PER];
-#pragma unroll
-        for (int i = 0; i < PER; i++) {
-            const int r = (wave - 1) + i * (RNN_WAVES - 1);
-            st[i] = (rowl && r < CEPS_MEM * NB) ? cm[(size_t)r * TILE] : 0.0f;
-        }
+    // stream blocks per wave unit of a GRU: one, or both of a 32-row block's when the layer has more than four neuron blocks
+    // (units = neuron blocks x stream-block groups must stay within the 8 waves)
+    const int mb_v = pl.vad.nb * mbt <= RNN_WAVES ? 1 : 2;
+    const int mb_n = pl.noise.nb * mbt <= RNN_WAVES ? 1 : 2;
+    const int mb_dn = pl.dn.nb * mbt <= RNN_WAVES ? 1 : 2;
+#define NNN_MB(mb, CALL)            \
+    {                               \
+        if ((mb) == 2) { CALL(2) }  \
+        else { CALL(1) }            \
+    }
+    // ---- once per launch: zero every operand plane (padding columns must read as 0), activation table, ring, states
+    {
         uint4 *z = (uint4 *)IN;
-        const int n16 = 3 * (in_ps + rec_ps) / 8;
-        for (int i = tid - 64; i < n16; i += RNN_LOADERS) z[i] = make_uint4(0u, 0u, 0u, 0u);
-        for (int i = tid - 64; i < 201; i += RNN_LOADERS) tab[i] = b.tansig[i];
+        const int n16 = (int)(((char *)crs - (char *)IN) / 16);
+        for (int i = tid; i < n16; i += 64 * RNN_WAVES) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = tid; i < 201; i += 64 * RNN_WAVES) tab[i] = b.tansig[i];
+        const float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, trow);
+        constexpr int PER = (CEPS_MEM * NB + RNN_WAVES - 1) / RNN_WAVES;   // 22 rows per wave, all in flight
+        float stg[PER];
 #pragma unroll
         for (int i = 0; i < PER; i++) {
-            const int r = (wave - 1) + i * (RNN_WAVES - 1);
-            if (rowl && r < CEPS_MEM * NB) crs[r * rm + lane] = st[i];
+            const int r = wave + i * RNN_WAVES;
+            stg[i] = (rowl && r < CEPS_MEM * NB) ? cm[(size_t)r * TILE] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int r = wave + i * RNN_WAVES;
+            if (rowl && r < CEPS_MEM * NB) crs[r * rm + lane] = stg[i];
         }
     }
     lds_barrier();
-    if (wave == 0) {
-        if (rowl) features_deltas(b, tile, trow, lane, rm, fh, crs, dists, fr);
-        live[lane] = fh.silent ? 0 : 1;
-    }
-    lds_barrier();
+    gru_state_io(pl.vad, rm, sv, SPv, sw_v, true);
+    gru_state_io(pl.noise, rm, sn, SPn, sw_n, true);
+    gru_state_io(pl.dn, rm, sdn, SPdn, sw_dn, true);
     if (rowl)
-        for (int p = wave; p < 28; p += RNN_WAVES) dists[p * rm + lane] = pair_dist(crs, p, lane, rm);
-    // the dense layers' weights and biases travel during the rest of the prologue
-    Frags<1> f_dense, f_out;
-    load_frags<1, 0>(f_dense, pl.dense.in, dense_frags(pl.dense, Wq, wave, mbt), lane);
-    load_frags<1, 0>(f_out, pl.out.in, dense_frags(pl.out, Wq, wave, mbt), lane);
-    const float bias_dense = dense_bias(pl.dense, fpar, wave, lane, mbt), bias_out = dense_bias(pl.out, fpar, wave, lane, mbt);
+        for (int p = wave; p < 28; p += RNN_WAVES) dc[p * rm + lane] = pair_dist(crs, p, lane, rm);
+    int mem_id = (wave == RNN_WAVES - 1 && rowl) ? NNN_TI(b.mem_id, 1, tile, trow)[0] : 0;
     lds_barrier();
+    // frame 0's features (the last wave; the others have nothing to do yet)
+    if (wave == RNN_WAVES - 1 && rowl) features_row(b, 0, tile, trow, lane, rm, crs, dc, FS, live_next, mem_id);
     NNN_STAMP(b, 9);
-    if (wave == 0 && rowl) {
-        if (!fh.silent) fr[41] = spectral_variability(dists, lane, rm);
-        float *f = NNN_TI(b.feat, NFEAT, tile, trow);
-#pragma unroll
-        for (int k = 0; k < NFEAT; k++) {
-            f[(size_t)k * TILE] = fr[k];
-            store_split(IN, in_ps, lane * pl.in_w + pl.cF + k, fr[k]);
-        }
-    }
-    lds_barrier();
-    NNN_STAMP(b, 10);
-    {   // input dense (ref: src/rnn.rs:353-355)
-        f32x4 o;
-        int neuron, mb0;
-        if (dense_unit(pl.dense, pl, lds, Wq, bias_dense, wave, lane, f_dense, o, neuron, mb0)) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) store_split(IN, in_ps, (mb0 * 16 + 4 * (lane >> 4) + q) * pl.in_w + pl.dense.out_col + neuron, o[q]);
-        }
-    }
-    lds_barrier();
-    // stream blocks per wave unit: as few as keep (neuron blocks) x (stream-block groups) within the 8 waves
-#define NNN_GRU(L, st)                                                                       \
-    {                                                                                        \
-        const int mb = (L).nb * mbt <= RNN_WAVES ? 1 : ((L).nb * mbt <= 2 * RNN_WAVES ? 2 : 4); \
-        if (mb == 4) gru_layer<4>(b, L, pl, lds, st, Wq, fpar, wave, lane);                  \
-        else if (mb == 2) gru_layer<2>(b, L, pl, lds, st, Wq, fpar, wave, lane);             \
-        else gru_layer<1>(b, L, pl, lds, st, Wq, fpar, wave, lane);                          \
-    }
-    NNN_STAMP(b, 11);
-    NNN_GRU(pl.vad, sv)                                                 // ref: src/rnn.rs:356-358
-    NNN_STAMP(b, 12);
-    if (wave == RNN_WAVES - 1 && rowl) {   // vad output, 1 x nv, lane = stream (ref: src/rnn.rs:359)
-        float acc = fpar[pl.vo_b];
-        for (int k = 0; k < pl.vad.n; k++) acc = fmaf(fpar[pl.vo_w + k], load_split(IN, in_ps, lane * pl.in_w + pl.cV + k), acc);
-        NNN_TI(b.vad, 1, tile, trow)[0] = live[lane] ? activate(pl.act_vo, acc * (1.0f / 256.0f), tab) : 0.0f;
-    }
-    NNN_GRU(pl.noise, sn)                                               // ref: src/rnn.rs:361-366
-    NNN_STAMP(b, 13);
-    NNN_GRU(pl.dn, sdn)                                                 // ref: src/rnn.rs:368-377
-    NNN_STAMP(b, 14);
-#undef NNN_GRU
-    {   // gains (ref: src/rnn.rs:378) and smoothing g = max(g, 0.6 lastg) (ref: src/denoise.rs:106-109)
-        f32x4 o;
-        int band, mb0;
-        if (dense_unit(pl.out, pl, lds, Wq, bias_out, wave, lane, f_out, o, band, mb0)) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int lrow = mb0 * 16 + 4 * (lane >> 4) + q, row = r0 + lrow;
-                const bool lv = live[lrow] != 0;
-                const float gr = lv ? o[q] : 0.0f;
-                NNN_TI(b.g_raw, NB, tile, row)[(size_t)band * TILE] = gr;
-                float g = 0.0f;
-                if (lv) {
-                    float *lg = NNN_TI(b.lastg, NB, tile, row) + (size_t)band * TILE;
-                    g = fmaxf(gr, 0.6f * *lg);
-                    *lg = g;
-                }
-                NNN_TI(b.g, NB, tile, row)[(size_t)band * TILE] = g;
+    for (int f = 0; f < g; f++) {
+        // keep the frame loop's addresses inside the loop (see launder_v)
+        lane = launder_v(lane0);
+        wave = launder_s(wave0);
+        tid = 64 * wave + lane;
+        lds_barrier();   // features of frame f staged; the previous frame is done with the input matrix
+        {   // staged features -> their columns of the input matrix; live flags
+            const int n8 = rm * 6;   // 48 columns = 6 x 16 bytes per row and plane
+            for (int i = tid; i < 3 * n8; i += 64 * RNN_WAVES) {
+                const int plx = i / n8, rem = i - plx * n8, row = rem / 6, c8 = rem - row * 6;
+                *(uint4 *)(IN + (size_t)plx * in_ps + row * pl.in_w + pl.cF + 8 * c8) =
+                    *(const uint4 *)(FS + (size_t)plx * rm * FS_W + row * FS_W + 8 * c8);
             }
+            if (tid < 64) live[tid] = live_next[tid];
         }
+        lds_barrier();
+        NNN_STAMP(b, 10);
+        bool feat_done = (f + 1 >= g);   // wave-uniform: the next frame's features are staged (or there is no next frame)
+        auto feat_next = [&]() {
+            if (wave == RNN_WAVES - 1 && !feat_done) {
+                if (rowl) features_row(b, f + 1, tile, trow, lane, rm, crs, dc, FS, live_next, mem_id);
+                feat_done = true;
+            }
+        };
+        auto no_idle = []() {};
+        // input dense (ref: src/rnn.rs:353-355)
+        dense_layer(pl.dense, pl, lds, Wq, fpar, wave, lane, [&](int row, int neuron, float v) {
+            store_split(IN, in_ps, row * pl.in_w + pl.dense.out_col + neuron, v);
+        });
+        lds_barrier();
+        NNN_STAMP(b, 11);
+#define NNN_GRU_V(M) gru_layer<M>(b, pl.vad, pl, lds, SPv, sw_v, Wq, fpar, wave, lane, no_idle);
+#define NNN_GRU_N(M) gru_layer<M>(b, pl.noise, pl, lds, SPn, sw_n, Wq, fpar, wave, lane, feat_next);
+#define NNN_GRU_DN(M) gru_layer<M>(b, pl.dn, pl, lds, SPdn, sw_dn, Wq, fpar, wave, lane, feat_next);
+        NNN_MB(mb_v, NNN_GRU_V)                                             // ref: src/rnn.rs:356-358
+        NNN_STAMP(b, 12);
+        if (wave == RNN_WAVES - 1 && rowl) {   // vad output, 1 x nv, lane = stream (ref: src/rnn.rs:359)
+            float acc = fpar[pl.vo_b];
+            for (int k = 0; k < pl.vad.n; k++) acc = fmaf(fpar[pl.vo_w + k], load_split(IN, in_ps, lane * pl.in_w + pl.cV + k), acc);
+            NNN_TIF(b, vad, 1, f, tile, trow)[0] = live[lane] ? activate(pl.act_vo, acc * (1.0f / 256.0f), tab) : 0.0f;
+        }
+        NNN_MB(mb_n, NNN_GRU_N)                                             // ref: src/rnn.rs:361-366
+        NNN_STAMP(b, 13);
+        NNN_MB(mb_dn, NNN_GRU_DN)                                           // ref: src/rnn.rs:368-377
+        NNN_STAMP(b, 14);
+        // gains (ref: src/rnn.rs:378) and smoothing g = max(g, 0.6 lastg) (ref: src/denoise.rs:106-109)
+        dense_layer(pl.out, pl, lds, Wq, fpar, wave, lane, [&](int lrow, int band, float v) {
+            const int row = r0 + lrow;
+            const bool lv = live[lrow] != 0;
+            const float gr = lv ? v : 0.0f;
+            NNN_TIF(b, g_raw, NB, f, tile, row)[(size_t)band * TILE] = gr;
+            float gs = 0.0f;
+            if (lv) {
+                float *lg = NNN_TI(b.lastg, NB, tile, row) + (size_t)band * TILE;
+                gs = fmaxf(gr, 0.6f * *lg);
+                *lg = gs;
+            }
+            NNN_TIF(b, g, NB, f, tile, row)[(size_t)band * TILE] = gs;
+        });
+        feat_next();   // layer shapes that keep every wave busy: the next frame's features go last
+        NNN_STAMP(b, 15);
     }
-    NNN_STAMP(b, 15);
+    // ---- states back to HBM (the last layer's update is behind its closing barrier)
+    gru_state_io(pl.vad, rm, sv, SPv, sw_v, false);
+    gru_state_io(pl.noise, rm, sn, SPn, sw_n, false);
+    gru_state_io(pl.dn, rm, sdn, SPdn, sw_dn, false);
+    if (wave == RNN_WAVES - 1 && rowl) NNN_TI(b.mem_id, 1, tile, trow)[0] = mem_id;
+#undef NNN_MB
 }
 
 // interpolated band gain at bin k (ref: src/lib.rs:84-97): zero for k >= 400
@@ -1704,12 +1813,11 @@ __device__ __forceinline__ float interp_gain(const float *g, int k, const float 
 
 // ---------------------------------------------------------------------------------------------
 // K11 synth: pitch filter, band renormalisation, gains, inverse FFT, window, overlap-add.
-//     ref: src/features.rs:223-275, src/denoise.rs:103-114.  One wave per stream.
+//     ref: src/features.rs:223-275, src/denoise.rs:103-114.  One wave per stream; the launch loops over the `g` frames of
+//     its group with the overlap memory in registers (read and written once per group, not per frame).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64 * FFT_SPB, 5) k_synth(Buffers b, const StepParams *sp)
+__global__ void __launch_bounds__(64 * FFT_SPB, 4) k_synth(Buffers b, const StepParams *sp0, int g)
 {
-    float *vad_out = sp->vad;
-    const int fmt = sp->fmt;
     __shared__ FftLds t;
     __shared__ float2 A_[FFT_SPB][FREQ + 3];   // also the per-bin energies of the band renormalisation (before A is filled)
     __shared__ float r_[FFT_SPB][3 * NB];
@@ -1717,146 +1825,182 @@ __global__ void __launch_bounds__(64 * FFT_SPB, 5) k_synth(Buffers b, const Step
     const int wave = threadIdx.x >> 6;
     float2 *A = A_[wave];
     float *ebuf = (float *)A, *r = r_[wave], *r2 = r + NB, *gg = r + 2 * NB, *part = part_[wave];
-    const int lane = threadIdx.x & 63, s = blockIdx.x * FFT_SPB + wave, tile = s >> 6, sl = s & 63;
+    const int lane0 = threadIdx.x & 63, s = blockIdx.x * FFT_SPB + wave, tile = s >> 6, sl = s & 63;
+    int lane = lane0;
     fft_tables_load(t, b, true);
-    const float2 *Xg = b.X + (size_t)s * FREQ, *Pg = b.P + (size_t)s * FREQ;
     float *sm = b.synth_mem + (size_t)s * FRAME;
-    // every global load of this block is independent of its own results: issue them all now
-    const bool live = NNN_TI(b.silence, 1, tile, sl)[0] == 0;
-    float2 Xr[8], Pr[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const int k = lane + 64 * u;
-        Xr[u] = k < FREQ ? Xg[k] : make_float2(0.0f, 0.0f);
-        Pr[u] = k < FREQ ? Pg[k] : make_float2(0.0f, 0.0f);
-    }
-    float b_ex = 0.0f, b_ep = 0.0f, b_xp = 0.0f, b_graw = 0.0f, b_g = 0.0f;
-    if (lane < NB) {
-        b_ex = NNN_TI(b.ex, NB, tile, sl)[(size_t)lane * TILE];
-        b_ep = NNN_TI(b.ep, NB, tile, sl)[(size_t)lane * TILE];
-        b_xp = NNN_TI(b.exp_, NB, tile, sl)[(size_t)lane * TILE];
-        b_graw = NNN_TI(b.g_raw, NB, tile, sl)[(size_t)lane * TILE];
-        b_g = NNN_TI(b.g, NB, tile, sl)[(size_t)lane * TILE];
-    }
-    float2 smv[4], wlo[4], whi[4];   // overlap memory and the two window halves, as sample pairs
+    float2 smv[4];   // overlap memory as sample pairs, carried from frame to frame in registers
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int n = lane + 64 * u;
-        const bool on = n < FRAME / 2;
-        smv[u] = on ? ((const float2 *)sm)[n] : make_float2(0.0f, 0.0f);
-        wlo[u] = on ? ((const float2 *)b.window)[n] : make_float2(0.0f, 0.0f);
-        whi[u] = on ? ((const float2 *)b.window)[FRAME / 2 + n] : make_float2(0.0f, 0.0f);
+        smv[u] = n < FRAME / 2 ? ((const float2 *)sm)[n] : make_float2(0.0f, 0.0f);
     }
-    const float vadv = NNN_TI(b.vad, 1, tile, sl)[0];
-    // this stream's first output sample; mono streams of matching alignment take one store per sample pair
-    const int ch = sp->channels, grp = s / ch, elem = pcm_elem_bytes(fmt), sstride = ch * elem;
-    char *o = sp->out + (long long)grp * sp->group_stride + (long long)(s - grp * ch) * elem;
-    const bool store = s < b.S && !sp->discard;
-    const bool pair_ok = ch == 1 && (((size_t)o) & (size_t)(2 * elem - 1)) == 0;
     __syncthreads();   // tables in place; from here on every wave is on its own (a silent stream skips the filter)
-    if (live) {
+    for (int f = 0; f < g; f++) {
+        lane = launder_v(lane0);   // keep the frame loop's addresses inside the loop (see launder_v)
+        const size_t fo = (size_t)b.S_pad * (size_t)f;   // this frame's scratch set
+        const StepParams *sp = sp0 + f;
+        float *vad_out = sp->vad;
+        const int fmt = sp->fmt;
+        const float2 *Xg = b.X + (fo + s) * FSTR, *Pg = b.P + (fo + s) * FSTR;
+        // every global load of this frame is independent of its own results: issue them all now
+        const bool live = NNN_TIF(b, silence, 1, f, tile, sl)[0] == 0;
+        float2 Xr[8], Pr[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = lane + 64 * u;
+            Xr[u] = k < FREQ ? Xg[k] : make_float2(0.0f, 0.0f);
+            Pr[u] = k < 400 ? Pg[k] : make_float2(0.0f, 0.0f);   // from bin 400 up the filter gain is zero
+        }
+        float b_ex = 0.0f, b_ep = 0.0f, b_xp = 0.0f, b_graw = 0.0f, b_g = 0.0f;
         if (lane < NB) {
-            float v;
-            if (b_xp > b_graw) v = 1.0f;
-            else {
-                float exp_sq = b_xp * b_xp, g_sq = b_graw * b_graw;
-                v = exp_sq * (1.0f - g_sq) / (0.001f + g_sq * (1.0f - exp_sq));
-            }
-            v = sqrtf(fminf(fmaxf(v, 0.0f), 1.0f));
-            v *= sqrtf(b_ex / (1e-8f + b_ep));
-            r[lane] = v;
-            gg[lane] = b_g;
+            b_ex = NNN_TIF(b, ex, NB, f, tile, sl)[(size_t)lane * TILE];
+            b_ep = NNN_TIF(b, ep, NB, f, tile, sl)[(size_t)lane * TILE];
+            b_xp = NNN_TIF(b, exp_, NB, f, tile, sl)[(size_t)lane * TILE];
+            b_graw = NNN_TIF(b, g_raw, NB, f, tile, sl)[(size_t)lane * TILE];
+            b_g = NNN_TIF(b, g, NB, f, tile, sl)[(size_t)lane * TILE];
         }
-        wave_lds_sync();
+        float2 wlo[4], whi[4];   // the two window halves, as sample pairs
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = lane + 64 * u;
-            if (k < FREQ) {
-                float2 X = Xr[u];
-                const float rf = interp_gain(r, k, t.frac, t.band);
-                X.x = X.x + Pr[u].x * rf;
-                X.y = X.y + Pr[u].y * rf;
-                Xr[u] = X;
-                if (k < 400) ebuf[k] = X.x * X.x + X.y * X.y;
-            }
+        for (int u = 0; u < 4; u++) {
+            const int n = lane + 64 * u;
+            const bool on = n < FRAME / 2;
+            wlo[u] = on ? ((const float2 *)b.window)[n] : make_float2(0.0f, 0.0f);
+            whi[u] = on ? ((const float2 *)b.window)[FRAME / 2 + n] : make_float2(0.0f, 0.0f);
         }
-        wave_lds_sync();
-        {
-            const float *const v[1] = {ebuf};
-            float ne[1];
-            band_sums_par<1>(t, v, part, ne, lane);
-            if (lane < NB) r2[lane] = sqrtf(b_ex / (1e-8f + ne[0]));
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = lane + 64 * u;
-            if (k < FREQ) {
-                const float rf = interp_gain(r2, k, t.frac, t.band);
-                Xr[u].x *= rf; Xr[u].y *= rf;
-                const float gf = interp_gain(gg, k, t.frac, t.band);
-                Xr[u].x *= gf; Xr[u].y *= gf;
-            }
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const int k = lane + 64 * u;
-        if (k < FREQ) A[k] = Xr[u];
-    }
-    wave_lds_sync();
-    // complex-to-real 960-point inverse as a 480-point complex inverse: Zin[k] = (X[k] + conj X[480-k])
-    // + i e^{+2 pi i k/960} (X[k] - conj X[480-k]); stored re/im-swapped so the forward FFT inverts.
-    float2 zin[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const int k = lane + 64 * u;
-        if (k < NFFT) {
-            float2 a = A[k], c = A[NFFT - k];
-            float2 e2 = make_float2(a.x + c.x, a.y - c.y);
-            float2 d = make_float2(a.x - c.x, a.y + c.y);
-            float2 w = t.tw[k];
-            w.y = -w.y;
-            float2 o2 = cmulf(d, w);
-            zin[u] = make_float2(e2.y + o2.x, e2.x - o2.y);
-        }
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const int k = lane + 64 * u;
-        if (k < NFFT) A[k] = zin[u];
-    }
-    wave_lds_sync();
-    fft480(A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
-    if (lane == 0 && vad_out && s < b.S) vad_out[s] = vadv;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int n = lane + 64 * u;
-        if (n < FRAME / 2) {
-            float2 lo = A[n], hi = A[n + FRAME / 2];
-            float v0 = lo.y / 2.0f * wlo[u].x, v1 = lo.x / 2.0f * wlo[u].y;
-            float u0 = hi.y / 2.0f * whi[u].x, u1 = hi.x / 2.0f * whi[u].y;
-            if (store) {
-                const float y0 = v0 + smv[u].x, y1 = v1 + smv[u].y;
-                if (pair_ok && fmt == PCM_F32) ((float2 *)o)[n] = make_float2(y0, y1);
-                else if (pair_ok && fmt == PCM_I16)
-                    ((unsigned *)o)[n] = (unsigned)(unsigned short)pcm_to_i16(y0) | ((unsigned)(unsigned short)pcm_to_i16(y1) << 16);
-                else if (pair_ok) ((float2 *)o)[n] = make_float2(pcm_to_unit(y0), pcm_to_unit(y1));
+        const float vadv = NNN_TIF(b, vad, 1, f, tile, sl)[0];
+        // this stream's first output sample; mono streams of matching alignment take one store per sample pair
+        const int ch = sp->channels, grp = s / ch, elem = pcm_elem_bytes(fmt), sstride = ch * elem;
+        char *o = sp->out + (long long)grp * sp->group_stride + (long long)(s - grp * ch) * elem;
+        const bool store = s < b.S && !sp->discard;
+        const bool pair_ok = ch == 1 && (((size_t)o) & (size_t)(2 * elem - 1)) == 0;
+        if (live) {
+            const bool up = b_xp > b_graw;   // the branch the parity tests compare (ref: src/features.rs:227)
+            if (lane < NB) {
+                part[lane] = up ? 1.0f : 0.0f;
+                float v;
+                if (up) v = 1.0f;
                 else {
-                    pcm_store(o + (long long)(2 * n) * sstride, fmt, y0);
-                    pcm_store(o + (long long)(2 * n + 1) * sstride, fmt, y1);
+                    float exp_sq = b_xp * b_xp, g_sq = b_graw * b_graw;
+                    v = exp_sq * (1.0f - g_sq) / (0.001f + g_sq * (1.0f - exp_sq));
+                }
+                v = sqrtf(fminf(fmaxf(v, 0.0f), 1.0f));
+                v *= sqrtf(b_ex / (1e-8f + b_ep));
+                r[lane] = v;
+                gg[lane] = b_g;
+            }
+            wave_lds_sync();
+            if (lane == 0) {
+                int mask = 0;
+#pragma unroll
+                for (int i = 0; i < NB; i++) mask |= part[i] != 0.0f ? 1 << i : 0;
+                NNN_TIF(b, branch, 1, f, tile, sl)[0] = mask;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = lane + 64 * u;
+                if (k < FREQ) {
+                    float2 X = Xr[u];
+                    const float rf = interp_gain(r, k, t.frac, t.band);
+                    X.x = X.x + Pr[u].x * rf;
+                    X.y = X.y + Pr[u].y * rf;
+                    Xr[u] = X;
+                    if (k < 400) ebuf[k] = X.x * X.x + X.y * X.y;
                 }
             }
-            ((float2 *)sm)[n] = make_float2(u0, u1);
+            wave_lds_sync();
+            {
+                const float *const v[1] = {ebuf};
+                float ne[1];
+                band_sums_par<1>(t, v, part, ne, lane);
+                if (lane < NB) r2[lane] = sqrtf(b_ex / (1e-8f + ne[0]));
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = lane + 64 * u;
+                if (k < FREQ) {
+                    const float rf = interp_gain(r2, k, t.frac, t.band);
+                    Xr[u].x *= rf; Xr[u].y *= rf;
+                    const float gf = interp_gain(gg, k, t.frac, t.band);
+                    Xr[u].x *= gf; Xr[u].y *= gf;
+                }
+            }
+        } else if (lane == 0) {
+            NNN_TIF(b, branch, 1, f, tile, sl)[0] = 1 << NB;
         }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = lane + 64 * u;
+            if (k < FREQ) A[k] = Xr[u];
+        }
+        wave_lds_sync();
+        // complex-to-real 960-point inverse as a 480-point complex inverse: Zin[k] = (X[k] + conj X[480-k])
+        // + i e^{+2 pi i k/960} (X[k] - conj X[480-k]); stored re/im-swapped so the forward FFT inverts.
+        float2 zin[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = lane + 64 * u;
+            if (k < NFFT) {
+                float2 a = A[k], c = A[NFFT - k];
+                float2 e2 = make_float2(a.x + c.x, a.y - c.y);
+                float2 d = make_float2(a.x - c.x, a.y + c.y);
+                float2 w = t.tw[k];
+                w.y = -w.y;
+                float2 o2 = cmulf(d, w);
+                zin[u] = make_float2(e2.y + o2.x, e2.x - o2.y);
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = lane + 64 * u;
+            if (k < NFFT) A[k] = zin[u];
+        }
+        wave_lds_sync();
+        fft480(A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
+        if (lane == 0 && vad_out && s < b.S) vad_out[s] = vadv;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int n = lane + 64 * u;
+            if (n < FRAME / 2) {
+                float2 lo = A[n], hi = A[n + FRAME / 2];
+                float v0 = lo.y / 2.0f * wlo[u].x, v1 = lo.x / 2.0f * wlo[u].y;
+                float u0 = hi.y / 2.0f * whi[u].x, u1 = hi.x / 2.0f * whi[u].y;
+                if (store) {
+                    const float y0 = v0 + smv[u].x, y1 = v1 + smv[u].y;
+                    if (pair_ok && fmt == PCM_F32) ((float2 *)o)[n] = make_float2(y0, y1);
+                    else if (pair_ok && fmt == PCM_I16)
+                        ((unsigned *)o)[n] = (unsigned)(unsigned short)pcm_to_i16(y0) | ((unsigned)(unsigned short)pcm_to_i16(y1) << 16);
+                    else if (pair_ok) ((float2 *)o)[n] = make_float2(pcm_to_unit(y0), pcm_to_unit(y1));
+                    else {
+                        pcm_store(o + (long long)(2 * n) * sstride, fmt, y0);
+                        pcm_store(o + (long long)(2 * n + 1) * sstride, fmt, y1);
+                    }
+                }
+                smv[u] = make_float2(u0, u1);
+            }
+        }
+        wave_lds_sync();   // A is refilled by the next frame
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int n = lane + 64 * u;
+        if (n < FRAME / 2) ((float2 *)sm)[n] = smv[u];
     }
 }
 
-// Launch-parameter bookkeeping (one thread each): set at the start of a process call, stepped
-// after every frame so the captured graph of one frame can be replayed unchanged.
-__global__ void k_set_params(StepParams *sp, StepParams v) { *sp = v; }
-// per-frame parameter table of a pipelined call: entry t describes frame t of the call (v = frame 0)
+// the activation functions on their own, for the direct known-answer sweep of the parity tests (ref: src/util.rs:29-53)
+__global__ void k_activation_kat(const float *tansig, const float *x, float *y, int act, int n)
+{
+    __shared__ float tab[201];
+    for (int i = threadIdx.x; i < 201; i += blockDim.x) tab[i] = tansig[i];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = activate(act, x[i], tab);
+}
+
+// Per-frame launch parameters of a call (one thread per frame): entry t describes frame t of the call (v = frame 0).
 __global__ void k_fill_params(StepParams *tab, StepParams v, int n)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1868,14 +2012,6 @@ __global__ void k_fill_params(StepParams *tab, StepParams v, int n)
     p.vad = v.vad ? v.vad + (size_t)t * v.n_streams : nullptr;
     p.slot = (v.slot + t) % NSLOT;
     tab[t] = p;
-}
-__global__ void k_advance(StepParams *sp, int nstep)
-{
-    sp->in += (long long)nstep * sp->frame_stride;
-    sp->out += (long long)nstep * sp->frame_stride;
-    sp->discard = 0;
-    if (sp->vad) sp->vad += (size_t)nstep * sp->n_streams;
-    sp->slot = (sp->slot + nstep) % NSLOT;
 }
 
 }  // namespace nnn

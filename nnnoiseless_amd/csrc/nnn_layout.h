@@ -25,21 +25,22 @@ constexpr int HIST = 1728;        // PITCH_BUF_SIZE, src/lib.rs:46
 #ifndef NNN_GROUP
 #define NNN_GROUP 4
 #endif
-#ifndef NNN_LANES
-#define NNN_LANES 3
+#ifndef NNN_DEPTH
+#define NNN_DEPTH 3
 #endif
-constexpr int GROUP = NNN_GROUP;  // frames handled by one launch of every kernel without a cross-frame recurrence
-constexpr int LANES = NNN_LANES;  // groups in flight, one lane stream each (a fourth HIP stream would share a hardware queue)
-constexpr int NSET = LANES * GROUP;   // per-frame scratch sets
-constexpr int NSLOT = LANES * GROUP + 4;   // history ring slots: the high-pass of group j may run while groups j-LANES+1 .. j-1
-                                  // still read their 1728-sample histories (3 slots behind their first frame):
-                                  // LANES GROUP + 3 <= NSLOT
+constexpr int GROUP = NNN_GROUP;  // frames per launch: every kernel is launched once per group of up to GROUP consecutive frames (kernels
+                                  // with a frame-to-frame recurrence loop over the group's frames inside the launch)
+constexpr int DEPTH = NNN_DEPTH;  // groups in flight (blocks of GROUP scratch sets in rotation)
+constexpr int NSET = DEPTH * GROUP;   // per-frame scratch sets
+constexpr int NSLOT = (DEPTH + 1) * GROUP + 4;   // history ring slots: the high-pass may run a group ahead of the DEPTH groups in flight,
+                                  // whose oldest frame still reads a 1728-sample history (3 slots behind it)
 constexpr int RING = NSLOT * 480; // history ring instead of the reference's memmove
 constexpr int XLP = 864;          // HIST / 2
 constexpr int PITCH_MIN = 60, PITCH_MAX = 768;
 constexpr int NLAG1 = 147;        // coarse lags  (PITCH_MAX - 3*PITCH_MIN) / 4
 constexpr int NLAG2 = 294;        // fine lags
 constexpr int TILE = 64;
+constexpr int FSTR = 496;         // row stride of the spectra (481 bins padded to 31 lines of 128 bytes)
 constexpr int MAXN = 127;         // layer sizes are non-negative i8 (src/rnn.rs:128-134)
 
 struct ModelDims {
@@ -84,8 +85,9 @@ struct Buffers {
     float *hist;         // SM [RING]   high-passed input history, ring of NSLOT frame slots
     float *hp_mem;       // TI [2]      biquad state
     float *hp_last;      // TI [1]      last filtered sample of the previous frame
-    float *dec;          // TI [2 DEC_RING]  2:1 decimated history: ring of NSLOT x 240 stored twice (p and p + DEC_RING) so that the
-                         //             864-value window of any frame is one contiguous run (240 values are new per frame)
+    float *dec;          // TI [DEC_LEN]  2:1 decimated history: ring of NSLOT x 240 values whose first 960 are mirrored behind its end,
+                         //             so that the 864-value window of any frame is one contiguous run (240 values are new per frame)
+    float *xlp0;         // TI [NSLOT]  per ring slot: pitch_downsample's special first element (x[1]/2 + x[0])/2 of that frame
     float *ceps_mem;     // TI [8*22]
     int *mem_id;         // TI [1]
     float *synth_mem;    // SM [480]
@@ -96,10 +98,8 @@ struct Buffers {
     int gru_v_w, gru_n_w, gru_dn_w;
     // ---- per-frame scratch (doubles as the parity taps)
     float *lpc;          // TI [10]     ac[5], lpc2[5]
-    float *xlp0;         // TI [1]      pitch_downsample's special first element (x[1]/2 + x[0])/2
     float *xlp_ti;       // TI [864]    pitch_buf
-    float *xlp_sm;       // SM [864]    pitch_buf
-    float *xc1;          // TI [147]
+    float *xc1;          // TI [147]    coarse cross-correlation (stored only while taps are on: it lives in LDS otherwise)
     int *best1;          // TI [2]
     float *xc2;          // TI [10]     fine xcorr at 2*best-2..+2, 2*second-2..+2
     float *ysq2;         // TI [294]    running energy seen by every fine lag
@@ -107,11 +107,13 @@ struct Buffers {
     float *xx_yy;        // TI [386]    [0] = xx, [1 + i] = yy_lookup[i]
     int *pitch;          // TI [1]
     float *pgain;        // TI [1]
-    float2 *X, *P;       // SM [481]
+    float2 *X, *P;       // SM [FSTR]   spectra, rows padded to whole 128-byte lines; P holds bins 0..399 unless taps are on (the
+                         //             pitch filter reads no more, ref: src/lib.rs:84-97 zero-fills from bin 400 up)
     float *ex, *ep, *exp_;  // TI [22]
     float *cn;           // TI [28]     the frame's own cepstrum (22) and pitch-correlation DCT (6), made at the end of k_fft_p
     float *feat;         // TI [42]
     int *silence;        // TI [1]
+    int *branch;         // TI [1]      bit i: pitch_filter took `exp > g` in band i (ref: src/features.rs:227); bit 22: silent frame
     float *g_raw, *g;    // TI [22]
     float *vad;          // TI [1]
     // ---- read-only tables
@@ -125,14 +127,15 @@ struct Buffers {
     const int *seg;          // [192] band-sum segments: k0[64], count[64], first segment[32], segments[32] per interval
     float wnorm;
     int S, S_pad, NT;
+    int taps;                // != 0: kernels also store the quantities only parity tests look at (xc1, xc2, P from bin 400 up)
 };
 
 // Per-frame scratch of set f lies f * S_pad * LEN elements after set 0 in every scratch array, so a launch that covers
 // several consecutive frames (block index = frame * blocks_per_frame + block) reaches its frame's set by offsetting.
 #define NNN_SCRATCH_FIELDS(F)                                                                                        \
-    F(lpc, 10) F(xlp0, 1) F(xlp_ti, XLP) F(xlp_sm, XLP) F(xc1, NLAG1) F(best1, 2) F(xc2, 10) F(ysq2, NLAG2) F(psearch, 1)  \
-    F(xx_yy, 386) F(pitch, 1) F(pgain, 1) F(X, FREQ) F(P, FREQ) F(ex, NB) F(ep, NB) F(exp_, NB) F(cn, 28) F(feat, NFEAT)      \
-    F(silence, 1) F(g_raw, NB) F(g, NB) F(vad, 1)
+    F(lpc, 10) F(xlp_ti, XLP) F(xc1, NLAG1) F(best1, 2) F(xc2, 10) F(ysq2, NLAG2) F(psearch, 1)  \
+    F(xx_yy, 386) F(pitch, 1) F(pgain, 1) F(X, FSTR) F(P, FSTR) F(ex, NB) F(ep, NB) F(exp_, NB) F(cn, 28) F(feat, NFEAT)      \
+    F(silence, 1) F(branch, 1) F(g_raw, NB) F(g, NB) F(vad, 1)
 __host__ __device__ inline Buffers frame_view(Buffers b, int f)
 {
     const size_t sp = (size_t)b.S_pad * (size_t)f;
@@ -165,6 +168,8 @@ struct StepParams {
 __host__ __device__ inline int ring_base(int slot) { return (FRAME * slot + RING - (HIST - FRAME)) % RING; }
 // ring position of logical decimated index 0 (864 logical values, the newest 240 in slot `slot`)
 constexpr int DEC_RING = NSLOT * 240;
+constexpr int DEC_MIRROR = 4;               // frames whose 240 values are stored twice (slots 0..3 cover the 864-value overhang)
+constexpr int DEC_LEN = DEC_RING + DEC_MIRROR * 240;
 __host__ __device__ inline int dec_base(int slot) { return (240 * slot + DEC_RING - (XLP - 240)) % DEC_RING; }
 
 }  // namespace nnn

@@ -54,4 +54,18 @@ template <class T> __device__ __forceinline__ void st_global(void *p, T v)
     *(__attribute__((address_space(1))) T *)p = v;
 }
 
+// Opaque identity on a per-lane / wave-uniform value.  Inside a loop over the frames of a group it makes everything derived
+// from the value loop-variant for the compiler: otherwise every address of every phase is hoisted out of the frame loop as
+// loop invariant, hundreds of registers wide, and spilled (measured: 300 spills in k_rnn without it, none with it).
+__device__ __forceinline__ int launder_v(int x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ int launder_s(int x)
+{
+    asm volatile("" : "+s"(x));
+    return x;
+}
+
 }  // namespace nnn

@@ -33,7 +33,6 @@ def test_native_library_is_what_runs(nn, gpu_lib):
     bd.process(np.zeros((1, 1, 480), np.float32))
     maps = open("/proc/self/maps").read()
     assert "libnnnoiseless_mi355x.so" in maps and "libamdhip64" in maps
-    assert "liboracle" not in maps or True  # the oracle may be loaded by other tests, never by the package
 
 
 def test_golden_vectors(nn, golden_io):
@@ -61,7 +60,7 @@ def test_every_stage_against_oracle_taps(nn, oracle_mod, weights_bytes, golden_i
     x[0] = golden_io[0][:T]
     om = oracle_mod.Model(weights_bytes)
     states = [oracle_mod.State(om) for _ in range(S)]
-    bd = nn.BatchDenoiser(S)
+    bd = nn.BatchDenoiser(S, taps=True)
     worst = {}
     for t in range(T):
         out, vad = bd.process(x[:, t:t + 1])
@@ -114,35 +113,58 @@ def test_pitch_every_frame_and_audio_1024x40(nn, oracle_mod, weights_bytes):
     assert np.array_equal(out2, out) and np.array_equal(vad2, np.concatenate(vads, axis=0))
 
 
+def flipped_frames(gpu_branch, ref_branch):
+    """Frames excused from the AUDIO comparison: those where a discrete decision of the reference's pitch filter
+    (`exp > g` per band, src/features.rs:227; the silence gate) came out differently on the GPU, plus the frame after each
+    (overlap-add memory).  Returns (mask [S, T], list of (stream, frame, xor of the two masks))."""
+    flip = gpu_branch != ref_branch
+    excused = flip.copy()
+    excused[:, 1:] |= flip[:, :-1]
+    lst = [(int(s), int(t), int(gpu_branch[s, t] ^ ref_branch[s, t])) for s, t in np.argwhere(flip)]
+    return excused, lst
+
+
 def test_parity_subset_1024x200(nn, oracle_mod, weights_bytes):
-    """SURVEY 8(d)'s parity subset: 1024 streams x 200 frames (2 s: GRU and cepstral state warm) against the oracle, in
-    20-frame calls; pitch index checked bit for bit at the end of every call, audio over all 200 frames."""
+    """SURVEY 8(d)'s parity subset: 1024 streams x 200 frames (2 s: GRU and cepstral state warm) against the oracle.
+    Pitch index bit for bit on every frame.  Audio on every frame except those where a discrete branch of the reference's
+    pitch filter flipped (listed, < 0.1 %): there the reference itself is a jump discontinuity decided by FFT rounding."""
     from nnnoiseless_amd.synthetic import make_streams
     S, T, C = 1024, 200, 20
     x = make_streams(7000, S, T)
-    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x, n_threads=os.cpu_count() or 1)
+    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x, n_threads=os.cpu_count() or 1,
+                                 want=("out", "pitch", "branch", "vad", "gains"))
     bd = nn.BatchDenoiser(S)
-    outs = []
-    for t in range(0, T, C):
-        o, _ = bd.process(x[:, t:t + C])
+    outs, branch, pitch, gains = [], [], [], []
+    for t in range(T):                               # frame by frame: the taps of every frame
+        o, _ = bd.process(x[:, t:t + 1])
         outs.append(o)
-        assert np.array_equal(bd.tap("pitch")[:, 0], ref["pitch"][:, t + C - 1]), t
+        branch.append(bd.tap("branch")[:, 0])
+        pitch.append(bd.tap("pitch")[:, 0])
+        gains.append(bd.tap("g"))
     out = np.concatenate(outs, axis=1)
-    # Frames where the reference's own pitch-filter branch (exp > g, src/features.rs:229-236) is decided by FFT rounding
-    # noise are excused from the AUDIO comparison, together with the next frame (overlap-add): on this input the
-    # oracle's f32-FFT and f64-FFT builds differ by 1.0e-4 rel rms overall, all of it from one such frame of one stream,
-    # and by 6e-7 on the rest.  |exp - g| < 1e-4 on a band where the branch is a jump marks them (oracle "cond").
-    ill = ref["cond"] < 1e-4
-    ill[:, 1:] |= ill[:, :-1].copy()
-    ok = ~ill[:, 1:]
-    assert ill.mean() < 0.08
+    branch, pitch = np.stack(branch, axis=1), np.stack(pitch, axis=1)
+    assert np.array_equal(pitch, ref["pitch"])
+    assert np.abs(np.stack(gains, axis=1) - ref["gains"]).max() <= 1e-4
+    excused, lst = flipped_frames(branch, ref["branch"])
     d = (out[:, 1:] - ref["out"][:, 1:]).astype(np.float64)
     rr = ref["out"][:, 1:].astype(np.float64)
+    ok = ~excused[:, 1:]
+    r_all = np.sqrt((d ** 2).sum() / (rr ** 2).sum())
     r = np.sqrt((d[ok] ** 2).sum() / (rr[ok] ** 2).sum())
+    report = {"streams": S, "frames": T, "flipped": lst, "flipped_fraction": len(lst) / (S * T),
+              "excused_fraction": float(excused.mean()), "rel_rms_unmasked": float(r_all), "rel_rms": float(r)}
+    print(json.dumps(report))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(report, open(os.path.join(ROOT, "gpurun_out", "parity_1024x200_flipped_frames.json"), "w"), indent=1)
+    assert excused.mean() < 1e-3, report["excused_fraction"]
     assert r <= 1e-4, r                                           # measured ~1e-6
-    assert np.abs(d).max() <= 0.05 * np.abs(rr).max()             # excused frames stay sane
-    per_stream = np.sqrt((d ** 2).sum(axis=(1, 2)) / np.maximum((rr ** 2).sum(axis=(1, 2)), 1e-9))
-    assert np.median(per_stream) <= 1e-5 and np.percentile(per_stream, 99) <= 1e-4
+    assert np.abs(d).max() <= 0.05 * np.abs(rr).max()             # flipped frames stay sane
+    per_stream = np.sqrt(((d * ok[..., None]) ** 2).sum(axis=(1, 2)) / np.maximum((rr ** 2).sum(axis=(1, 2)), 1e-9))
+    assert np.median(per_stream) <= 1e-5 and per_stream.max() <= 1e-4
+    # the same 200 frames in 20-frame calls (frame groups in flight on several streams): bit-identical
+    bd.reset()
+    out2 = np.concatenate([bd.process(x[:, t:t + C])[0] for t in range(0, T, C)], axis=1)
+    assert np.array_equal(out2, out)
 
 
 @pytest.mark.parametrize("S", [4096, 65536])
@@ -220,24 +242,36 @@ def test_two_frames_in_flight_is_bit_identical(nn):
 
 def test_edge_case_inputs(nn, oracle_mod, weights_bytes):
     """Full scale, DC, impulses, +-1 LSB noise, onsets, pitch-range ends, chirp, clipped noise, silence:
-    pitch index bit-identical on every frame, gains and audio within tolerance of the oracle."""
-    from edge_streams import make_edge_streams, oracle_reference
+    pitch index bit-identical on every frame, VAD and gains within 1e-4 (or, per stream, three times the distance between the
+    oracle's own f32-FFT and f64-FFT builds where that is larger), audio within 1e-4 of the stream's peak on every frame
+    whose pitch-filter branches agree with the oracle's."""
+    from edge_streams import make_edge_streams
     x = make_edge_streams(60)
-    ref = oracle_reference(oracle_mod, weights_bytes, x)
-    bd = nn.BatchDenoiser(x.shape[0])
+    S, T = x.shape[:2]
+    want = ("out", "pitch", "branch", "vad", "gains")
+    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x, want=want)
+    ref32 = oracle_mod.run_streams(oracle_mod.Model(weights_bytes, f32_fft=True), x, want=want)
+    spread = np.abs(ref["gains"] - ref32["gains"]).max(axis=(1, 2))          # what f32 FFT rounding alone does to the gains
+    gtol = np.maximum(1e-4, 3.0 * spread)
+    print("per-stream gain tolerance:", [f"{v:.1e}" for v in gtol])
+    bd = nn.BatchDenoiser(S)
     out = np.empty_like(x)
-    for t in range(x.shape[1]):
+    branch = np.empty((S, T), np.int32)
+    for t in range(T):
         o, v = bd.process(x[:, t:t + 1])
         out[:, t] = o[:, 0]
+        branch[:, t] = bd.tap("branch")[:, 0]
         assert np.array_equal(bd.tap("pitch")[:, 0], ref["pitch"][:, t]), t
         assert np.abs(v[0] - ref["vad"][:, t]).max() < 1e-4
-        assert np.abs(bd.tap("g") - ref["g"][:, t]).max() < 1e-3   # oracle f32-vs-f64 FFT spread here is ~2e-4
+        gerr = np.abs(bd.tap("g") - ref["gains"][:, t]).max(axis=1)
+        assert (gerr <= gtol).all(), (t, gerr, gtol)
+    excused, lst = flipped_frames(branch, ref["branch"])
+    print("flipped (stream, frame, bands):", lst)
     scale = np.maximum(np.abs(ref["out"]).max(axis=(1, 2)), 1.0)[:, None]
     err = np.abs(out - ref["out"]).max(axis=2) / scale
-    # 1e-4 of the stream's peak wherever the reference itself is well conditioned (edge_streams.oracle_reference);
-    # a sanity bound on the frames where its pitch-filter branch is decided by f32 rounding noise
-    assert err[~ref["ill"]].max() <= 1e-4, np.argwhere((err > 1e-4) & ~ref["ill"])
+    assert err[~excused].max() <= 1e-4, np.argwhere((err > 1e-4) & ~excused)
     assert err.max() <= 5e-2
+    assert excused.mean() < 0.05
     assert not out[-1].any()
 
 
@@ -412,9 +446,9 @@ def test_grouped_models(nn, oracle_mod, weights_bytes):
         lo += n
 
 
-@pytest.mark.parametrize("rows", [64, 32, 16])
+@pytest.mark.parametrize("rows", [32, 16])
 def test_rnn_rows_per_block_variants(nn, oracle_mod, weights_bytes, rows, monkeypatch):
-    """The RNN kernel's 64/32/16-row block shapes give identical results (same arithmetic, different work split)."""
+    """The RNN kernel's 32/16-row block shapes give identical results (same arithmetic, different work split)."""
     from nnnoiseless_amd.synthetic import make_streams
     x = make_streams(43, 200, 6)
     monkeypatch.setenv("NNN_RNN_ROWS", str(rows))
@@ -488,22 +522,135 @@ def test_nonfinite_inputs_stay_contained(nn, oracle_mod, weights_bytes):
     assert np.allclose(out[ok], ref["out"][ok], rtol=1e-4, atol=1e-2)
 
 
-def test_pipelined_runs_repeat_bit_identically(nn):
-    """Race probe: the same 454-stream, 20-frame input through eight fresh batches in pipelined mode (frame groups in
-    flight on two streams) must reproduce one sequential run bit for bit, every time."""
+def _stress(nn, S, T, reps, schedules):
     from nnnoiseless_amd.synthetic import make_streams
-    x = make_streams(41, 454, 20)
-
-    def run(pipe):
-        bd = nn.BatchDenoiser(454)
-        bd.set_pipeline(pipe)
-        out, vad = bd.process(x)
+    x = make_streams(41, S, T)
+    ref_bd = nn.BatchDenoiser(S)
+    ref_bd.set_pipeline(False)
+    ref, vref = ref_bd.process(x)
+    ref_bd.close()
+    n = 0
+    for it in range(reps):
+        mode, lanes = schedules[it % len(schedules)]
+        bd = nn.BatchDenoiser(S)
+        bd.set_schedule(mode, lanes)
+        cut = 8 + (5 * it) % (T - 16)                   # two calls of varying length: ramp phases, rotation phases
+        out = np.concatenate([bd.process(x[:, :cut])[0], bd.process(x[:, cut:])[0]], axis=1)
         bd.close()
-        return out, vad
-
-    ref, vref = run(False)
-    for it in range(8):
-        out, vad = run(True)
         bad = np.argwhere(np.abs(out - ref).max(axis=2) > 0)
-        assert not len(bad), (it, bad[:8])
-        assert np.array_equal(vad, vref)
+        assert not len(bad), (S, it, mode, lanes, bad[:8])
+        n += 1
+    return n
+
+
+def test_pipelined_runs_repeat_bit_identically(nn):
+    """Race stress: pipelined calls (frame groups on several HIP streams, every schedule the library has) must reproduce one
+    sequential run bit for bit, every time: 240 runs over stream counts on both sides of a tile boundary, a mid-size and
+    the headline batch."""
+    sched = [("lanes", 1), ("lanes", 2), ("lanes", 3), ("lanes", 4), ("stages", 0)]
+    total = 0
+    for S, T, reps in ((63, 40, 70), (65, 40, 70), (454, 40, 70), (4096, 32, 30)):
+        total += _stress(nn, S, T, reps, sched)
+    assert total >= 200
+
+
+@pytest.mark.parametrize("queues", ["2", "8"])
+def test_race_stress_other_queue_counts(queues):
+    """The same stress under GPU_MAX_HW_QUEUES 2 and 8 (the variable is read when the HIP runtime starts: own process)."""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=queues, NNN_STRESS_CHILD="1")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import nnnoiseless_amd as nn; import test_gpu_parity as t; "
+            "n = sum(t._stress(nn, S, 40, 25, [('lanes', 3), ('stages', 0), ('lanes', 2)]) for S in (65, 454)); print('runs', n)"
+            % (ROOT, os.path.join(ROOT, "tests")))
+    txt = subprocess.check_output([os.sys.executable, "-c", code], env=env, timeout=900).decode()
+    assert "runs 50" in txt
+
+
+def test_clone_continues_bit_identically(nn):
+    """DenoiseState: Clone (src/denoise.rs:36): clone mid-stream (mid ring, mid group rotation), feed both the same input:
+    bit-identical; feed them different input: independent; a saved snapshot restores the same future."""
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(90, 200, 31)
+    a = nn.BatchDenoiser(200)
+    a.process(x[:, :13])
+    snap = a.save_state()
+    b = a.clone()
+    oa, va = a.process(x[:, 13:])
+    ob, vb = b.process(x[:, 13:])
+    assert np.array_equal(oa, ob) and np.array_equal(va, vb)
+    c = nn.BatchDenoiser(200)
+    c.load_state(snap)
+    oc, vc = c.process(x[:, 13:])
+    assert np.array_equal(oa, oc) and np.array_equal(va, vc)
+    b2 = a.clone()
+    o1, _ = a.process(x[:, :5])
+    o2, _ = b2.process(x[:, 5:10])
+    assert not np.array_equal(o1, o2)
+    st = nn.DenoiseState.new()
+    buf = np.zeros(480, np.float32)
+    for f in x[0, :4]:
+        st.process_frame(buf, f)
+    st2 = st.clone()
+    b1, b2_ = np.zeros(480, np.float32), np.zeros(480, np.float32)
+    assert st.process_frame(b1, x[0, 4]) == st2.process_frame(b2_, x[0, 4]) and np.array_equal(b1, b2_)
+
+
+def test_activation_functions_known_answers(nn, gpu_lib, oracle_mod):
+    """tansig_approx / sigmoid_approx (src/util.rs:29-53) on their own, device vs oracle, bit for bit: every table knot and
+    its two neighbours in f32, the saturation edges +-8, values beyond, zeros, denormals, infinities, NaN."""
+    import ctypes as C
+    knots = (np.arange(201, dtype=np.float64) * 0.04).astype(np.float32)
+    mids = ((np.arange(200, dtype=np.float64) + 0.5) * 0.04).astype(np.float32)
+    base = np.concatenate([knots, mids, np.float32([8.0, 7.9999995, 8.000001, 16.0, 15.999999, 100.0, 1e30, 1e-30, 1e-45, 0.0])])
+    xs = np.concatenate([base, np.nextafter(base, np.float32(np.inf)), np.nextafter(base, np.float32(-np.inf))])
+    xs = np.concatenate([xs, -xs, np.float32([np.inf, -np.inf, np.nan]),
+                         np.random.default_rng(3).uniform(-20, 20, 4000).astype(np.float32)])
+    for act in (0, 1):
+        y = np.empty_like(xs)
+        gpu_lib.check(gpu_lib.L.nnn_debug_activations(0, act, xs.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), len(xs)))
+        ref = oracle_mod.activation(xs, act)
+        assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), (act, xs[y.view(np.uint32) != ref.view(np.uint32)][:10])
+    y = np.empty_like(xs)
+    gpu_lib.check(gpu_lib.L.nnn_debug_activations(0, 2, xs.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), len(xs)))
+    relu = np.where(xs > 0, xs, np.float32(0.0))          # f32::max(x, 0): NaN -> 0
+    assert np.array_equal(y.view(np.uint32), relu.view(np.uint32))
+
+
+@pytest.mark.parametrize("rows", ["32", "16"])
+@pytest.mark.parametrize("nd", [40, 80])
+def test_wide_dense_layers(nn, oracle_mod, rows, nd, monkeypatch):
+    """Input dense layers wider than one round of the RNN block's 8 waves (neurons beyond the first round were
+    dropped): nd = 40 and 80 at both block shapes, against the oracle."""
+    from model_fixtures import make_model
+    from nnnoiseless_amd.synthetic import make_streams
+    blob = make_model(nd, 16 if nd == 40 else 4, 32, 64, seed=nd)   # nd + nv + 42 <= 127 (i8 sizes)
+    x = make_streams(17, 100, 6)
+    ref = oracle_mod.run_streams(oracle_mod.Model(blob), x)
+    monkeypatch.setenv("NNN_RNN_ROWS", rows)
+    bd = nn.BatchDenoiser(100, model=nn.RnnModel.from_bytes(blob))
+    out, vad = bd.process(x)
+    assert rel_rms(out[:, 1:], ref["out"][:, 1:]) <= 1e-5
+    assert np.abs(vad.T - ref["vad"]).max() <= 1e-4
+
+
+def test_long_calls_stay_inside_their_buffers():
+    """65 536 streams x 128-frame calls through nnn_batch_process_device with guard regions behind x, y and vad (VERDICT r1:
+    the round-1 bench harness ran past its pool at this size; the library itself must not)."""
+    import torch
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams_device
+    S, T, G = 65536, 128, 1 << 20
+    dev = torch.device("cuda", 0)
+    n = S * T * 480
+    xbuf = torch.full((n + G,), 12345.0, device=dev)
+    ybuf = torch.full((n + G,), -777.0, device=dev)
+    vbuf = torch.full((T * S + G,), -777.0, device=dev)
+    base = make_streams_device(torch, dev, S, 8, seed=5)
+    xbuf[:n].view(S, T // 8, 8 * 480)[:] = base.view(S, 1, 8 * 480)
+    bd = nn.BatchDenoiser(S)
+    for _ in range(2):
+        bd.process_device(xbuf.data_ptr(), ybuf.data_ptr(), vbuf.data_ptr(), T, T * 480, 480, torch.cuda.current_stream().cuda_stream)
+    bd.synchronize()
+    torch.cuda.synchronize()
+    assert bool((xbuf[n:] == 12345.0).all()) and bool((ybuf[n:] == -777.0).all()) and bool((vbuf[T * S:] == -777.0).all())
+    assert bool(torch.isfinite(ybuf[:n]).all()) and bool((vbuf[:T * S] >= 0).all())
+    bd.close()

@@ -22,7 +22,7 @@ def test_every_stage_against_oracle_taps(hostsim_lib, oracle_mod, weights_bytes,
     x[0] = golden_io[0][:T]
     om = oracle_mod.Model(weights_bytes)
     states = [oracle_mod.State(om) for _ in range(S)]
-    bd = nn.BatchDenoiser(S, lib=hostsim_lib)
+    bd = nn.BatchDenoiser(S, lib=hostsim_lib, taps=True)
     for t in range(T):
         out, vad = bd.process(x[:, t:t + 1])
         taps = {k: bd.tap(k) for k in list(INT_TAPS) + list(EXACT_TAPS) + list(TOL_TAPS)}
@@ -92,21 +92,6 @@ def test_rnnoise_c_abi_flow(hostsim_lib, golden_io):
     L.rnnoise_destroy(st)
     got = np.concatenate(outs[1:])
     assert golden_metric(got, ref[: got.size]) < 1e-4
-
-
-@pytest.mark.parametrize("chunk", ["8", "16"])
-def test_xcorr_chunk_variants_bit_identical(hostsim_lib, monkeypatch, chunk):
-    """k_xcorr<8> and <16> (picked for large batches) give the same bits as <4>: the per-lag sums stay sequential."""
-    import nnnoiseless_amd as nn
-    from nnnoiseless_amd.synthetic import make_streams
-    x = make_streams(40, 3, 3)
-    base = nn.BatchDenoiser(3, lib=hostsim_lib)
-    base.process(x)
-    want = base.tap("xcorr1")
-    monkeypatch.setenv("NNN_XCORR_CHUNK", chunk)
-    other = nn.BatchDenoiser(3, lib=hostsim_lib)
-    other.process(x)
-    assert np.array_equal(other.tap("xcorr1").view(np.uint32), want.view(np.uint32))
 
 
 def test_edge_case_inputs(hostsim_lib, oracle_mod, weights_bytes):
@@ -209,3 +194,52 @@ def test_rnnoise_c_abi_through_the_kernels(hostsim_lib, oracle_mod, weights_byte
         if t:
             assert rel_rms(buf, ref["out"][0, t]) < 1e-5
     L.rnnoise_destroy(st)
+
+
+def test_clone_and_snapshot(hostsim_lib):
+    """DenoiseState: Clone (src/denoise.rs:36) on the interpreter build: clone / saved snapshot continue bit-identically."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(90, 5, 11)
+    a = nn.BatchDenoiser(5, lib=hostsim_lib)
+    a.process(x[:, :5])
+    snap = a.save_state()
+    b = a.clone()
+    oa, va = a.process(x[:, 5:])
+    ob, vb = b.process(x[:, 5:])
+    assert np.array_equal(oa, ob) and np.array_equal(va, vb)
+    c = nn.BatchDenoiser(5, lib=hostsim_lib)
+    c.load_state(snap)
+    oc, vc = c.process(x[:, 5:])
+    assert np.array_equal(oa, oc) and np.array_equal(va, vc)
+    with pytest.raises(RuntimeError):
+        nn.BatchDenoiser(6, lib=hostsim_lib).load_state(snap)          # another shape: refused
+
+
+def test_activation_functions_known_answers(hostsim_lib, oracle_mod):
+    """tansig_approx / sigmoid_approx / relu of the kernels (src/util.rs:29-53) bit for bit against the oracle."""
+    knots = (np.arange(201, dtype=np.float64) * 0.04).astype(np.float32)
+    base = np.concatenate([knots, np.float32([8.0, 7.9999995, 8.000001, 16.0, 100.0, 1e30, 1e-30, 0.0])])
+    xs = np.concatenate([base, np.nextafter(base, np.float32(np.inf)), np.nextafter(base, np.float32(-np.inf))])
+    xs = np.concatenate([xs, -xs, np.float32([np.inf, -np.inf, np.nan]), np.random.default_rng(3).uniform(-20, 20, 500).astype(np.float32)])
+    for act in (0, 1):
+        y = np.empty_like(xs)
+        hostsim_lib.check(hostsim_lib.L.nnn_debug_activations(0, act, xs.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), len(xs)))
+        ref = oracle_mod.activation(xs, act)
+        assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), act
+
+
+@pytest.mark.parametrize("rows", ["32", "16"])
+def test_wide_dense_layers(hostsim_lib, oracle_mod, rows, monkeypatch):
+    """An input dense layer wider than one round of the RNN block's waves: nd = 80, both block shapes."""
+    import nnnoiseless_amd as nn
+    from model_fixtures import make_model
+    from nnnoiseless_amd.synthetic import make_streams
+    blob = make_model(80, 4, 32, 64, seed=80)       # 80 + 4 + 42 inputs to the noise GRU: the format's limit is 127
+    x = make_streams(17, 3, 4)
+    ref = oracle_mod.run_streams(oracle_mod.Model(blob), x)
+    monkeypatch.setenv("NNN_RNN_ROWS", rows)
+    bd = nn.BatchDenoiser(3, model=nn.RnnModel.from_bytes(blob, lib=hostsim_lib), lib=hostsim_lib)
+    out, vad = bd.process(x)
+    assert rel_rms(out[:, 1:], ref["out"][:, 1:]) <= 1e-5
+    assert np.abs(vad.T - ref["vad"]).max() <= 1e-4
