@@ -157,7 +157,7 @@ int nnn_batch_set_graph(nnn_batch *b, int on);
  * overlap (default), 0 = every call runs its groups back to back on the caller's stream.  Results are bit-identical. */
 int nnn_batch_set_pipeline(nnn_batch *b, int on);
 /* How a pipelined call uses the internal streams: mode 0 = not at all (as set_pipeline(0)); 1 = "lanes": the high-pass
- * chain on its own stream, the other six stages of group k on lane stream k mod `lanes` (1..4; default 3);
+ * chain on its own stream, the other six stages of group k on lane k mod `lanes` (1..4; default 2; lane 0 is the caller's stream);
  * 2 = "stages": one stream per stage pair, every stream a chain of groups.  Environment: NNN_SCHED=seq|lanes|stages,
  * NNN_LANES=n. */
 int nnn_batch_set_schedule(nnn_batch *b, int mode, int lanes);

@@ -131,8 +131,11 @@ def test_parity_subset_1024x200(nn, oracle_mod, weights_bytes):
     from nnnoiseless_amd.synthetic import make_streams
     S, T, C = 1024, 200, 20
     x = make_streams(7000, S, T)
-    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x, n_threads=os.cpu_count() or 1,
-                                 want=("out", "pitch", "branch", "vad", "gains"))
+    want = ("out", "pitch", "branch", "vad", "gains")
+    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x, n_threads=os.cpu_count() or 1, want=want)
+    # what f32 rounding in the FFT alone does to the gains, per stream: the oracle's f32-FFT build against its f64-FFT build
+    ref32 = oracle_mod.run_streams(oracle_mod.Model(weights_bytes, f32_fft=True), x, n_threads=os.cpu_count() or 1, want=("gains",))
+    gtol = np.maximum(1e-4, 3.0 * np.abs(ref["gains"] - ref32["gains"]).max(axis=(1, 2)))
     bd = nn.BatchDenoiser(S)
     outs, branch, pitch, gains = [], [], [], []
     for t in range(T):                               # frame by frame: the taps of every frame
@@ -144,7 +147,9 @@ def test_parity_subset_1024x200(nn, oracle_mod, weights_bytes):
     out = np.concatenate(outs, axis=1)
     branch, pitch = np.stack(branch, axis=1), np.stack(pitch, axis=1)
     assert np.array_equal(pitch, ref["pitch"])
-    assert np.abs(np.stack(gains, axis=1) - ref["gains"]).max() <= 1e-4
+    gerr = np.abs(np.stack(gains, axis=1) - ref["gains"]).max(axis=(1, 2))
+    print(f"gains: worst error {gerr.max():.2e}; streams with a tolerance above 1e-4: {int((gtol > 1e-4).sum())} of {S}, largest {gtol.max():.2e}")
+    assert (gerr <= gtol).all(), (gerr.max(), np.argwhere(gerr > gtol)[:8])
     excused, lst = flipped_frames(branch, ref["branch"])
     d = (out[:, 1:] - ref["out"][:, 1:]).astype(np.float64)
     rr = ref["out"][:, 1:].astype(np.float64)
