@@ -63,6 +63,9 @@ struct nnn_batch {
         const uint4 *wq = nullptr;     // packed bf16 weights (device)
         const float *fpar = nullptr;   // biases + vad output layer (device)
         size_t rnn_lds = 0;            // dynamic LDS bytes at `rows`
+        bool wf = false;               // the layer-pipelined kernel (k_rnn_wf) runs this group
+        WfPlan wp;
+        size_t wf_lds = 0;
         int rows = 32;                 // stream rows per RNN block: 32 or 16
         int tile0 = 0, ntiles = 0;
     };
@@ -201,6 +204,28 @@ static size_t rnn_lds_bytes(const RnnPlan &pl, int rows)
     return (256 + 128) * 4 + (size_t)3 * rows * cols * 2 + (size_t)(CEPS_MEM * NB + 28) * rows * 4;
 }
 constexpr size_t kLdsMax = 160 * 1024;
+// the layer-pipelined kernel: strides of its per-layer matrices and its dynamic LDS (mirrors k_rnn_wf's carve-up)
+static WfPlan rnn_wf_plan(const RnnPlan &pl)
+{
+    WfPlan w;
+    w.w_v = 32 * pl.vad.in.ksteps + 8;
+    w.w_n = 32 * pl.noise.in.ksteps + 8;
+    w.w_dn = 32 * pl.dn.in.ksteps + 8;
+    w.sw_v = 32 * pl.vad.rec.ksteps + 8;
+    w.sw_n = 32 * pl.noise.rec.ksteps + 8;
+    w.sw_dn = 32 * pl.dn.rec.ksteps + 8;
+    return w;
+}
+static size_t rnn_wf_lds_bytes(const WfPlan &w)
+{
+    const size_t cols = (size_t)w.w_v + 2 * w.w_n + 3 * w.w_dn + 2 * ((size_t)w.sw_v + w.sw_n + w.sw_dn) + WF_FS_W;
+    return (256 + 128) * 4 + (size_t)3 * WF_ROWS * cols * 2 + (size_t)(CEPS_MEM * NB + 28 + 28) * WF_ROWS * 4;
+}
+static bool rnn_wf_enabled()
+{
+    const char *e = getenv("NNN_RNN_WF");
+    return !e || atoi(e) != 0;
+}
 // below this many RNN blocks a launch leaves compute units idle and the per-block chain dominates
 static int rnn_small_batch_blocks()
 {
@@ -282,6 +307,12 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
         while (G.rows > 16 && G.ntiles * (TILE / G.rows) < rnn_small_batch_blocks()) G.rows /= 2;
         if (h->rnn_rows && rnn_lds_bytes(G.plan, h->rnn_rows) <= kLdsMax) G.rows = h->rnn_rows;
         G.rnn_lds = rnn_lds_bytes(G.plan, G.rows);
+        // models of the built-in shape class run the layer-pipelined kernel (its fixed wave roles cover 2 / 2 / 3 / 6 neuron
+        // blocks in the input dense / vad / noise / denoise layers)
+        G.wp = rnn_wf_plan(G.plan);
+        G.wf_lds = rnn_wf_lds_bytes(G.wp);
+        G.wf = rnn_wf_enabled() && !h->rnn_rows && G.plan.dense.nb <= 2 && G.plan.vad.nb <= 2 && G.plan.noise.nb <= 3 && G.plan.dn.nb <= 6 && G.plan.vad.rec.ksteps <= WF_KS_REC &&
+               G.plan.noise.rec.ksteps <= WF_KS_REC && G.plan.dn.rec.ksteps <= WF_KS_REC && G.wf_lds <= kLdsMax;   // (k_rnn_wf's wave roles)
         tile0 += G.ntiles;
         h->md.nd = md.nd > h->md.nd ? md.nd : h->md.nd;
         h->md.nv = md.nv > h->md.nv ? md.nv : h->md.nv;
@@ -357,6 +388,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     }
     // the RNN kernel's dynamic LDS limit is a per-device function attribute: raise it to the hardware's 160 KB once
     HIPCHK(hipFuncSetAttribute((const void *)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+    HIPCHK(hipFuncSetAttribute((const void *)k_rnn_wf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     HIPCHK(hipDeviceSynchronize());
     return 0;
 }
@@ -540,9 +572,14 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
     case ST_P2: L.go(K_PITCH2, k_pitch2, dim3(Sp / P2_SPB), dim3(64 * P2_SPB), 0, b, g); break;
     case ST_FFT: L.go(K_FFT_XP, k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0); break;
     case ST_RNN:
-        for (const nnn_batch::ModelGroup &G : h->groups)   // one launch per resident model (a run of whole tiles)
-            L.go(K_RNN, k_rnn, dim3((unsigned)(G.ntiles * (TILE / G.rows))), dim3(64 * RNN_WAVES), G.rnn_lds, b, G.plan, G.wq, G.fpar,
-                 G.tile0, G.rows, g);
+        for (const nnn_batch::ModelGroup &G : h->groups) {   // one launch per resident model (a run of whole tiles)
+            if (G.wf)
+                L.go(K_RNN, k_rnn_wf, dim3((unsigned)(G.ntiles * (TILE / WF_ROWS))), dim3(64 * WF_WAVES), G.wf_lds, b, G.plan, G.wp, G.wq,
+                     G.fpar, G.tile0, g);
+            else
+                L.go(K_RNN, k_rnn, dim3((unsigned)(G.ntiles * (TILE / G.rows))), dim3(64 * RNN_WAVES), G.rnn_lds, b, G.plan, G.wq, G.fpar,
+                     G.tile0, G.rows, g);
+        }
         break;
     case ST_SYN: L.go(K_SYNTH, k_synth, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0, g); break;
     }

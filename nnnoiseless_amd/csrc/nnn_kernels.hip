@@ -33,8 +33,11 @@ namespace nnn {
 // shader clock at labelled points so a phase breakdown can be read back through nnn_batch_read_stamps.
 #ifdef NNN_STAMPS
 #define NNN_STAMP(b, i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) (b).stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+// the same from lane 0 of any wave of block 0, when `cond` holds (role-by-role breakdowns)
+#define NNN_STAMPW(b, i, cond) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (cond)) (b).stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define NNN_STAMP(b, i) do { } while (0)
+#define NNN_STAMPW(b, i, cond) do { } while (0)
 #endif
 
 // Bark-ish band edges in units of 4 bins (ref: src/lib.rs:55-58) and SECOND_CHECK (ref: src/pitch.rs:489)
@@ -217,7 +220,8 @@ __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp, int 
 //     lane = stream; the five sequential chains run on the five waves of the block, which then share the
 //     (elementwise) FIR and write pitch_buf as TI (scans, coarse xcorr) and SM (wave = stream kernels).
 // ---------------------------------------------------------------------------------------------
-constexpr int LPC_CH = 216;                 // rows per staged chunk (864 = 4 chunks), + 4 look-ahead rows
+constexpr int LPC_CH = 96;                  // rows per staged chunk (864 = 9 chunks), + 4 look-ahead rows: 51 KB of LDS, 3 blocks per CU
+constexpr int LPC_NCH = XLP / LPC_CH;
 constexpr int LPC_ROWS = LPC_CH + 4;
 constexpr int LPC_PER_WAVE = LPC_ROWS / 5;  // 44 row loads in flight per wave
 
@@ -257,7 +261,7 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
                 }
             }
             const float (*cb)[64] = buf[ch & 1];
-            const int n = (j0 + LPC_CH <= fast_n) ? LPC_CH : fast_n - j0;   // 216, 216, 216, 212
+            const int n = (j0 + LPC_CH <= fast_n) ? LPC_CH : fast_n - j0;   // 96 x 8, then 92
             for (int i0 = 0; i0 < n; i0 += 4) {
                 float a[4], bb[4];
 #pragma unroll
@@ -272,10 +276,10 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
             __syncthreads();
         }
         // tail d_k = sum_{i = k+860}^{863} x[i] x[i-k], added after the main sum (ref: src/pitch.rs:439-445);
-        // rows 856..863 sit in the last chunk (buffer 1) at offset row - 648
-        const float (*cb)[64] = buf[1];
+        // rows 856..863 sit in the last chunk, at offset row - (first row of that chunk)
+        const float (*cb)[64] = buf[(LPC_NCH - 1) & 1];
         float d = 0.0f;
-        for (int i = k + fast_n; i < XLP; i++) d += cb[i - 3 * LPC_CH][lane] * cb[i - k - 3 * LPC_CH][lane];
+        for (int i = k + fast_n; i < XLP; i++) d += cb[i - (LPC_NCH - 1) * LPC_CH][lane] * cb[i - k - (LPC_NCH - 1) * LPC_CH][lane];
         acs[k][lane] = c + d;
     }
     __syncthreads();
@@ -1398,13 +1402,13 @@ __device__ __forceinline__ float load_split(const unsigned short *P, int plane_s
 // Weight fragments of one GEMM group: all k-steps (up to KSMAX) are requested together so that a layer pays
 // one trip to the Infinity Cache / HBM instead of one per k-step.
 constexpr int KSMAX = 4;
-template <int NG> struct Frags { uint4 f[KSMAX][NG]; };
+template <int NG, int KS = KSMAX> struct Frags { uint4 f[KS][NG]; };
 
-template <int NG, int G0>
-__device__ __forceinline__ void load_frags(Frags<NG> &fr, const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane)
+template <int NG, int G0, int KS = KSMAX>
+__device__ __forceinline__ void load_frags(Frags<NG, KS> &fr, const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane)
 {
 #pragma unroll
-    for (int ks = 0; ks < KSMAX; ks++)
+    for (int ks = 0; ks < KS; ks++)
 #pragma unroll
         for (int gi = 0; gi < NG; gi++)
             fr.f[ks][gi] = ks < g.ksteps ? Bnb[((G0 + gi) * g.ksteps + ks) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
@@ -1412,9 +1416,9 @@ __device__ __forceinline__ void load_frags(Frags<NG> &fr, const GemmDesc &g, con
 
 // acc[G0 + g][mb] += A[16 (mb0 + mb) .. +15][kbase ..] * B(gate G0 + g), g < NG, mb < MB, over all k-steps and
 // the three activation planes.  Bnb points at this neuron block's fragments ([gate][k-step][lane]).
-template <int NG, int MB, int G0>
+template <int NG, int MB, int G0, int KS = KSMAX>
 __device__ __forceinline__ void gemm_acc(f32x4 (&acc)[3][2], const unsigned short *A, int plane_stride, int row_w, int mb0,
-                                         const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane, const Frags<NG> &fr)
+                                         const GemmDesc &g, const uint4 *__restrict__ Bnb, int lane, const Frags<NG, KS> &fr)
 {
     const unsigned short *a0 = A + (size_t)(mb0 * 16 + (lane & 15)) * row_w + g.kbase + 8 * (lane >> 4);
     const size_t mb_stride = (size_t)16 * row_w;
@@ -1426,14 +1430,14 @@ __device__ __forceinline__ void gemm_acc(f32x4 (&acc)[3][2], const unsigned shor
     for (int pl = 0; pl < 3; pl++) cur[pl] = *(const uint4 *)(a0 + (size_t)pl * plane_stride);
     for (int ks = 0; ks < g.ksteps; ks++) {
         uint4 bfr[NG];
-        if (ks < KSMAX) {
+        if (ks < KS) {
 #pragma unroll
             for (int gi = 0; gi < NG; gi++) {
                 bfr[gi] = fr.f[0][gi];
 #pragma unroll
-                for (int u = 1; u < KSMAX; u++) bfr[gi] = (ks == u) ? fr.f[u][gi] : bfr[gi];
+                for (int u = 1; u < KS; u++) bfr[gi] = (ks == u) ? fr.f[u][gi] : bfr[gi];
             }
-        } else {   // models wider than 128 columns: fetch as we go
+        } else {   // more k-steps than the fragment set holds: fetch as we go
 #pragma unroll
             for (int gi = 0; gi < NG; gi++) bfr[gi] = Bnb[((G0 + gi) * g.ksteps + ks) * 64 + lane];
         }
@@ -1507,8 +1511,8 @@ __device__ __forceinline__ void gru_layer(const Buffers &b, const LayerDesc &L, 
 #pragma unroll
             for (int mb = 0; mb < MB; mb++) acc[g][mb] = f32x4{bias[g], bias[g], bias[g], bias[g]};
         }
+        gemm_acc<2, MB, 0>(acc, SP, sp_ps, sw, mb0, L.rec, Brec, lane, f_zr);   // (recurrent part first: the order k_rnn_wf uses)
         gemm_acc<3, MB, 0>(acc, lds.IN, lds.in_ps, pl.in_w, mb0, L.in, Bin, lane, f_in);
-        gemm_acc<2, MB, 0>(acc, SP, sp_ps, sw, mb0, L.rec, Brec, lane, f_zr);
         // r * state: the columns of this neuron block, plus (last block) the padding up to the GEMM's k range, as zeros
         const int kcols = 32 * L.rec.ksteps;
 #pragma unroll
@@ -1597,7 +1601,7 @@ __device__ __forceinline__ int pair_index(int i, int j) { return i * (15 - i) / 
 // three bf16 planes into the staging `FS` (row stride FS_W) and the row's live flag for that frame.
 constexpr int FS_W = 56;   // 48 feature columns + 8: 16-byte rows, odd multiple of 16 bytes
 __device__ __forceinline__ void features_row(const Buffers &b, int f, int tile, int trow, int ll, int rm, float *crs, float *dc,
-                                             unsigned short *FS, int *live_next, int &mem_id)
+                                             unsigned short *FS, int fs_w, int *live_next, int &mem_id)
 {
     const float *cg = NNN_TIF(b, cn, 28, f, tile, trow);
     float cn[28];
@@ -1651,7 +1655,7 @@ __device__ __forceinline__ void features_row(const Buffers &b, int f, int tile, 
         for (int k = 0; k < NFEAT; k++) fo[(size_t)k * TILE] = fr[k];
     }
 #pragma unroll
-    for (int k = 0; k < NFEAT; k++) store_split(FS, rm * FS_W, ll * FS_W + k, fr[k]);
+    for (int k = 0; k < NFEAT; k++) store_split(FS, rm * fs_w, ll * fs_w + k, fr[k]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1730,7 +1734,7 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     int mem_id = (wave == RNN_WAVES - 1 && rowl) ? NNN_TI(b.mem_id, 1, tile, trow)[0] : 0;
     lds_barrier();
     // frame 0's features (the last wave; the others have nothing to do yet)
-    if (wave == RNN_WAVES - 1 && rowl) features_row(b, 0, tile, trow, lane, rm, crs, dc, FS, live_next, mem_id);
+    if (wave == RNN_WAVES - 1 && rowl) features_row(b, 0, tile, trow, lane, rm, crs, dc, FS, FS_W, live_next, mem_id);
     NNN_STAMP(b, 9);
     for (int f = 0; f < g; f++) {
         // keep the frame loop's addresses inside the loop (see launder_v)
@@ -1752,7 +1756,7 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
         bool feat_done = (f + 1 >= g);   // wave-uniform: the next frame's features are staged (or there is no next frame)
         auto feat_next = [&]() {
             if (wave == RNN_WAVES - 1 && !feat_done) {
-                if (rowl) features_row(b, f + 1, tile, trow, lane, rm, crs, dc, FS, live_next, mem_id);
+                if (rowl) features_row(b, f + 1, tile, trow, lane, rm, crs, dc, FS, FS_W, live_next, mem_id);
                 feat_done = true;
             }
         };
@@ -1800,6 +1804,418 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     gru_state_io(pl.dn, rm, sdn, SPdn, sw_dn, false);
     if (wave == RNN_WAVES - 1 && rowl) NNN_TI(b.mem_id, 1, tile, trow)[0] = mem_id;
 #undef NNN_MB
+}
+
+// ---------------------------------------------------------------------------------------------
+// K10w rnn, layer-pipelined ("wavefront"): the same computation as k_rnn for models of the built-in shape class (at most 2 / 2 /
+//     3 / 6 neuron blocks of 16 in the input dense, vad, noise and denoise layers), 16 stream rows per block, 10 waves.
+//     The chain of a frame -- dense, three GRUs of two phases each, output dense -- is eleven dependent phases of ~1-2 us of
+//     mostly latency; here the layers of DIFFERENT frames run side by side, each on its own waves: in tick t the vad GRU works
+//     on frame t, the noise GRU on frame t - 1, the denoise GRU on frame t - 2, the output layer on frame t - 3, the input
+//     dense and the feature stage on frame t + 1, and a tick is two phases (everybody's first GEMM phase; everybody's second).
+//     A group of g frames takes g + 4 ticks instead of 11 g phases.
+//     Every layer reads its inputs from its own LDS matrix, written by its producers one to three ticks earlier into the
+//     slot of that frame (noise: 2 slots, denoise: 3), so nothing is overwritten before its last reader has passed; all
+//     matrices use the column coordinates of the packed weights (k_rnn's single input matrix), each holding the window its
+//     layer reads.  Roles (every phase of every layer is a latency chain, so no wave carries two of the long ones): waves 0..5
+//     denoise neuron block w; waves 6..8 noise block w - 6; waves 9, 10 vad block w - 9 plus the output and input dense units
+//     (dealt alternately); wave 11 features (lane = row), vad output, feature fan-out.
+// ---------------------------------------------------------------------------------------------
+constexpr int WF_ROWS = 16, WF_WAVES = 12, WF_FS_W = 72;   // feature staging: the input dense layer's two k-steps wide + 8
+
+struct WfGru {   // what a GRU unit keeps from its first phase to its second
+    f32x4 acc[3][2];
+    float zz[4], sold[4];
+};
+// The recurrent weight fragments of a wave's GRU unit (and its biases) stay in its registers for the whole launch; the input
+// fragments -- too many to keep beside them at three waves per SIMD -- are requested at the head of the first phase and
+// travel behind the recurrent GEMM.  Recurrent GEMMs of the shape class have <= 3 k-steps.
+constexpr int WF_KS_REC = 3;
+struct WfWeights {
+    Frags<2, WF_KS_REC> zr;
+    Frags<1, WF_KS_REC> h;
+    float bias[3];
+};
+__device__ __forceinline__ void wf_load_weights(WfWeights &w, const LayerDesc &L, const uint4 *__restrict__ Wq, const float *__restrict__ fpar,
+                                                int nbi, int lane)
+{
+    const uint4 *Brec = Wq + L.rec.wofs + (size_t)nbi * 3 * L.rec.ksteps * 64;
+    load_frags<2, 0, WF_KS_REC>(w.zr, L.rec, Brec, lane);
+    load_frags<1, 2, WF_KS_REC>(w.h, L.rec, Brec, lane);
+    const int neuron = nbi * 16 + (lane & 15);
+#pragma unroll
+    for (int g = 0; g < 3; g++) w.bias[g] = neuron < L.n ? fpar[L.bias + g * L.n + neuron] : 0.0f;
+}
+
+// first phase of GRU layer L for neuron block nbi: z, r, input part of the candidate; r * state -> RS (ref: src/rnn.rs:292-318)
+__device__ __forceinline__ void wf_gru_a(const LayerDesc &L, const unsigned short *Ain, int in_w, const unsigned short *SP, unsigned short *RS,
+                                         int sw, const uint4 *__restrict__ Wq, const WfWeights &w, const float *tab, int nbi, int lane, WfGru &u)
+{
+    const float scale = 1.0f / 256.0f;
+    const int neuron = nbi * 16 + (lane & 15);
+    const bool nvalid = neuron < L.n;
+    const uint4 *Bin = Wq + L.in.wofs + (size_t)nbi * 3 * L.in.ksteps * 64;
+    const uint4 *Brec = Wq + L.rec.wofs + (size_t)nbi * 3 * L.rec.ksteps * 64;
+    Frags<3> f_in;
+    load_frags<3, 0>(f_in, L.in, Bin, lane);
+#pragma unroll
+    for (int g = 0; g < 3; g++) u.acc[g][0] = f32x4{w.bias[g], w.bias[g], w.bias[g], w.bias[g]};
+    const int ps = WF_ROWS * sw;
+    gemm_acc<2, 1, 0, WF_KS_REC>(u.acc, SP, ps, sw, 0, L.rec, Brec, lane, w.zr);
+    gemm_acc<3, 1, 0>(u.acc, Ain, WF_ROWS * in_w, in_w, 0, L.in, Bin, lane, f_in);
+    const int kcols = 32 * L.rec.ksteps;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int row = 4 * (lane >> 4) + q;
+        const float so = nvalid ? load_split(SP, ps, row * sw + neuron) : 0.0f;   // the three planes hold the state exactly
+        u.sold[q] = so;
+        u.zz[q] = sigmoid_approx(scale * u.acc[0][0][q], tab);
+        const float rs = so * sigmoid_approx(scale * u.acc[1][0][q], tab);
+        if (neuron < kcols) store_split(RS, ps, row * sw + neuron, rs);
+        if (nbi == L.nb - 1 && neuron + 16 < kcols) store_split(RS, ps, row * sw + neuron + 16, 0.0f);
+    }
+}
+
+// second phase: recurrent part of the candidate on r * state, state update (ref: src/rnn.rs:319-326); sink(row, neuron, new state)
+template <class Sink>
+__device__ __forceinline__ void wf_gru_b(const LayerDesc &L, const unsigned short *RS, int sw, const uint4 *__restrict__ Wq, const WfWeights &w,
+                                         const float *tab, const int *live, int nbi, int lane, WfGru &u, Sink &&sink)
+{
+    const float scale = 1.0f / 256.0f;
+    const int neuron = nbi * 16 + (lane & 15);
+    const uint4 *Brec = Wq + L.rec.wofs + (size_t)nbi * 3 * L.rec.ksteps * 64;
+    gemm_acc<1, 1, 2, WF_KS_REC>(u.acc, RS, WF_ROWS * sw, sw, 0, L.rec, Brec, lane, w.h);
+    if (neuron < L.n) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int row = 4 * (lane >> 4) + q;
+            const float hh = activate(L.act, scale * u.acc[2][0][q], tab);
+            const float z = u.zz[q], so = u.sold[q];
+            float snew = z * so + (1.0f - z) * hh;
+            snew = live[row] ? snew : so;   // silent frames leave the state alone (ref: src/denoise.rs:100)
+            sink(row, neuron, snew);
+        }
+    }
+}
+
+// The feature stage of one frame on all 64 lanes of the features wave: lane = (row, part), row = lane & 15, part = lane >> 4.
+// Same arithmetic as features_row (which one lane per row runs start to finish); the four parts of a row share the new
+// cepstrum through LDS (`cnb`), split the 7 pair distances the new ring row takes part in and the 42 outputs.  The frame's
+// inputs (written by k_fft_xp / k_pitch2, in HBM) are requested a tick ahead: WfFeatIn.
+// (they live in the registers of the features wave's otherwise unused weight set: one register allocation serves all roles)
+struct WfFeatIn {
+    float mine[7];
+    int pitch, silent;
+};
+__device__ __forceinline__ void wf_features_load(WfWeights &w, const Buffers &b, int f, int tile, int r0, int lane)
+{
+    const int row = lane & 15, part = lane >> 4, trow = r0 + row;
+    const float *cg = NNN_TIF(b, cn, 28, f, tile, trow);
+    unsigned m[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) m[i] = __float_as_uint(cg[(size_t)(7 * part + i) * TILE]);
+    w.zr.f[0][0] = make_uint4(m[0], m[1], m[2], m[3]);
+    w.zr.f[0][1] = make_uint4(m[4], m[5], m[6], (unsigned)NNN_TIF(b, pitch, 1, f, tile, trow)[0]);
+    w.h.f[0][0].x = (unsigned)NNN_TIF(b, silence, 1, f, tile, trow)[0];
+}
+__device__ __forceinline__ WfFeatIn wf_features_in(const WfWeights &w)
+{
+    WfFeatIn in;
+    const uint4 a = w.zr.f[0][0], c = w.zr.f[0][1];
+    in.mine[0] = __uint_as_float(a.x); in.mine[1] = __uint_as_float(a.y); in.mine[2] = __uint_as_float(a.z); in.mine[3] = __uint_as_float(a.w);
+    in.mine[4] = __uint_as_float(c.x); in.mine[5] = __uint_as_float(c.y); in.mine[6] = __uint_as_float(c.z);
+    in.pitch = (int)c.w;
+    in.silent = (int)w.h.f[0][0].x;
+    return in;
+}
+__device__ __forceinline__ void wf_features(const Buffers &b, const WfFeatIn &in, int f, int tile, int r0, int lane, float *crs, float *dc,
+                                            float *cnb, unsigned short *FS, int *live_f, int &mem_id)
+{
+    constexpr int rm = WF_ROWS;
+    const int row = lane & 15, part = lane >> 4, trow = r0 + row;
+    const int pitch = in.pitch;
+    const bool silent = in.silent != 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) cnb[(7 * part + i) * rm + row] = in.mine[i];
+    wave_lds_sync();
+    if (part == 0) live_f[row] = silent ? 0 : 1;
+    const int c0 = mem_id, c1 = mem_id < 1 ? CEPS_MEM + mem_id - 1 : mem_id - 1;
+    const int c2 = mem_id < 2 ? CEPS_MEM + mem_id - 2 : mem_id - 2;
+    if (!silent) {   // "if there's no audio, avoid messing up the state" (ref: src/features.rs:160-166)
+        float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, trow);
+        for (int k = part; k < NB; k += 4) {
+            const float v = cnb[k * rm + row];
+            cm[(size_t)(c0 * NB + k) * TILE] = v;
+            crs[(c0 * NB + k) * rm + row] = v;
+        }
+        mem_id = mem_id + 1 == CEPS_MEM ? 0 : mem_id + 1;
+        // the 7 distances the new row takes part in, each summed over the 22 bands in order (ref: src/features.rs:203-208);
+        // they read the new row from cnb and the others from the ring (rows j != c0 are not being written)
+        for (int i = part; i < CEPS_MEM - 1; i += 4) {
+            const int j = i < c0 ? i : i + 1;
+            float dist = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const float d = cnb[k * rm + row] - crs[(j * NB + k) * rm + row];
+                dist += d * d;
+            }
+            dc[pair_index(j < c0 ? j : c0, j < c0 ? c0 : j) * rm + row] = dist;
+        }
+    }
+    wave_lds_sync();
+    // outputs k = part, part + 4, ...: 0..39 without a branch (every output is v0 [+ a v1] [+- v2] on the new cepstrum v0 and the
+    // two ring rows before it, the operations of features_row in its order; the LDS reads of several travel together)
+#pragma unroll 2
+    for (int j = 0; j < 10; j++) {
+        const int k = part + 4 * j;
+        const int type = k < 6 ? 0 : (k < NB ? 1 : (k < NB + 6 ? 2 : (k < NB + 12 ? 3 : 4)));
+        const int i0 = type == 2 ? k - NB : (type == 3 ? k - NB - 6 : (type == 4 ? k - 12 : k));   // type 4: cn[22 + (k - 34)]
+        const int i1 = (type == 0 || type == 2 || type == 3) ? i0 : 0;
+        const float v0 = cnb[i0 * rm + row], v1 = crs[(c1 * NB + i1) * rm + row], v2 = crs[(c2 * NB + i1) * rm + row];
+        const float a = type == 0 ? v1 : (type == 3 ? -(2.0f * v1) : 0.0f);
+        const float c = (type == 0 || type == 3) ? v2 : (type == 2 ? -v2 : 0.0f);
+        float v = (v0 + a) + c;
+        v = silent ? 0.0f : v;
+        if (b.taps) NNN_TIF(b, feat, NFEAT, f, tile, trow)[(size_t)k * TILE] = v;
+        store_split(FS, rm * WF_FS_W, row * WF_FS_W + k, v);
+    }
+    if (part < 2) {   // k = 40 (pitch) on part 0, k = 41 (spectral variability) on part 1
+        float v = part == 0 ? 0.01f * ((float)pitch - 300.0f) : spectral_variability(dc, row, rm);
+        v = silent ? 0.0f : v;
+        if (b.taps) NNN_TIF(b, feat, NFEAT, f, tile, trow)[(size_t)(40 + part) * TILE] = v;
+        store_split(FS, rm * WF_FS_W, row * WF_FS_W + 40 + part, v);
+    }
+}
+
+// dense unit nbi of layer L on the 16 rows of the block; sink(row, neuron, value).  Its weights are requested by wf_dense_load,
+// placed ahead of other work of the phase so that they travel behind it.
+template <int KS> struct WfDenseW {
+    Frags<1, KS> fr;
+    float bias;
+};
+template <int KS>
+__device__ __forceinline__ void wf_dense_load(WfDenseW<KS> &w, const LayerDesc &L, const uint4 *__restrict__ Wq, const float *__restrict__ fpar,
+                                              int nbi, int lane)
+{
+    load_frags<1, 0, KS>(w.fr, L.in, Wq + L.in.wofs + (size_t)nbi * L.in.ksteps * 64, lane);
+    const int neuron = nbi * 16 + (lane & 15);
+    w.bias = neuron < L.n ? fpar[L.bias + neuron] : 0.0f;
+}
+template <int KS, class Sink>
+__device__ __forceinline__ void wf_dense(const LayerDesc &L, const unsigned short *Ain, int in_w, const uint4 *__restrict__ Wq, const WfDenseW<KS> &w,
+                                         const float *tab, int nbi, int lane, Sink &&sink)
+{
+    const int neuron = nbi * 16 + (lane & 15);
+    const uint4 *Bnb = Wq + L.in.wofs + (size_t)nbi * L.in.ksteps * 64;
+    f32x4 acc[3][2];
+    acc[0][0] = f32x4{w.bias, w.bias, w.bias, w.bias};
+    gemm_acc<1, 1, 0, KS>(acc, Ain, WF_ROWS * in_w, in_w, 0, L.in, Bnb, lane, w.fr);
+    if (neuron < L.n) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) sink(4 * (lane >> 4) + q, neuron, activate(L.act, acc[0][0][q] * (1.0f / 256.0f), tab));
+    }
+}
+
+struct WfPlan {   // LDS strides (bf16 elements) of the per-layer matrices, set by the host from the model
+    int w_v, w_n, w_dn;         // input windows: vad [cD ..], noise [cV ..], denoise [0 ..]
+    int sw_v, sw_n, sw_dn;      // state / r * state matrices
+};
+
+__global__ void __launch_bounds__(64 * WF_WAVES) k_rnn_wf(Buffers b, RnnPlan pl, WfPlan wp, const uint4 *__restrict__ Wq,
+                                                            const float *__restrict__ fpar, int tile0, int g)
+{
+    HIP_DYNAMIC_SHARED(float, lds_raw)
+    constexpr int rm = WF_ROWS;
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane0 = threadIdx.x & 63;
+    int wave = wave0, lane = lane0;
+    const int tile = tile0 + (int)blockIdx.x / (TILE / rm);
+    const int r0 = ((int)blockIdx.x % (TILE / rm)) * rm;     // first row of the tile handled here
+    const bool rowl = lane0 < rm;
+    const int trow = r0 + (rowl ? lane0 : 0);
+    NNN_STAMP(b, 50);
+    // ---- LDS carve-up (rnn_wf_lds_bytes on the host mirrors it)
+    float *tab = lds_raw;
+    int *live = (int *)(lds_raw + 256);                  // [8][16]: live flags of frame f at slot f mod 8 (written a tick before the
+                                                         // first reader, read until three ticks after)
+    unsigned short *Xv = (unsigned short *)(lds_raw + 256 + 128);
+    unsigned short *Xn = Xv + 3 * rm * wp.w_v;           // 2 slots
+    unsigned short *Xdn = Xn + 2 * 3 * rm * wp.w_n;      // 3 slots
+    unsigned short *SPv = Xdn + 3 * 3 * rm * wp.w_dn, *SPn = SPv + 3 * rm * wp.sw_v, *SPdn = SPn + 3 * rm * wp.sw_n;
+    unsigned short *RSv = SPdn + 3 * rm * wp.sw_dn, *RSn = RSv + 3 * rm * wp.sw_v, *RSdn = RSn + 3 * rm * wp.sw_n;
+    unsigned short *FS = RSdn + 3 * rm * wp.sw_dn;
+    float *crs = (float *)(FS + 3 * rm * WF_FS_W);       // cepstral ring [8 * 22][rm]
+    float *dc = crs + CEPS_MEM * NB * rm;                // pair distances [28][rm]
+    float *cnb = dc + 28 * rm;                           // the frame's own cepstrum + pitch-correlation DCT [28][rm] (features wave)
+    const int cD = pl.dense.out_col, cV = pl.cV, cF = pl.cF;
+    float *sv = b.gru_v + ((size_t)tile * TILE * b.gru_v_w + (size_t)r0 * pl.vad.n),
+          *sn = b.gru_n + ((size_t)tile * TILE * b.gru_n_w + (size_t)r0 * pl.noise.n),
+          *sdn = b.gru_dn + ((size_t)tile * TILE * b.gru_dn_w + (size_t)r0 * pl.dn.n);
+    // ---- once per launch: zero every operand plane, activation table, cepstral ring, states, pair distances
+    {
+        uint4 *z = (uint4 *)Xv;
+        const int n16 = (int)(((char *)crs - (char *)Xv) / 16);
+        for (int i = (int)threadIdx.x; i < n16; i += 64 * WF_WAVES) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = (int)threadIdx.x; i < 201; i += 64 * WF_WAVES) tab[i] = b.tansig[i];
+        const float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, trow);
+        constexpr int PER = (CEPS_MEM * NB + WF_WAVES - 1) / WF_WAVES;
+        float stg[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int r = wave + i * WF_WAVES;
+            stg[i] = (rowl && r < CEPS_MEM * NB) ? cm[(size_t)r * TILE] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int r = wave + i * WF_WAVES;
+            if (rowl && r < CEPS_MEM * NB) crs[r * rm + lane] = stg[i];
+        }
+    }
+    lds_barrier();
+    {
+        auto load_state = [&](const LayerDesc &L, const float *state, unsigned short *SP, int sw) {
+            for (int e = (int)threadIdx.x; e < rm * L.n; e += 64 * WF_WAVES) {
+                const int row = e / L.n, col = e - row * L.n;
+                store_split(SP, rm * sw, row * sw + col, state[e]);
+            }
+        };
+        load_state(pl.vad, sv, SPv, wp.sw_v);
+        load_state(pl.noise, sn, SPn, wp.sw_n);
+        load_state(pl.dn, sdn, SPdn, wp.sw_dn);
+        if (rowl)
+            for (int p = wave; p < 28; p += WF_WAVES) dc[p * rm + lane] = pair_dist(crs, p, lane, rm);
+    }
+    int mem_id = wave == WF_WAVES - 1 ? NNN_TI(b.mem_id, 1, tile, r0 + (lane & 15))[0] : 0;   // every part of a row keeps a copy
+    // this wave's GRU unit: its weights stay in registers for all ticks
+    const int W_N = 6, W_V = 9, W_F = 11;   // first wave of the noise / vad roles; the features wave
+    WfWeights wts;
+    if (wave < W_N) wf_load_weights(wts, pl.dn, Wq, fpar, wave < pl.dn.nb ? wave : 0, lane);
+    else if (wave < W_V) wf_load_weights(wts, pl.noise, Wq, fpar, wave - W_N < pl.noise.nb ? wave - W_N : 0, lane);
+    else if (wave < W_F) wf_load_weights(wts, pl.vad, Wq, fpar, wave - W_V < pl.vad.nb ? wave - W_V : 0, lane);
+    else wf_load_weights(wts, pl.vad, Wq, fpar, 0, lane);   // (the features wave keeps its prefetched inputs there)
+    lds_barrier();
+    NNN_STAMP(b, 51);
+    WfGru ua;   // the GRU unit of this wave (denoise / noise / vad by role), first phase -> second phase
+    if (wave == WF_WAVES - 1 && g > 0) wf_features_load(wts, b, 0, tile, r0, lane);
+    // the features wave is all vector ALU on one wave while the GRU waves wait on matrix results: let it issue first
+    if (wave0 == WF_WAVES - 1) wf_setprio_high();
+    for (int t = -1; t < g + 3; t++) {
+        lane = launder_v(lane0);   // keep the tick loop's addresses inside the loop (see launder_v)
+        wave = launder_s(wave0);
+        const int fv = t, fn = t - 1, fd = t - 2, fo = t - 3, ff = t + 1;   // the frame each layer works on in this tick
+        const bool on_v = fv >= 0 && fv < g, on_n = fn >= 0 && fn < g, on_d = fd >= 0 && fd < g, on_o = fo >= 0 && fo < g,
+                   on_f = ff >= 0 && ff < g;
+        unsigned short *Xn_n = Xn + (fn & 1) * 3 * rm * wp.w_n;               // noise input of frame fn
+        unsigned short *Xdn_d = Xdn + ((fd + 3) % 3) * 3 * rm * wp.w_dn;      // denoise input of frame fd
+        // role stamps of a mid-group tick: slots 30 + 5 role + {0: tick start, 1: first phase done, 2: past barrier, 3: second phase done, 4: past barrier}
+        const int srole = wave0 == 0 ? 0 : (wave0 == 6 ? 1 : (wave0 == 9 ? 2 : (wave0 == 11 ? 3 : -1)));
+        NNN_STAMPW(b, 30 + 5 * srole, t == 2 && srole >= 0);
+        // ---------------- first phase
+        if (wave < W_N) {
+            if (on_d && wave < pl.dn.nb) wf_gru_a(pl.dn, Xdn_d, wp.w_dn, SPdn, RSdn, wp.sw_dn, Wq, wts, tab, wave, lane, ua);
+        } else if (wave < W_V) {
+            if (on_n && wave - W_N < pl.noise.nb) wf_gru_a(pl.noise, Xn_n - cV, wp.w_n, SPn, RSn, wp.sw_n, Wq, wts, tab, wave - W_N, lane, ua);
+        } else if (wave < W_F) {
+            WfDenseW<3> dw;   // the output layer reads the denoise state: <= 96 columns in this shape class
+            const bool mine_o = on_o && wave - W_V < pl.out.nb;   // (the output layer has 22 neurons: two units, one per vad wave)
+            if (on_v && wave - W_V < pl.vad.nb) wf_gru_a(pl.vad, Xv - cD, wp.w_v, SPv, RSv, wp.sw_v, Wq, wts, tab, wave - W_V, lane, ua);
+            if (mine_o) {   // gains of frame fo (ref: src/rnn.rs:378) and smoothing g = max(g, 0.6 lastg) (ref: src/denoise.rs:106-109)
+                const int *lv = live + 16 * (fo & 7);
+                {
+                    const int nbi = wave - W_V;
+                    wf_dense_load(dw, pl.out, Wq, fpar, wave - W_V, lane);
+                    wf_dense(pl.out, SPdn, wp.sw_dn, Wq, dw, tab, nbi, lane, [&](int lrow, int band, float v) {
+                        const int row = r0 + lrow;
+                        const bool on = lv[lrow] != 0;
+                        const float gr = on ? v : 0.0f;
+                        NNN_TIF(b, g_raw, NB, fo, tile, row)[(size_t)band * TILE] = gr;
+                        float gs = 0.0f;
+                        if (on) {
+                            float *lg = NNN_TI(b.lastg, NB, tile, row) + (size_t)band * TILE;
+                            gs = fmaxf(gr, 0.6f * *lg);
+                            *lg = gs;
+                        }
+                        NNN_TIF(b, g, NB, fo, tile, row)[(size_t)band * TILE] = gs;
+                    });
+                }
+            }
+        } else {
+            if (on_f) wf_features(b, wf_features_in(wts), ff, tile, r0, lane, crs, dc, cnb, FS, live + 16 * (ff & 7), mem_id);
+            if (ff + 1 >= 0 && ff + 1 < g) wf_features_load(wts, b, ff + 1, tile, r0, lane);   // the next tick's inputs start travelling
+        }
+        NNN_STAMPW(b, 31 + 5 * srole, t == 2 && srole >= 0);
+        lds_barrier();
+        NNN_STAMPW(b, 32 + 5 * srole, t == 2 && srole >= 0);
+        // ---------------- second phase
+        if (wave < W_N) {
+            if (on_d && wave < pl.dn.nb)
+                wf_gru_b(pl.dn, RSdn, wp.sw_dn, Wq, wts, tab, live + 16 * (fd & 7), wave, lane, ua,
+                         [&](int row, int n, float v) { store_split(SPdn, rm * wp.sw_dn, row * wp.sw_dn + n, v); });
+        } else if (wave < W_V) {
+            if (on_n && wave - W_N < pl.noise.nb) {
+                unsigned short *Xd = Xdn + (fn % 3) * 3 * rm * wp.w_dn;   // the denoise layer's input of the same frame
+                wf_gru_b(pl.noise, RSn, wp.sw_n, Wq, wts, tab, live + 16 * (fn & 7), wave - W_N, lane, ua, [&](int row, int n, float v) {
+                    store_split(SPn, rm * wp.sw_n, row * wp.sw_n + n, v);
+                    store_split(Xd, rm * wp.w_dn, row * wp.w_dn + n, v);
+                });
+            }
+        } else if (wave < W_F) {
+            WfDenseW<2> dw;   // the input dense layer reads the 42 features: two k-steps
+            const bool mine_d = on_f && wave - W_V < pl.dense.nb;
+            if (on_v && wave - W_V < pl.vad.nb) {
+                unsigned short *Xnn = Xn + (fv & 1) * 3 * rm * wp.w_n, *Xd = Xdn + (fv % 3) * 3 * rm * wp.w_dn;
+                wf_gru_b(pl.vad, RSv, wp.sw_v, Wq, wts, tab, live + 16 * (fv & 7), wave - W_V, lane, ua, [&](int row, int n, float v) {
+                    store_split(SPv, rm * wp.sw_v, row * wp.sw_v + n, v);
+                    store_split(Xnn, rm * wp.w_n, row * wp.w_n + n, v);               // noise window starts at cV
+                    store_split(Xd, rm * wp.w_dn, row * wp.w_dn + cV + n, v);
+                });
+            }
+            if (mine_d) {   // input dense of frame ff (ref: src/rnn.rs:353-355) on the features staged in the first phase
+                unsigned short *Xnn = Xn + (ff & 1) * 3 * rm * wp.w_n;
+                wf_dense_load(dw, pl.dense, Wq, fpar, wave - W_V, lane);
+                wf_dense(pl.dense, FS - cF, WF_FS_W, Wq, dw, tab, wave - W_V, lane, [&](int row, int n, float v) {
+                    store_split(Xv, rm * wp.w_v, row * wp.w_v + n, v);                      // vad window starts at cD
+                    store_split(Xnn, rm * wp.w_n, row * wp.w_n + (cD - cV) + n, v);
+                });
+            }
+        } else {
+            if (on_f) {
+                // feature fan-out: the staged features of frame ff -> the noise and denoise inputs of that frame (48 columns)
+                unsigned short *Xnn = Xn + (ff & 1) * 3 * rm * wp.w_n, *Xd = Xdn + (ff % 3) * 3 * rm * wp.w_dn;
+                for (int i = lane; i < 3 * rm * 6; i += 64) {
+                    const int plx = i / (rm * 6), rem = i - plx * rm * 6, row = rem / 6, c8 = rem - row * 6;
+                    const uint4 v = *(const uint4 *)(FS + (size_t)plx * rm * WF_FS_W + row * WF_FS_W + 8 * c8);
+                    *(uint4 *)(Xnn + (size_t)plx * rm * wp.w_n + row * wp.w_n + (cF - cV) + 8 * c8) = v;
+                    *(uint4 *)(Xd + (size_t)plx * rm * wp.w_dn + row * wp.w_dn + cF + 8 * c8) = v;
+                }
+            }
+            if (on_n && rowl) {
+                // vad output of frame fn, 1 x nv, lane = stream (ref: src/rnn.rs:359), from the copy of that frame's vad state in
+                // the noise layer's input (columns 0.. of its window; not rewritten before tick fn + 2)
+                const unsigned short *Xv1 = Xn + (fn & 1) * 3 * rm * wp.w_n;
+                float acc = fpar[pl.vo_b];
+                for (int k = 0; k < pl.vad.n; k++) acc = fmaf(fpar[pl.vo_w + k], load_split(Xv1, rm * wp.w_n, lane * wp.w_n + k), acc);
+                NNN_TIF(b, vad, 1, fn, tile, trow)[0] = live[16 * (fn & 7) + lane] ? activate(pl.act_vo, acc * (1.0f / 256.0f), tab) : 0.0f;
+            }
+        }
+        NNN_STAMPW(b, 33 + 5 * srole, t == 2 && srole >= 0);
+        lds_barrier();
+        NNN_STAMPW(b, 34 + 5 * srole, t == 2 && srole >= 0);
+    }
+    // ---- states back to HBM
+    {
+        auto save_state = [&](const LayerDesc &L, float *state, const unsigned short *SP, int sw) {
+            for (int e = (int)threadIdx.x; e < rm * L.n; e += 64 * WF_WAVES) {
+                const int row = e / L.n, col = e - row * L.n;
+                state[e] = load_split(SP, rm * sw, row * sw + col);
+            }
+        };
+        save_state(pl.vad, sv, SPv, wp.sw_v);
+        save_state(pl.noise, sn, SPn, wp.sw_n);
+        save_state(pl.dn, sdn, SPdn, wp.sw_dn);
+    }
+    if (wave0 == WF_WAVES - 1 && rowl) NNN_TI(b.mem_id, 1, tile, trow)[0] = mem_id;   // (part 0 of every row)
+    NNN_STAMP(b, 52);
 }
 
 // interpolated band gain at bin k (ref: src/lib.rs:84-97): zero for k >= 400

@@ -23,7 +23,7 @@ constexpr int NFEAT = 42;         // src/lib.rs:53
 constexpr int CEPS_MEM = 8;       // src/lib.rs:50
 constexpr int HIST = 1728;        // PITCH_BUF_SIZE, src/lib.rs:46
 #ifndef NNN_GROUP
-#define NNN_GROUP 4
+#define NNN_GROUP 8
 #endif
 #ifndef NNN_DEPTH
 #define NNN_DEPTH 3

@@ -57,6 +57,7 @@ template <class T> __device__ __forceinline__ void st_global(void *p, T v)
 // Opaque identity on a per-lane / wave-uniform value.  Inside a loop over the frames of a group it makes everything derived
 // from the value loop-variant for the compiler: otherwise every address of every phase is hoisted out of the frame loop as
 // loop invariant, hundreds of registers wide, and spilled (measured: 300 spills in k_rnn without it, none with it).
+__device__ __forceinline__ void wf_setprio_high() { __builtin_amdgcn_s_setprio(3); }
 __device__ __forceinline__ int launder_v(int x)
 {
     asm volatile("" : "+v"(x));

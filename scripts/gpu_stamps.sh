@@ -14,18 +14,23 @@ from nnnoiseless_amd import _ffi
 from nnnoiseless_amd.synthetic import make_streams_fast
 lib = _ffi.Library('/tmp/libnnn_stamps.so')
 lib.L.nnn_batch_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
-for S, rows, T in ((4096, 32, 4), (4096, 16, 4), (4096, 32, 1), (65536, 32, 4)):
-    os.environ['NNN_RNN_ROWS'] = str(rows)
+for S, rows, T in ((4096, 0, 4), (4096, 32, 4), (65536, 0, 4)):
+    os.environ.pop('NNN_RNN_ROWS', None)
+    if rows: os.environ['NNN_RNN_ROWS'] = str(rows)
     bd = nn.BatchDenoiser(S, lib=lib)
     bd.set_pipeline(False)
     x = make_streams_fast(S, 2 * T)
     bd.process(x[:, :T]); bd.process(x[:, T:])
     st = np.zeros(64, np.int64)
     lib.L.nnn_batch_read_stamps(bd._h, st.ctypes.data_as(C.c_void_p))
-    d = lambda a, b: round((st[b] - st[a]) / 100.0, 2)   # s_memtime ticks at 100 MHz -> us
+    d = lambda a, b: round((st[b] - st[a]) / 2100.0, 2)   # shader-clock cycles at ~2.1 GHz -> us (approximate)
     print(f"S={S} rnn rows={rows} frames/launch={T}  [us]")
     print("  k_rnn: setup+feat0", d(8, 9), "| last frame: copy..dense", d(10, 11), "vad", d(11, 12), "noise(+vadout)", d(12, 13), "dn", d(13, 14), "out+featnext", d(14, 15), " frame total", d(10, 15))
     print("  dn layer: frag issue..phaseA done", d(16, 22), "barrier wait", d(22, 18), "gemm h", d(18, 23), "epilogue", d(23, 26), "closing barrier", d(26, 14))
+    print("  k_rnn_wf: setup", d(50, 51), "ticks", d(51, 52), "| tick 2 by role [first phase, barrier wait, second phase, barrier wait]:")
+    for r, name in enumerate(("denoise unit", "noise unit", "vad + out + dense", "features")):
+        o = 30 + 5 * r
+        print("     ", name, d(o, o + 1), d(o + 1, o + 2), d(o + 2, o + 3), d(o + 3, o + 4), " tick", d(o, o + 4))
     print("  k_hp total (last frame)", d(24, 25), " k_lpc: autocorr", d(0, 1), "lpc", d(1, 2), "fir", d(2, 3))
     bd.close()
 PY

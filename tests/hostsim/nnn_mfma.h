@@ -58,6 +58,7 @@ template <class T> static inline T ld_global(const void *p) { T v; memcpy(&v, p,
 static inline uint4 ld_global_u4(const void *p) { return ld_global<uint4>(p); }
 template <class T> static inline void st_global(void *p, T v) { memcpy(p, &v, sizeof(T)); }
 
+static inline void wf_setprio_high() {}
 static inline int launder_v(int x) { return x; }
 static inline int launder_s(int x) { return x; }
 

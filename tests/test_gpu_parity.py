@@ -223,7 +223,7 @@ def test_two_frames_in_flight_is_bit_identical(nn):
     b2, vb = bd.process(x[:, 3:])
     assert np.array_equal(np.concatenate([a, b2], axis=1), want)
     assert np.array_equal(np.concatenate([va, vb], axis=0), want_vad)
-    for k in ("pitch", "g", "features"):
+    for k in ("pitch", "g", "branch", "vad"):
         assert np.array_equal(bd.tap(k), ref.tap(k)), k
     # call lengths that leave the group rotation (3 set blocks) and the ramped group sizes in every phase
     for cuts in ((1, 2, 5, 7, 11, 4, 7), (2, 2, 2, 13, 1, 1, 16), (9, 9, 9, 10), (37,)):
