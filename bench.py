@@ -53,7 +53,7 @@ G = 8
 KERNEL_BYTES = {
     "k_hp": 1920 + 1920 + 960 + 960 // 5 + 4 + (16 + 8) // G,     # input, history slot, 240 decimated values (+ mirrored share), x_lp[0]; biquad state per group
     "k_lpc": 3456 + 4 + 40 + 3456,                                 # decimated window in; taps + pitch_buf (tile-interleaved only) out
-    "k_pitch1": 3456 + 8 + 1176 + 1544,                            # pitch_buf in; best / second lag, fine-lag energies, xx / yy_lookup out
+    "k_pitch1": 3456 + 8 + 588 + 1176 + 1544,                      # pitch_buf in; best / second lag, coarse- and fine-lag energies, xx / yy_lookup out
     "k_pitch2": 3456 + 8 + 40 + 120 + 12 + 16 // G,                # pitch_buf in (16-stream slices through LDS), lags / energies looked up; pitch out
     "k_fft_xp": 3840 + 1200 + 4 + 3848 + 3200 + 264 + 112 + 4,     # 960 + (mean lag 300) history samples; X (481 bins), P (400 bins), band energies, cepstrum head out
     "k_rnn": 120 + 88 + 4 + 2 * 88 + 2 * 88 + (704 + 2 * 672 + 8) // G,   # features head in; ring row, vad, gains, last gains; ring + GRU states per group
@@ -157,6 +157,7 @@ def parse_args(argv=None):
     ap.add_argument("--channels", type=int, default=1, help="interleaved channels per group (with --pcm i16/unit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-tick", action="store_true", help="skip the one-frame-per-call measurement")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs[2] / configs[4] measurements of the default run")
     ap.add_argument("--pool-bytes", type=float, default=6e9, help="HBM budget for the resident input pool (and as much again for the output)")
     ap.add_argument("--dry-run", action="store_true",
@@ -372,7 +373,7 @@ def main():
         args.frames_per_step = min(args.frames_per_step, 3)
         args.steps, args.warmup = min(args.steps, 2), min(args.warmup, 1)
     model_path = args.model or cfg["model"]
-    res = measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want_roofline=not args.no_roofline)
+    res = measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want_tick=not args.no_tick, want_roofline=not args.no_roofline)
 
     also = None
     default_run = (args.config == 1 and args.streams is None and args.model is None and world == 1 and args.pcm == "f32"

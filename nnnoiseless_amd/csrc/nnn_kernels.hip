@@ -359,8 +359,8 @@ __global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
 //                    16-deep sliding window of y in registers, 2 coalesced row loads per 16 multiply-adds
 //       wave 10      xx = |x|^2 over the analysis frame and the 384-step running energy yy_lookup of
 //                    remove_doubling (ref: src/pitch.rs:133-142)
-//       wave 11      the running energy every fine lag sees in find_best_pitch (ref: src/pitch.rs:97, :401-402)
-//                    and the coarse search's start energy
+//       wave 11      the running energies every fine and every coarse lag sees in find_best_pitch (ref: src/pitch.rs:83, :97,
+//                    :380-402), kept per lag
 //     then wave 0 runs find_best_pitch over the coarse lags (ref: src/pitch.rs:372-405, call site :83-84) on the
 //     block's cross-correlation, which never leaves LDS (stored to HBM only for the parity taps).
 // ---------------------------------------------------------------------------------------------
@@ -488,18 +488,11 @@ struct BestPitch {
     }
 };
 
-__global__ void __launch_bounds__(64 * P1_WAVES) k_pitch1(Buffers b)
+// the running energy y_sq_norm seen by every coarse lag (ref: src/pitch.rs:83 -> :380-402)
+__device__ __forceinline__ void coarse_energy(const Buffers &b, int tile, int lane)
 {
-    __shared__ float xc[P1_CHUNKS * P1_LC][TILE];
-    NNN_FRAME_SPLIT(b.NT)
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, tile = bx;
-    if (wave < P1_CHUNKS) xcorr_chunk(b, tile, lane, wave * P1_LC, xc);
-    else if (wave == P1_CHUNKS) yy_lookup(b, tile, lane);
-    else fine_energy(b, tile, lane);
-    __syncthreads();
-    if (wave != 0) return;
-    // find_best_pitch over the coarse lags: the running energy with its >= 1 clamp is a serial scan
     const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
+    float *yq = NNN_TI(b.ysq1, NLAG1, tile, lane);
     float ysq = 1.0f;
     for (int j0 = 0; j0 < 240; j0 += 24) {
         float v[24];
@@ -508,22 +501,59 @@ __global__ void __launch_bounds__(64 * P1_WAVES) k_pitch1(Buffers b)
 #pragma unroll
         for (int i = 0; i < 24; i++) ysq += v[i] * v[i];
     }
-    BestPitch bp;
-    bp.init();
     for (int i0 = 0; i0 < NLAG1; i0 += 21) {   // 147 = 7 x 21
-        float c[21], a[21], d[21];
+        float a[21], d[21];
 #pragma unroll
         for (int i = 0; i < 21; i++) {
-            c[i] = xc[i0 + i][lane];
             a[i] = p[(size_t)(2 * (i0 + i + 240)) * TILE];
             d[i] = p[(size_t)(2 * (i0 + i)) * TILE];
         }
 #pragma unroll
         for (int i = 0; i < 21; i++) {
-            bp.update(i0 + i, c[i], ysq);
+            yq[(size_t)(i0 + i) * TILE] = ysq;
             ysq += a[i] * a[i] - d[i] * d[i];
             ysq = fmaxf(ysq, 1.0f);
         }
+    }
+}
+
+// (The scans as a launch of their own, three small waves per tile at full occupancy, measured slower: 177 + 182 us at 65 536
+// streams against 224 us for this kernel -- beside the cross-correlation waves they find pitch_buf's rows in the CU's L1 / L2,
+// on their own they fetch them from HBM again.)
+#ifndef NNN_P1_MINWAVES
+#define NNN_P1_MINWAVES 3
+#endif
+__global__ void __launch_bounds__(64 * P1_WAVES, NNN_P1_MINWAVES) k_pitch1(Buffers b)
+{
+    __shared__ float xc[P1_CHUNKS * P1_LC][TILE];
+    NNN_FRAME_SPLIT(b.NT)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, tile = bx;
+#ifndef NNN_P1_COARSE_WITH_YY
+#define NNN_P1_COARSE_WITH_YY 0
+#endif
+    if (wave < P1_CHUNKS) xcorr_chunk(b, tile, lane, wave * P1_LC, xc);
+    else if (wave == P1_CHUNKS) {
+        yy_lookup(b, tile, lane);
+        if (NNN_P1_COARSE_WITH_YY) coarse_energy(b, tile, lane);
+    } else {
+        fine_energy(b, tile, lane);
+        if (!NNN_P1_COARSE_WITH_YY) coarse_energy(b, tile, lane);
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // find_best_pitch over the coarse lags with the running energies kept per lag
+    const float *yq = NNN_TI(b.ysq1, NLAG1, tile, lane);
+    BestPitch bp;
+    bp.init();
+    for (int i0 = 0; i0 < NLAG1; i0 += 21) {   // 147 = 7 x 21
+        float c[21], e[21];
+#pragma unroll
+        for (int i = 0; i < 21; i++) {
+            c[i] = xc[i0 + i][lane];
+            e[i] = yq[(size_t)(i0 + i) * TILE];
+        }
+#pragma unroll
+        for (int i = 0; i < 21; i++) bp.update(i0 + i, c[i], e[i]);
     }
     int *o = (int *)NNN_TI(b.best1, 2, tile, lane);
     o[0] = bp.best;
@@ -543,6 +573,21 @@ __device__ __forceinline__ float ip480_partial(const float *xs, const float *ys,
         for (int i = 0; i < 8; i++) s += xv[i] * yv[i];
     }
     return s;
+}
+
+// two inner products against the same x at once (one x read for two multiply-adds): partials q of candidates ys1, ys2
+__device__ __forceinline__ void ip480_partial2(const float *xs, const float *ys1, const float *ys2, int q, float &r1, float &r2)
+{
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int m0 = 0; m0 < 120; m0 += 6) {
+        float xv[6], y1[6], y2[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { xv[i] = xs[4 * (m0 + i) + q]; y1[i] = ys1[4 * (m0 + i) + q]; y2[i] = ys2[4 * (m0 + i) + q]; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) { s1 += xv[i] * y1[i]; s2 += xv[i] * y2[i]; }
+    }
+    r1 = s1;
+    r2 = s2;
 }
 
 struct Xc2 {   // xcorr[] of the fine search: zero except within 2 of 2*best / 2*second (ref: src/pitch.rs:88-96)
@@ -578,7 +623,10 @@ __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) { retu
 constexpr int P2_SPB = 16;
 constexpr int P2_ROW = XLP + 1;   // odd row length: the transposing LDS writes of the staging spread over the banks
 
-__global__ void __launch_bounds__(64 * P2_SPB) k_pitch2(Buffers b, int g)
+#ifndef NNN_P2_MINWAVES
+#define NNN_P2_MINWAVES 8   // two blocks per CU: <= 64 registers
+#endif
+__global__ void __launch_bounds__(64 * P2_SPB, NNN_P2_MINWAVES) k_pitch2(Buffers b, int g)
 {
     __shared__ float sh[P2_SPB][P2_ROW];
     __shared__ float part[P2_SPB][64];
@@ -667,9 +715,12 @@ __global__ void __launch_bounds__(64 * P2_SPB) k_pitch2(Buffers b, int g)
         int t0 = (PITCH_MAX - ps) / 2;
         if (t0 > max_period - 1) t0 = max_period - 1;
         const int prev_period = last_period / 2;
-        if (lane < 29) {
+        // 29 candidates of the decision loop + the two neighbours of t0 (candidates 29, 30): if the loop keeps t0 -- the usual
+        // case -- the final +-1 refinement needs no inner products of its own
+        if (lane < 31) {
             int t;
             if (lane == 0) t = t0;
+            else if (lane >= 29) t = lane == 29 ? t0 - 1 : t0 + 1;
             else {
                 int k = 2 + (lane - 1) / 2;
                 int t1 = (2 * t0 + k) / (2 * k);
@@ -679,17 +730,22 @@ __global__ void __launch_bounds__(64 * P2_SPB) k_pitch2(Buffers b, int g)
                 } else t = t1;
             }
             cand[wave][lane] = t;
-            yyc[wave][lane] = xy_tab[(size_t)(1 + t) * TILE];
+            yyc[wave][lane] = lane < 29 ? xy_tab[(size_t)(1 + t) * TILE] : 0.0f;
+        } else if (lane == 31) {
+            cand[wave][31] = t0;   // (filler for the paired loop below)
         }
         wave_lds_sync();
-        for (int pass = 0; pass < 2; pass++) {
-            int e = pass * 16 + (lane >> 2), q = lane & 3;
-            float v = 0.0f;
-            if (e < 29) v = ip480_partial(&sh[wave][max_period], &sh[wave][max_period - cand[wave][e]], q);
-            part[wave][lane] = v;
+        {   // lane (e, q) takes partial q of candidates e and e + 16: one read of x serves both
+            const int e = lane >> 2, q = lane & 3;
+            float v1, v2;
+            ip480_partial2(&sh[wave][max_period], &sh[wave][max_period - cand[wave][e]], &sh[wave][max_period - cand[wave][e + 16]], q, v1, v2);
+            part[wave][lane] = v1;
             wave_lds_sync();
-            if ((lane & 3) == 0 && e < 29)
-                ipv[wave][e] = part[wave][lane] + part[wave][lane + 1] + part[wave][lane + 2] + part[wave][lane + 3];
+            if (q == 0) ipv[wave][e] = part[wave][lane] + part[wave][lane + 1] + part[wave][lane + 2] + part[wave][lane + 3];
+            wave_lds_sync();
+            part[wave][lane] = v2;
+            wave_lds_sync();
+            if (q == 0) ipv[wave][e + 16] = part[wave][lane] + part[wave][lane + 1] + part[wave][lane + 2] + part[wave][lane + 3];
             wave_lds_sync();
         }
         // decision loop on scalars (every lane computes the same thing)
@@ -719,18 +775,20 @@ __global__ void __launch_bounds__(64 * P2_SPB) k_pitch2(Buffers b, int g)
         }
         best_xy = fmaxf(best_xy, 0.0f);
         float pg = (best_yy <= best_xy) ? 1.0f : best_xy / (best_yy + 1.0f);
-        // final +-1 refinement: three inner products around t
-        {
+        // final +-1 refinement: the inner products at t - 1, t, t + 1 (the same sums whichever way they are obtained)
+        float x3[3];
+        if (t == t0) {   // wave-uniform
+            x3[0] = ipv[wave][29]; x3[1] = ipv[wave][0]; x3[2] = ipv[wave][30];
+        } else {
             int e = lane >> 2, q = lane & 3;
             float v = 0.0f;
             if (e < 3) v = ip480_partial(&sh[wave][max_period], &sh[wave][max_period - (t + e - 1)], q);
             part[wave][lane] = v;
-        }
-        wave_lds_sync();
-        float x3[3];
+            wave_lds_sync();
 #pragma unroll
-        for (int e = 0; e < 3; e++)
-            x3[e] = part[wave][4 * e] + part[wave][4 * e + 1] + part[wave][4 * e + 2] + part[wave][4 * e + 3];
+            for (int e3 = 0; e3 < 3; e3++)
+                x3[e3] = part[wave][4 * e3] + part[wave][4 * e3 + 1] + part[wave][4 * e3 + 2] + part[wave][4 * e3 + 3];
+        }
         int offset = 0;
         if (x3[2] - x3[0] > 0.7f * (x3[1] - x3[0])) offset = 1;
         else if (x3[0] - x3[2] > 0.7f * (x3[1] - x3[2])) offset = -1;
@@ -875,20 +933,27 @@ __device__ __forceinline__ float2 tw960_at(const float2 *tw, int k)   // k in [0
 
 // one Stockham pass of the 480-point transform, in place: every lane pulls its butterflies into registers,
 // the wave synchronises, then scatters the results (autosort order).  Radix R, NS = product of the radices
-// already applied; tw = the LDS half-table of exp(-2 pi i k / 960).  One 3.8 KB buffer per transform keeps LDS small
+// already applied; tw = the LDS half-table of exp(-2 pi i k / 960).  One buffer per transform keeps LDS small
 // enough for a full complement of waves per CU.
-template <int R, int NS>
+// The first pass scatters with a stride of 8 elements (64 bytes): 32 lanes on 4 bank pairs, every store 8-way conflicted
+// -- as many LDS cycles as all other accesses of the transform together.  Its output (and the second pass's input) is
+// therefore skewed, element i at i + i / 8 (stride 9: conflict-free); the buffer holds NFFT_BUF elements for that.
+constexpr int NFFT_BUF = NFFT + NFFT / 8;
+template <int R, int NS, bool SKEW_IN, bool SKEW_OUT>
 __device__ __forceinline__ void fft_pass(float2 *buf, const float2 *tw, int lane)
 {
     constexpr int NBF = NFFT / R, IT = (NBF + 63) / 64;
+    static_assert(!SKEW_IN || NBF % 8 == 0, "skewed reads assume r * NBF is a multiple of 8");
+    static_assert(!SKEW_OUT || (NS == 1 && R == 8), "skewed writes are the first pass's");
     float2 v[IT][R];
 #pragma unroll
     for (int it = 0; it < IT; it++) {
         const int j = lane + 64 * it;
         if (j < NBF) {
             const int k = j % NS;
+            const int jj = SKEW_IN ? j + (j >> 3) : j;
 #pragma unroll
-            for (int r = 0; r < R; r++) v[it][r] = buf[j + r * NBF];
+            for (int r = 0; r < R; r++) v[it][r] = buf[jj + (SKEW_IN ? r * NBF + r * NBF / 8 : r * NBF)];
             if (NS > 1) {
                 constexpr int step = 960 / (NS * R);
 #pragma unroll
@@ -902,7 +967,7 @@ __device__ __forceinline__ void fft_pass(float2 *buf, const float2 *tw, int lane
     for (int it = 0; it < IT; it++) {
         const int j = lane + 64 * it;
         if (j < NBF) {
-            const int base = (j / NS) * NS * R + (j % NS);
+            const int base = SKEW_OUT ? 9 * j : (j / NS) * NS * R + (j % NS);   // skewed: element 8 j + r at 9 j + r
 #pragma unroll
             for (int r = 0; r < R; r++) buf[base + r * NS] = v[it][r];
         }
@@ -910,12 +975,12 @@ __device__ __forceinline__ void fft_pass(float2 *buf, const float2 *tw, int lane
     wave_lds_sync();
 }
 
-// forward 480-point FFT in place (natural order in, natural order out)
+// forward 480-point FFT in place (natural order in, natural order out); buf has room for NFFT_BUF elements
 __device__ __forceinline__ void fft480(float2 *buf, const float2 *tw, int lane)
 {
-    fft_pass<8, 1>(buf, tw, lane);
-    fft_pass<6, 8>(buf, tw, lane);
-    fft_pass<10, 48>(buf, tw, lane);
+    fft_pass<8, 1, false, true>(buf, tw, lane);
+    fft_pass<6, 8, true, false>(buf, tw, lane);
+    fft_pass<10, 48, false, false>(buf, tw, lane);
 }
 
 // bin k (0..480) of the real 960-point spectrum from Z = FFT480(x[2n] + i x[2n+1])
@@ -1142,7 +1207,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
 __global__ void __launch_bounds__(64 * FFT_SPB) k_fft_xp(Buffers b, const StepParams *sp)
 {
     __shared__ FftLds t;
-    __shared__ float2 Z[FFT_SPB][NFFT];
+    __shared__ float2 Z[FFT_SPB][NFFT_BUF];
     __shared__ float part[FFT_SPB][4 * 64];
     NNN_FRAME_SPLIT(b.S_pad / FFT_SPB)
     const int wave = threadIdx.x >> 6;
@@ -1153,7 +1218,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB) k_fft_xp(Buffers b, const StepPa
 __global__ void __launch_bounds__(64 * FFT_SPB) k_fft_x(Buffers b, const StepParams *sp)
 {
     __shared__ FftLds t;
-    __shared__ float2 Z[FFT_SPB][NFFT];
+    __shared__ float2 Z[FFT_SPB][NFFT_BUF];
     __shared__ float part[FFT_SPB][2 * 64];
     NNN_FRAME_SPLIT(b.S_pad / FFT_SPB)
     const int wave = threadIdx.x >> 6;
@@ -2235,7 +2300,7 @@ __device__ __forceinline__ float interp_gain(const float *g, int k, const float 
 __global__ void __launch_bounds__(64 * FFT_SPB, 4) k_synth(Buffers b, const StepParams *sp0, int g)
 {
     __shared__ FftLds t;
-    __shared__ float2 A_[FFT_SPB][FREQ + 3];   // also the per-bin energies of the band renormalisation (before A is filled)
+    __shared__ float2 A_[FFT_SPB][NFFT_BUF];   // also the per-bin energies of the band renormalisation (before A is filled)
     __shared__ float r_[FFT_SPB][3 * NB];
     __shared__ float part_[FFT_SPB][2 * 64];
     const int wave = threadIdx.x >> 6;
