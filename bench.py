@@ -235,6 +235,8 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
     elapsed = time.perf_counter() - t0
     d = dist if world > 1 else None
     frames_done, elapsed_max = aggregate(d, S * fps * K, elapsed, dev)
+    if os.environ.get("NNN_PMC_CALIB"):   # a kernel of known traffic (reads N bytes, writes N bytes) for the PMC passes' calibration
+        torch.abs(x)
     res = {"value": frames_done / elapsed_max, "ms_per_step": elapsed_max * 1e3 / K, "timed_s": elapsed_max,
            "host_enqueue_ms_per_step": t_enq * 1e3 / K, "pool_frames": pool,
            "outputs_finite": bool(torch.isfinite(y.float()).all().item())}

@@ -24,6 +24,10 @@ BATCH_SYMBOLS = [
 TRAIN_SYMBOLS = [
     "nnn_train_create", "nnn_train_destroy", "nnn_train_reset", "nnn_train_process_device", "nnn_train_process_host",
 ]
+RESAMPLE_SYMBOLS = [
+    "nnn_resampler_create", "nnn_resampler_destroy", "nnn_resampler_reset", "nnn_resampler_max_output",
+    "nnn_resampler_process_device", "nnn_resampler_process_host",
+]
 RNNOISE_SYMBOLS = [
     "rnnoise_get_frame_size", "rnnoise_get_size", "rnnoise_init", "rnnoise_create", "rnnoise_destroy",
     "rnnoise_process_frame", "rnnoise_model_from_file", "rnnoise_model_free",
@@ -95,6 +99,14 @@ class Library:
         L.nnn_train_reset.argtypes = [vp]
         L.nnn_train_process_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, sz, sz, vp]
         L.nnn_train_process_host.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32]
+        L.nnn_resampler_create.restype = vp
+        L.nnn_resampler_create.argtypes = [i32, C.c_double, i32]
+        L.nnn_resampler_destroy.argtypes = [vp]
+        L.nnn_resampler_reset.argtypes = [vp]
+        L.nnn_resampler_max_output.restype = C.c_long
+        L.nnn_resampler_max_output.argtypes = [vp, C.c_long]
+        L.nnn_resampler_process_device.argtypes = [vp, vp, C.c_long, sz, vp, C.c_long, sz, C.POINTER(C.c_long), vp]
+        L.nnn_resampler_process_host.argtypes = [vp, vp, C.c_long, vp, C.c_long, C.POINTER(C.c_long)]
         L.nnn_last_error.restype = C.c_char_p
         L.rnnoise_create.restype = vp
         L.rnnoise_create.argtypes = [vp]

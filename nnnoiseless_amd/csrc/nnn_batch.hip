@@ -37,6 +37,7 @@ static int fail(const char *fmt, ...)
     g_err = buf;
     return 1;
 }
+int nnn_set_error(const char *msg) { return fail("%s", msg); }   // for the library's other translation units
 #define HIPCHK(expr)                                                                       \
     do {                                                                                   \
         hipError_t e_ = (expr);                                                            \

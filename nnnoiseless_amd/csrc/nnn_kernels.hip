@@ -633,8 +633,16 @@ __global__ void __launch_bounds__(64 * P2_SPB, NNN_P2_MINWAVES) k_pitch2(Buffers
     __shared__ float ipv[P2_SPB][32], yyc[P2_SPB][32];
     __shared__ int cand[P2_SPB][32];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int s = blockIdx.x * P2_SPB + wave, tile = s >> 6, sl = s & 63;
-    const int q0 = (blockIdx.x * P2_SPB) & 63;            // first stream of this block within its tile
+    // Workgroup b runs on XCD b mod 8 (observed dispatch order; a speed matter only).  The four quarter-tile blocks of tile t are
+    // sent to XCD t mod 8 -- the one whose L2 holds the tile's pitch_buf rows, written there by k_lpc's block t and read by
+    // k_pitch1's: consecutive block indices would spread them over four XCDs, each fetching the same lines again.
+    int blk = (int)blockIdx.x;
+    if ((gridDim.x & 31) == 0) {
+        const int xcd = blk & 7, i = blk >> 3;
+        blk = 4 * (8 * (i >> 2) + xcd) + (i & 3);
+    }
+    const int s = blk * P2_SPB + wave, tile = s >> 6, sl = s & 63;
+    const int q0 = (blk * P2_SPB) & 63;                   // first stream of this block within its tile
     const int min_period = PITCH_MIN / 2, max_period = PITCH_MAX / 2;
     int last_period = NNN_TI(b.last_period, 1, tile, sl)[0];
     float last_gain = NNN_TI(b.last_gain, 1, tile, sl)[0];

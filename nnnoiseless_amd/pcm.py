@@ -87,3 +87,40 @@ class DenoiseSignal:
 
     def __len__(self):
         return len(self._out)
+
+
+class Resampler:
+    """n_streams mono streams of one common sample rate -> 48 kHz with the CLI's 16-tap windowed sinc
+    (src/nnnoiseless.rs:19-32, 106-131), batched on the GPU (include/nnn_resample.h).  Feed the streams in chunks of any
+    size: the output does not depend on the chunking."""
+
+    def __init__(self, n_streams, source_rate, device=0, lib=None):
+        from . import library
+        self._lib = lib or library()
+        self.n_streams = int(n_streams)
+        self.ratio = float(source_rate) / 48000.0
+        self._h = self._lib.L.nnn_resampler_create(self.n_streams, self.ratio, device)
+        if not self._h:
+            raise RuntimeError("nnnoiseless_amd: " + self._lib.error())
+
+    def process(self, x):
+        """x: float32 [n_streams, n] source samples -> float32 [n_streams, n_out]."""
+        import ctypes as C
+        x = _ffi.as_f32(x)
+        S, n = x.shape
+        assert S == self.n_streams
+        cap = self._lib.L.nnn_resampler_max_output(self._h, n)
+        out = np.zeros((S, cap), np.float32)
+        n_out = C.c_long(0)
+        self._lib.check(self._lib.L.nnn_resampler_process_host(self._h, _ffi.ptr(x), n, _ffi.ptr(out), cap, C.byref(n_out)))
+        return np.ascontiguousarray(out[:, :n_out.value])
+
+    def reset(self):
+        self._lib.check(self._lib.L.nnn_resampler_reset(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.L.nnn_resampler_destroy(self._h)
+            self._h = None
+
+    __del__ = close

@@ -1153,3 +1153,64 @@ long nnno_denoise_signal(const nnno_model *m, const float *in, long n, int chann
     free(ob);
     return written;
 }
+
+/* ---- 16-tap sinc resampler of the CLI ------------------------------------------------ */
+
+/* dasp_ring_buffer 0.11.0 Fixed<[f32; 16]>: push overwrites the oldest element, index i counts from the oldest and wraps
+ * modulo the length (get() does not bounds-check the logical index).  dasp_interpolate 0.11.0 sinc::Sinc: idx counts
+ * the frames pushed, up to depth = len / 2.  Neither crate is part of the reference tree: restated from their published
+ * sources, UNPINNED by any reference test. */
+typedef struct { float data[16]; int first; int idx; } sinc16;
+
+static void sinc16_push(sinc16 *s, float x)            /* Sinc::next_source_frame */
+{
+    s->data[s->first] = x;
+    s->first = (s->first + 1) & 15;
+    if (s->idx < 8) s->idx++;
+}
+static float sinc16_at(const sinc16 *s, int i) { return s->data[(s->first + i) & 15]; }
+
+static float sinc16_interpolate(const sinc16 *s, double x)   /* Sinc::interpolate */
+{
+    const double pi = 3.14159265358979323846;
+    const double phil = x, phir = 1.0 - x;
+    const int depth = 8, nl = s->idx, nr = s->idx + 1;
+    const int rightmost = nl + depth, leftmost = nr - depth;
+    const int max_depth = rightmost >= 16 ? 16 - depth : (leftmost < 0 ? depth + leftmost : depth);
+    float v = 0.0f;
+    for (int n = 0; n < max_depth; n++) {
+        double a = pi * (phil + (double)n);
+        double first = a == 0.0 ? 1.0 : sin(a) / a, second = 0.5 + 0.5 * cos(a / (double)depth);
+        v += (float)(first * second * (double)sinc16_at(s, nl - n));
+        a = pi * (phir + (double)n);
+        first = a == 0.0 ? 1.0 : sin(a) / a;
+        second = 0.5 + 0.5 * cos(a / (double)depth);
+        v += (float)(first * second * (double)sinc16_at(s, nr + n));
+    }
+    return v;
+}
+
+/* ref: src/nnnoiseless.rs:19-32 (resampled), :106-131 (Resample::next_sample): `in` = n sample frames of `channels` interleaved
+ * floats at the source rate, ratio = source_rate / 48000; writes up to cap output sample frames and returns their number
+ * (the loop ends when an output needs a source sample that is not there). */
+long nnno_resample(const float *in, long n, int channels, double ratio, float *out, long cap)
+{
+    sinc16 *st = (sinc16 *)calloc((size_t)channels, sizeof(sinc16));
+    double pos = 0.0;
+    long consumed = 0, written = 0;
+    while (written < cap) {
+        int ended = 0;
+        pos += ratio;
+        while (pos >= 1.0) {
+            pos -= 1.0;
+            if (consumed >= n) { ended = 1; break; }
+            for (int c = 0; c < channels; c++) sinc16_push(&st[c], in[(size_t)consumed * channels + c]);
+            consumed++;
+        }
+        if (ended) break;
+        for (int c = 0; c < channels; c++) out[(size_t)written * channels + c] = sinc16_interpolate(&st[c], pos);
+        written++;
+    }
+    free(st);
+    return written;
+}

@@ -131,6 +131,10 @@ long nnno_denoise_signal(const nnno_model *m, const float *in, long n, int chann
 void nnno_training_rows(const nnno_model *m, int n_streams, int n_frames, const float *signal, const float *noise,
                         const float *combined, const int32_t *cutoff, const float *vad, float *rows, int n_threads);
 
+/* The CLI's resampler to 48 kHz (src/nnnoiseless.rs:19-32, 106-131; dasp_interpolate 0.11.0 Sinc<[f32; 16]>, a crate outside
+ * the reference tree: restated from its published source, unpinned).  See nnn_oracle.c. */
+long nnno_resample(const float *in, long n, int channels, double ratio, float *out, long cap);
+
 /* Stand-alone FFT entry points so tests can pin the restated FFT against a naive DFT. */
 void nnno_rfft960(const float *in960, float *out_re_im_481x2);   /* un-normalised forward  */
 void nnno_irfft960(const float *in_re_im_481x2, float *out960);  /* un-normalised inverse  */

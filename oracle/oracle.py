@@ -209,6 +209,19 @@ def denoise_signal(model: Model, x, channels=1):
     return out[:n]
 
 
+def resample(x, ratio, channels=1):
+    """The CLI's 16-tap sinc resampler (src/nnnoiseless.rs:106-131): x float32 [n, channels] at the source rate,
+    ratio = source_rate / 48000 -> float32 [n_out, channels]."""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, channels)
+    cap = int(len(x) / ratio) + 8
+    out = np.zeros((cap, channels), np.float32)
+    fn = lib().nnno_resample
+    fn.restype = C.c_long
+    fn.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_double, C.c_void_p, C.c_long]
+    n = fn(_ptr(x), len(x), channels, float(ratio), _ptr(out), cap)
+    return out[:n]
+
+
 def training_rows(model: Model, signal, noise, combined, cutoff, vad, n_threads=1):
     """src/training.rs:113-160 for [S][T][480] inputs and [T][S] cutoff / vad -> rows [T][S][87]."""
     signal, noise, combined = (np.ascontiguousarray(a, dtype=np.float32) for a in (signal, noise, combined))

@@ -243,3 +243,20 @@ def test_wide_dense_layers(hostsim_lib, oracle_mod, rows, monkeypatch):
     out, vad = bd.process(x)
     assert rel_rms(out[:, 1:], ref["out"][:, 1:]) <= 1e-5
     assert np.abs(vad.T - ref["vad"]).max() <= 1e-4
+
+
+def test_quarter_tile_block_remap(hostsim_lib, oracle_mod, weights_bytes):
+    """512 streams = 32 quarter-tile blocks of k_pitch2: the XCD-aware block remap is active (a permutation of the blocks);
+    every stream still gets its own result."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    base = make_streams(0, 16, 2)
+    x = np.tile(base, (32, 1, 1))                       # 512 streams, 16 distinct ones
+    bd = nn.BatchDenoiser(512, lib=hostsim_lib)
+    out, vad = bd.process(x)
+    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), base)
+    pitch = bd.tap("pitch")[:, 0].reshape(32, 16)
+    assert all(np.array_equal(pitch[i], ref["pitch"][:, -1]) for i in range(32))
+    o = out.reshape(32, 16, 2, 480)
+    assert all(np.array_equal(o[0], o[i]) for i in range(1, 32))
+    assert rel_rms(o[0][:, 1:], ref["out"][:, 1:]) < 1e-5
