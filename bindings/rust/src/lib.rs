@@ -19,6 +19,7 @@ extern "C" {
     fn nnn_batch_create(model: *const RawModel, n_streams: c_int, device: c_int) -> *mut RawBatch;
     fn nnn_batch_destroy(b: *mut RawBatch);
     fn nnn_batch_reset(b: *mut RawBatch) -> c_int;
+    fn nnn_batch_clone(b: *mut RawBatch) -> *mut RawBatch;
     fn nnn_batch_process_host(
         b: *mut RawBatch,
         input: *const c_float,
@@ -158,13 +159,23 @@ impl BatchDenoiser {
         unsafe { nnn_batch_reset(self.raw) };
     }
 }
+/// `DenoiseState` is `Clone` in the reference (src/denoise.rs:36): a second batch with the same models and a device-side
+/// copy of every stream's state (`nnn_batch_clone`).
+impl Clone for BatchDenoiser {
+    fn clone(&self) -> BatchDenoiser {
+        let raw = unsafe { nnn_batch_clone(self.raw) };
+        assert!(!raw.is_null(), "nnnoiseless-mi355x: clone failed");
+        BatchDenoiser { raw, n: self.n }
+    }
+}
 impl Drop for BatchDenoiser {
     fn drop(&mut self) {
         unsafe { nnn_batch_destroy(self.raw) }
     }
 }
 
-/// Same surface as `nnnoiseless::DenoiseState` (src/denoise.rs:36-116).
+/// Same surface as `nnnoiseless::DenoiseState` (src/denoise.rs:36-116), `Clone` included.
+#[derive(Clone)]
 pub struct DenoiseState(BatchDenoiser);
 
 impl DenoiseState {

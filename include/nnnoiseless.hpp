@@ -9,6 +9,7 @@
 //   DenoiseState::FRAME_SIZE                                 DenoiseState::FRAME_SIZE                                   src/denoise.rs:46
 //   DenoiseState::new() / from_model / with_model            DenoiseState::create() / from_model / with_model           src/denoise.rs:53-74
 //   process_frame(&mut self, &mut [f32], &[f32]) -> f32      process_frame(float* out, const float* in) -> float        src/denoise.rs:95-116
+//   #[derive(Clone)] DenoiseState                            DenoiseState::clone() / BatchDenoiser::clone()             src/denoise.rs:36
 //   for ch { states[ch].process_frame(..) }                  BatchDenoiser::process(...)                                src/signal.rs:102-104
 //
 // Everything runs in the HIP kernels behind include/nnn_batch.h; failures throw std::runtime_error.
@@ -23,6 +24,7 @@
 #include <vector>
 
 #include "nnn_batch.h"
+#include "nnn_resample.h"
 #include "nnn_train.h"
 
 namespace nnnoiseless {
@@ -94,9 +96,25 @@ class BatchDenoiser {
     }
     void synchronize() { check(nnn_batch_synchronize(b_.get())); }
     void reset() { check(nnn_batch_reset(b_.get())); }
+    // a second batch with the same models and a copy of every stream's state (DenoiseState: Clone)
+    BatchDenoiser clone() const
+    {
+        nnn_batch *c = nnn_batch_clone(b_.get());
+        if (!c) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+        return BatchDenoiser(c);
+    }
+    // the streams' state as bytes (a raw image: loads into a batch of the same shape made by the same build)
+    std::vector<uint8_t> save_state() const
+    {
+        std::vector<uint8_t> buf(nnn_batch_state_bytes(b_.get()));
+        check(nnn_batch_save_state(b_.get(), buf.data(), buf.size()));
+        return buf;
+    }
+    void load_state(const std::vector<uint8_t> &buf) { check(nnn_batch_load_state(b_.get(), buf.data(), buf.size())); }
     nnn_batch *raw() { return b_.get(); }
 
   private:
+    explicit BatchDenoiser(nnn_batch *owned) : b_(owned, nnn_batch_destroy) {}
     static void check(int rc)
     {
         if (rc) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
@@ -138,10 +156,34 @@ class DenoiseState {
         b_.process(in, out, &vad, 1, FRAME_SIZE, FRAME_SIZE);
         return vad;
     }
+    DenoiseState clone() const { return DenoiseState(b_.clone()); }   // #[derive(Clone)], src/denoise.rs:36
 
   private:
     DenoiseState(const RnnModel *m, int device) : b_(1, m, device) {}
+    explicit DenoiseState(BatchDenoiser b) : b_(std::move(b)) {}
     BatchDenoiser b_;
+};
+
+// n mono streams of one common sample rate -> 48 kHz with the CLI's 16-tap windowed sinc (src/nnnoiseless.rs:19-32, 106-131)
+class Resampler {
+  public:
+    Resampler(int n_streams, double source_rate, int device = 0)
+        : r_(nnn_resampler_create(n_streams, source_rate / 48000.0, device), nnn_resampler_destroy)
+    {
+        if (!r_) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+    }
+    long max_output(long n_in) const { return nnn_resampler_max_output(r_.get(), n_in); }
+    // host buffers, dense [n_streams][n_in] -> [n_streams][cap_out]; returns the samples produced per stream
+    long process(const float *in, long n_in, float *out, long cap_out)
+    {
+        long n = 0;
+        if (nnn_resampler_process_host(r_.get(), in, n_in, out, cap_out, &n)) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+        return n;
+    }
+    void reset() { nnn_resampler_reset(r_.get()); }
+
+  private:
+    std::shared_ptr<nnn_resampler> r_;
 };
 
 }  // namespace nnnoiseless

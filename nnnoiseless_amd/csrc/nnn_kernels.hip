@@ -1417,9 +1417,10 @@ __global__ void __launch_bounds__(64) k_train_rows(Buffers comb, Buffers clean, 
 // ---------------------------------------------------------------------------------------------
 // K10 rnn: dense + 3 GRUs + 2 dense, i8-origin weights, activations via the 201-entry tanh table.
 //     ref: src/rnn.rs:251-272, 292-327, 343-379, 402-410; src/util.rs:29-53.
-//     lane = stream (one 64-stream tile per block); the weight of (input k, neuron n) is the same
-//     for all lanes, so it is a scalar (SGPR) operand: one v_fmac per 64 stream-MACs.  Neurons are
-//     split over the block's 8 waves in register blocks of OB; layer outputs are exchanged in LDS.
+//     Batched GEMMs on the matrix cores: a tile's activations live in LDS as [stream][column] matrices in three bf16 planes
+//     (x = hi + mid + lo exactly), the weights are small integers (exact in bf16) packed on the host in MFMA B-fragment order,
+//     so v_mfma_f32_16x16x32_bf16 accumulates exact products.  Two kernels share these pieces: k_rnn (layers one after the
+//     other, any model the format allows) and k_rnn_wf (layers of different frames side by side, the built-in shape class).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float tansig_approx(float x, const float *tab)
 {

@@ -46,16 +46,9 @@ constexpr int MAXN = 127;         // layer sizes are non-negative i8 (src/rnn.rs
 struct ModelDims {
     int nd, nv, nn, ndn;                       // input_dense, vad_gru, noise_gru, denoise_gru neurons
     int act_d, act_v, act_n, act_dn, act_o, act_vo;
-    // offsets (floats) into the expanded f32 weight buffer, all matrices input-major like the file
-    int w_d, b_d;
-    int w_v, r_v, b_v;
-    int w_n, r_n, b_n;
-    int w_dn, r_dn, b_dn;
-    int w_o, b_o;
-    int w_vo, b_vo;
 };
 
-// RNN as batched GEMMs on the matrix cores (k_rnn).  Activations of a 64-stream tile live in LDS as
+// RNN as batched GEMMs on the matrix cores (k_rnn, k_rnn_wf).  Activations of a 64-stream tile live in LDS as
 // [stream][column] matrices in three bf16 planes (x = hi + mid + lo exactly), weights are small integers
 // (exact in bf16) pre-packed on the host in MFMA B-fragment order [neuron block][gate][k-step][lane][8].
 struct GemmDesc {
@@ -68,7 +61,6 @@ struct LayerDesc {
     GemmDesc in, rec;
     int n;            // neurons
     int nb;           // neuron blocks of 16
-    int mb;           // stream blocks (of 16) per wave work unit: 1, 2 or 4
     int act;
     int bias;         // float index into the f32 parameter buffer ([gate][n])
     int out_col;      // LDS column of the input matrix that receives this layer's output

@@ -1,5 +1,5 @@
 // nnn_model.cpp -- .rnn model container: parser with the reference's validation rules, the
-// built-in weights, and the i8 -> f32 expansion the RNN kernel consumes.
+// built-in weights, and the packing the RNN kernels consume (bf16 weights in MFMA B-fragment order, f32 biases).
 #include "nnn_model.h"
 
 #include <string.h>
@@ -149,7 +149,6 @@ size_t nnn_model_pack(const RNNModel &m, std::vector<uint16_t> &wq, std::vector<
     auto finish = [&](LayerDesc &L, int n, int act, int bias, int out_col) {
         L.n = n;
         L.nb = pad_to(n, 16) / 16;
-        L.mb = L.nb >= 5 ? 4 : (L.nb >= 3 ? 2 : 1);
         L.act = act;
         L.bias = bias;
         L.out_col = out_col;
