@@ -52,9 +52,9 @@ FLOPS_PER_FRAME = 0.42e6
 G = 8
 KERNEL_BYTES = {
     "k_hp": 1920 + 1920 + 960 + 960 // 5 + 4 + (16 + 8) // G,     # input, history slot, 240 decimated values (+ mirrored share), x_lp[0]; biquad state per group
-    "k_lpc": 3456 + 4 + 40 + 3456,                                 # decimated window in; taps + pitch_buf (tile-interleaved only) out
-    "k_pitch1": 3456 + 8 + 588 + 1176 + 1544,                      # pitch_buf in; best / second lag, coarse- and fine-lag energies, xx / yy_lookup out
-    "k_pitch2": 3456 + 8 + 40 + 120 + 12 + 16 // G,                # pitch_buf in (16-stream slices through LDS), lags / energies looked up; pitch out
+    "k_pitch": 3456 + 4 + 8 + 16 // G,                              # decimated window + x_lp[0] in; pitch index + gain out; last pitch per group
+                                                                   # (pitch_buf, coarse xcorr and energies never leave LDS; the two energy tables
+                                                                   # that go through global scratch, 2.7 KB, are the design's own and not counted)
     "k_fft_xp": 3840 + 1200 + 4 + 3848 + 3200 + 264 + 112 + 4,     # 960 + (mean lag 300) history samples; X (481 bins), P (400 bins), band energies, cepstrum head out
     "k_rnn": 120 + 88 + 4 + 2 * 88 + 2 * 88 + (704 + 2 * 672 + 8) // G,   # features head in; ring row, vad, gains, last gains; ring + GRU states per group
     "k_synth": 3848 + 3200 + 440 + 8 + 1920 + 8 + 3840 // G,       # X, P, band quantities in; audio, vad, branch out; overlap memory per group

@@ -44,13 +44,13 @@ int nnn_set_error(const char *msg) { return fail("%s", msg); }   // for the libr
         if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));  \
     } while (0)
 
-enum KernelId { K_HP, K_LPC, K_PITCH1, K_PITCH2, K_FFT_XP, K_RNN, K_SYNTH, K_COUNT };
-static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_pitch1", "k_pitch2", "k_fft_xp", "k_rnn", "k_synth"};
+enum KernelId { K_HP, K_PITCH, K_FFT_XP, K_RNN, K_SYNTH, K_COUNT };
+static const char *kKernelNames[K_COUNT] = {"k_hp", "k_pitch", "k_fft_xp", "k_rnn", "k_synth"};
 
-// The seven stages of a frame group, one kernel launch each (k_rnn: one per resident model).  hp, pitch2, rnn and synth carry
-// state from frame to frame and loop over the group's frames inside the launch; the others cover all frames of the group
+// The five stages of a frame group, one kernel launch each (k_rnn: one per resident model).  hp, pitch, rnn and synth carry
+// state from frame to frame and loop over the group's frames inside the launch; fft_xp covers all frames of the group
 // side by side (block index = frame * blocks_per_frame + block).
-enum Stage { ST_HP, ST_LPC, ST_P1, ST_P2, ST_FFT, ST_RNN, ST_SYN, ST_COUNT };
+enum Stage { ST_HP, ST_PITCH, ST_FFT, ST_RNN, ST_SYN, ST_COUNT };
 constexpr int NSTREAMS = 5;    // internal streams of a pipelined call
 constexpr int EVR = 16;        // event ring: groups of one call that may still be referred to
 enum SchedMode { SCHED_SEQ = 0, SCHED_LANES = 1, SCHED_STAGES = 2 };
@@ -558,8 +558,8 @@ struct Launcher {
     }
 };
 
-// Per-group DAG: hp -> lpc -> pitch1 -> pitch2 -> fft_xp -> rnn -> synth.  Four stages carry state from group to group -- the
-// biquad (hp), the last pitch (pitch2), GRU / cepstral / last-gain state (rnn), the overlap memory (synth).
+// Per-group DAG: hp -> pitch -> fft_xp -> rnn -> synth.  Four stages carry state from group to group -- the
+// biquad (hp), the last pitch (pitch), GRU / cepstral / last-gain state (rnn), the overlap memory (synth).
 // stage `s` of the group of `g` frames in scratch sets set0 .. set0 + g - 1, parameters at sp0[0..g), on stream `st`
 static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams *sp0, hipStream_t st, bool prof)
 {
@@ -568,9 +568,7 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
     Launcher L{h, st, prof};
     switch (s) {
     case ST_HP: L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g); break;
-    case ST_LPC: L.go(K_LPC, k_lpc, dim3(NT * ug), dim3(320), 0, b, sp0); break;
-    case ST_P1: L.go(K_PITCH1, k_pitch1, dim3(NT * ug), dim3(64 * P1_WAVES), 0, b); break;
-    case ST_P2: L.go(K_PITCH2, k_pitch2, dim3(Sp / P2_SPB), dim3(64 * P2_SPB), 0, b, g); break;
+    case ST_PITCH: L.go(K_PITCH, k_pitch, dim3(Sp / PK_SPB), dim3(PK_T), 0, b, sp0, g); break;
     case ST_FFT: L.go(K_FFT_XP, k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0); break;
     case ST_RNN:
         for (const nnn_batch::ModelGroup &G : h->groups) {   // one launch per resident model (a run of whole tiles)
@@ -607,12 +605,12 @@ static int drain_profile(nnn_batch *h)
 // A call is cut into groups of up to GROUP frames; group k uses scratch-set block (group_count mod DEPTH).  Short calls
 // (and profiling) run the groups' stages back to back on the caller's stream.  Longer calls spread over the batch's
 // internal streams so that independent stages overlap (at 4096 streams a lone stage cannot fill the GPU):
-//   lanes   the high-pass chain on its own stream, running ahead as far as the history rings allow; stages lpc .. synth of
+//   lanes   the high-pass chain on its own stream, running ahead as far as the history rings allow; stages pitch .. synth of
 //           group k on lane stream k mod n_lanes
-//   stages  one stream per stage pair: hp | lpc, pitch1 | pitch2, fft_xp | rnn | synth; every stream is a chain of groups
+//   stages  one stream per stage: hp | pitch | fft_xp | rnn | synth; every stream is a chain of groups
 // An edge of the DAG whose ends share a stream needs nothing (streams are in-order); the others are an event record + wait.
 // Edges: previous stage of the same group; the same stage of the previous group for the four stateful stages; the scratch-set
-// block's previous user (synth of group k - DEPTH, before lpc of group k); the history rings (synth of the group holding the
+// block's previous user (synth of group k - DEPTH, before pitch of group k); the history rings (synth of the group holding the
 // newest frame whose history slots group k's high-pass overwrites).  Everything before this call is ordered by the caller's
 // stream, which every internal stream waits for at its first use and which waits for the last synth at the end.
 static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_vad, int n_frames, int fmt, int channels,
@@ -676,7 +674,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
         chk(hipEventRecord(h->ev_in, st));
         // index into h->pool; -1 = the caller's stream (lane 0 of the lanes schedule, the synthesis chain of the stages one)
         auto stream_of = [&](int s, int k) -> int {
-            if (h->sched == SCHED_STAGES) return s == ST_HP ? 0 : (s <= ST_P1 ? 1 : (s <= ST_FFT ? 2 : (s == ST_RNN ? 3 : -1)));
+            if (h->sched == SCHED_STAGES) return s == ST_HP ? 0 : (s == ST_PITCH ? 1 : (s == ST_FFT ? 2 : (s == ST_RNN ? 3 : -1)));
             return s == ST_HP ? 0 : (k % h->n_lanes) - (k % h->n_lanes == 0 ? 1 : 0);
         };
         std::vector<int> first(n_groups);   // first frame (within the call) of every group
@@ -685,7 +683,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
         auto consumers_elsewhere = [&](int s, int k) {
             const int me = stream_of(s, k);
             if (s + 1 < ST_COUNT && stream_of(s + 1, k) != me) return true;
-            if ((s == ST_HP || s == ST_P2 || s == ST_RNN || s == ST_SYN) && k + 1 < n_groups && stream_of(s, k + 1) != me) return true;
+            if ((s == ST_HP || s == ST_PITCH || s == ST_RNN || s == ST_SYN) && k + 1 < n_groups && stream_of(s, k + 1) != me) return true;
             if (s == ST_SYN) return true;   // scratch-set / ring edges and the end of the call
             return false;
         };
@@ -704,8 +702,8 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
                     if (stream_of(ds, dk) != si) chk(hipStreamWaitEvent(ss, h->ev[ds][dk % EVR], 0));
                 };
                 if (s > 0) wait_for(s - 1, k);
-                if (s == ST_HP || s == ST_P2 || s == ST_RNN || s == ST_SYN) wait_for(s, k - 1);
-                if (s == ST_LPC) wait_for(ST_SYN, k - DEPTH);
+                if (s == ST_HP || s == ST_PITCH || s == ST_RNN || s == ST_SYN) wait_for(s, k - 1);
+                if (s == ST_PITCH) wait_for(ST_SYN, k - DEPTH);
                 if (s == ST_HP) {
                     // slots written now held frames (newest of this group) - NSLOT and older; their last readers are the
                     // frames up to 3 later
@@ -1062,9 +1060,7 @@ static void enqueue_feature_frame(nnn_batch *h, hipStream_t st, StepParams *sp, 
     hipLaunchKernelGGL(k_fill_params, dim3(1), dim3(64), 0, st, sp, v, 1);
     hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, (const StepParams *)sp, 1);
     if (full) {
-        hipLaunchKernelGGL(k_lpc, dim3(NT), dim3(320), 0, st, b, (const StepParams *)sp);
-        hipLaunchKernelGGL(k_pitch1, dim3(NT), dim3(64 * P1_WAVES), 0, st, b);
-        hipLaunchKernelGGL(k_pitch2, dim3(Sp / P2_SPB), dim3(64 * P2_SPB), 0, st, b, 1);
+        hipLaunchKernelGGL(k_pitch, dim3(Sp / PK_SPB), dim3(PK_T), 0, st, b, (const StepParams *)sp, 1);
         hipLaunchKernelGGL(k_fft_xp, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp);
         hipLaunchKernelGGL(k_features, dim3(NT), dim3(64 * FEAT_WAVES), 0, st, b);
     } else {

@@ -214,259 +214,45 @@ __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3  lpc + fir5: 5-lag autocorrelation (strictly sequential per lag), lag window, order-4 Levinson,
-//     bandwidth expansion and the extra zero (ref: src/pitch.rs:433-446, 460-480, 257-292), then
-//     pitch_buf = FIR5(decimated history) with zero initial memory (ref: src/pitch.rs:407-429).
-//     lane = stream; the five sequential chains run on the five waves of the block, which then share the
-//     (elementwise) FIR and write pitch_buf as TI (scans, coarse xcorr) and SM (wave = stream kernels).
+// K3  pitch: the whole pitch analysis of a frame in ONE launch, one block per 16 consecutive streams (a quarter tile):
+//       pitch_downsample's LPC part  5-lag autocorrelation, lag window, order-4 Levinson, bandwidth expansion + the extra
+//                                    zero, FIR5 -> pitch_buf (ref: src/pitch.rs:433-446, 460-480, 257-292, 407-429)
+//       pitch_search                 coarse cross-correlation 147 lags x 240 taps on the 4x-decimated signal, find_best_pitch,
+//                                    fine cross-correlation within +-2 of 2*best / 2*second, find_best_pitch, pseudo-
+//                                    interpolation (ref: src/pitch.rs:63-115, 296-405)
+//       remove_doubling              (ref: src/pitch.rs:118-221)
+//     pitch_buf (864 values per stream) lives in LDS from the FIR that makes it to the last inner product that reads it and
+//     never travels to HBM (round 2a: written once and read by two more launches, 17 KB per stream-frame); so do the coarse
+//     cross-correlation and the coarse-lag energies.  Only the two long energy tables that are looked up at data-dependent
+//     lags later in the frame (fine-lag energies, yy_lookup) go through global scratch.
+//
+//     Every sum that feeds the integer pitch index keeps the reference's order (sequential per lag / per partial), so the
+//     parallelism is over streams x independent chains, lane = (stream, chain):
+//       autocorrelation      (stream, lag)                  5 chains of 860 steps
+//       FIR                  (stream, 27-row chunk)         elementwise
+//       coarse xcorr         (stream, group of 7 lags)      21 groups; 8 x-rows + 8 y-rows from LDS per 56 multiply-adds
+//       energy scans         (stream) on three waves        serial running sums with their clamps
+//       inner products       (stream, partial q of 4), the wave picks the candidate lags: 2 (fine) or 4 (remove_doubling)
+//                            candidates share every read of the fixed operand
+//       decisions            (stream) on wave 0             find_best_pitch x 2, the k = 2..15 loop of remove_doubling
+//     LDS layout of pitch_buf: row pairs interleaved per stream, element (r, s) at ((r >> 1) * 16 + s) * 2 + (r & 1).  A
+//     32-lane group of ds_read_b32 = 16 streams x 2 chains reading rows r, r + 1 (inner-product partials, lags of the
+//     autocorrelation) or rows 27 apart (FIR chunks) hits 32 different banks; the coarse cross-correlation, whose rows are
+//     all even, reads row PAIRS with ds_read_b64 (bank = dword address mod 64), and its two lag groups per 32 lanes start 7
+//     lags apart, on different pair parities: conflict-free as well (round 2a: 31 % of k_pitch2's LDS cycles were conflicts).
+//     remove_doubling carries last_period / last_gain from frame to frame: the launch loops over the `g` frames of its
+//     group; the next frame's decimated window is requested a frame ahead and waits in registers.
 // ---------------------------------------------------------------------------------------------
-constexpr int LPC_CH = 96;                  // rows per staged chunk (864 = 9 chunks), + 4 look-ahead rows: 51 KB of LDS, 3 blocks per CU
-constexpr int LPC_NCH = XLP / LPC_CH;
-constexpr int LPC_ROWS = LPC_CH + 4;
-constexpr int LPC_PER_WAVE = LPC_ROWS / 5;  // 44 row loads in flight per wave
+constexpr int PK_SPB = 16;                       // streams per block
+constexpr int PK_WAVES = 8;
+constexpr int PK_T = 64 * PK_WAVES;
+constexpr int PK_LC = 7;                         // coarse lags per lane: 147 = 21 x 7
+constexpr int PK_NG = NLAG1 / PK_LC;
+static_assert(PK_NG * PK_LC == NLAG1 && (PK_LC & 1), "odd group size: neighbouring groups start on different row-pair parities");
+constexpr int PK_JB = 8;                         // taps per unrolled step of the coarse cross-correlation (240 = 30 x 8)
+constexpr int PK_NC = 36;                        // inner-product slots: 10 fine lags | 32 candidates of remove_doubling (+ 3 refinement)
 
-__global__ void __launch_bounds__(320) k_lpc(Buffers b, const StepParams *sp)
-{
-    NNN_FRAME_SPLIT(b.NT)
-    sp += frame;
-    __shared__ float buf[2][LPC_ROWS][64];   // double-buffered window chunks
-    __shared__ float acs[5][64];
-    __shared__ float coef[5][64];
-    const int lane = threadIdx.x & 63, tile = bx;
-    const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // this wave's lag
-    NNN_STAMP(b, 0);
-    const int slot = sp->slot;
-    const float *xw = NNN_TI(b.dec, DEC_LEN, tile, lane) + (size_t)dec_base(slot) * TILE;   // x_lp[0..863]
-#define x(j) xw[(size_t)(j) * TILE]
-    const float x_first = NNN_TI(b.xlp0, NSLOT, tile, lane)[(size_t)slot * TILE];   // x_lp[0] is special (ref: src/pitch.rs:458)
-    const int fast_n = XLP - 4;
-    {
-        // Every row of the window is fetched once per block (wave w takes rows w, w+5, ...), parked in LDS, and
-        // read from there by the five chains; chunk c+1 travels while chunk c is being summed.
-        float st[LPC_PER_WAVE];
-#pragma unroll
-        for (int i = 0; i < LPC_PER_WAVE; i++) st[i] = x(k + 5 * i);
-        if (k == 0) st[0] = x_first;
-#pragma unroll
-        for (int i = 0; i < LPC_PER_WAVE; i++) buf[0][k + 5 * i][lane] = st[i];
-        __syncthreads();
-        float c = 0.0f;
-        for (int ch = 0; ch < XLP / LPC_CH; ch++) {
-            const int j0 = ch * LPC_CH;
-            if (ch + 1 < XLP / LPC_CH) {
-#pragma unroll
-                for (int i = 0; i < LPC_PER_WAVE; i++) {
-                    const int r = j0 + LPC_CH + k + 5 * i;
-                    st[i] = r < XLP ? x(r) : 0.0f;
-                }
-            }
-            const float (*cb)[64] = buf[ch & 1];
-            const int n = (j0 + LPC_CH <= fast_n) ? LPC_CH : fast_n - j0;   // 96 x 8, then 92
-            for (int i0 = 0; i0 < n; i0 += 4) {
-                float a[4], bb[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) { a[i] = cb[i0 + i][lane]; bb[i] = cb[i0 + i + k][lane]; }
-#pragma unroll
-                for (int i = 0; i < 4; i++) c += a[i] * bb[i];
-            }
-            if (ch + 1 < XLP / LPC_CH) {
-#pragma unroll
-                for (int i = 0; i < LPC_PER_WAVE; i++) buf[(ch + 1) & 1][k + 5 * i][lane] = st[i];
-            }
-            __syncthreads();
-        }
-        // tail d_k = sum_{i = k+860}^{863} x[i] x[i-k], added after the main sum (ref: src/pitch.rs:439-445);
-        // rows 856..863 sit in the last chunk, at offset row - (first row of that chunk)
-        const float (*cb)[64] = buf[(LPC_NCH - 1) & 1];
-        float d = 0.0f;
-        for (int i = k + fast_n; i < XLP; i++) d += cb[i - (LPC_NCH - 1) * LPC_CH][lane] * cb[i - k - (LPC_NCH - 1) * LPC_CH][lane];
-        acs[k][lane] = c + d;
-    }
-    __syncthreads();
-    NNN_STAMP(b, 1);
-    if (k == 0) {
-        float ac[5];
-#pragma unroll
-        for (int i = 0; i < 5; i++) ac[i] = acs[i][lane];
-        ac[0] *= 1.0001f;
-#pragma unroll
-        for (int i = 1; i < 5; i++) ac[i] -= ac[i] * (0.008f * (float)i) * (0.008f * (float)i);
-
-        float lpc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (ac[0] != 0.0f) {
-            float error = ac[0];
-            bool done = false;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (!done) {
-                    float rr = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
-                    rr += ac[i + 1];
-                    float r = -rr / error;
-                    lpc[i] = r;
-#pragma unroll
-                    for (int j = 0; j < (i + 1) / 2; j++) {
-                        float t1 = lpc[j], t2 = lpc[i - 1 - j];
-                        lpc[j] = t1 + r * t2;
-                        lpc[i - 1 - j] = t2 + r * t1;
-                    }
-                    error = error - r * r * error;
-                    if (error < 0.001f * ac[0]) done = true;
-                }
-            }
-        }
-        float tmp = 1.0f;
-#pragma unroll
-        for (int i = 0; i < 4; i++) { tmp *= 0.9f; lpc[i] *= tmp; }
-        float l2[5];
-        l2[0] = lpc[0] + 0.8f;
-        l2[1] = lpc[1] + 0.8f * lpc[0];
-        l2[2] = lpc[2] + 0.8f * lpc[1];
-        l2[3] = lpc[3] + 0.8f * lpc[2];
-        l2[4] = 0.8f * lpc[3];
-        float *o = NNN_TI(b.lpc, 10, tile, lane);
-#pragma unroll
-        for (int i = 0; i < 5; i++) { o[(size_t)i * TILE] = ac[i]; o[(size_t)(5 + i) * TILE] = l2[i]; coef[i][lane] = l2[i]; }
-    }
-    __syncthreads();
-    NNN_STAMP(b, 2);
-    // FIR5 over 27 chunks of 32 outputs, 5 waves round-robin; pitch_buf goes out tile-interleaved only (the wave = stream
-    // consumer stages 16-stream slices of it through LDS)
-    const float n0 = coef[0][lane], n1 = coef[1][lane], n2 = coef[2][lane], n3 = coef[3][lane], n4 = coef[4][lane];
-    float *o = NNN_TI(b.xlp_ti, XLP, tile, lane);
-    for (int c = k; c < XLP / 32; c += 5) {
-        const int i0 = 32 * c;
-        float v[37];
-#pragma unroll
-        for (int u = 0; u < 37; u++) v[u] = (i0 + u - 5 >= 0) ? x(i0 + u - 5) : 0.0f;
-        if (c == 0) v[5] = x_first;
-#pragma unroll
-        for (int u = 0; u < 32; u++) {
-            // out = x + n0 m0 + n1 m1 + n2 m2 + n3 m3 + n4 m4, left to right (m0 = previous input, ...)
-            o[(size_t)(i0 + u) * TILE] = v[u + 5] + n0 * v[u + 4] + n1 * v[u + 3] + n2 * v[u + 2] + n3 * v[u + 1] + n4 * v[u];
-        }
-    }
-#undef x
-    NNN_STAMP(b, 3);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K5  pitch1: everything of the pitch search that is a strictly sequential sum per stream, lane = stream on the
-//     tile-interleaved pitch_buf, one block per (tile, frame), the independent chains spread over its 12 waves:
-//       waves 0..9   coarse cross-correlation, 147 lags x 240 taps on the 4x-decimated signal, every lag a sequential
-//                    sum in j (ref: src/pitch.rs:296-363, call site :82); 16 lags per wave: 16 accumulators and a
-//                    16-deep sliding window of y in registers, 2 coalesced row loads per 16 multiply-adds
-//       wave 10      xx = |x|^2 over the analysis frame and the 384-step running energy yy_lookup of
-//                    remove_doubling (ref: src/pitch.rs:133-142)
-//       wave 11      the running energies every fine and every coarse lag sees in find_best_pitch (ref: src/pitch.rs:83, :97,
-//                    :380-402), kept per lag
-//     then wave 0 runs find_best_pitch over the coarse lags (ref: src/pitch.rs:372-405, call site :83-84) on the
-//     block's cross-correlation, which never leaves LDS (stored to HBM only for the parity taps).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void yy_lookup(const Buffers &b, int tile, int lane)
-{
-    const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    for (int j0 = 0; j0 < 480; j0 += 24) {
-        float v[24];
-#pragma unroll
-        for (int i = 0; i < 24; i++) v[i] = p[(size_t)(384 + j0 + i) * TILE];
-#pragma unroll
-        for (int i = 0; i < 24; i += 4) {
-            s0 += v[i] * v[i]; s1 += v[i + 1] * v[i + 1]; s2 += v[i + 2] * v[i + 2]; s3 += v[i + 3] * v[i + 3];
-        }
-    }
-    const float xx = s0 + s1 + s2 + s3;
-    float *yo = NNN_TI(b.xx_yy, 386, tile, lane);
-    yo[0] = xx;
-    yo[TILE] = xx;  // yy_lookup[0]
-    float yy = xx;
-    for (int i0 = 1; i0 <= 384; i0 += 24) {
-        float a[24], c[24];
-#pragma unroll
-        for (int i = 0; i < 24; i++) {
-            a[i] = p[(size_t)(384 - (i0 + i)) * TILE];
-            c[i] = p[(size_t)(384 + 480 - (i0 + i)) * TILE];
-        }
-#pragma unroll
-        for (int i = 0; i < 24; i++) {
-            yy += a[i] * a[i] - c[i] * c[i];
-            yo[(size_t)(1 + i0 + i) * TILE] = fmaxf(yy, 0.0f);
-        }
-    }
-}
-
-constexpr int P1_LC = 16;                                   // lags per cross-correlation wave
-constexpr int P1_CHUNKS = (NLAG1 + P1_LC - 1) / P1_LC;      // 10
-constexpr int P1_WAVES = P1_CHUNKS + 2;
-
-// lags L0 .. L0 + 15 of the coarse cross-correlation -> xc[lag][lane]
-__device__ __forceinline__ void xcorr_chunk(const Buffers &b, int tile, int lane, int L0, float (*xc)[TILE])
-{
-    constexpr int LC = P1_LC;
-    const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
-#define X4(j) p[(size_t)(384 + 2 * (j)) * TILE]
-#define Y4(m) p[(size_t)(2 * (m)) * TILE]
-    float acc[LC], y[LC];
-#pragma unroll
-    for (int q = 0; q < LC; q++) { acc[q] = 0.0f; y[q] = Y4(L0 + q); }
-    for (int j = 0; j < 240; j += LC) {
-        float xv[LC], yn[LC];
-#pragma unroll
-        for (int k = 0; k < LC; k++) {               // this block's 2 LC row loads are issued together
-            xv[k] = X4(j + k);
-            int mn = L0 + j + k + LC;                // next y entering the window
-            yn[k] = Y4(mn < 432 ? mn : 431);         // stays inside pitch_buf; lags >= 147 are discarded
-        }
-#pragma unroll
-        for (int k = 0; k < LC; k++) {
-#pragma unroll
-            for (int q = 0; q < LC; q++) acc[q] += xv[k] * y[(k + q) % LC];
-            y[k % LC] = yn[k];
-        }
-    }
-#undef X4
-#undef Y4
-#pragma unroll
-    for (int q = 0; q < LC; q++) xc[L0 + q][lane] = acc[q];
-    if (b.taps) {
-        float *o = NNN_TI(b.xc1, NLAG1, tile, lane);
-#pragma unroll
-        for (int q = 0; q < LC; q++)
-            if (L0 + q < NLAG1) o[(size_t)(L0 + q) * TILE] = acc[q];
-    }
-}
-
-// the running energy y_sq_norm seen by every fine lag (ref: src/pitch.rs:97 -> :380-402), kept per lag: only <= 10
-// lags can update the best pitch there, and they are replayed by pitch2 with the energy each of them saw
-__device__ __forceinline__ void fine_energy(const Buffers &b, int tile, int lane)
-{
-    const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
-    float *yq = NNN_TI(b.ysq2, NLAG2, tile, lane);
-    float ysq = 1.0f;
-    for (int j0 = 0; j0 < 480; j0 += 24) {
-        float v[24];
-#pragma unroll
-        for (int i = 0; i < 24; i++) v[i] = p[(size_t)(j0 + i) * TILE];
-#pragma unroll
-        for (int i = 0; i < 24; i++) ysq += v[i] * v[i];
-    }
-    for (int i0 = 0; i0 < NLAG2; i0 += 21) {   // 294 = 14 x 21
-        float a[21], d[21];
-#pragma unroll
-        for (int i = 0; i < 21; i++) {
-            a[i] = p[(size_t)(i0 + i + 480) * TILE];
-            d[i] = p[(size_t)(i0 + i) * TILE];
-        }
-#pragma unroll
-        for (int i = 0; i < 21; i++) {
-            yq[(size_t)(i0 + i) * TILE] = ysq;
-            ysq += a[i] * a[i] - d[i] * d[i];
-            ysq = fmaxf(ysq, 1.0f);
-        }
-    }
-}
+__device__ __forceinline__ int pk_at(int r, int s) { return (((r >> 1) * PK_SPB + s) << 1) | (r & 1); }
 
 // running best / second-best update of find_best_pitch, ref: src/pitch.rs:383-400
 struct BestPitch {
@@ -488,108 +274,6 @@ struct BestPitch {
     }
 };
 
-// the running energy y_sq_norm seen by every coarse lag (ref: src/pitch.rs:83 -> :380-402)
-__device__ __forceinline__ void coarse_energy(const Buffers &b, int tile, int lane)
-{
-    const float *p = NNN_TI(b.xlp_ti, XLP, tile, lane);
-    float *yq = NNN_TI(b.ysq1, NLAG1, tile, lane);
-    float ysq = 1.0f;
-    for (int j0 = 0; j0 < 240; j0 += 24) {
-        float v[24];
-#pragma unroll
-        for (int i = 0; i < 24; i++) v[i] = p[(size_t)(2 * (j0 + i)) * TILE];
-#pragma unroll
-        for (int i = 0; i < 24; i++) ysq += v[i] * v[i];
-    }
-    for (int i0 = 0; i0 < NLAG1; i0 += 21) {   // 147 = 7 x 21
-        float a[21], d[21];
-#pragma unroll
-        for (int i = 0; i < 21; i++) {
-            a[i] = p[(size_t)(2 * (i0 + i + 240)) * TILE];
-            d[i] = p[(size_t)(2 * (i0 + i)) * TILE];
-        }
-#pragma unroll
-        for (int i = 0; i < 21; i++) {
-            yq[(size_t)(i0 + i) * TILE] = ysq;
-            ysq += a[i] * a[i] - d[i] * d[i];
-            ysq = fmaxf(ysq, 1.0f);
-        }
-    }
-}
-
-// (The scans as a launch of their own, three small waves per tile at full occupancy, measured slower: 177 + 182 us at 65 536
-// streams against 224 us for this kernel -- beside the cross-correlation waves they find pitch_buf's rows in the CU's L1 / L2,
-// on their own they fetch them from HBM again.)
-#ifndef NNN_P1_MINWAVES
-#define NNN_P1_MINWAVES 3
-#endif
-__global__ void __launch_bounds__(64 * P1_WAVES, NNN_P1_MINWAVES) k_pitch1(Buffers b)
-{
-    __shared__ float xc[P1_CHUNKS * P1_LC][TILE];
-    NNN_FRAME_SPLIT(b.NT)
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, tile = bx;
-#ifndef NNN_P1_COARSE_WITH_YY
-#define NNN_P1_COARSE_WITH_YY 0
-#endif
-    if (wave < P1_CHUNKS) xcorr_chunk(b, tile, lane, wave * P1_LC, xc);
-    else if (wave == P1_CHUNKS) {
-        yy_lookup(b, tile, lane);
-        if (NNN_P1_COARSE_WITH_YY) coarse_energy(b, tile, lane);
-    } else {
-        fine_energy(b, tile, lane);
-        if (!NNN_P1_COARSE_WITH_YY) coarse_energy(b, tile, lane);
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    // find_best_pitch over the coarse lags with the running energies kept per lag
-    const float *yq = NNN_TI(b.ysq1, NLAG1, tile, lane);
-    BestPitch bp;
-    bp.init();
-    for (int i0 = 0; i0 < NLAG1; i0 += 21) {   // 147 = 7 x 21
-        float c[21], e[21];
-#pragma unroll
-        for (int i = 0; i < 21; i++) {
-            c[i] = xc[i0 + i][lane];
-            e[i] = yq[(size_t)(i0 + i) * TILE];
-        }
-#pragma unroll
-        for (int i = 0; i < 21; i++) bp.update(i0 + i, c[i], e[i]);
-    }
-    int *o = (int *)NNN_TI(b.best1, 2, tile, lane);
-    o[0] = bp.best;
-    o[TILE] = bp.second;
-}
-
-// 4-way interleaved inner product partial (ref: src/pitch.rs:225-244): lane (e, q) accumulates
-// xs[4m+q]*ys[4m+q]; the caller combines ((s0+s1)+s2)+s3.
-__device__ __forceinline__ float ip480_partial(const float *xs, const float *ys, int q)
-{
-    float s = 0.0f;
-    for (int m0 = 0; m0 < 120; m0 += 8) {
-        float xv[8], yv[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) { xv[i] = xs[4 * (m0 + i) + q]; yv[i] = ys[4 * (m0 + i) + q]; }
-#pragma unroll
-        for (int i = 0; i < 8; i++) s += xv[i] * yv[i];
-    }
-    return s;
-}
-
-// two inner products against the same x at once (one x read for two multiply-adds): partials q of candidates ys1, ys2
-__device__ __forceinline__ void ip480_partial2(const float *xs, const float *ys1, const float *ys2, int q, float &r1, float &r2)
-{
-    float s1 = 0.0f, s2 = 0.0f;
-    for (int m0 = 0; m0 < 120; m0 += 6) {
-        float xv[6], y1[6], y2[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) { xv[i] = xs[4 * (m0 + i) + q]; y1[i] = ys1[4 * (m0 + i) + q]; y2[i] = ys2[4 * (m0 + i) + q]; }
-#pragma unroll
-        for (int i = 0; i < 6; i++) { s1 += xv[i] * y1[i]; s2 += xv[i] * y2[i]; }
-    }
-    r1 = s1;
-    r2 = s2;
-}
-
 struct Xc2 {   // xcorr[] of the fine search: zero except within 2 of 2*best / 2*second (ref: src/pitch.rs:88-96)
     float v[10];
     int lo1, lo2;
@@ -609,105 +293,410 @@ struct Xc2 {   // xcorr[] of the fine search: zero except within 2 of 2*best / 2
 
 __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1.0f + xx * yy); }
 
-// ---------------------------------------------------------------------------------------------
-// K7  pitch2: the data-dependent-lag part of the pitch search, wave = stream with the stream's pitch_buf in LDS:
-//       fine cross-correlation at the <= 10 lags within +-2 of 2*best / 2*second (ref: src/pitch.rs:88-96), lane
-//       (candidate, partial) keeping the reference's 4 interleaved partial sums; find_best_pitch over the fine lags
-//       replayed on those <= 10 lags with the running energies of pitch1, pseudo-interpolation (ref: :97-114);
-//       remove_doubling (ref: :118-221): the 29 candidate periods depend only on t0, so their inner products are
-//       computed up front, lane (candidate, partial), and the k = 2..15 decision loop runs on scalars.
-//     A block takes 16 consecutive streams (a quarter tile, one wave each): the tile-interleaved pitch_buf reaches LDS
-//     as 864 coalesced 64-byte segments, so no stream-major copy of it exists.  remove_doubling carries
-//     last_period / last_gain from frame to frame: the launch loops over the `g` frames of its group.
-// ---------------------------------------------------------------------------------------------
-constexpr int P2_SPB = 16;
-constexpr int P2_ROW = XLP + 1;   // odd row length: the transposing LDS writes of the staging spread over the banks
+struct PkLds {
+    float pb[XLP * PK_SPB];                      // the decimated window, then (in place) pitch_buf
+    float acs[5][PK_SPB], coef[5][PK_SPB];
+    union {
+        struct { float xc[NLAG1][PK_SPB], ysq[NLAG1][PK_SPB]; } c;   // coarse search: cross-correlation, running energy per lag
+        struct {                                                       // from the fine search on
+            float part[PK_NC][4][PK_SPB];        // inner-product partials [slot][q][stream] (ref: src/pitch.rs:225-244)
+            float yy[29][PK_SPB];                // yy_lookup at the candidate periods
+            int cand[32][PK_SPB];                // candidate periods of remove_doubling
+            int lo[2][PK_SPB];                   // first fine lag of the two windows
+            int tsel[PK_SPB];                    // the period the decision loop chose
+            int any_refine;                      // some stream of the block left t0: the +-1 refinement needs inner products
+        } f;
+    } u;
+};
 
-#ifndef NNN_P2_MINWAVES
-#define NNN_P2_MINWAVES 8   // two blocks per CU: <= 64 registers
-#endif
-__global__ void __launch_bounds__(64 * P2_SPB, NNN_P2_MINWAVES) k_pitch2(Buffers b, int g)
+// Window and FIR mapping: thread = (stream col, chunk ch of 32 rows), 27 chunks (the block's last 80 threads idle here); a
+// chunk starts on an even row, so every LDS address of its 16 row pairs is the thread's base plus a constant.
+constexpr int PK_CH = 32, PK_NCH = XLP / PK_CH;
+static_assert(PK_NCH * PK_CH == XLP && PK_NCH * PK_SPB <= PK_T, "");
+
+// a frame's window from the decimated-history ring: 16 lanes share a 64-byte segment of a tile row
+__device__ __forceinline__ void pk_window_load(const Buffers &b, const StepParams *sp, int tile, int q0, int tid, float (&v)[PK_CH])
 {
-    __shared__ float sh[P2_SPB][P2_ROW];
-    __shared__ float part[P2_SPB][64];
-    __shared__ float ipv[P2_SPB][32], yyc[P2_SPB][32];
-    __shared__ int cand[P2_SPB][32];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int col = tid & 15, ch = tid >> 4;
+    if (ch >= PK_NCH) return;
+    const int slot = sp->slot;
+    const float *base = b.dec + ((size_t)tile * DEC_LEN + (size_t)dec_base(slot)) * TILE + q0;   // uniform
+    const unsigned off = (unsigned)(ch * PK_CH) * TILE + (unsigned)col;
+#pragma unroll
+    for (int i = 0; i < PK_CH; i++) v[i] = base[off + (unsigned)i * TILE];
+    if (ch == 0) v[0] = NNN_TI(b.xlp0, NSLOT, tile, q0 + col)[(size_t)slot * TILE];   // x_lp[0] is special (ref: src/pitch.rs:458)
+}
+
+// 4-way interleaved inner-product partials (ref: src/pitch.rs:225-244) of NCAND candidates against the fixed operand
+// p[384 ..]: lane (s, q) accumulates x[4m+q] * y_c[4m+q] over m in order, one read of x serving every candidate;
+// the caller combines ((s0+s1)+s2)+s3.  y_c starts at row yr[c].  Rows 4m + const of one stream are 64 floats apart.
+template <int NCAND>
+__device__ __forceinline__ void pk_inner(const float *pb, int s, int q, const int (&yr)[NCAND], float (&acc)[NCAND])
+{
+    constexpr int MB = NCAND >= 4 ? 4 : (NCAND == 2 ? 6 : 8);
+    static_assert(120 % MB == 0, "");
+    const float *xp = pb + pk_at(PITCH_MAX / 2 + q, s);
+    const float *yp[NCAND];
+#pragma unroll
+    for (int c = 0; c < NCAND; c++) { acc[c] = 0.0f; yp[c] = pb + pk_at(yr[c] + q, s); }
+    for (int m0 = 0; m0 < 120; m0 += MB) {
+        float xv[MB], yv[NCAND][MB];
+#pragma unroll
+        for (int i = 0; i < MB; i++) {
+            xv[i] = xp[64 * (m0 + i)];
+#pragma unroll
+            for (int c = 0; c < NCAND; c++) yv[c][i] = yp[c][64 * (m0 + i)];
+        }
+#pragma unroll
+        for (int i = 0; i < MB; i++)
+#pragma unroll
+            for (int c = 0; c < NCAND; c++) acc[c] += xv[i] * yv[c][i];
+    }
+}
+
+#ifndef NNN_PK_MINWAVES
+#define NNN_PK_MINWAVES 4   // waves per SIMD: two blocks of 8 waves per CU, <= 128 registers
+#endif
+__global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, const StepParams *sp0, int g)
+{
+    __shared__ PkLds L;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane0 = threadIdx.x & 63;
+    int lane = lane0, s = lane & 15, q = lane >> 4;  // lane = (stream, chain)
     // Workgroup b runs on XCD b mod 8 (observed dispatch order; a speed matter only).  The four quarter-tile blocks of tile t are
-    // sent to XCD t mod 8 -- the one whose L2 holds the tile's pitch_buf rows, written there by k_lpc's block t and read by
-    // k_pitch1's: consecutive block indices would spread them over four XCDs, each fetching the same lines again.
+    // sent to XCD t mod 8 -- the one whose L2 holds the tile's decimated history, written there by k_hp's block t: consecutive
+    // block indices would spread them over four XCDs, each fetching the same lines.
     int blk = (int)blockIdx.x;
     if ((gridDim.x & 31) == 0) {
         const int xcd = blk & 7, i = blk >> 3;
         blk = 4 * (8 * (i >> 2) + xcd) + (i & 3);
     }
-    const int s = blk * P2_SPB + wave, tile = s >> 6, sl = s & 63;
-    const int q0 = (blk * P2_SPB) & 63;                   // first stream of this block within its tile
+    const int tile = (blk * PK_SPB) >> 6, q0 = (blk * PK_SPB) & 63;   // first stream of this block within its tile
     const int min_period = PITCH_MIN / 2, max_period = PITCH_MAX / 2;
-    int last_period = NNN_TI(b.last_period, 1, tile, sl)[0];
-    float last_gain = NNN_TI(b.last_gain, 1, tile, sl)[0];
+    const bool dec_lane = wave == 0 && lane0 < PK_SPB;                // lane = stream decisions
+    int last_period = 0;
+    float last_gain = 0.0f;
+    if (dec_lane) {
+        last_period = NNN_TI(b.last_period, 1, tile, q0 + s)[0];
+        last_gain = NNN_TI(b.last_gain, 1, tile, q0 + s)[0];
+    }
+    float win[PK_CH];
+    pk_window_load(b, sp0, tile, q0, (int)threadIdx.x, win);
     for (int f = 0; f < g; f++) {
-        {   // stage the 16 streams' pitch_buf: thread -> (row, stream), 16 lanes share a 64-byte segment
-            const float *src = NNN_TIF(b, xlp_ti, XLP, f, tile, q0);
-            const int col = threadIdx.x & 15, r0 = threadIdx.x >> 4;
-            float v[(XLP + 63) / 64];
+        lane = launder_v(lane0);   // keep the frame loop's addresses inside the loop (see launder_v)
+        s = lane & 15;
+        q = lane >> 4;
+        const int sl = q0 + s;
+        const int tid = 64 * wave + lane, col = tid & 15, ch = tid >> 4;
+        float2 *chp = (float2 *)L.pb + (ch * (PK_CH / 2)) * PK_SPB + col;   // this thread's chunk: row pair m at chp[16 m]
+        // ---- the window -> LDS
+        if (ch < PK_NCH) {
 #pragma unroll
-            for (int i = 0; i < (XLP + 63) / 64; i++) {
-                const int r = r0 + 64 * i;
-                v[i] = r < XLP ? src[(size_t)r * TILE + col] : 0.0f;
-            }
-            if (f) __syncthreads();   // every wave is done with the previous frame's rows
-#pragma unroll
-            for (int i = 0; i < (XLP + 63) / 64; i++) {
-                const int r = r0 + 64 * i;
-                if (r < XLP) sh[col][r] = v[i];
-            }
+            for (int m = 0; m < PK_CH / 2; m++) chp[m * PK_SPB] = make_float2(win[2 * m], win[2 * m + 1]);
         }
-        const int *b1 = NNN_TIF(b, best1, 2, f, tile, sl);
-        const int best = b1[0], second = b1[TILE];
-        const float *yq = NNN_TIF(b, ysq2, NLAG2, f, tile, sl);
-        const float *xy_tab = NNN_TIF(b, xx_yy, 386, f, tile, sl);
-        const float xx = xy_tab[0];
         __syncthreads();
-        // ---- fine cross-correlation
-        Xc2 xc;
-        xc.lo1 = 2 * best - 2;
-        xc.lo2 = 2 * second - 2;
-        {
-            const int c = lane >> 2, q = lane & 3;
-            const int lag = (c < 5) ? xc.lo1 + c : xc.lo2 + (c - 5);
-            const bool valid = c < 10 && lag >= 0 && lag < NLAG2;
-            part[wave][lane] = valid ? ip480_partial(&sh[wave][384], &sh[wave][lag], q) : 0.0f;
-            wave_lds_sync();
-            float v = 0.0f;
-            if (q == 0 && valid) {
-                v = part[wave][lane] + part[wave][lane + 1] + part[wave][lane + 2] + part[wave][lane + 3];
-                v = fmaxf(v, -1.0f);
-            }
-            wave_lds_sync();
-            if (q == 0 && c < 10) {
-                ipv[wave][c] = v;
-                // the energy this lag saw in the serial scan (pitch1), for the replay below
-                yyc[wave][c] = valid ? yq[(size_t)lag * TILE] : 0.0f;
-                if (b.taps) NNN_TIF(b, xc2, 10, f, tile, sl)[(size_t)c * TILE] = v;
-            }
-            wave_lds_sync();
+        // ---- autocorrelation: lags 0..3 on wave 0, lag 4 on the first 16 lanes of wave 1 (ref: src/pitch.rs:433-446)
+        if (wave == 0 || (wave == 1 && lane < PK_SPB)) {
+            const int k = wave == 0 ? q : 4;
+            const int fast_n = XLP - 4;
+            // rows i0 + u and i0 + u + k, i0 a multiple of 4: with F(j) = 32 (j >> 1) + (j & 1) the offset of row j within a
+            // stream's column, row i0 + u + k sits F(u + (k & 1)) + 32 (k >> 1) after row i0
+            const float *pa = L.pb + 2 * s;
+            int ob[4];
 #pragma unroll
-            for (int u = 0; u < 10; u++) xc.v[u] = ipv[wave][u];
+            for (int u = 0; u < 4; u++) {
+                const int j0 = u, j1 = u + 1;
+                ob[u] = 32 * (k >> 1) + ((k & 1) ? 32 * (j1 >> 1) + (j1 & 1) : 32 * (j0 >> 1) + (j0 & 1));
+            }
+            float c = 0.0f;
+            for (int i0 = 0; i0 < fast_n; i0 += 4) {
+                const float *r = pa + 16 * i0;
+                float a[4], bb[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { a[u] = r[32 * (u >> 1) + (u & 1)]; bb[u] = r[ob[u]]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) c += a[u] * bb[u];
+            }
+            float d = 0.0f;   // tail d_k = sum_{i = k+860}^{863} x[i] x[i-k], added after the main sum
+            for (int i = k + fast_n; i < XLP; i++) d += L.pb[pk_at(i, s)] * L.pb[pk_at(i - k, s)];
+            L.acs[k][s] = c + d;
         }
-        // ---- find_best_pitch over the fine lags: xcorr is zero outside the two 5-lag windows, so only they can
-        //      update the best pitch; replayed in increasing lag order (every lane computes the same thing)
-        int ps;
+        __syncthreads();
+        // ---- lag window, Levinson, bandwidth expansion, extra zero (ref: src/pitch.rs:460-480, 257-292)
+        if (dec_lane) {
+            float ac[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) ac[i] = L.acs[i][s];
+            ac[0] *= 1.0001f;
+#pragma unroll
+            for (int i = 1; i < 5; i++) ac[i] -= ac[i] * (0.008f * (float)i) * (0.008f * (float)i);
+            float lpc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (ac[0] != 0.0f) {
+                float error = ac[0];
+                bool done = false;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (!done) {
+                        float rr = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
+                        rr += ac[i + 1];
+                        float r = -rr / error;
+                        lpc[i] = r;
+#pragma unroll
+                        for (int j = 0; j < (i + 1) / 2; j++) {
+                            float t1 = lpc[j], t2 = lpc[i - 1 - j];
+                            lpc[j] = t1 + r * t2;
+                            lpc[i - 1 - j] = t2 + r * t1;
+                        }
+                        error = error - r * r * error;
+                        if (error < 0.001f * ac[0]) done = true;
+                    }
+                }
+            }
+            float tmp = 1.0f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { tmp *= 0.9f; lpc[i] *= tmp; }
+            float l2[5];
+            l2[0] = lpc[0] + 0.8f;
+            l2[1] = lpc[1] + 0.8f * lpc[0];
+            l2[2] = lpc[2] + 0.8f * lpc[1];
+            l2[3] = lpc[3] + 0.8f * lpc[2];
+            l2[4] = 0.8f * lpc[3];
+#pragma unroll
+            for (int i = 0; i < 5; i++) L.coef[i][s] = l2[i];
+            if (b.taps) {
+                float *o = NNN_TIF(b, lpc, 10, f, tile, sl);
+#pragma unroll
+                for (int i = 0; i < 5; i++) { o[(size_t)i * TILE] = ac[i]; o[(size_t)(5 + i) * TILE] = l2[i]; }
+            }
+        }
+        __syncthreads();
+        // ---- FIR5 with zero initial memory, in place (ref: src/pitch.rs:407-429): the chunk's inputs are still in the
+        //      thread's registers, the five rows before it come from LDS before anyone overwrites them
         {
+            float v[PK_CH + 5];
+            if (ch < PK_NCH) {
+                float2 h0 = make_float2(0.0f, 0.0f), h1 = h0, h2 = h0;
+                if (ch > 0) { h0 = chp[-3 * PK_SPB]; h1 = chp[-2 * PK_SPB]; h2 = chp[-1 * PK_SPB]; }
+                v[0] = h0.y; v[1] = h1.x; v[2] = h1.y; v[3] = h2.x; v[4] = h2.y;
+#pragma unroll
+                for (int u = 0; u < PK_CH; u++) v[5 + u] = win[u];
+            }
+            __syncthreads();   // every chunk has its inputs
+            if (ch < PK_NCH) {
+                const float n0 = L.coef[0][col], n1 = L.coef[1][col], n2 = L.coef[2][col], n3 = L.coef[3][col], n4 = L.coef[4][col];
+                float *tap = b.taps ? NNN_TIF(b, xlp_ti, XLP, f, tile, q0 + col) + (size_t)(ch * PK_CH) * TILE : nullptr;
+#pragma unroll
+                for (int m = 0; m < PK_CH / 2; m++) {
+                    float o[2];
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const int u = 2 * m + e;
+                        // out = x + n0 m0 + n1 m1 + n2 m2 + n3 m3 + n4 m4, left to right (m0 = previous input, ...)
+                        o[e] = v[u + 5] + n0 * v[u + 4] + n1 * v[u + 3] + n2 * v[u + 2] + n3 * v[u + 1] + n4 * v[u];
+                        if (tap) tap[(size_t)u * TILE] = o[e];
+                    }
+                    chp[m * PK_SPB] = make_float2(o[0], o[1]);
+                }
+            }
+        }
+        if (f + 1 < g) pk_window_load(b, sp0 + f + 1, tile, q0, tid, win);   // the next frame's window travels behind this frame's work
+        __syncthreads();
+        // ---- coarse search: cross-correlation on waves 0..5, the serial energy scans behind / beside it
+        {
+            const float2 *p2 = (const float2 *)L.pb;   // row pair m of stream s: p2[m * 16 + s], .x = row 2m
+            const int grp = 4 * wave + q;
+            if (grp < PK_NG) {
+                // xcorr[L] = sum_j x4[j] y4[L + j], x4[j] = p[384 + 2j], y4[m] = p[2m]: a sequential sum per lag (ref: src/pitch.rs:296-363)
+                // (the odd row of a pair is not needed, but the 8-byte read is: 4-byte reads bank modulo 32 and the two lag
+                // groups of a 32-lane group would collide)
+                auto even = [&](int m) { const float2 v = p2[m * PK_SPB + s]; keep_v(v.y); return v.x; };
+                const int L0 = PK_LC * grp;
+                float acc[PK_LC], w[PK_JB + PK_LC - 1];
+#pragma unroll
+                for (int i = 0; i < PK_LC; i++) acc[i] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < PK_LC - 1; i++) w[i] = even(L0 + i);
+#pragma unroll 2
+                for (int j = 0; j < 240; j += PK_JB) {
+                    float xv[PK_JB];
+#pragma unroll
+                    for (int k = 0; k < PK_JB; k++) {
+                        xv[k] = even(192 + j + k);
+                        w[PK_LC - 1 + k] = even(L0 + j + k + PK_LC - 1);   // <= row pair 385
+                    }
+#pragma unroll
+                    for (int k = 0; k < PK_JB; k++)
+#pragma unroll
+                        for (int i = 0; i < PK_LC; i++) acc[i] += xv[k] * w[k + i];
+#pragma unroll
+                    for (int i = 0; i < PK_LC - 1; i++) w[i] = w[i + PK_JB];
+                }
+#pragma unroll
+                for (int i = 0; i < PK_LC; i++) L.u.c.xc[L0 + i][s] = acc[i];
+                if (b.taps) {
+                    float *o = NNN_TIF(b, xc1, NLAG1, f, tile, sl);
+#pragma unroll
+                    for (int i = 0; i < PK_LC; i++) o[(size_t)(L0 + i) * TILE] = acc[i];
+                }
+            }
+            const float2 *ps = p2 + s;   // row pair m of this lane's stream: ps[16 m]
+            if (wave == 5 && lane < PK_SPB) {
+                // the running energy every coarse lag sees in find_best_pitch (ref: src/pitch.rs:83 -> :380-402): even rows only
+                float ysq = 1.0f;
+                for (int j0 = 0; j0 < 240; j0 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] = ps[(j0 + i) * PK_SPB].x;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) ysq += v[i] * v[i];
+                }
+                for (int i0 = 0; i0 < NLAG1; i0 += 7) {
+                    float a[7], d[7];
+#pragma unroll
+                    for (int i = 0; i < 7; i++) { a[i] = ps[(i0 + i + 240) * PK_SPB].x; d[i] = ps[(i0 + i) * PK_SPB].x; }
+#pragma unroll
+                    for (int i = 0; i < 7; i++) {
+                        L.u.c.ysq[i0 + i][s] = ysq;
+                        ysq += a[i] * a[i] - d[i] * d[i];
+                        ysq = fmaxf(ysq, 1.0f);
+                    }
+                }
+            } else if (wave == 6 && lane < PK_SPB) {
+                // the running energy every fine lag sees (ref: src/pitch.rs:97 -> :380-402), kept per lag in global scratch:
+                // <= 10 lags can update the best pitch there, and they are replayed below with the energy each of them saw
+                float *yq = NNN_TIF(b, ysq2, NLAG2, f, tile, sl);
+                float ysq = 1.0f;
+                for (int m0 = 0; m0 < 240; m0 += 4) {
+                    float2 v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = ps[(m0 + i) * PK_SPB];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { ysq += v[i].x * v[i].x; ysq += v[i].y * v[i].y; }
+                }
+                for (int n0 = 0; n0 < NLAG2 / 2; n0 += 7) {   // lags 2n, 2n + 1: rows (2n, 2n + 1) leave, rows (2n + 480, 2n + 481) enter
+                    float2 a[7], d[7];
+#pragma unroll
+                    for (int i = 0; i < 7; i++) { a[i] = ps[(n0 + i + 240) * PK_SPB]; d[i] = ps[(n0 + i) * PK_SPB]; }
+#pragma unroll
+                    for (int i = 0; i < 7; i++) {
+                        yq[(size_t)(2 * (n0 + i)) * TILE] = ysq;
+                        ysq += a[i].x * a[i].x - d[i].x * d[i].x;
+                        ysq = fmaxf(ysq, 1.0f);
+                        yq[(size_t)(2 * (n0 + i) + 1) * TILE] = ysq;
+                        ysq += a[i].y * a[i].y - d[i].y * d[i].y;
+                        ysq = fmaxf(ysq, 1.0f);
+                    }
+                }
+            } else if (wave == 7 && lane < PK_SPB) {
+                // xx = |x|^2 over the analysis frame and the 384-step running energy yy_lookup of remove_doubling
+                // (ref: src/pitch.rs:133-142)
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+                for (int m0 = 192; m0 < 432; m0 += 4) {
+                    float2 v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = ps[(m0 + i) * PK_SPB];
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {
+                        s0 += v[i].x * v[i].x; s1 += v[i].y * v[i].y; s2 += v[i + 1].x * v[i + 1].x; s3 += v[i + 1].y * v[i + 1].y;
+                    }
+                }
+                const float xx = s0 + s1 + s2 + s3;
+                float *yo = NNN_TIF(b, xx_yy, 386, f, tile, sl);
+                yo[0] = xx;
+                yo[TILE] = xx;  // yy_lookup[0]
+                float yy = xx;
+                for (int n0 = 0; n0 < 192; n0 += 4) {   // steps i = 2n + 1, 2n + 2: rows 383 - 2n, 382 - 2n enter, rows 863 - 2n, 862 - 2n leave
+                    float2 a[4], c[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { a[i] = ps[(191 - (n0 + i)) * PK_SPB]; c[i] = ps[(431 - (n0 + i)) * PK_SPB]; }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        yy += a[i].y * a[i].y - c[i].y * c[i].y;
+                        yo[(size_t)(2 * (n0 + i) + 2) * TILE] = fmaxf(yy, 0.0f);
+                        yy += a[i].x * a[i].x - c[i].x * c[i].x;
+                        yo[(size_t)(2 * (n0 + i) + 3) * TILE] = fmaxf(yy, 0.0f);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- find_best_pitch over the coarse lags (ref: src/pitch.rs:372-405, call site :83-84)
+        int lo1 = 0, lo2 = 0;
+        if (dec_lane) {
             BestPitch bp;
             bp.init();
-            const int loA = min(xc.lo1, xc.lo2), loB = max(xc.lo1, xc.lo2);
-            const int baseA = xc.lo1 <= xc.lo2 ? 0 : 5, baseB = 5 - baseA;
+            for (int i0 = 0; i0 < NLAG1; i0 += 7) {
+                float c[7], e[7];
+#pragma unroll
+                for (int i = 0; i < 7; i++) { c[i] = L.u.c.xc[i0 + i][s]; e[i] = L.u.c.ysq[i0 + i][s]; }
+#pragma unroll
+                for (int i = 0; i < 7; i++) bp.update(i0 + i, c[i], e[i]);
+            }
+            if (b.taps) {
+                int *o = (int *)NNN_TIF(b, best1, 2, f, tile, sl);
+                o[0] = bp.best;
+                o[TILE] = bp.second;
+            }
+            lo1 = 2 * bp.best - 2;
+            lo2 = 2 * bp.second - 2;
+        }
+        __syncthreads();   // the coarse arrays are dead: their space takes the partial sums from here on
+        if (dec_lane) {
+            L.u.f.lo[0][s] = lo1;
+            L.u.f.lo[1][s] = lo2;
+            if (s == 0) L.u.f.any_refine = 0;
+        }
+        __syncthreads();
+        // ---- fine cross-correlation at the <= 10 lags within +-2 of 2*best / 2*second (ref: src/pitch.rs:88-96): wave w
+        //      takes lags lo1 + w and lo2 + w
+        if (wave < 5) {
+            const int la = L.u.f.lo[0][s] + wave, lb = L.u.f.lo[1][s] + wave;
+            const bool va = la >= 0 && la < NLAG2, vb = lb >= 0 && lb < NLAG2;
+            const int yr[2] = {va ? la : 0, vb ? lb : 0};
+            float acc[2];
+            pk_inner<2>(L.pb, s, q, yr, acc);
+            L.u.f.part[wave][q][s] = acc[0];
+            L.u.f.part[5 + wave][q][s] = acc[1];
+        }
+        __syncthreads();
+        // ---- find_best_pitch over the fine lags: xcorr is zero outside the two 5-lag windows, so only they can update the
+        //      best pitch; replayed in increasing lag order with the energy each of them saw.  Then the candidate periods.
+        Xc2 xc;
+        int t0 = 0;
+        float xx = 0.0f;
+        if (dec_lane) {
+            const float *yq = NNN_TIF(b, ysq2, NLAG2, f, tile, sl);
+            const float *xy_tab = NNN_TIF(b, xx_yy, 386, f, tile, sl);
+            xx = xy_tab[0];
+            xc.lo1 = lo1;
+            xc.lo2 = lo2;
+            float ye[10];
+#pragma unroll
+            for (int c = 0; c < 10; c++) {
+                const int lag = c < 5 ? lo1 + c : lo2 + (c - 5);
+                const bool valid = lag >= 0 && lag < NLAG2;
+                float v = L.u.f.part[c][0][s] + L.u.f.part[c][1][s] + L.u.f.part[c][2][s] + L.u.f.part[c][3][s];
+                v = fmaxf(v, -1.0f);
+                xc.v[c] = valid ? v : 0.0f;
+                ye[c] = valid ? yq[(size_t)lag * TILE] : 0.0f;
+            }
+            if (b.taps) {
+                float *o = NNN_TIF(b, xc2, 10, f, tile, sl);
+#pragma unroll
+                for (int c = 0; c < 10; c++) o[(size_t)c * TILE] = xc.v[c];
+            }
+            BestPitch bp;
+            bp.init();
+            const int loA = min(lo1, lo2), loB = max(lo1, lo2);
+            const bool a_first = lo1 <= lo2;
 #pragma unroll
             for (int u = 0; u < 10; u++) {
                 const int i = u < 5 ? loA + u : loB + (u - 5);
                 const bool on = i >= 0 && i < NLAG2 && (u < 5 || i > loA + 4);
-                if (on) bp.update(i, xc.at(i), yyc[wave][(u < 5 ? baseA + u : baseB + (u - 5))]);
+                // the energy of the lower window's lags sits at ye[0..4] when lo1 <= lo2, at ye[5..9] otherwise
+                const float e = (u < 5) == a_first ? ye[u < 5 ? u : u - 5] : ye[5 + (u < 5 ? u : u - 5)];
+                if (on) bp.update(i, xc.at(i), e);
             }
             int offset = 0;
             if (bp.best > 0 && bp.best < NLAG2 - 1) {
@@ -715,105 +704,109 @@ __global__ void __launch_bounds__(64 * P2_SPB, NNN_P2_MINWAVES) k_pitch2(Buffers
                 if (c - a > 0.7f * (bb - a)) offset = 1;
                 else if (a - c > 0.7f * (bb - c)) offset = -1;
             }
-            ps = 2 * bp.best - offset;
-            if (lane == 0) NNN_TIF(b, psearch, 1, f, tile, sl)[0] = ps;
-        }
-        wave_lds_sync();   // ipv / yyc are reused below
-        // ---- remove_doubling
-        int t0 = (PITCH_MAX - ps) / 2;
-        if (t0 > max_period - 1) t0 = max_period - 1;
-        const int prev_period = last_period / 2;
-        // 29 candidates of the decision loop + the two neighbours of t0 (candidates 29, 30): if the loop keeps t0 -- the usual
-        // case -- the final +-1 refinement needs no inner products of its own
-        if (lane < 31) {
-            int t;
-            if (lane == 0) t = t0;
-            else if (lane >= 29) t = lane == 29 ? t0 - 1 : t0 + 1;
-            else {
-                int k = 2 + (lane - 1) / 2;
-                int t1 = (2 * t0 + k) / (2 * k);
-                if ((lane - 1) & 1) {
-                    const int sc = kSecondCheck[k];
-                    t = (k == 2) ? ((t1 + t0 > max_period) ? t0 : t0 + t1) : (2 * sc * t0 + k) / (2 * k);
-                } else t = t1;
-            }
-            cand[wave][lane] = t;
-            yyc[wave][lane] = lane < 29 ? xy_tab[(size_t)(1 + t) * TILE] : 0.0f;
-        } else if (lane == 31) {
-            cand[wave][31] = t0;   // (filler for the paired loop below)
-        }
-        wave_lds_sync();
-        {   // lane (e, q) takes partial q of candidates e and e + 16: one read of x serves both
-            const int e = lane >> 2, q = lane & 3;
-            float v1, v2;
-            ip480_partial2(&sh[wave][max_period], &sh[wave][max_period - cand[wave][e]], &sh[wave][max_period - cand[wave][e + 16]], q, v1, v2);
-            part[wave][lane] = v1;
-            wave_lds_sync();
-            if (q == 0) ipv[wave][e] = part[wave][lane] + part[wave][lane + 1] + part[wave][lane + 2] + part[wave][lane + 3];
-            wave_lds_sync();
-            part[wave][lane] = v2;
-            wave_lds_sync();
-            if (q == 0) ipv[wave][e + 16] = part[wave][lane] + part[wave][lane + 1] + part[wave][lane + 2] + part[wave][lane + 3];
-            wave_lds_sync();
-        }
-        // decision loop on scalars (every lane computes the same thing)
-        int t = t0;
-        float xy = ipv[wave][0], yy = yyc[wave][0];
-        float best_xy = xy, best_yy = yy;
-        const float g0 = pitch_gain(xy, xx, yy);
-        float gg = g0;
-        for (int k = 2; k <= 15; k++) {
-            int t1 = cand[wave][1 + 2 * (k - 2)];
-            if (t1 < min_period) break;
-            int e1 = 1 + 2 * (k - 2), e2 = e1 + 1;
-            xy = (ipv[wave][e1] + ipv[wave][e2]) / 2.0f;
-            yy = (yyc[wave][e1] + yyc[wave][e2]) / 2.0f;
-            float g1 = pitch_gain(xy, xx, yy);
-            int d = t1 - prev_period;
-            if (d < 0) d = -d;
-            float cont;
-            if (d <= 1) cont = last_gain;
-            else if (d <= 2 && 5 * k * k < t0) cont = last_gain / 2.0f;
-            else cont = 0.0f;
-            float thresh;
-            if (t1 < 3 * min_period) thresh = fmaxf(0.85f * g0 - cont, 0.4f);
-            else if (t1 < 2 * min_period) thresh = fmaxf(0.9f * g0 - cont, 0.5f);
-            else thresh = fmaxf(0.7f * g0 - cont, 0.3f);
-            if (g1 > thresh) { best_xy = xy; best_yy = yy; t = t1; gg = g1; }
-        }
-        best_xy = fmaxf(best_xy, 0.0f);
-        float pg = (best_yy <= best_xy) ? 1.0f : best_xy / (best_yy + 1.0f);
-        // final +-1 refinement: the inner products at t - 1, t, t + 1 (the same sums whichever way they are obtained)
-        float x3[3];
-        if (t == t0) {   // wave-uniform
-            x3[0] = ipv[wave][29]; x3[1] = ipv[wave][0]; x3[2] = ipv[wave][30];
-        } else {
-            int e = lane >> 2, q = lane & 3;
-            float v = 0.0f;
-            if (e < 3) v = ip480_partial(&sh[wave][max_period], &sh[wave][max_period - (t + e - 1)], q);
-            part[wave][lane] = v;
-            wave_lds_sync();
+            const int psr = 2 * bp.best - offset;
+            if (b.taps) NNN_TIF(b, psearch, 1, f, tile, sl)[0] = psr;
+            // ---- remove_doubling: 29 candidates of the decision loop + the two neighbours of t0 (slots 29, 30): if the
+            //      loop keeps t0 the final +-1 refinement needs no inner products of its own
+            t0 = (PITCH_MAX - psr) / 2;
+            if (t0 > max_period - 1) t0 = max_period - 1;
 #pragma unroll
-            for (int e3 = 0; e3 < 3; e3++)
-                x3[e3] = part[wave][4 * e3] + part[wave][4 * e3 + 1] + part[wave][4 * e3 + 2] + part[wave][4 * e3 + 3];
+            for (int e = 0; e < 32; e++) {   // (unrolled: k is a constant in every copy)
+                int t;
+                if (e == 0 || e == 31) t = t0;
+                else if (e >= 29) t = e == 29 ? t0 - 1 : t0 + 1;
+                else {
+                    const int k = 2 + (e - 1) / 2;
+                    const int t1 = (2 * t0 + k) / (2 * k);
+                    if ((e - 1) & 1) {
+                        const int sc = kSecondCheck[k];
+                        t = (k == 2) ? ((t1 + t0 > max_period) ? t0 : t0 + t1) : (2 * sc * t0 + k) / (2 * k);
+                    } else t = t1;
+                }
+                L.u.f.cand[e][s] = t;
+                if (e < 29) L.u.f.yy[e][s] = xy_tab[(size_t)(1 + t) * TILE];
+            }
         }
-        int offset = 0;
-        if (x3[2] - x3[0] > 0.7f * (x3[1] - x3[0])) offset = 1;
-        else if (x3[0] - x3[2] > 0.7f * (x3[1] - x3[2])) offset = -1;
-        pg = fminf(pg, gg);
-        int res = 2 * t + offset;
-        if (res < PITCH_MIN) res = PITCH_MIN;
-        if (lane == 0) {
+        __syncthreads();
+        // ---- the candidates' inner products against p[384 ..]: wave w takes slots w, w + 8, w + 16, w + 24
+        {
+            int yr[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) yr[c] = max_period - L.u.f.cand[wave + 8 * c][s];
+            float acc[4];
+            pk_inner<4>(L.pb, s, q, yr, acc);
+#pragma unroll
+            for (int c = 0; c < 4; c++) L.u.f.part[wave + 8 * c][q][s] = acc[c];
+        }
+        __syncthreads();
+        // ---- decision loop (ref: src/pitch.rs:150-206)
+        int t = 0;
+        float pg = 0.0f, gg = 0.0f;
+        if (dec_lane) {
+            auto ipv = [&](int e) { return L.u.f.part[e][0][s] + L.u.f.part[e][1][s] + L.u.f.part[e][2][s] + L.u.f.part[e][3][s]; };
+            const int prev_period = last_period / 2;
+            t = t0;
+            float xy = ipv(0), yy = L.u.f.yy[0][s];
+            float best_xy = xy, best_yy = yy;
+            const float g0 = pitch_gain(xy, xx, yy);
+            gg = g0;
+            for (int k = 2; k <= 15; k++) {
+                const int e1 = 1 + 2 * (k - 2), e2 = e1 + 1;
+                const int t1 = L.u.f.cand[e1][s];
+                if (t1 < min_period) break;
+                xy = (ipv(e1) + ipv(e2)) / 2.0f;
+                yy = (L.u.f.yy[e1][s] + L.u.f.yy[e2][s]) / 2.0f;
+                const float g1 = pitch_gain(xy, xx, yy);
+                int d = t1 - prev_period;
+                if (d < 0) d = -d;
+                float cont;
+                if (d <= 1) cont = last_gain;
+                else if (d <= 2 && 5 * k * k < t0) cont = last_gain / 2.0f;
+                else cont = 0.0f;
+                float thresh;
+                if (t1 < 3 * min_period) thresh = fmaxf(0.85f * g0 - cont, 0.4f);
+                else if (t1 < 2 * min_period) thresh = fmaxf(0.9f * g0 - cont, 0.5f);
+                else thresh = fmaxf(0.7f * g0 - cont, 0.3f);
+                if (g1 > thresh) { best_xy = xy; best_yy = yy; t = t1; gg = g1; }
+            }
+            best_xy = fmaxf(best_xy, 0.0f);
+            pg = (best_yy <= best_xy) ? 1.0f : best_xy / (best_yy + 1.0f);
+            L.u.f.tsel[s] = t;
+            if (t != t0) L.u.f.any_refine = 1;
+        }
+        __syncthreads();
+        // ---- final +-1 refinement: the inner products at t - 1, t, t + 1 (the same sums whichever way they are obtained)
+        const bool refine = L.u.f.any_refine != 0;   // block-uniform
+        if (refine) {
+            if (wave < 3) {
+                const int yr[1] = {max_period - (L.u.f.tsel[s] + wave - 1)};
+                float acc[1];
+                pk_inner<1>(L.pb, s, q, yr, acc);
+                L.u.f.part[32 + wave][q][s] = acc[0];
+            }
+            __syncthreads();
+        }
+        if (dec_lane) {
+            auto ipv = [&](int e) { return L.u.f.part[e][0][s] + L.u.f.part[e][1][s] + L.u.f.part[e][2][s] + L.u.f.part[e][3][s]; };
+            float x3[3];
+            if (t == t0) { x3[0] = ipv(29); x3[1] = ipv(0); x3[2] = ipv(30); }
+            else { x3[0] = ipv(32); x3[1] = ipv(33); x3[2] = ipv(34); }
+            int offset = 0;
+            if (x3[2] - x3[0] > 0.7f * (x3[1] - x3[0])) offset = 1;
+            else if (x3[0] - x3[2] > 0.7f * (x3[1] - x3[2])) offset = -1;
+            pg = fminf(pg, gg);
+            int res = 2 * t + offset;
+            if (res < PITCH_MIN) res = PITCH_MIN;
             NNN_TIF(b, pitch, 1, f, tile, sl)[0] = res;
             NNN_TIF(b, pgain, 1, f, tile, sl)[0] = pg;
+            last_period = res;
+            last_gain = pg;
         }
-        last_period = res;
-        last_gain = pg;
-        wave_lds_sync();   // part / ipv / yyc / cand are rewritten by the next frame
+        // (the next frame's first writes to anything this frame still reads sit behind barriers wave 0 takes part in)
     }
-    if (lane == 0) {
-        NNN_TI(b.last_period, 1, tile, sl)[0] = last_period;
-        NNN_TI(b.last_gain, 1, tile, sl)[0] = last_gain;
+    if (dec_lane) {
+        NNN_TI(b.last_period, 1, tile, q0 + s)[0] = last_period;
+        NNN_TI(b.last_gain, 1, tile, q0 + s)[0] = last_gain;
     }
 }
 

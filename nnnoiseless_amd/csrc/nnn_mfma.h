@@ -63,6 +63,8 @@ __device__ __forceinline__ int launder_v(int x)
     asm volatile("" : "+v"(x));
     return x;
 }
+// marks a value as used (an 8-byte LDS read whose second half is not needed stays an 8-byte read)
+__device__ __forceinline__ void keep_v(float x) { asm volatile("" ::"v"(x)); }
 __device__ __forceinline__ int launder_s(int x)
 {
     asm volatile("" : "+s"(x));

@@ -61,5 +61,6 @@ template <class T> static inline void st_global(void *p, T v) { memcpy(p, &v, si
 static inline void wf_setprio_high() {}
 static inline int launder_v(int x) { return x; }
 static inline int launder_s(int x) { return x; }
+static inline void keep_v(float) {}
 
 }  // namespace nnn

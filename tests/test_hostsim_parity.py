@@ -246,7 +246,7 @@ def test_wide_dense_layers(hostsim_lib, oracle_mod, rows, monkeypatch):
 
 
 def test_quarter_tile_block_remap(hostsim_lib, oracle_mod, weights_bytes):
-    """512 streams = 32 quarter-tile blocks of k_pitch2: the XCD-aware block remap is active (a permutation of the blocks);
+    """512 streams = 32 quarter-tile blocks of k_pitch: the XCD-aware block remap is active (a permutation of the blocks);
     every stream still gets its own result."""
     import nnnoiseless_amd as nn
     from nnnoiseless_amd.synthetic import make_streams
