@@ -235,11 +235,15 @@ __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp, int 
 //       inner products       (stream, partial q of 4), the wave picks the candidate lags: 2 (fine) or 4 (remove_doubling)
 //                            candidates share every read of the fixed operand
 //       decisions            (stream) on wave 0             find_best_pitch x 2, the k = 2..15 loop of remove_doubling
-//     LDS layout of pitch_buf: row pairs interleaved per stream, element (r, s) at ((r >> 1) * 16 + s) * 2 + (r & 1).  A
-//     32-lane group of ds_read_b32 = 16 streams x 2 chains reading rows r, r + 1 (inner-product partials, lags of the
-//     autocorrelation) or rows 27 apart (FIR chunks) hits 32 different banks; the coarse cross-correlation, whose rows are
-//     all even, reads row PAIRS with ds_read_b64 (bank = dword address mod 64), and its two lag groups per 32 lanes start 7
-//     lags apart, on different pair parities: conflict-free as well (round 2a: 31 % of k_pitch2's LDS cycles were conflicts).
+//     LDS layout of pitch_buf: even rows and odd rows apart, element (r, s) at (r & 1 ? ODD : 0) + (r >> 1) * 16 + s with ODD =
+//     432 * 16 + 16.  ds_read_b32 / ds_read2_b32 bank modulo 32, a 32-lane group is 16 streams x 2 chains: chains reading rows r
+//     and r + 2 (the inner-product partials, dealt to the lanes as q = 0, 2 | 1, 3) sit on neighbouring rows of one half,
+//     chains reading rows r and r + 1 (lags of the autocorrelation) on the same row index of the two halves, which the pad
+//     of 16 puts on different banks; the coarse cross-correlation reads the even half only -- the 4x-decimated signal,
+//     compact -- and its two lag groups per 32 lanes start 7 rows apart: all conflict-free (round 2a: 31 % of k_pitch2's LDS
+//     cycles were conflicts).  Rows 2 apart (consecutive taps of one partial, of the decimated signal, of the window pairs)
+//     are 16 or 32 floats apart at any parity: one ds_read2_b32 fetches two of them into a register pair, which is what
+//     v_pk_mul_f32 wants.
 //     remove_doubling carries last_period / last_gain from frame to frame: the launch loops over the `g` frames of its
 //     group; the next frame's decimated window is requested a frame ahead and waits in registers.
 // ---------------------------------------------------------------------------------------------
@@ -252,7 +256,10 @@ static_assert(PK_NG * PK_LC == NLAG1 && (PK_LC & 1), "odd group size: neighbouri
 constexpr int PK_JB = 8;                         // taps per unrolled step of the coarse cross-correlation (240 = 30 x 8)
 constexpr int PK_NC = 36;                        // inner-product slots: 10 fine lags | 32 candidates of remove_doubling (+ 3 refinement)
 
-__device__ __forceinline__ int pk_at(int r, int s) { return (((r >> 1) * PK_SPB + s) << 1) | (r & 1); }
+constexpr int PK_HALF = (XLP / 2) * PK_SPB;      // floats of the even rows
+constexpr int PK_ODD = PK_HALF + 16;             // first odd row
+__device__ __forceinline__ int pk_at(int r, int s) { return ((r & 1) ? PK_ODD : 0) + (r >> 1) * PK_SPB + s; }
+
 
 // running best / second-best update of find_best_pitch, ref: src/pitch.rs:383-400
 struct BestPitch {
@@ -294,7 +301,7 @@ struct Xc2 {   // xcorr[] of the fine search: zero except within 2 of 2*best / 2
 __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1.0f + xx * yy); }
 
 struct PkLds {
-    float pb[XLP * PK_SPB];                      // the decimated window, then (in place) pitch_buf
+    float pb[PK_ODD + PK_HALF];                  // the decimated window, then (in place) pitch_buf
     float acs[5][PK_SPB], coef[5][PK_SPB];
     union {
         struct { float xc[NLAG1][PK_SPB], ysq[NLAG1][PK_SPB]; } c;   // coarse search: cross-correlation, running energy per lag
@@ -329,28 +336,35 @@ __device__ __forceinline__ void pk_window_load(const Buffers &b, const StepParam
 
 // 4-way interleaved inner-product partials (ref: src/pitch.rs:225-244) of NCAND candidates against the fixed operand
 // p[384 ..]: lane (s, q) accumulates x[4m+q] * y_c[4m+q] over m in order, one read of x serving every candidate;
-// the caller combines ((s0+s1)+s2)+s3.  y_c starts at row yr[c].  Rows 4m + const of one stream are 64 floats apart.
+// the caller combines ((s0+s1)+s2)+s3.  y_c starts at row yr[c].  Rows 4m + const of one stream are 32 floats apart: one
+// ds_read2_b32 brings taps m, m + 1 as a register pair, one v_pk_mul_f32 forms both products, two adds in order.
 template <int NCAND>
 __device__ __forceinline__ void pk_inner(const float *pb, int s, int q, const int (&yr)[NCAND], float (&acc)[NCAND])
 {
-    constexpr int MB = NCAND >= 4 ? 4 : (NCAND == 2 ? 6 : 8);
-    static_assert(120 % MB == 0, "");
+    constexpr int U = NCAND >= 4 ? 2 : (NCAND == 2 ? 3 : 4);   // tap pairs per unrolled step
+    static_assert(120 % (2 * U) == 0, "");
     const float *xp = pb + pk_at(PITCH_MAX / 2 + q, s);
     const float *yp[NCAND];
 #pragma unroll
     for (int c = 0; c < NCAND; c++) { acc[c] = 0.0f; yp[c] = pb + pk_at(yr[c] + q, s); }
-    for (int m0 = 0; m0 < 120; m0 += MB) {
-        float xv[MB], yv[NCAND][MB];
+#pragma nounroll
+    for (int m0 = 0; m0 < 120; m0 += 2 * U) {
+        v2f xv[U], yv[NCAND][U];
 #pragma unroll
-        for (int i = 0; i < MB; i++) {
-            xv[i] = xp[64 * (m0 + i)];
+        for (int u = 0; u < U; u++) {
+            const int o = 32 * (m0 + 2 * u);
+            xv[u] = mk2(xp[o], xp[o + 32]);
 #pragma unroll
-            for (int c = 0; c < NCAND; c++) yv[c][i] = yp[c][64 * (m0 + i)];
+            for (int c = 0; c < NCAND; c++) yv[c][u] = mk2(yp[c][o], yp[c][o + 32]);
         }
 #pragma unroll
-        for (int i = 0; i < MB; i++)
+        for (int u = 0; u < U; u++)
 #pragma unroll
-            for (int c = 0; c < NCAND; c++) acc[c] += xv[i] * yv[c][i];
+            for (int c = 0; c < NCAND; c++) {
+                const v2f pr = pk_mul(xv[u], yv[c][u]);
+                acc[c] = sadd(acc[c], pr.x);
+                acc[c] = sadd(acc[c], pr.y);
+            }
     }
 }
 
@@ -386,41 +400,47 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         s = lane & 15;
         q = lane >> 4;
         const int sl = q0 + s;
+        NNN_STAMP(b, 0);
         const int tid = 64 * wave + lane, col = tid & 15, ch = tid >> 4;
-        float2 *chp = (float2 *)L.pb + (ch * (PK_CH / 2)) * PK_SPB + col;   // this thread's chunk: row pair m at chp[16 m]
+        const int qi = ((q & 1) << 1) | (q >> 1);   // inner-product partial of this lane: q = 0, 2 | 1, 3 over the wave's quarters
+        const int chc = ch < PK_NCH ? ch : PK_NCH - 1;   // (idle threads shadow the last chunk's reads and store nothing)
+        float *chE = L.pb + (chc * (PK_CH / 2)) * PK_SPB + col, *chO = chE + PK_ODD;   // this thread's chunk: rows 2m / 2m + 1 at ch?[16 m]
         // ---- the window -> LDS
         if (ch < PK_NCH) {
 #pragma unroll
-            for (int m = 0; m < PK_CH / 2; m++) chp[m * PK_SPB] = make_float2(win[2 * m], win[2 * m + 1]);
+            for (int m = 0; m < PK_CH / 2; m++) { chE[m * PK_SPB] = win[2 * m]; chO[m * PK_SPB] = win[2 * m + 1]; }
         }
         __syncthreads();
+        NNN_STAMP(b, 1);
         // ---- autocorrelation: lags 0..3 on wave 0, lag 4 on the first 16 lanes of wave 1 (ref: src/pitch.rs:433-446)
         if (wave == 0 || (wave == 1 && lane < PK_SPB)) {
             const int k = wave == 0 ? q : 4;
             const int fast_n = XLP - 4;
-            // rows i0 + u and i0 + u + k, i0 a multiple of 4: with F(j) = 32 (j >> 1) + (j & 1) the offset of row j within a
-            // stream's column, row i0 + u + k sits F(u + (k & 1)) + 32 (k >> 1) after row i0
-            const float *pa = L.pb + 2 * s;
-            int ob[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j0 = u, j1 = u + 1;
-                ob[u] = 32 * (k >> 1) + ((k & 1) ? 32 * (j1 >> 1) + (j1 & 1) : 32 * (j0 >> 1) + (j0 & 1));
-            }
+            // rows i0 .. i0 + 3 (i0 a multiple of 4) are E[a0], O[a0], E[a0 + 1], O[a0 + 1] with a0 = i0 / 2; rows i0 + k + u
+            // the same pattern started k rows later.  Pairs (u = 0, 2) and (u = 1, 3) come as one ds_read2_b32 each.
+            const float *aE = L.pb + s, *aO = aE + PK_ODD;
+            const float *bA = L.pb + ((k & 1) ? PK_ODD : 0) + (k >> 1) * PK_SPB + s;
+            const float *bB = L.pb + ((k & 1) ? 0 : PK_ODD) + ((k + 1) >> 1) * PK_SPB + s;
             float c = 0.0f;
-            for (int i0 = 0; i0 < fast_n; i0 += 4) {
-                const float *r = pa + 16 * i0;
-                float a[4], bb[4];
+#pragma nounroll
+            for (int i1 = 0; i1 < fast_n; i1 += 20)   // 860 = 43 x 5 x 4
 #pragma unroll
-                for (int u = 0; u < 4; u++) { a[u] = r[32 * (u >> 1) + (u & 1)]; bb[u] = r[ob[u]]; }
-#pragma unroll
-                for (int u = 0; u < 4; u++) c += a[u] * bb[u];
+            for (int i0 = i1; i0 < i1 + 20; i0 += 4) {
+                const int o = (i0 >> 1) * PK_SPB;
+                const v2f a02 = mk2(aE[o], aE[o + PK_SPB]), a13 = mk2(aO[o], aO[o + PK_SPB]);
+                const v2f b02 = mk2(bA[o], bA[o + PK_SPB]), b13 = mk2(bB[o], bB[o + PK_SPB]);
+                const v2f p02 = pk_mul(a02, b02), p13 = pk_mul(a13, b13);
+                c = sadd(c, p02.x);
+                c = sadd(c, p13.x);
+                c = sadd(c, p02.y);
+                c = sadd(c, p13.y);
             }
             float d = 0.0f;   // tail d_k = sum_{i = k+860}^{863} x[i] x[i-k], added after the main sum
             for (int i = k + fast_n; i < XLP; i++) d += L.pb[pk_at(i, s)] * L.pb[pk_at(i - k, s)];
             L.acs[k][s] = c + d;
         }
         __syncthreads();
+        NNN_STAMP(b, 2);
         // ---- lag window, Levinson, bandwidth expansion, extra zero (ref: src/pitch.rs:460-480, 257-292)
         if (dec_lane) {
             float ac[5];
@@ -471,14 +491,17 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             }
         }
         __syncthreads();
+        NNN_STAMP(b, 3);
         // ---- FIR5 with zero initial memory, in place (ref: src/pitch.rs:407-429): the chunk's inputs are still in the
         //      thread's registers, the five rows before it come from LDS before anyone overwrites them
         {
             float v[PK_CH + 5];
-            if (ch < PK_NCH) {
-                float2 h0 = make_float2(0.0f, 0.0f), h1 = h0, h2 = h0;
-                if (ch > 0) { h0 = chp[-3 * PK_SPB]; h1 = chp[-2 * PK_SPB]; h2 = chp[-1 * PK_SPB]; }
-                v[0] = h0.y; v[1] = h1.x; v[2] = h1.y; v[3] = h2.x; v[4] = h2.y;
+            {
+                const int hb = chc > 0 ? 0 : 3 * PK_SPB;   // chunk 0 has no rows before it: read in range, use zeros
+                const float h0 = chO[hb - 3 * PK_SPB], h1 = chE[hb - 2 * PK_SPB], h2 = chO[hb - 2 * PK_SPB], h3 = chE[hb - 1 * PK_SPB],
+                            h4 = chO[hb - 1 * PK_SPB];
+                v[0] = chc > 0 ? h0 : 0.0f; v[1] = chc > 0 ? h1 : 0.0f; v[2] = chc > 0 ? h2 : 0.0f; v[3] = chc > 0 ? h3 : 0.0f;
+                v[4] = chc > 0 ? h4 : 0.0f;
 #pragma unroll
                 for (int u = 0; u < PK_CH; u++) v[5 + u] = win[u];
             }
@@ -496,42 +519,62 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                         o[e] = v[u + 5] + n0 * v[u + 4] + n1 * v[u + 3] + n2 * v[u + 2] + n3 * v[u + 1] + n4 * v[u];
                         if (tap) tap[(size_t)u * TILE] = o[e];
                     }
-                    chp[m * PK_SPB] = make_float2(o[0], o[1]);
+                    chE[m * PK_SPB] = o[0];
+                    chO[m * PK_SPB] = o[1];
                 }
             }
         }
         if (f + 1 < g) pk_window_load(b, sp0 + f + 1, tile, q0, tid, win);   // the next frame's window travels behind this frame's work
         __syncthreads();
+        NNN_STAMP(b, 4);
         // ---- coarse search: cross-correlation on waves 0..5, the serial energy scans behind / beside it
         {
-            const float2 *p2 = (const float2 *)L.pb;   // row pair m of stream s: p2[m * 16 + s], .x = row 2m
             const int grp = 4 * wave + q;
             if (grp < PK_NG) {
-                // xcorr[L] = sum_j x4[j] y4[L + j], x4[j] = p[384 + 2j], y4[m] = p[2m]: a sequential sum per lag (ref: src/pitch.rs:296-363)
-                // (the odd row of a pair is not needed, but the 8-byte read is: 4-byte reads bank modulo 32 and the two lag
-                // groups of a 32-lane group would collide)
-                auto even = [&](int m) { const float2 v = p2[m * PK_SPB + s]; keep_v(v.y); return v.x; };
+                // xcorr[L] = sum_j x4[j] y4[L + j], x4[j] = p[384 + 2j], y4[m] = p[2m] (the even rows, compact): a sequential sum
+                // per lag (ref: src/pitch.rs:296-363).  Lags L0 .. L0 + 5 in three packed accumulators, L0 + 6 single.  The y window
+                // w[i] = y4[L0 + j + i] is kept as pairs in both alignments, PE[t] = (w[2t], w[2t+1]) and PO[t] = (w[2t+1], w[2t+2]):
+                // tap k multiplies pairs w[k+2n], w[k+2n+1], whichever alignment that is, with x4[j+k] from either half of its pair.
                 const int L0 = PK_LC * grp;
-                float acc[PK_LC], w[PK_JB + PK_LC - 1];
+                const float *yb = L.pb + L0 * PK_SPB + s, *xb = L.pb + 192 * PK_SPB + s;
+                v2f acc2[3], PE[7], PO[7];
+                float acc6 = 0.0f;
 #pragma unroll
-                for (int i = 0; i < PK_LC; i++) acc[i] = 0.0f;
+                for (int n = 0; n < 3; n++) acc2[n] = mk2(0.0f, 0.0f);
 #pragma unroll
-                for (int i = 0; i < PK_LC - 1; i++) w[i] = even(L0 + i);
+                for (int t = 0; t < 3; t++) {
+                    PE[t] = mk2(yb[(2 * t) * PK_SPB], yb[(2 * t + 1) * PK_SPB]);
+                    PO[t] = mk2(yb[(2 * t + 1) * PK_SPB], yb[(2 * t + 2) * PK_SPB]);
+                }
 #pragma unroll 2
                 for (int j = 0; j < 240; j += PK_JB) {
-                    float xv[PK_JB];
+                    const float *yj = yb + j * PK_SPB, *xj = xb + j * PK_SPB;
+                    v2f X[PK_JB / 2];
 #pragma unroll
-                    for (int k = 0; k < PK_JB; k++) {
-                        xv[k] = even(192 + j + k);
-                        w[PK_LC - 1 + k] = even(L0 + j + k + PK_LC - 1);   // <= row pair 385
+                    for (int t = 0; t < PK_JB / 2; t++) X[t] = mk2(xj[(2 * t) * PK_SPB], xj[(2 * t + 1) * PK_SPB]);
+#pragma unroll
+                    for (int t = 3; t < 7; t++) {
+                        PE[t] = mk2(yj[(2 * t) * PK_SPB], yj[(2 * t + 1) * PK_SPB]);
+                        PO[t] = mk2(yj[(2 * t + 1) * PK_SPB], yj[(2 * t + 2) * PK_SPB]);   // <= row 386 of the even half
                     }
 #pragma unroll
-                    for (int k = 0; k < PK_JB; k++)
+                    for (int k = 0; k < PK_JB; k++) {
+                        const v2f xp2 = X[k >> 1];
 #pragma unroll
-                        for (int i = 0; i < PK_LC; i++) acc[i] += xv[k] * w[k + i];
+                        for (int n = 0; n < 3; n++) {
+                            const v2f wp = (k & 1) ? PO[(k >> 1) + n] : PE[(k >> 1) + n];
+                            acc2[n] = pk_add(acc2[n], (k & 1) ? pk_mul_by(xp2, wp) : pk_mul_bx(xp2, wp));
+                        }
+                        const float w6 = (k & 1) ? PO[(k >> 1) + 3].x : PE[(k >> 1) + 3].x;
+                        acc6 = sadd(acc6, ((k & 1) ? xp2.y : xp2.x) * w6);
+                    }
 #pragma unroll
-                    for (int i = 0; i < PK_LC - 1; i++) w[i] = w[i + PK_JB];
+                    for (int t = 0; t < 3; t++) { PE[t] = PE[t + 4]; PO[t] = PO[t + 4]; }
                 }
+                float acc[PK_LC];
+#pragma unroll
+                for (int n = 0; n < 3; n++) { acc[2 * n] = acc2[n].x; acc[2 * n + 1] = acc2[n].y; }
+                acc[6] = acc6;
 #pragma unroll
                 for (int i = 0; i < PK_LC; i++) L.u.c.xc[L0 + i][s] = acc[i];
                 if (b.taps) {
@@ -540,21 +583,23 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                     for (int i = 0; i < PK_LC; i++) o[(size_t)(L0 + i) * TILE] = acc[i];
                 }
             }
-            const float2 *ps = p2 + s;   // row pair m of this lane's stream: ps[16 m]
+            const float *pE = L.pb + s, *pO = pE + PK_ODD;   // rows 2m / 2m + 1 of this lane's stream at p?[16 m]
             if (wave == 5 && lane < PK_SPB) {
                 // the running energy every coarse lag sees in find_best_pitch (ref: src/pitch.rs:83 -> :380-402): even rows only
                 float ysq = 1.0f;
+#pragma nounroll
                 for (int j0 = 0; j0 < 240; j0 += 8) {
                     float v[8];
 #pragma unroll
-                    for (int i = 0; i < 8; i++) v[i] = ps[(j0 + i) * PK_SPB].x;
+                    for (int i = 0; i < 8; i++) v[i] = pE[(j0 + i) * PK_SPB];
 #pragma unroll
                     for (int i = 0; i < 8; i++) ysq += v[i] * v[i];
                 }
+#pragma nounroll
                 for (int i0 = 0; i0 < NLAG1; i0 += 7) {
                     float a[7], d[7];
 #pragma unroll
-                    for (int i = 0; i < 7; i++) { a[i] = ps[(i0 + i + 240) * PK_SPB].x; d[i] = ps[(i0 + i) * PK_SPB].x; }
+                    for (int i = 0; i < 7; i++) { a[i] = pE[(i0 + i + 240) * PK_SPB]; d[i] = pE[(i0 + i) * PK_SPB]; }
 #pragma unroll
                     for (int i = 0; i < 7; i++) {
                         L.u.c.ysq[i0 + i][s] = ysq;
@@ -567,24 +612,29 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 // <= 10 lags can update the best pitch there, and they are replayed below with the energy each of them saw
                 float *yq = NNN_TIF(b, ysq2, NLAG2, f, tile, sl);
                 float ysq = 1.0f;
+#pragma nounroll
                 for (int m0 = 0; m0 < 240; m0 += 4) {
-                    float2 v[4];
+                    float ve[4], vo[4];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) v[i] = ps[(m0 + i) * PK_SPB];
+                    for (int i = 0; i < 4; i++) { ve[i] = pE[(m0 + i) * PK_SPB]; vo[i] = pO[(m0 + i) * PK_SPB]; }
 #pragma unroll
-                    for (int i = 0; i < 4; i++) { ysq += v[i].x * v[i].x; ysq += v[i].y * v[i].y; }
+                    for (int i = 0; i < 4; i++) { ysq += ve[i] * ve[i]; ysq += vo[i] * vo[i]; }
                 }
+#pragma nounroll
                 for (int n0 = 0; n0 < NLAG2 / 2; n0 += 7) {   // lags 2n, 2n + 1: rows (2n, 2n + 1) leave, rows (2n + 480, 2n + 481) enter
-                    float2 a[7], d[7];
+                    float ae[7], ao[7], de[7], dd[7];
 #pragma unroll
-                    for (int i = 0; i < 7; i++) { a[i] = ps[(n0 + i + 240) * PK_SPB]; d[i] = ps[(n0 + i) * PK_SPB]; }
+                    for (int i = 0; i < 7; i++) {
+                        ae[i] = pE[(n0 + i + 240) * PK_SPB]; ao[i] = pO[(n0 + i + 240) * PK_SPB];
+                        de[i] = pE[(n0 + i) * PK_SPB]; dd[i] = pO[(n0 + i) * PK_SPB];
+                    }
 #pragma unroll
                     for (int i = 0; i < 7; i++) {
                         yq[(size_t)(2 * (n0 + i)) * TILE] = ysq;
-                        ysq += a[i].x * a[i].x - d[i].x * d[i].x;
+                        ysq += ae[i] * ae[i] - de[i] * de[i];
                         ysq = fmaxf(ysq, 1.0f);
                         yq[(size_t)(2 * (n0 + i) + 1) * TILE] = ysq;
-                        ysq += a[i].y * a[i].y - d[i].y * d[i].y;
+                        ysq += ao[i] * ao[i] - dd[i] * dd[i];
                         ysq = fmaxf(ysq, 1.0f);
                     }
                 }
@@ -592,13 +642,14 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 // xx = |x|^2 over the analysis frame and the 384-step running energy yy_lookup of remove_doubling
                 // (ref: src/pitch.rs:133-142)
                 float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma nounroll
                 for (int m0 = 192; m0 < 432; m0 += 4) {
-                    float2 v[4];
+                    float ve[4], vo[4];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) v[i] = ps[(m0 + i) * PK_SPB];
+                    for (int i = 0; i < 4; i++) { ve[i] = pE[(m0 + i) * PK_SPB]; vo[i] = pO[(m0 + i) * PK_SPB]; }
 #pragma unroll
                     for (int i = 0; i < 4; i += 2) {
-                        s0 += v[i].x * v[i].x; s1 += v[i].y * v[i].y; s2 += v[i + 1].x * v[i + 1].x; s3 += v[i + 1].y * v[i + 1].y;
+                        s0 += ve[i] * ve[i]; s1 += vo[i] * vo[i]; s2 += ve[i + 1] * ve[i + 1]; s3 += vo[i + 1] * vo[i + 1];
                     }
                 }
                 const float xx = s0 + s1 + s2 + s3;
@@ -606,26 +657,32 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 yo[0] = xx;
                 yo[TILE] = xx;  // yy_lookup[0]
                 float yy = xx;
+#pragma nounroll
                 for (int n0 = 0; n0 < 192; n0 += 4) {   // steps i = 2n + 1, 2n + 2: rows 383 - 2n, 382 - 2n enter, rows 863 - 2n, 862 - 2n leave
-                    float2 a[4], c[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { a[i] = ps[(191 - (n0 + i)) * PK_SPB]; c[i] = ps[(431 - (n0 + i)) * PK_SPB]; }
+                    float ae[4], ao[4], ce[4], co[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        yy += a[i].y * a[i].y - c[i].y * c[i].y;
+                        ae[i] = pE[(191 - (n0 + i)) * PK_SPB]; ao[i] = pO[(191 - (n0 + i)) * PK_SPB];
+                        ce[i] = pE[(431 - (n0 + i)) * PK_SPB]; co[i] = pO[(431 - (n0 + i)) * PK_SPB];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        yy += ao[i] * ao[i] - co[i] * co[i];
                         yo[(size_t)(2 * (n0 + i) + 2) * TILE] = fmaxf(yy, 0.0f);
-                        yy += a[i].x * a[i].x - c[i].x * c[i].x;
+                        yy += ae[i] * ae[i] - ce[i] * ce[i];
                         yo[(size_t)(2 * (n0 + i) + 3) * TILE] = fmaxf(yy, 0.0f);
                     }
                 }
             }
         }
         __syncthreads();
+        NNN_STAMP(b, 5);
         // ---- find_best_pitch over the coarse lags (ref: src/pitch.rs:372-405, call site :83-84)
         int lo1 = 0, lo2 = 0;
         if (dec_lane) {
             BestPitch bp;
             bp.init();
+#pragma nounroll
             for (int i0 = 0; i0 < NLAG1; i0 += 7) {
                 float c[7], e[7];
 #pragma unroll
@@ -648,6 +705,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             if (s == 0) L.u.f.any_refine = 0;
         }
         __syncthreads();
+        NNN_STAMP(b, 6);
         // ---- fine cross-correlation at the <= 10 lags within +-2 of 2*best / 2*second (ref: src/pitch.rs:88-96): wave w
         //      takes lags lo1 + w and lo2 + w
         if (wave < 5) {
@@ -655,11 +713,12 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             const bool va = la >= 0 && la < NLAG2, vb = lb >= 0 && lb < NLAG2;
             const int yr[2] = {va ? la : 0, vb ? lb : 0};
             float acc[2];
-            pk_inner<2>(L.pb, s, q, yr, acc);
-            L.u.f.part[wave][q][s] = acc[0];
-            L.u.f.part[5 + wave][q][s] = acc[1];
+            pk_inner<2>(L.pb, s, qi, yr, acc);
+            L.u.f.part[wave][qi][s] = acc[0];
+            L.u.f.part[5 + wave][qi][s] = acc[1];
         }
         __syncthreads();
+        NNN_STAMP(b, 7);
         // ---- find_best_pitch over the fine lags: xcorr is zero outside the two 5-lag windows, so only they can update the
         //      best pitch; replayed in increasing lag order with the energy each of them saw.  Then the candidate periods.
         Xc2 xc;
@@ -728,17 +787,19 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             }
         }
         __syncthreads();
+        NNN_STAMP(b, 53);
         // ---- the candidates' inner products against p[384 ..]: wave w takes slots w, w + 8, w + 16, w + 24
         {
             int yr[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) yr[c] = max_period - L.u.f.cand[wave + 8 * c][s];
             float acc[4];
-            pk_inner<4>(L.pb, s, q, yr, acc);
+            pk_inner<4>(L.pb, s, qi, yr, acc);
 #pragma unroll
-            for (int c = 0; c < 4; c++) L.u.f.part[wave + 8 * c][q][s] = acc[c];
+            for (int c = 0; c < 4; c++) L.u.f.part[wave + 8 * c][qi][s] = acc[c];
         }
         __syncthreads();
+        NNN_STAMP(b, 54);
         // ---- decision loop (ref: src/pitch.rs:150-206)
         int t = 0;
         float pg = 0.0f, gg = 0.0f;
@@ -775,17 +836,19 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             if (t != t0) L.u.f.any_refine = 1;
         }
         __syncthreads();
+        NNN_STAMP(b, 55);
         // ---- final +-1 refinement: the inner products at t - 1, t, t + 1 (the same sums whichever way they are obtained)
         const bool refine = L.u.f.any_refine != 0;   // block-uniform
         if (refine) {
             if (wave < 3) {
                 const int yr[1] = {max_period - (L.u.f.tsel[s] + wave - 1)};
                 float acc[1];
-                pk_inner<1>(L.pb, s, q, yr, acc);
-                L.u.f.part[32 + wave][q][s] = acc[0];
+                pk_inner<1>(L.pb, s, qi, yr, acc);
+                L.u.f.part[32 + wave][qi][s] = acc[0];
             }
             __syncthreads();
         }
+        NNN_STAMP(b, 56);
         if (dec_lane) {
             auto ipv = [&](int e) { return L.u.f.part[e][0][s] + L.u.f.part[e][1][s] + L.u.f.part[e][2][s] + L.u.f.part[e][3][s]; };
             float x3[3];
@@ -802,6 +865,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             last_period = res;
             last_gain = pg;
         }
+        NNN_STAMP(b, 57);
         // (the next frame's first writes to anything this frame still reads sit behind barriers wave 0 takes part in)
     }
     if (dec_lane) {

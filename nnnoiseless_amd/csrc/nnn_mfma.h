@@ -71,4 +71,43 @@ __device__ __forceinline__ int launder_s(int x)
     return x;
 }
 
+// Packed FP32 (two lanes of a 64-bit register pair per instruction), spelled out where the pairing matters: the
+// compiler's own SLP pairing of scalar code put the two products of one v_pk_mul_f32 in registers that the next
+// instruction wanted somewhere else (one v_mov per product in the inner-product loops).  Products and sums round exactly
+// like v_mul_f32 / v_add_f32.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f mk2(float x, float y) { v2f r = {x, y}; return r; }
+__device__ __forceinline__ v2f pk_mul(v2f a, v2f b)       // (a.x b.x, a.y b.y)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_mul_bx(v2f a, v2f b)    // (a.x b.x, a.x b.y): a's low half against both of b
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_mul_by(v2f a, v2f b)    // (a.y b.x, a.y b.y)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a single add that stays a single add (sequential sums of packed products: the compiler's pairing across accumulators
+// would cost register moves)
+__device__ __forceinline__ float sadd(float a, float b)
+{
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_add(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 }  // namespace nnn

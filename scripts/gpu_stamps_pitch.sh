@@ -1,0 +1,30 @@
+#!/bin/bash
+# Developer tool: phase breakdown of k_pitch as block 0 / wave 0 sees it (shader-clock stamps of the LAST frame of a launch; the
+# times include that wave's waits at the block barriers).
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+W=$R/nnnoiseless_amd/data/weights.rnn
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -DNNN_STAMPS -I nnnoiseless_amd/csrc -DNNN_WEIGHTS_PATH="\"$W\"" -x hip nnnoiseless_amd/csrc/nnn_batch.hip nnnoiseless_amd/csrc/nnn_resample.hip nnnoiseless_amd/csrc/nnn_model.cpp nnnoiseless_amd/csrc/rnnoise_capi.cpp -o /tmp/libnnn_stamps.so || exit 1
+python - <<'PY'
+import ctypes as C, numpy as np, sys, os
+sys.path.insert(0, '.')
+import nnnoiseless_amd as nn
+from nnnoiseless_amd import _ffi
+from nnnoiseless_amd.synthetic import make_streams_fast
+lib = _ffi.Library('/tmp/libnnn_stamps.so')
+lib.L.nnn_batch_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
+for S, T in ((4096, 4), (65536, 4)):
+    bd = nn.BatchDenoiser(S, lib=lib)
+    bd.set_pipeline(False)
+    x = make_streams_fast(S, 2 * T)
+    bd.process(x[:, :T]); bd.process(x[:, T:])
+    st = np.zeros(64, np.int64)
+    lib.L.nnn_batch_read_stamps(bd._h, st.ctypes.data_as(C.c_void_p))
+    names = ["window->lds", "autocorr", "lpc", "fir", "coarse xcorr+scans", "find_best coarse", "fine xcorr", "replay+candidates", "cand inner", "decision", "refine", "final"]
+    idx = [0, 1, 2, 3, 4, 5, 6, 7, 53, 54, 55, 56, 57]
+    d = [(st[idx[i + 1]] - st[idx[i]]) / 2100.0 for i in range(len(names))]   # shader-clock cycles at ~2.1 GHz -> us (approximate)
+    print(f"S={S} k_pitch last frame of block 0 [us, approximate]: total {sum(d):.1f}")
+    print("   " + "  ".join(f"{n} {v:.2f}" for n, v in zip(names, d)))
+    bd.close()
+PY

@@ -63,4 +63,12 @@ static inline int launder_v(int x) { return x; }
 static inline int launder_s(int x) { return x; }
 static inline void keep_v(float) {}
 
+struct v2f { float x, y; };
+static inline v2f mk2(float x, float y) { v2f r = {x, y}; return r; }
+static inline v2f pk_mul(v2f a, v2f b) { return mk2(a.x * b.x, a.y * b.y); }
+static inline v2f pk_mul_bx(v2f a, v2f b) { return mk2(a.x * b.x, a.x * b.y); }
+static inline v2f pk_mul_by(v2f a, v2f b) { return mk2(a.y * b.x, a.y * b.y); }
+static inline v2f pk_add(v2f a, v2f b) { return mk2(a.x + b.x, a.y + b.y); }
+static inline float sadd(float a, float b) { return a + b; }
+
 }  // namespace nnn
