@@ -250,10 +250,17 @@ __global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp, int 
 constexpr int PK_SPB = 16;                       // streams per block
 constexpr int PK_WAVES = 8;
 constexpr int PK_T = 64 * PK_WAVES;
-constexpr int PK_LC = 7;                         // coarse lags per lane: 147 = 21 x 7
-constexpr int PK_NG = NLAG1 / PK_LC;
-static_assert(PK_NG * PK_LC == NLAG1 && (PK_LC & 1), "odd group size: neighbouring groups start on different row-pair parities");
+#ifndef NNN_PK_LC
+#define NNN_PK_LC 13
+#endif
+constexpr int PK_LC = NNN_PK_LC;                 // coarse lags per lane: 12 groups of 13 (the last one 4 lags wide) on three waves
+constexpr int PK_NG = (NLAG1 + PK_LC - 1) / PK_LC;
+static_assert((PK_LC & 1) && PK_NG <= 4 * 8, "odd group size: neighbouring groups start on different row parities");
+constexpr int PK_XW = (PK_NG + 3) / 4;           // waves of the coarse cross-correlation
 constexpr int PK_JB = 8;                         // taps per unrolled step of the coarse cross-correlation (240 = 30 x 8)
+constexpr int PK_NP = PK_LC / 2;                 // packed accumulators per lane (+ one single: PK_LC is odd)
+constexpr int PK_NT = PK_JB / 2 + PK_NP;         // window pairs per alignment
+static_assert((PK_NG - 1) * PK_LC + 239 + PK_JB + PK_LC < XLP / 2, "the window stays inside the even rows");
 constexpr int PK_NC = 36;                        // inner-product slots: 10 fine lags | 32 candidates of remove_doubling (+ 3 refinement)
 
 constexpr int PK_HALF = (XLP / 2) * PK_SPB;      // floats of the even rows
@@ -266,18 +273,19 @@ struct BestPitch {
     float best_num, second_num, best_den, second_den;
     int best, second;
     __device__ void init() { best_num = -1.0f; second_num = -1.0f; best_den = 0.0f; second_den = 0.0f; best = 0; second = 1; }
-    __device__ void update(int i, float corr, float y_sq_norm) {
-        if (corr > 0.0f) {
-            float num = corr * corr;
-            if (num * second_den > second_num * y_sq_norm) {
-                if (num * best_den > best_num * y_sq_norm) {
-                    second_num = best_num; second_den = best_den; second = best;
-                    best_num = num; best_den = y_sq_norm; best = i;
-                } else {
-                    second_num = num; second_den = y_sq_norm; second = i;
-                }
-            }
-        }
+    // the reference's nested ifs as selects (the same comparisons on the same values: a NaN fails them either way); this runs
+    // on one wave with the rest of the block waiting, where a taken branch costs more than the selects
+    __device__ __forceinline__ void update(int i, float corr, float y_sq_norm) {
+        const float num = corr * corr;
+        const bool in = corr > 0.0f && num * second_den > second_num * y_sq_norm;
+        const bool top = in && num * best_den > best_num * y_sq_norm;
+        const bool mid = in && !top;
+        second_num = top ? best_num : (mid ? num : second_num);
+        second_den = top ? best_den : (mid ? y_sq_norm : second_den);
+        second = top ? best : (mid ? i : second);
+        best_num = top ? num : best_num;
+        best_den = top ? y_sq_norm : best_den;
+        best = top ? i : best;
     }
 };
 
@@ -311,6 +319,10 @@ struct PkLds {
             int cand[32][PK_SPB];                // candidate periods of remove_doubling
             int lo[2][PK_SPB];                   // first fine lag of the two windows
             int tsel[PK_SPB];                    // the period the decision loop chose
+            float xx[PK_SPB], lgain[PK_SPB];     // per stream: |x|^2, the previous frame's gain ...
+            int t0[PK_SPB], pprev[PK_SPB];       // ... the period before remove_doubling, the previous frame's period / 2
+            float kxy[16][PK_SPB], kyy[16][PK_SPB], kg[16][PK_SPB];   // per candidate divisor k: its xy, yy, gain ...
+            int kpass[16][PK_SPB];               // ... and whether it replaces the best so far
             int any_refine;                      // some stream of the block left t0: the +-1 refinement needs inner products
         } f;
     } u;
@@ -421,20 +433,34 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             const float *aE = L.pb + s, *aO = aE + PK_ODD;
             const float *bA = L.pb + ((k & 1) ? PK_ODD : 0) + (k >> 1) * PK_SPB + s;
             const float *bB = L.pb + ((k & 1) ? 0 : PK_ODD) + ((k + 1) >> 1) * PK_SPB + s;
+            // a ring of four 4-step groups: a lone wave issues an instruction every four cycles, so group g + 3 is requested
+            // before group g is summed and the LDS round trip stays off the chain
+            constexpr int NGRP = (XLP - 4) / 4;   // 215
+            v2f ra[4][2], rb[4][2];
+            auto fetch = [&](int slot, int grp) {
+                const int o = (2 * grp) * PK_SPB;
+                ra[slot][0] = mk2(aE[o], aE[o + PK_SPB]); ra[slot][1] = mk2(aO[o], aO[o + PK_SPB]);
+                rb[slot][0] = mk2(bA[o], bA[o + PK_SPB]); rb[slot][1] = mk2(bB[o], bB[o + PK_SPB]);
+            };
             float c = 0.0f;
+            auto sum = [&](int slot) {
+                const v2f p02 = ra[slot][0] * rb[slot][0], p13 = ra[slot][1] * rb[slot][1];
+                c += p02.x;
+                c += p13.x;
+                c += p02.y;
+                c += p13.y;
+            };
+            fetch(0, 0); fetch(1, 1); fetch(2, 2);
 #pragma nounroll
-            for (int i1 = 0; i1 < fast_n; i1 += 20)   // 860 = 43 x 5 x 4
+            for (int g4 = 0; g4 + 4 <= NGRP; g4 += 4) {   // 212 groups
 #pragma unroll
-            for (int i0 = i1; i0 < i1 + 20; i0 += 4) {
-                const int o = (i0 >> 1) * PK_SPB;
-                const v2f a02 = mk2(aE[o], aE[o + PK_SPB]), a13 = mk2(aO[o], aO[o + PK_SPB]);
-                const v2f b02 = mk2(bA[o], bA[o + PK_SPB]), b13 = mk2(bB[o], bB[o + PK_SPB]);
-                const v2f p02 = pk_mul(a02, b02), p13 = pk_mul(a13, b13);
-                c = sadd(c, p02.x);
-                c = sadd(c, p13.x);
-                c = sadd(c, p02.y);
-                c = sadd(c, p13.y);
+                for (int u = 0; u < 4; u++) {
+                    const int nx = g4 + u + 3;
+                    fetch((u + 3) & 3, nx < NGRP ? nx : NGRP - 1);
+                    sum(u);
+                }
             }
+            sum(0); sum(1); sum(2);   // groups 212, 213, 214 (the ring slots they were fetched into)
             float d = 0.0f;   // tail d_k = sum_{i = k+860}^{863} x[i] x[i-k], added after the main sum
             for (int i = k + fast_n; i < XLP; i++) d += L.pb[pk_at(i, s)] * L.pb[pk_at(i - k, s)];
             L.acs[k][s] = c + d;
@@ -527,64 +553,66 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         if (f + 1 < g) pk_window_load(b, sp0 + f + 1, tile, q0, tid, win);   // the next frame's window travels behind this frame's work
         __syncthreads();
         NNN_STAMP(b, 4);
-        // ---- coarse search: cross-correlation on waves 0..5, the serial energy scans behind / beside it
+        // ---- coarse search: the cross-correlation on waves 0..2, the running energy of the coarse lags on wave 3
+        const float *pE = L.pb + s, *pO = pE + PK_ODD;   // rows 2m / 2m + 1 of this lane's stream at p?[16 m]
         {
             const int grp = 4 * wave + q;
             if (grp < PK_NG) {
                 // xcorr[L] = sum_j x4[j] y4[L + j], x4[j] = p[384 + 2j], y4[m] = p[2m] (the even rows, compact): a sequential sum
-                // per lag (ref: src/pitch.rs:296-363).  Lags L0 .. L0 + 5 in three packed accumulators, L0 + 6 single.  The y window
+                // per lag (ref: src/pitch.rs:296-363).  Lags L0 .. L0 + 11 in six packed accumulators, L0 + 12 single.  The y window
                 // w[i] = y4[L0 + j + i] is kept as pairs in both alignments, PE[t] = (w[2t], w[2t+1]) and PO[t] = (w[2t+1], w[2t+2]):
                 // tap k multiplies pairs w[k+2n], w[k+2n+1], whichever alignment that is, with x4[j+k] from either half of its pair.
                 const int L0 = PK_LC * grp;
                 const float *yb = L.pb + L0 * PK_SPB + s, *xb = L.pb + 192 * PK_SPB + s;
-                v2f acc2[3], PE[7], PO[7];
-                float acc6 = 0.0f;
+                v2f acc2[PK_NP], PE[PK_NT], PO[PK_NT];
+                float acc1 = 0.0f;
 #pragma unroll
-                for (int n = 0; n < 3; n++) acc2[n] = mk2(0.0f, 0.0f);
+                for (int n = 0; n < PK_NP; n++) acc2[n] = mk2(0.0f, 0.0f);
 #pragma unroll
-                for (int t = 0; t < 3; t++) {
+                for (int t = 0; t < PK_NT - PK_JB / 2; t++) {
                     PE[t] = mk2(yb[(2 * t) * PK_SPB], yb[(2 * t + 1) * PK_SPB]);
                     PO[t] = mk2(yb[(2 * t + 1) * PK_SPB], yb[(2 * t + 2) * PK_SPB]);
                 }
-#pragma unroll 2
+#pragma unroll 5   // (the window's register pairs come round after five steps: no moves at the back edge)
                 for (int j = 0; j < 240; j += PK_JB) {
                     const float *yj = yb + j * PK_SPB, *xj = xb + j * PK_SPB;
                     v2f X[PK_JB / 2];
 #pragma unroll
                     for (int t = 0; t < PK_JB / 2; t++) X[t] = mk2(xj[(2 * t) * PK_SPB], xj[(2 * t + 1) * PK_SPB]);
 #pragma unroll
-                    for (int t = 3; t < 7; t++) {
+                    for (int t = PK_NT - PK_JB / 2; t < PK_NT; t++) {
                         PE[t] = mk2(yj[(2 * t) * PK_SPB], yj[(2 * t + 1) * PK_SPB]);
-                        PO[t] = mk2(yj[(2 * t + 1) * PK_SPB], yj[(2 * t + 2) * PK_SPB]);   // <= row 386 of the even half
+                        PO[t] = mk2(yj[(2 * t + 1) * PK_SPB], yj[(2 * t + 2) * PK_SPB]);
                     }
 #pragma unroll
                     for (int k = 0; k < PK_JB; k++) {
                         const v2f xp2 = X[k >> 1];
 #pragma unroll
-                        for (int n = 0; n < 3; n++) {
+                        for (int n = 0; n < PK_NP; n++) {
                             const v2f wp = (k & 1) ? PO[(k >> 1) + n] : PE[(k >> 1) + n];
-                            acc2[n] = pk_add(acc2[n], (k & 1) ? pk_mul_by(xp2, wp) : pk_mul_bx(xp2, wp));
+                            acc2[n] = acc2[n] + ((k & 1) ? pk_mul_by(xp2, wp) : pk_mul_bx(xp2, wp));
                         }
-                        const float w6 = (k & 1) ? PO[(k >> 1) + 3].x : PE[(k >> 1) + 3].x;
-                        acc6 = sadd(acc6, ((k & 1) ? xp2.y : xp2.x) * w6);
+                        const float w1 = (k & 1) ? PO[(k >> 1) + PK_NP].x : PE[(k >> 1) + PK_NP].x;
+                        acc1 = sadd(acc1, ((k & 1) ? xp2.y : xp2.x) * w1);
                     }
 #pragma unroll
-                    for (int t = 0; t < 3; t++) { PE[t] = PE[t + 4]; PO[t] = PO[t + 4]; }
+                    for (int t = 0; t < PK_NT - PK_JB / 2; t++) { PE[t] = PE[t + PK_JB / 2]; PO[t] = PO[t + PK_JB / 2]; }
                 }
                 float acc[PK_LC];
 #pragma unroll
-                for (int n = 0; n < 3; n++) { acc[2 * n] = acc2[n].x; acc[2 * n + 1] = acc2[n].y; }
-                acc[6] = acc6;
+                for (int n = 0; n < PK_NP; n++) { acc[2 * n] = acc2[n].x; acc[2 * n + 1] = acc2[n].y; }
+                acc[PK_LC - 1] = acc1;
 #pragma unroll
-                for (int i = 0; i < PK_LC; i++) L.u.c.xc[L0 + i][s] = acc[i];
+                for (int i = 0; i < PK_LC; i++)
+                    if (L0 + i < NLAG1) L.u.c.xc[L0 + i][s] = acc[i];
                 if (b.taps) {
                     float *o = NNN_TIF(b, xc1, NLAG1, f, tile, sl);
 #pragma unroll
-                    for (int i = 0; i < PK_LC; i++) o[(size_t)(L0 + i) * TILE] = acc[i];
+                    for (int i = 0; i < PK_LC; i++)
+                        if (L0 + i < NLAG1) o[(size_t)(L0 + i) * TILE] = acc[i];
                 }
             }
-            const float *pE = L.pb + s, *pO = pE + PK_ODD;   // rows 2m / 2m + 1 of this lane's stream at p?[16 m]
-            if (wave == 5 && lane < PK_SPB) {
+            if (wave == PK_XW && lane < PK_SPB) {
                 // the running energy every coarse lag sees in find_best_pitch (ref: src/pitch.rs:83 -> :380-402): even rows only
                 float ysq = 1.0f;
 #pragma nounroll
@@ -607,88 +635,29 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                         ysq = fmaxf(ysq, 1.0f);
                     }
                 }
-            } else if (wave == 6 && lane < PK_SPB) {
-                // the running energy every fine lag sees (ref: src/pitch.rs:97 -> :380-402), kept per lag in global scratch:
-                // <= 10 lags can update the best pitch there, and they are replayed below with the energy each of them saw
-                float *yq = NNN_TIF(b, ysq2, NLAG2, f, tile, sl);
-                float ysq = 1.0f;
-#pragma nounroll
-                for (int m0 = 0; m0 < 240; m0 += 4) {
-                    float ve[4], vo[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { ve[i] = pE[(m0 + i) * PK_SPB]; vo[i] = pO[(m0 + i) * PK_SPB]; }
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { ysq += ve[i] * ve[i]; ysq += vo[i] * vo[i]; }
-                }
-#pragma nounroll
-                for (int n0 = 0; n0 < NLAG2 / 2; n0 += 7) {   // lags 2n, 2n + 1: rows (2n, 2n + 1) leave, rows (2n + 480, 2n + 481) enter
-                    float ae[7], ao[7], de[7], dd[7];
-#pragma unroll
-                    for (int i = 0; i < 7; i++) {
-                        ae[i] = pE[(n0 + i + 240) * PK_SPB]; ao[i] = pO[(n0 + i + 240) * PK_SPB];
-                        de[i] = pE[(n0 + i) * PK_SPB]; dd[i] = pO[(n0 + i) * PK_SPB];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 7; i++) {
-                        yq[(size_t)(2 * (n0 + i)) * TILE] = ysq;
-                        ysq += ae[i] * ae[i] - de[i] * de[i];
-                        ysq = fmaxf(ysq, 1.0f);
-                        yq[(size_t)(2 * (n0 + i) + 1) * TILE] = ysq;
-                        ysq += ao[i] * ao[i] - dd[i] * dd[i];
-                        ysq = fmaxf(ysq, 1.0f);
-                    }
-                }
-            } else if (wave == 7 && lane < PK_SPB) {
-                // xx = |x|^2 over the analysis frame and the 384-step running energy yy_lookup of remove_doubling
-                // (ref: src/pitch.rs:133-142)
-                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-#pragma nounroll
-                for (int m0 = 192; m0 < 432; m0 += 4) {
-                    float ve[4], vo[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { ve[i] = pE[(m0 + i) * PK_SPB]; vo[i] = pO[(m0 + i) * PK_SPB]; }
-#pragma unroll
-                    for (int i = 0; i < 4; i += 2) {
-                        s0 += ve[i] * ve[i]; s1 += vo[i] * vo[i]; s2 += ve[i + 1] * ve[i + 1]; s3 += vo[i + 1] * vo[i + 1];
-                    }
-                }
-                const float xx = s0 + s1 + s2 + s3;
-                float *yo = NNN_TIF(b, xx_yy, 386, f, tile, sl);
-                yo[0] = xx;
-                yo[TILE] = xx;  // yy_lookup[0]
-                float yy = xx;
-#pragma nounroll
-                for (int n0 = 0; n0 < 192; n0 += 4) {   // steps i = 2n + 1, 2n + 2: rows 383 - 2n, 382 - 2n enter, rows 863 - 2n, 862 - 2n leave
-                    float ae[4], ao[4], ce[4], co[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        ae[i] = pE[(191 - (n0 + i)) * PK_SPB]; ao[i] = pO[(191 - (n0 + i)) * PK_SPB];
-                        ce[i] = pE[(431 - (n0 + i)) * PK_SPB]; co[i] = pO[(431 - (n0 + i)) * PK_SPB];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        yy += ao[i] * ao[i] - co[i] * co[i];
-                        yo[(size_t)(2 * (n0 + i) + 2) * TILE] = fmaxf(yy, 0.0f);
-                        yy += ae[i] * ae[i] - ce[i] * ce[i];
-                        yo[(size_t)(2 * (n0 + i) + 3) * TILE] = fmaxf(yy, 0.0f);
-                    }
-                }
             }
         }
         __syncthreads();
         NNN_STAMP(b, 5);
-        // ---- find_best_pitch over the coarse lags (ref: src/pitch.rs:372-405, call site :83-84)
+        // ---- find_best_pitch over the coarse lags (ref: src/pitch.rs:372-405, call site :83-84) on wave 0, a serial scan; beside it,
+        //      on waves 5 and 6 (other SIMDs), the two serial energy scans whose results are looked up later in the frame
         int lo1 = 0, lo2 = 0;
         if (dec_lane) {
             BestPitch bp;
             bp.init();
+            float c[7], e[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) { c[i] = L.u.c.xc[i][s]; e[i] = L.u.c.ysq[i][s]; }
 #pragma nounroll
             for (int i0 = 0; i0 < NLAG1; i0 += 7) {
-                float c[7], e[7];
+                float cn[7], en[7];   // the next seven lags travel while these are judged
+                const int i1 = i0 + 7 < NLAG1 ? i0 + 7 : i0;
 #pragma unroll
-                for (int i = 0; i < 7; i++) { c[i] = L.u.c.xc[i0 + i][s]; e[i] = L.u.c.ysq[i0 + i][s]; }
+                for (int i = 0; i < 7; i++) { cn[i] = L.u.c.xc[i1 + i][s]; en[i] = L.u.c.ysq[i1 + i][s]; }
 #pragma unroll
                 for (int i = 0; i < 7; i++) bp.update(i0 + i, c[i], e[i]);
+#pragma unroll
+                for (int i = 0; i < 7; i++) { c[i] = cn[i]; e[i] = en[i]; }
             }
             if (b.taps) {
                 int *o = (int *)NNN_TIF(b, best1, 2, f, tile, sl);
@@ -697,6 +666,72 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             }
             lo1 = 2 * bp.best - 2;
             lo2 = 2 * bp.second - 2;
+        } else if (wave == 5 && lane < PK_SPB) {
+            // the running energy every fine lag sees (ref: src/pitch.rs:97 -> :380-402), kept per lag in global scratch:
+            // <= 10 lags can update the best pitch there, and they are replayed below with the energy each of them saw
+            float *yq = NNN_TIF(b, ysq2, NLAG2, f, tile, sl);
+            float ysq = 1.0f;
+#pragma nounroll
+            for (int m0 = 0; m0 < 240; m0 += 4) {
+                float ve[4], vo[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { ve[i] = pE[(m0 + i) * PK_SPB]; vo[i] = pO[(m0 + i) * PK_SPB]; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) { ysq += ve[i] * ve[i]; ysq += vo[i] * vo[i]; }
+            }
+#pragma nounroll
+            for (int n0 = 0; n0 < NLAG2 / 2; n0 += 7) {   // lags 2n, 2n + 1: rows (2n, 2n + 1) leave, rows (2n + 480, 2n + 481) enter
+                float ae[7], ao[7], de[7], dd[7];
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+                    ae[i] = pE[(n0 + i + 240) * PK_SPB]; ao[i] = pO[(n0 + i + 240) * PK_SPB];
+                    de[i] = pE[(n0 + i) * PK_SPB]; dd[i] = pO[(n0 + i) * PK_SPB];
+                }
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+                    yq[(size_t)(2 * (n0 + i)) * TILE] = ysq;
+                    ysq += ae[i] * ae[i] - de[i] * de[i];
+                    ysq = fmaxf(ysq, 1.0f);
+                    yq[(size_t)(2 * (n0 + i) + 1) * TILE] = ysq;
+                    ysq += ao[i] * ao[i] - dd[i] * dd[i];
+                    ysq = fmaxf(ysq, 1.0f);
+                }
+            }
+        } else if (wave == 6 && lane < PK_SPB) {
+            // xx = |x|^2 over the analysis frame and the 384-step running energy yy_lookup of remove_doubling
+            // (ref: src/pitch.rs:133-142)
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma nounroll
+            for (int m0 = 192; m0 < 432; m0 += 4) {
+                float ve[4], vo[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { ve[i] = pE[(m0 + i) * PK_SPB]; vo[i] = pO[(m0 + i) * PK_SPB]; }
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    s0 += ve[i] * ve[i]; s1 += vo[i] * vo[i]; s2 += ve[i + 1] * ve[i + 1]; s3 += vo[i + 1] * vo[i + 1];
+                }
+            }
+            const float xx = s0 + s1 + s2 + s3;
+            float *yo = NNN_TIF(b, xx_yy, 386, f, tile, sl);
+            yo[0] = xx;
+            yo[TILE] = xx;  // yy_lookup[0]
+            float yy = xx;
+#pragma nounroll
+            for (int n0 = 0; n0 < 192; n0 += 4) {   // steps i = 2n + 1, 2n + 2: rows 383 - 2n, 382 - 2n enter, rows 863 - 2n, 862 - 2n leave
+                float ae[4], ao[4], ce[4], co[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    ae[i] = pE[(191 - (n0 + i)) * PK_SPB]; ao[i] = pO[(191 - (n0 + i)) * PK_SPB];
+                    ce[i] = pE[(431 - (n0 + i)) * PK_SPB]; co[i] = pO[(431 - (n0 + i)) * PK_SPB];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    yy += ao[i] * ao[i] - co[i] * co[i];
+                    yo[(size_t)(2 * (n0 + i) + 2) * TILE] = fmaxf(yy, 0.0f);
+                    yy += ae[i] * ae[i] - ce[i] * ce[i];
+                    yo[(size_t)(2 * (n0 + i) + 3) * TILE] = fmaxf(yy, 0.0f);
+                }
+            }
         }
         __syncthreads();   // the coarse arrays are dead: their space takes the partial sums from here on
         if (dec_lane) {
@@ -745,6 +780,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
 #pragma unroll
                 for (int c = 0; c < 10; c++) o[(size_t)c * TILE] = xc.v[c];
             }
+            NNN_STAMP(b, 59);
             BestPitch bp;
             bp.init();
             const int loA = min(lo1, lo2), loB = max(lo1, lo2);
@@ -755,7 +791,9 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 const bool on = i >= 0 && i < NLAG2 && (u < 5 || i > loA + 4);
                 // the energy of the lower window's lags sits at ye[0..4] when lo1 <= lo2, at ye[5..9] otherwise
                 const float e = (u < 5) == a_first ? ye[u < 5 ? u : u - 5] : ye[5 + (u < 5 ? u : u - 5)];
-                if (on) bp.update(i, xc.at(i), e);
+                // (lag i is the u-th of its window: no search needed; where the windows overlap the values are the same)
+                const float cv = (u < 5) == a_first ? xc.v[u < 5 ? u : u - 5] : xc.v[5 + (u < 5 ? u : u - 5)];
+                if (on) bp.update(i, cv, e);
             }
             int offset = 0;
             if (bp.best > 0 && bp.best < NLAG2 - 1) {
@@ -767,8 +805,10 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             if (b.taps) NNN_TIF(b, psearch, 1, f, tile, sl)[0] = psr;
             // ---- remove_doubling: 29 candidates of the decision loop + the two neighbours of t0 (slots 29, 30): if the
             //      loop keeps t0 the final +-1 refinement needs no inner products of its own
+            NNN_STAMP(b, 60);
             t0 = (PITCH_MAX - psr) / 2;
             if (t0 > max_period - 1) t0 = max_period - 1;
+            int tc[32];
 #pragma unroll
             for (int e = 0; e < 32; e++) {   // (unrolled: k is a constant in every copy)
                 int t;
@@ -782,9 +822,18 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                         t = (k == 2) ? ((t1 + t0 > max_period) ? t0 : t0 + t1) : (2 * sc * t0 + k) / (2 * k);
                     } else t = t1;
                 }
+                tc[e] = t;
                 L.u.f.cand[e][s] = t;
-                if (e < 29) L.u.f.yy[e][s] = xy_tab[(size_t)(1 + t) * TILE];
             }
+            float yv[29];   // yy_lookup at the candidates: all requests together, one round trip
+#pragma unroll
+            for (int e = 0; e < 29; e++) yv[e] = xy_tab[(size_t)(1 + tc[e]) * TILE];
+#pragma unroll
+            for (int e = 0; e < 29; e++) L.u.f.yy[e][s] = yv[e];
+            L.u.f.xx[s] = xx;
+            L.u.f.t0[s] = t0;
+            L.u.f.pprev[s] = last_period / 2;
+            L.u.f.lgain[s] = last_gain;
         }
         __syncthreads();
         NNN_STAMP(b, 53);
@@ -800,35 +849,54 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         }
         __syncthreads();
         NNN_STAMP(b, 54);
-        // ---- decision loop (ref: src/pitch.rs:150-206)
-        int t = 0;
-        float pg = 0.0f, gg = 0.0f;
-        if (dec_lane) {
-            auto ipv = [&](int e) { return L.u.f.part[e][0][s] + L.u.f.part[e][1][s] + L.u.f.part[e][2][s] + L.u.f.part[e][3][s]; };
-            const int prev_period = last_period / 2;
-            t = t0;
-            float xy = ipv(0), yy = L.u.f.yy[0][s];
-            float best_xy = xy, best_yy = yy;
-            const float g0 = pitch_gain(xy, xx, yy);
-            gg = g0;
-            for (int k = 2; k <= 15; k++) {
+        // ---- decision loop (ref: src/pitch.rs:150-206).  Whether divisor k replaces the best candidate depends on t0, the previous
+        //      frame and k's own inner products, not on the other divisors: lane (stream, k) judges k = 2 .. 15 on four waves, the
+        //      stream's lane then takes the last k that passed (the loop's break at the first t1 < min_period cuts a suffix: t1
+        //      falls with k).
+        if (wave < 4) {
+            const int k = 2 + 4 * wave + q;
+            if (k <= 15) {
+                auto ipv = [&](int e) { return L.u.f.part[e][0][s] + L.u.f.part[e][1][s] + L.u.f.part[e][2][s] + L.u.f.part[e][3][s]; };
                 const int e1 = 1 + 2 * (k - 2), e2 = e1 + 1;
-                const int t1 = L.u.f.cand[e1][s];
-                if (t1 < min_period) break;
-                xy = (ipv(e1) + ipv(e2)) / 2.0f;
-                yy = (L.u.f.yy[e1][s] + L.u.f.yy[e2][s]) / 2.0f;
-                const float g1 = pitch_gain(xy, xx, yy);
-                int d = t1 - prev_period;
+                const int t1 = L.u.f.cand[e1][s], t0s = L.u.f.t0[s];
+                const float xxs = L.u.f.xx[s], lg = L.u.f.lgain[s];
+                const float g0 = pitch_gain(ipv(0), xxs, L.u.f.yy[0][s]);
+                const float xy = (ipv(e1) + ipv(e2)) / 2.0f;
+                const float yy = (L.u.f.yy[e1][s] + L.u.f.yy[e2][s]) / 2.0f;
+                const float g1 = pitch_gain(xy, xxs, yy);
+                int d = t1 - L.u.f.pprev[s];
                 if (d < 0) d = -d;
                 float cont;
-                if (d <= 1) cont = last_gain;
-                else if (d <= 2 && 5 * k * k < t0) cont = last_gain / 2.0f;
+                if (d <= 1) cont = lg;
+                else if (d <= 2 && 5 * k * k < t0s) cont = lg / 2.0f;
                 else cont = 0.0f;
                 float thresh;
                 if (t1 < 3 * min_period) thresh = fmaxf(0.85f * g0 - cont, 0.4f);
                 else if (t1 < 2 * min_period) thresh = fmaxf(0.9f * g0 - cont, 0.5f);
                 else thresh = fmaxf(0.7f * g0 - cont, 0.3f);
-                if (g1 > thresh) { best_xy = xy; best_yy = yy; t = t1; gg = g1; }
+                L.u.f.kpass[k][s] = (t1 >= min_period && g1 > thresh) ? 1 : 0;
+                L.u.f.kxy[k][s] = xy;
+                L.u.f.kyy[k][s] = yy;
+                L.u.f.kg[k][s] = g1;
+            }
+        }
+        __syncthreads();
+        NNN_STAMP(b, 58);
+        int t = 0;
+        float pg = 0.0f, gg = 0.0f;
+        if (dec_lane) {
+            auto ipv = [&](int e) { return L.u.f.part[e][0][s] + L.u.f.part[e][1][s] + L.u.f.part[e][2][s] + L.u.f.part[e][3][s]; };
+            t = t0;
+            float best_xy = ipv(0), best_yy = L.u.f.yy[0][s];
+            gg = pitch_gain(best_xy, xx, best_yy);
+            int kw = 0;
+#pragma unroll
+            for (int k = 2; k <= 15; k++) kw = L.u.f.kpass[k][s] ? k : kw;
+            if (kw) {
+                best_xy = L.u.f.kxy[kw][s];
+                best_yy = L.u.f.kyy[kw][s];
+                gg = L.u.f.kg[kw][s];
+                t = L.u.f.cand[1 + 2 * (kw - 2)][s];
             }
             best_xy = fmaxf(best_xy, 0.0f);
             pg = (best_yy <= best_xy) ? 1.0f : best_xy / (best_yy + 1.0f);

@@ -21,8 +21,8 @@ for S, T in ((4096, 4), (65536, 4)):
     bd.process(x[:, :T]); bd.process(x[:, T:])
     st = np.zeros(64, np.int64)
     lib.L.nnn_batch_read_stamps(bd._h, st.ctypes.data_as(C.c_void_p))
-    names = ["window->lds", "autocorr", "lpc", "fir", "coarse xcorr+scans", "find_best coarse", "fine xcorr", "replay+candidates", "cand inner", "decision", "refine", "final"]
-    idx = [0, 1, 2, 3, 4, 5, 6, 7, 53, 54, 55, 56, 57]
+    names = ["window->lds", "autocorr", "lpc", "fir", "coarse xcorr+scans", "find_best coarse", "fine xcorr", "combine+energies", "replay", "candidates", "cand inner", "judge k", "pick", "refine", "final"]
+    idx = [0, 1, 2, 3, 4, 5, 6, 7, 59, 60, 53, 54, 58, 55, 56, 57]
     d = [(st[idx[i + 1]] - st[idx[i]]) / 2100.0 for i in range(len(names))]   # shader-clock cycles at ~2.1 GHz -> us (approximate)
     print(f"S={S} k_pitch last frame of block 0 [us, approximate]: total {sum(d):.1f}")
     print("   " + "  ".join(f"{n} {v:.2f}" for n, v in zip(names, d)))

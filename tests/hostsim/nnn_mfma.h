@@ -64,6 +64,8 @@ static inline int launder_s(int x) { return x; }
 static inline void keep_v(float) {}
 
 struct v2f { float x, y; };
+static inline v2f operator*(v2f a, v2f b) { v2f r = {a.x * b.x, a.y * b.y}; return r; }
+static inline v2f operator+(v2f a, v2f b) { v2f r = {a.x + b.x, a.y + b.y}; return r; }
 static inline v2f mk2(float x, float y) { v2f r = {x, y}; return r; }
 static inline v2f pk_mul(v2f a, v2f b) { return mk2(a.x * b.x, a.y * b.y); }
 static inline v2f pk_mul_bx(v2f a, v2f b) { return mk2(a.x * b.x, a.x * b.y); }
