@@ -100,6 +100,7 @@ struct nnn_batch {
     int n_lanes = 2;                // SCHED_LANES: lanes (the caller's stream + internal ones) besides the high-pass stream; env NNN_LANES, 1..4
                                     // (measured at 4096 streams x 48 frames: 1: 28.5, 2: 37.1, 3: 32.9, 4: 32.2 M frames/s -- the default 4 hardware
                                     // queues are shared with the host's own streams)
+    int pitch_chain = 1;            // k_pitch: one workgroup per (frame, quarter tile) instead of a frame loop: 1 = below 16384 streams, 0 = never, 2 = always (env NNN_PITCH_CHAIN)
     bool use_pipeline = true;
     bool profiling = false;
     std::vector<hipEvent_t> evp;    // pairs per launch while profiling
@@ -259,6 +260,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     for (int s = 0; s < ST_COUNT; s++)
         for (int i = 0; i < EVR; i++) HIPCHK(hipEventCreateWithFlags(&h->ev[s][i], hipEventDisableTiming));
     if (const char *e = getenv("NNN_PIPELINE")) h->use_pipeline = atoi(e) != 0;
+    if (const char *e = getenv("NNN_PITCH_CHAIN")) h->pitch_chain = atoi(e);
     if (const char *e = getenv("NNN_SCHED")) {
         if (!strcmp(e, "seq")) h->sched = SCHED_SEQ;
         else if (!strcmp(e, "lanes")) h->sched = SCHED_LANES;
@@ -386,6 +388,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
         NNN_SCRATCH_FIELDS(NNN_F)
 #undef NNN_F
         for (int set = 1; set < NSET; set++) h->b[set] = frame_view(h->b[0], set);
+        h->state_bufs.push_back({(void *)q.pflag, Sp * NSET * sizeof(int)});   // frame numbers restart with reset / load_state
     }
     // the RNN kernel's dynamic LDS limit is a per-device function attribute: raise it to the hardware's 160 KB once
     HIPCHK(hipFuncSetAttribute((const void *)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
@@ -530,6 +533,7 @@ extern "C" nnn_batch *nnn_batch_clone(nnn_batch *h)
     c->sched = h->sched;
     c->n_lanes = h->n_lanes;
     c->use_pipeline = h->use_pipeline;
+    c->pitch_chain = h->pitch_chain;
     c->b[0].taps = h->b[0].taps;
     for (int set = 1; set < NSET; set++) c->b[set].taps = h->b[0].taps;
     return c;
@@ -568,7 +572,14 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
     Launcher L{h, st, prof};
     switch (s) {
     case ST_HP: L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g); break;
-    case ST_PITCH: L.go(K_PITCH, k_pitch, dim3(Sp / PK_SPB), dim3(PK_T), 0, b, sp0, g); break;
+    case ST_PITCH: {
+        // frames side by side, chained through flags (k_pitch), while one frame's workgroups cannot fill the GPU (below 16384
+        // streams; measured at 4096: 46.8 -> 32.8 us per frame; at 65536, where the frame loop's prefetch of the next window
+        // matters instead: 468 -> 515); flag values are frame numbers (> 0)
+        const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
+        L.go(K_PITCH, k_pitch, dim3(Sp / PK_SPB * (chain ? ug : 1u)), dim3(PK_T), 0, b, sp0, g, chain, seq0);
+        break;
+    }
     case ST_FFT: L.go(K_FFT_XP, k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0); break;
     case ST_RNN:
         for (const nnn_batch::ModelGroup &G : h->groups) {   // one launch per resident model (a run of whole tiles)
@@ -1060,7 +1071,7 @@ static void enqueue_feature_frame(nnn_batch *h, hipStream_t st, StepParams *sp, 
     hipLaunchKernelGGL(k_fill_params, dim3(1), dim3(64), 0, st, sp, v, 1);
     hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, (const StepParams *)sp, 1);
     if (full) {
-        hipLaunchKernelGGL(k_pitch, dim3(Sp / PK_SPB), dim3(PK_T), 0, st, b, (const StepParams *)sp, 1);
+        hipLaunchKernelGGL(k_pitch, dim3(Sp / PK_SPB), dim3(PK_T), 0, st, b, (const StepParams *)sp, 1, 0, 0);
         hipLaunchKernelGGL(k_fft_xp, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp);
         hipLaunchKernelGGL(k_features, dim3(NT), dim3(64 * FEAT_WAVES), 0, st, b);
     } else {

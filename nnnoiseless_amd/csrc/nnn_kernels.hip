@@ -308,14 +308,23 @@ struct Xc2 {   // xcorr[] of the fine search: zero except within 2 of 2*best / 2
 
 __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1.0f + xx * yy); }
 
+// The two long energy scans run once per frame, serially, and are looked up at a few data-dependent lags later in the frame.
+// They leave check points in LDS (every 16th fine lag, every 4th step of yy); a lookup replays the few steps from the check
+// point below it -- the same additions in the same order.  (Whole tables would be 43 KB per block; through global scratch the
+// scans were bound by the depth of a wave's store queue.)
+constexpr int PK_CKF = 16, PK_NCKF = (NLAG2 + PK_CKF - 1) / PK_CKF;   // 19
+constexpr int PK_CKY = 4, PK_NCKY = 384 / PK_CKY + 1;                  // 97
 struct PkLds {
     float pb[PK_ODD + PK_HALF];                  // the decimated window, then (in place) pitch_buf
-    float acs[5][PK_SPB], coef[5][PK_SPB];
+    float ckf[PK_NCKF][PK_SPB];                  // running energy of the fine lags before lag 16 m (find_best_pitch, ref: src/pitch.rs:380-402)
+    float cky[PK_NCKY][PK_SPB];                  // running energy yy of remove_doubling after step 4 m (ref: src/pitch.rs:133-142); [0] = xx
     union {
+        struct { float acs[5][PK_SPB], coef[5][PK_SPB]; } a;         // LPC analysis: autocorrelation, FIR taps
         struct { float xc[NLAG1][PK_SPB], ysq[NLAG1][PK_SPB]; } c;   // coarse search: cross-correlation, running energy per lag
         struct {                                                       // from the fine search on
             float part[PK_NC][4][PK_SPB];        // inner-product partials [slot][q][stream] (ref: src/pitch.rs:225-244)
-            float yy[29][PK_SPB];                // yy_lookup at the candidate periods
+            float yy[32][PK_SPB];                // yy_lookup at the candidate periods
+            float ye[10][PK_SPB];                // the running energy the fine lags of the two windows saw
             int cand[32][PK_SPB];                // candidate periods of remove_doubling
             int lo[2][PK_SPB];                   // first fine lag of the two windows
             int tsel[PK_SPB];                    // the period the decision loop chose
@@ -383,7 +392,12 @@ __device__ __forceinline__ void pk_inner(const float *pb, int s, int q, const in
 #ifndef NNN_PK_MINWAVES
 #define NNN_PK_MINWAVES 4   // waves per SIMD: two blocks of 8 waves per CU, <= 128 registers
 #endif
-__global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, const StepParams *sp0, int g)
+// `chain` != 0: one workgroup per (frame, quarter tile), block index = frame * blocks_per_frame + quarter tile.  Everything but the
+// decision loop of remove_doubling is independent from frame to frame, so the frames of a group run side by side and a workgroup
+// waits -- just before that loop -- for the flag its predecessor (same streams, previous frame: a lower block index, dispatched
+// earlier) sets once its pitch and gain are in memory.  `seq0` numbers the group's first frame; flag values are frame numbers, so a
+// flag left by an earlier use of the scratch set never matches.  `chain` == 0: one workgroup per quarter tile loops over the frames.
+__global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, const StepParams *sp0, int g, int chain, int seq0)
 {
     __shared__ PkLds L;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane0 = threadIdx.x & 63;
@@ -391,8 +405,10 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
     // Workgroup b runs on XCD b mod 8 (observed dispatch order; a speed matter only).  The four quarter-tile blocks of tile t are
     // sent to XCD t mod 8 -- the one whose L2 holds the tile's decimated history, written there by k_hp's block t: consecutive
     // block indices would spread them over four XCDs, each fetching the same lines.
-    int blk = (int)blockIdx.x;
-    if ((gridDim.x & 31) == 0) {
+    const int per = b.S_pad / PK_SPB;   // blocks per frame
+    const int f_begin = chain ? (int)blockIdx.x / per : 0, f_end = chain ? f_begin + 1 : g;
+    int blk = (int)blockIdx.x - f_begin * per;
+    if ((per & 31) == 0) {
         const int xcd = blk & 7, i = blk >> 3;
         blk = 4 * (8 * (i >> 2) + xcd) + (i & 3);
     }
@@ -401,13 +417,13 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
     const bool dec_lane = wave == 0 && lane0 < PK_SPB;                // lane = stream decisions
     int last_period = 0;
     float last_gain = 0.0f;
-    if (dec_lane) {
+    if (dec_lane && f_begin == 0) {
         last_period = NNN_TI(b.last_period, 1, tile, q0 + s)[0];
         last_gain = NNN_TI(b.last_gain, 1, tile, q0 + s)[0];
     }
     float win[PK_CH];
-    pk_window_load(b, sp0, tile, q0, (int)threadIdx.x, win);
-    for (int f = 0; f < g; f++) {
+    pk_window_load(b, sp0 + f_begin, tile, q0, (int)threadIdx.x, win);
+    for (int f = f_begin; f < f_end; f++) {
         lane = launder_v(lane0);   // keep the frame loop's addresses inside the loop (see launder_v)
         s = lane & 15;
         q = lane >> 4;
@@ -463,7 +479,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             sum(0); sum(1); sum(2);   // groups 212, 213, 214 (the ring slots they were fetched into)
             float d = 0.0f;   // tail d_k = sum_{i = k+860}^{863} x[i] x[i-k], added after the main sum
             for (int i = k + fast_n; i < XLP; i++) d += L.pb[pk_at(i, s)] * L.pb[pk_at(i - k, s)];
-            L.acs[k][s] = c + d;
+            L.u.a.acs[k][s] = c + d;
         }
         __syncthreads();
         NNN_STAMP(b, 2);
@@ -471,7 +487,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         if (dec_lane) {
             float ac[5];
 #pragma unroll
-            for (int i = 0; i < 5; i++) ac[i] = L.acs[i][s];
+            for (int i = 0; i < 5; i++) ac[i] = L.u.a.acs[i][s];
             ac[0] *= 1.0001f;
 #pragma unroll
             for (int i = 1; i < 5; i++) ac[i] -= ac[i] * (0.008f * (float)i) * (0.008f * (float)i);
@@ -509,7 +525,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             l2[3] = lpc[3] + 0.8f * lpc[2];
             l2[4] = 0.8f * lpc[3];
 #pragma unroll
-            for (int i = 0; i < 5; i++) L.coef[i][s] = l2[i];
+            for (int i = 0; i < 5; i++) L.u.a.coef[i][s] = l2[i];
             if (b.taps) {
                 float *o = NNN_TIF(b, lpc, 10, f, tile, sl);
 #pragma unroll
@@ -533,7 +549,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             }
             __syncthreads();   // every chunk has its inputs
             if (ch < PK_NCH) {
-                const float n0 = L.coef[0][col], n1 = L.coef[1][col], n2 = L.coef[2][col], n3 = L.coef[3][col], n4 = L.coef[4][col];
+                const float n0 = L.u.a.coef[0][col], n1 = L.u.a.coef[1][col], n2 = L.u.a.coef[2][col], n3 = L.u.a.coef[3][col], n4 = L.u.a.coef[4][col];
                 float *tap = b.taps ? NNN_TIF(b, xlp_ti, XLP, f, tile, q0 + col) + (size_t)(ch * PK_CH) * TILE : nullptr;
 #pragma unroll
                 for (int m = 0; m < PK_CH / 2; m++) {
@@ -550,7 +566,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 }
             }
         }
-        if (f + 1 < g) pk_window_load(b, sp0 + f + 1, tile, q0, tid, win);   // the next frame's window travels behind this frame's work
+        if (f + 1 < f_end) pk_window_load(b, sp0 + f + 1, tile, q0, tid, win);   // the next frame's window travels behind this frame's work
         __syncthreads();
         NNN_STAMP(b, 4);
         // ---- coarse search: the cross-correlation on waves 0..2, the running energy of the coarse lags on wave 3
@@ -667,9 +683,8 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             lo1 = 2 * bp.best - 2;
             lo2 = 2 * bp.second - 2;
         } else if (wave == 5 && lane < PK_SPB) {
-            // the running energy every fine lag sees (ref: src/pitch.rs:97 -> :380-402), kept per lag in global scratch:
-            // <= 10 lags can update the best pitch there, and they are replayed below with the energy each of them saw
-            float *yq = NNN_TIF(b, ysq2, NLAG2, f, tile, sl);
+            // the running energy every fine lag sees (ref: src/pitch.rs:97 -> :380-402): <= 10 lags can update the best pitch there,
+            // and they are replayed below with the energy each of them saw
             float ysq = 1.0f;
 #pragma nounroll
             for (int m0 = 0; m0 < 240; m0 += 4) {
@@ -680,19 +695,19 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 for (int i = 0; i < 4; i++) { ysq += ve[i] * ve[i]; ysq += vo[i] * vo[i]; }
             }
 #pragma nounroll
-            for (int n0 = 0; n0 < NLAG2 / 2; n0 += 7) {   // lags 2n, 2n + 1: rows (2n, 2n + 1) leave, rows (2n + 480, 2n + 481) enter
-                float ae[7], ao[7], de[7], dd[7];
+            for (int m = 0; m < PK_NCKF; m++) {   // lags 16 m .. 16 m + 15 (the last few past the table: computed, never looked up)
+                L.ckf[m][s] = ysq;
+                const int n0 = m * (PK_CKF / 2);
+                float ae[8], ao[8], de[8], dd[8];   // lags 2n, 2n + 1: rows (2n, 2n + 1) leave, rows (2n + 480, 2n + 481) enter
 #pragma unroll
-                for (int i = 0; i < 7; i++) {
+                for (int i = 0; i < 8; i++) {
                     ae[i] = pE[(n0 + i + 240) * PK_SPB]; ao[i] = pO[(n0 + i + 240) * PK_SPB];
                     de[i] = pE[(n0 + i) * PK_SPB]; dd[i] = pO[(n0 + i) * PK_SPB];
                 }
 #pragma unroll
-                for (int i = 0; i < 7; i++) {
-                    yq[(size_t)(2 * (n0 + i)) * TILE] = ysq;
+                for (int i = 0; i < 8; i++) {
                     ysq += ae[i] * ae[i] - de[i] * de[i];
                     ysq = fmaxf(ysq, 1.0f);
-                    yq[(size_t)(2 * (n0 + i) + 1) * TILE] = ysq;
                     ysq += ao[i] * ao[i] - dd[i] * dd[i];
                     ysq = fmaxf(ysq, 1.0f);
                 }
@@ -711,11 +726,8 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                     s0 += ve[i] * ve[i]; s1 += vo[i] * vo[i]; s2 += ve[i + 1] * ve[i + 1]; s3 += vo[i + 1] * vo[i + 1];
                 }
             }
-            const float xx = s0 + s1 + s2 + s3;
-            float *yo = NNN_TIF(b, xx_yy, 386, f, tile, sl);
-            yo[0] = xx;
-            yo[TILE] = xx;  // yy_lookup[0]
-            float yy = xx;
+            float yy = s0 + s1 + s2 + s3;
+            L.cky[0][s] = yy;   // xx = yy_lookup[0]
 #pragma nounroll
             for (int n0 = 0; n0 < 192; n0 += 4) {   // steps i = 2n + 1, 2n + 2: rows 383 - 2n, 382 - 2n enter, rows 863 - 2n, 862 - 2n leave
                 float ae[4], ao[4], ce[4], co[4];
@@ -727,9 +739,8 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     yy += ao[i] * ao[i] - co[i] * co[i];
-                    yo[(size_t)(2 * (n0 + i) + 2) * TILE] = fmaxf(yy, 0.0f);
                     yy += ae[i] * ae[i] - ce[i] * ce[i];
-                    yo[(size_t)(2 * (n0 + i) + 3) * TILE] = fmaxf(yy, 0.0f);
+                    if (i & 1) L.cky[(n0 + i + 1) / 2][s] = yy;   // after step 2 (n0 + i) + 2, a multiple of 4
                 }
             }
         }
@@ -756,13 +767,32 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         NNN_STAMP(b, 7);
         // ---- find_best_pitch over the fine lags: xcorr is zero outside the two 5-lag windows, so only they can update the
         //      best pitch; replayed in increasing lag order with the energy each of them saw.  Then the candidate periods.
+        if (wave == 0) {
+            if (q < 2) {
+                // the energy lags lo .. lo + 4 of window q saw: from the check point below the first of them, the scan's own steps
+                const int lo = L.u.f.lo[q][s], first = lo > 0 ? lo : 0, last = lo + 4 < NLAG2 - 1 ? lo + 4 : NLAG2 - 1;
+                const int m = (first < NLAG2 ? first : NLAG2 - 1) / PK_CKF;
+                float y = L.ckf[m][s], ev[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma nounroll
+                for (int st = 0; st < PK_CKF + 4; st++) {
+                    const int i = PK_CKF * m + st;
+                    if (i > last) break;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) ev[c] = (i == lo + c) ? y : ev[c];
+                    const float a = L.pb[pk_at(i + 480, s)], d = L.pb[pk_at(i, s)];
+                    y += a * a - d * d;
+                    y = fmaxf(y, 1.0f);
+                }
+#pragma unroll
+                for (int c = 0; c < 5; c++) L.u.f.ye[5 * q + c][s] = ev[c];
+            }
+            wave_lds_sync();
+        }
         Xc2 xc;
         int t0 = 0;
         float xx = 0.0f;
         if (dec_lane) {
-            const float *yq = NNN_TIF(b, ysq2, NLAG2, f, tile, sl);
-            const float *xy_tab = NNN_TIF(b, xx_yy, 386, f, tile, sl);
-            xx = xy_tab[0];
+            xx = L.cky[0][s];
             xc.lo1 = lo1;
             xc.lo2 = lo2;
             float ye[10];
@@ -773,7 +803,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 float v = L.u.f.part[c][0][s] + L.u.f.part[c][1][s] + L.u.f.part[c][2][s] + L.u.f.part[c][3][s];
                 v = fmaxf(v, -1.0f);
                 xc.v[c] = valid ? v : 0.0f;
-                ye[c] = valid ? yq[(size_t)lag * TILE] : 0.0f;
+                ye[c] = valid ? L.u.f.ye[c][s] : 0.0f;
             }
             if (b.taps) {
                 float *o = NNN_TIF(b, xc2, 10, f, tile, sl);
@@ -808,8 +838,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             NNN_STAMP(b, 60);
             t0 = (PITCH_MAX - psr) / 2;
             if (t0 > max_period - 1) t0 = max_period - 1;
-            int tc[32];
-#pragma unroll
+            #pragma unroll
             for (int e = 0; e < 32; e++) {   // (unrolled: k is a constant in every copy)
                 int t;
                 if (e == 0 || e == 31) t = t0;
@@ -822,18 +851,29 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                         t = (k == 2) ? ((t1 + t0 > max_period) ? t0 : t0 + t1) : (2 * sc * t0 + k) / (2 * k);
                     } else t = t1;
                 }
-                tc[e] = t;
                 L.u.f.cand[e][s] = t;
             }
-            float yv[29];   // yy_lookup at the candidates: all requests together, one round trip
-#pragma unroll
-            for (int e = 0; e < 29; e++) yv[e] = xy_tab[(size_t)(1 + tc[e]) * TILE];
-#pragma unroll
-            for (int e = 0; e < 29; e++) L.u.f.yy[e][s] = yv[e];
+
             L.u.f.xx[s] = xx;
             L.u.f.t0[s] = t0;
-            L.u.f.pprev[s] = last_period / 2;
-            L.u.f.lgain[s] = last_gain;
+        }
+        if (wave == 0) {
+            // yy_lookup at the candidate periods (ref: src/pitch.rs:138-142): lane (s, q) takes candidates q, q + 4, ..; from the
+            // check point below T, at most three of the scan's steps
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int e = q + 4 * i, T = L.u.f.cand[e][s], m = T / PK_CKY;
+                float y = L.cky[m][s];
+#pragma unroll
+                for (int st = 1; st < PK_CKY; st++) {
+                    const int j = PK_CKY * m + st, jc = j <= 384 ? j : 384;   // step j: row 384 - j enters, row 864 - j leaves
+                    const float a = L.pb[pk_at(384 - jc, s)], c = L.pb[pk_at(864 - jc, s)];
+                    const float yn = y + (a * a - c * c);
+                    y = j <= T ? yn : y;
+                }
+                L.u.f.yy[e][s] = fmaxf(y, 0.0f);
+            }
         }
         __syncthreads();
         NNN_STAMP(b, 53);
@@ -846,6 +886,17 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             pk_inner<4>(L.pb, s, qi, yr, acc);
 #pragma unroll
             for (int c = 0; c < 4; c++) L.u.f.part[wave + 8 * c][qi][s] = acc[c];
+        }
+        if (dec_lane) {
+            if (chain && f > 0) {
+                // the previous frame of these streams is another workgroup's: wait for its flag, then take its pitch and gain
+                const int *flag = (const int *)NNN_TIF(b, pflag, 1, f - 1, tile, q0);
+                for (int spins = 0; flag_read(flag) != seq0 + f - 1 && spins < (1 << 22); spins++) chain_pause();
+                last_period = NNN_TIF(b, pitch, 1, f - 1, tile, sl)[0];
+                last_gain = NNN_TIF(b, pgain, 1, f - 1, tile, sl)[0];
+            }
+            L.u.f.pprev[s] = last_period / 2;
+            L.u.f.lgain[s] = last_gain;
         }
         __syncthreads();
         NNN_STAMP(b, 54);
@@ -932,11 +983,15 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             NNN_TIF(b, pgain, 1, f, tile, sl)[0] = pg;
             last_period = res;
             last_gain = pg;
+            if (chain) {
+                __threadfence();   // every stream's pitch and gain before the flag
+                if (lane0 == 0) flag_publish((int *)NNN_TIF(b, pflag, 1, f, tile, q0), seq0 + f);
+            }
         }
         NNN_STAMP(b, 57);
         // (the next frame's first writes to anything this frame still reads sit behind barriers wave 0 takes part in)
     }
-    if (dec_lane) {
+    if (dec_lane && f_end == g) {
         NNN_TI(b.last_period, 1, tile, q0 + s)[0] = last_period;
         NNN_TI(b.last_gain, 1, tile, q0 + s)[0] = last_gain;
     }

@@ -94,11 +94,9 @@ struct Buffers {
     float *xc1;          // TI [147]    coarse cross-correlation (stored only while taps are on: it lives in LDS otherwise)
     int *best1;          // TI [2]
     float *xc2;          // TI [10]     fine xcorr at 2*best-2..+2, 2*second-2..+2
-    float *ysq1;         // TI [147]    running energy seen by every coarse lag
-    float *ysq2;         // TI [294]    running energy seen by every fine lag
     int *psearch;        // TI [1]
-    float *xx_yy;        // TI [386]    [0] = xx, [1 + i] = yy_lookup[i]
     int *pitch;          // TI [1]
+    int *pflag;          // TI [1]      per quarter tile (its first stream's entry): number of the frame whose pitch and gain are in memory
     float *pgain;        // TI [1]
     float2 *X, *P;       // SM [FSTR]   spectra, rows padded to whole 128-byte lines; P holds bins 0..399 unless taps are on (the
                          //             pitch filter reads no more, ref: src/lib.rs:84-97 zero-fills from bin 400 up)
@@ -126,8 +124,8 @@ struct Buffers {
 // Per-frame scratch of set f lies f * S_pad * LEN elements after set 0 in every scratch array, so a launch that covers
 // several consecutive frames (block index = frame * blocks_per_frame + block) reaches its frame's set by offsetting.
 #define NNN_SCRATCH_FIELDS(F)                                                                                        \
-    F(lpc, 10) F(xlp_ti, XLP) F(xc1, NLAG1) F(best1, 2) F(xc2, 10) F(ysq1, NLAG1) F(ysq2, NLAG2) F(psearch, 1)  \
-    F(xx_yy, 386) F(pitch, 1) F(pgain, 1) F(X, FSTR) F(P, FSTR) F(ex, NB) F(ep, NB) F(exp_, NB) F(cn, 28) F(feat, NFEAT)      \
+    F(lpc, 10) F(xlp_ti, XLP) F(xc1, NLAG1) F(best1, 2) F(xc2, 10) F(psearch, 1)  \
+    F(pitch, 1) F(pflag, 1) F(pgain, 1) F(X, FSTR) F(P, FSTR) F(ex, NB) F(ep, NB) F(exp_, NB) F(cn, 28) F(feat, NFEAT)      \
     F(silence, 1) F(branch, 1) F(g_raw, NB) F(g, NB) F(vad, 1)
 __host__ __device__ inline Buffers frame_view(Buffers b, int f)
 {

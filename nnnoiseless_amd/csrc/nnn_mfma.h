@@ -110,4 +110,16 @@ __device__ __forceinline__ v2f pk_add(v2f a, v2f b)
     return r;
 }
 
+// Frame-to-frame hand-off between workgroups of one launch (k_pitch): the producer makes its results visible device-wide
+// and then stores the flag; the consumer polls the flag and only then reads the results.
+__device__ __forceinline__ void flag_publish(int *flag, int value)
+{
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int flag_read(const int *flag)
+{
+    return __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_pause() { __builtin_amdgcn_s_sleep(4); }
+
 }  // namespace nnn

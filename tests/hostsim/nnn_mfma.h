@@ -73,4 +73,10 @@ static inline v2f pk_mul_by(v2f a, v2f b) { return mk2(a.y * b.x, a.y * b.y); }
 static inline v2f pk_add(v2f a, v2f b) { return mk2(a.x + b.x, a.y + b.y); }
 static inline float sadd(float a, float b) { return a + b; }
 
+// (the interpreter runs the workgroups of a launch one after the other in index order: a flag is always set when it is read)
+static inline void flag_publish(int *flag, int value) { *flag = value; }
+static inline int flag_read(const int *flag) { return *flag; }
+static inline void chain_pause() {}
+static inline void __threadfence() {}
+
 }  // namespace nnn
