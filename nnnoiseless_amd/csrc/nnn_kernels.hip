@@ -68,12 +68,18 @@ __device__ __forceinline__ void pcm_store(char *p, int fmt, float v)
     if (fmt == PCM_I16) *(short *)p = pcm_to_i16(v);
     else *(float *)p = fmt == PCM_F32_UNIT ? pcm_to_unit(v) : v;
 }
-// One lane's next 32 samples of its own stream, kept in raw form until the recurrence of the previous 32 is done (so
+// One lane's next HP_CH samples of its own stream, kept in raw form until the recurrence of the previous HP_CH is done (so
 // the loads stay in flight behind it).  VEC: mono stream with 16-byte aligned rows, 16 bytes per load.
+// (HP_CH = 16 at 168 registers, tried so that the 64 lone waves of a 4096-stream launch would slip in beside the group's other
+// kernels: 20 -> 26 us per frame on its own, 70 -> 90 at 65536 streams, and no gain in the pipelined run.)
+#ifndef NNN_HP_CH
+#define NNN_HP_CH 32
+#endif
+constexpr int HP_CH = NNN_HP_CH;
 template <int FMT, bool VEC> struct HpChunk {
-    static constexpr int NV = FMT == PCM_I16 ? 4 : 8;
+    static constexpr int NV = FMT == PCM_I16 ? HP_CH / 8 : HP_CH / 4;
     uint4 v[VEC ? NV : 1];
-    unsigned w[VEC ? 1 : 32];
+    unsigned w[VEC ? 1 : HP_CH];
     __device__ __forceinline__ void load(const char *p, int sstride)
     {
         if (VEC) {
@@ -81,16 +87,16 @@ template <int FMT, bool VEC> struct HpChunk {
             for (int q = 0; q < NV; q++) v[q] = ld_global_u4(p + 16 * q);
         } else {
 #pragma unroll
-            for (int j = 0; j < 32; j++)
+            for (int j = 0; j < HP_CH; j++)
                 w[j] = FMT == PCM_I16 ? (unsigned)(int)ld_global<short>(p + (long long)j * sstride)
                                       : ld_global<unsigned>(p + (long long)j * sstride);
         }
     }
-    __device__ __forceinline__ void get(float (&x)[32]) const
+    __device__ __forceinline__ void get(float (&x)[HP_CH]) const
     {
         if (VEC && FMT == PCM_I16) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < NV; q++) {
                 const unsigned u[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -100,17 +106,17 @@ template <int FMT, bool VEC> struct HpChunk {
             }
         } else if (VEC) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
+            for (int q = 0; q < NV; q++) {
                 x[4 * q] = __uint_as_float(v[q].x); x[4 * q + 1] = __uint_as_float(v[q].y);
                 x[4 * q + 2] = __uint_as_float(v[q].z); x[4 * q + 3] = __uint_as_float(v[q].w);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 32; j++) x[j] = FMT == PCM_I16 ? (float)(int)w[j] : __uint_as_float(w[j]);
+            for (int j = 0; j < HP_CH; j++) x[j] = FMT == PCM_I16 ? (float)(int)w[j] : __uint_as_float(w[j]);
         }
         if (FMT == PCM_F32_UNIT) {
 #pragma unroll
-            for (int j = 0; j < 32; j++) x[j] *= 32768.0f;
+            for (int j = 0; j < HP_CH; j++) x[j] *= 32768.0f;
         }
     }
 };
@@ -154,27 +160,27 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp,
     const bool mirror = slot < DEC_MIRROR;
     float4 *hw = (float4 *)(h + slot * FRAME);   // RING * 4 and FRAME * 4 are multiples of 16
     const double a0 = (double)-1.99599f, a1 = (double)0.99600f, b0 = (double)-2.0f, b1 = (double)1.0f;
-    // Software pipeline over 32-sample chunks.  Loads and stores share one in-order counter (vmcnt), so waiting for
+    // Software pipeline over HP_CH-sample chunks.  Loads and stores share one in-order counter (vmcnt), so waiting for
     // chunk c's samples also waits for every store issued before: the stores of chunk c - 1 are therefore issued right
     // after that wait, and both they and the loads of chunk c + 1 travel behind the ~0.7 us recurrence of chunk c.
-    float ys[32], dvs[16];
-    for (int c = 0; c <= FRAME / 32; c++) {
-        float xs[32];
-        if (c < FRAME / 32) nxt.get(xs);
+    float ys[HP_CH], dvs[HP_CH / 2];
+    for (int c = 0; c <= FRAME / HP_CH; c++) {
+        float xs[HP_CH];
+        if (c < FRAME / HP_CH) nxt.get(xs);
         if (c > 0) {
 #pragma unroll
-            for (int t = 0; t < 16; t++) dec[(size_t)(16 * (c - 1) + t) * TILE] = dvs[t];
+            for (int t = 0; t < HP_CH / 2; t++) dec[(size_t)(HP_CH / 2 * (c - 1) + t) * TILE] = dvs[t];
             if (mirror) {
 #pragma unroll
-                for (int t = 0; t < 16; t++) dec[(size_t)(DEC_RING + 16 * (c - 1) + t) * TILE] = dvs[t];
+                for (int t = 0; t < HP_CH / 2; t++) dec[(size_t)(DEC_RING + HP_CH / 2 * (c - 1) + t) * TILE] = dvs[t];
             }
 #pragma unroll
-            for (int q = 0; q < 8; q++) hw[8 * (c - 1) + q] = make_float4(ys[4 * q], ys[4 * q + 1], ys[4 * q + 2], ys[4 * q + 3]);
+            for (int q = 0; q < HP_CH / 4; q++) hw[HP_CH / 4 * (c - 1) + q] = make_float4(ys[4 * q], ys[4 * q + 1], ys[4 * q + 2], ys[4 * q + 3]);
         }
-        if (c == FRAME / 32) break;
-        if (c + 1 < FRAME / 32) nxt.load(in + (long long)(c + 1) * 32 * sstride, sstride);
+        if (c == FRAME / HP_CH) break;
+        if (c + 1 < FRAME / HP_CH) nxt.load(in + (long long)(c + 1) * HP_CH * sstride, sstride);
 #pragma unroll
-        for (int j = 0; j < 32; j++) {
+        for (int j = 0; j < HP_CH; j++) {
             double x64 = (double)xs[j];
             double y64 = x64 + (double)m0;
             m0 = (float)((double)m1 + (b0 * x64 - a0 * y64));
@@ -182,11 +188,11 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp,
             ys[j] = (float)y64;
         }
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
+        for (int t = 0; t < HP_CH / 2; t++) {
             const float a = t == 0 ? prev : ys[2 * t - 1], m = ys[2 * t], n = ys[2 * t + 1];
             dvs[t] = ((a + n) / 2.0f + m) / 2.0f;
         }
-        prev = ys[31];
+        prev = ys[HP_CH - 1];
     }
     st.m0 = m0; st.m1 = m1; st.prev = prev;
     NNN_STAMP(b, 25);
@@ -204,7 +210,7 @@ __device__ __forceinline__ void hp_group(const Buffers &b, const StepParams *sp,
     hl[0] = st.prev;
 }
 
-__global__ void __launch_bounds__(64) k_hp(Buffers b, const StepParams *sp, int g)
+__global__ void __launch_bounds__(64, HP_CH <= 16 ? 3 : 1) k_hp(Buffers b, const StepParams *sp, int g)
 {
     const int lane = threadIdx.x, tile = blockIdx.x, fmt = sp->fmt;
     const bool vec = sp->channels == 1 && ((((size_t)sp->in) | (size_t)sp->group_stride | (size_t)sp->frame_stride) & 15) == 0;
@@ -287,6 +293,20 @@ struct BestPitch {
         best_den = top ? y_sq_norm : best_den;
         best = top ? i : best;
     }
+    // the same with corr * corr handed in, NaN standing for "corr > 0 failed" (every comparison with it fails): the coarse search
+    // squares its 147 correlations on the lanes that made them
+    __device__ __forceinline__ void update_sq(int i, float num, float y_sq_norm) {
+        const bool in = num * second_den > second_num * y_sq_norm;
+        if (!wave_any(in)) return;   // none of the wave's streams takes this lag: nothing changes
+        const bool top = in && num * best_den > best_num * y_sq_norm;
+        const bool mid = in && !top;
+        second_num = top ? best_num : (mid ? num : second_num);
+        second_den = top ? best_den : (mid ? y_sq_norm : second_den);
+        second = top ? best : (mid ? i : second);
+        best_num = top ? num : best_num;
+        best_den = top ? y_sq_norm : best_den;
+        best = top ? i : best;
+    }
 };
 
 struct Xc2 {   // xcorr[] of the fine search: zero except within 2 of 2*best / 2*second (ref: src/pitch.rs:88-96)
@@ -309,18 +329,18 @@ struct Xc2 {   // xcorr[] of the fine search: zero except within 2 of 2*best / 2
 __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1.0f + xx * yy); }
 
 // The two long energy scans run once per frame, serially, and are looked up at a few data-dependent lags later in the frame.
-// They leave check points in LDS (every 16th fine lag, every 4th step of yy); a lookup replays the few steps from the check
+// They leave check points in LDS (every 8th fine lag, every 5th step of yy); a lookup replays the few steps from the check
 // point below it -- the same additions in the same order.  (Whole tables would be 43 KB per block; through global scratch the
 // scans were bound by the depth of a wave's store queue.)
-constexpr int PK_CKF = 16, PK_NCKF = (NLAG2 + PK_CKF - 1) / PK_CKF;   // 19
-constexpr int PK_CKY = 4, PK_NCKY = 384 / PK_CKY + 1;                  // 97
+constexpr int PK_CKF = 8, PK_NCKF = (NLAG2 + PK_CKF - 1) / PK_CKF;    // 37
+constexpr int PK_CKY = 5, PK_NCKY = 384 / PK_CKY + 1;                  // 77
 struct PkLds {
     float pb[PK_ODD + PK_HALF];                  // the decimated window, then (in place) pitch_buf
-    float ckf[PK_NCKF][PK_SPB];                  // running energy of the fine lags before lag 16 m (find_best_pitch, ref: src/pitch.rs:380-402)
-    float cky[PK_NCKY][PK_SPB];                  // running energy yy of remove_doubling after step 4 m (ref: src/pitch.rs:133-142); [0] = xx
+    float ckf[PK_NCKF][PK_SPB];                  // running energy of the fine lags before lag 8 m (find_best_pitch, ref: src/pitch.rs:380-402)
+    float cky[PK_NCKY][PK_SPB];                  // running energy yy of remove_doubling after step 5 m (ref: src/pitch.rs:133-142); [0] = xx
     union {
         struct { float acs[5][PK_SPB], coef[5][PK_SPB]; } a;         // LPC analysis: autocorrelation, FIR taps
-        struct { float xc[NLAG1][PK_SPB], ysq[NLAG1][PK_SPB]; } c;   // coarse search: cross-correlation, running energy per lag
+        struct { float xc[NLAG1][PK_SPB], ysq[NLAG1][PK_SPB]; } c;   // coarse search: squared positive cross-correlation (else NaN), running energy per lag
         struct {                                                       // from the fine search on
             float part[PK_NC][4][PK_SPB];        // inner-product partials [slot][q][stream] (ref: src/pitch.rs:225-244)
             float yy[32][PK_SPB];                // yy_lookup at the candidate periods
@@ -619,8 +639,8 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 for (int n = 0; n < PK_NP; n++) { acc[2 * n] = acc2[n].x; acc[2 * n + 1] = acc2[n].y; }
                 acc[PK_LC - 1] = acc1;
 #pragma unroll
-                for (int i = 0; i < PK_LC; i++)
-                    if (L0 + i < NLAG1) L.u.c.xc[L0 + i][s] = acc[i];
+                for (int i = 0; i < PK_LC; i++)   // (what find_best_pitch needs of a correlation: its square if it is positive)
+                    if (L0 + i < NLAG1) L.u.c.xc[L0 + i][s] = acc[i] > 0.0f ? acc[i] * acc[i] : __builtin_nanf("");
                 if (b.taps) {
                     float *o = NNN_TIF(b, xc1, NLAG1, f, tile, sl);
 #pragma unroll
@@ -671,7 +691,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
 #pragma unroll
                 for (int i = 0; i < 7; i++) { cn[i] = L.u.c.xc[i1 + i][s]; en[i] = L.u.c.ysq[i1 + i][s]; }
 #pragma unroll
-                for (int i = 0; i < 7; i++) bp.update(i0 + i, c[i], e[i]);
+                for (int i = 0; i < 7; i++) bp.update_sq(i0 + i, c[i], e[i]);
 #pragma unroll
                 for (int i = 0; i < 7; i++) { c[i] = cn[i]; e[i] = en[i]; }
             }
@@ -695,17 +715,17 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 for (int i = 0; i < 4; i++) { ysq += ve[i] * ve[i]; ysq += vo[i] * vo[i]; }
             }
 #pragma nounroll
-            for (int m = 0; m < PK_NCKF; m++) {   // lags 16 m .. 16 m + 15 (the last few past the table: computed, never looked up)
+            for (int m = 0; m < PK_NCKF; m++) {   // lags 8 m .. 8 m + 7 (the last few past the table: computed, never looked up)
                 L.ckf[m][s] = ysq;
                 const int n0 = m * (PK_CKF / 2);
-                float ae[8], ao[8], de[8], dd[8];   // lags 2n, 2n + 1: rows (2n, 2n + 1) leave, rows (2n + 480, 2n + 481) enter
+                float ae[4], ao[4], de[4], dd[4];   // lags 2n, 2n + 1: rows (2n, 2n + 1) leave, rows (2n + 480, 2n + 481) enter
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
+                for (int i = 0; i < 4; i++) {
                     ae[i] = pE[(n0 + i + 240) * PK_SPB]; ao[i] = pO[(n0 + i + 240) * PK_SPB];
                     de[i] = pE[(n0 + i) * PK_SPB]; dd[i] = pO[(n0 + i) * PK_SPB];
                 }
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
+                for (int i = 0; i < 4; i++) {
                     ysq += ae[i] * ae[i] - de[i] * de[i];
                     ysq = fmaxf(ysq, 1.0f);
                     ysq += ao[i] * ao[i] - dd[i] * dd[i];
@@ -729,19 +749,21 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             float yy = s0 + s1 + s2 + s3;
             L.cky[0][s] = yy;   // xx = yy_lookup[0]
 #pragma nounroll
-            for (int n0 = 0; n0 < 192; n0 += 4) {   // steps i = 2n + 1, 2n + 2: rows 383 - 2n, 382 - 2n enter, rows 863 - 2n, 862 - 2n leave
-                float ae[4], ao[4], ce[4], co[4];
+            for (int bk = 0; bk < 38; bk++) {   // steps 10 bk + 1 .. 10 bk + 10 (380 steps: the last four are only ever replayed)
+                const int n0 = 5 * bk;          // steps 2n + 1, 2n + 2: rows 383 - 2n, 382 - 2n enter, rows 863 - 2n, 862 - 2n leave
+                float ae[5], ao[5], ce[5], co[5];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < 5; i++) {
                     ae[i] = pE[(191 - (n0 + i)) * PK_SPB]; ao[i] = pO[(191 - (n0 + i)) * PK_SPB];
                     ce[i] = pE[(431 - (n0 + i)) * PK_SPB]; co[i] = pO[(431 - (n0 + i)) * PK_SPB];
                 }
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < 5; i++) {
                     yy += ao[i] * ao[i] - co[i] * co[i];
+                    if (i == 2) L.cky[2 * bk + 1][s] = yy;   // after step 10 bk + 5
                     yy += ae[i] * ae[i] - ce[i] * ce[i];
-                    if (i & 1) L.cky[(n0 + i + 1) / 2][s] = yy;   // after step 2 (n0 + i) + 2, a multiple of 4
                 }
+                L.cky[2 * bk + 2][s] = yy;                   // after step 10 bk + 10
             }
         }
         __syncthreads();   // the coarse arrays are dead: their space takes the partial sums from here on
@@ -769,18 +791,23 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         //      best pitch; replayed in increasing lag order with the energy each of them saw.  Then the candidate periods.
         if (wave == 0) {
             if (q < 2) {
-                // the energy lags lo .. lo + 4 of window q saw: from the check point below the first of them, the scan's own steps
-                const int lo = L.u.f.lo[q][s], first = lo > 0 ? lo : 0, last = lo + 4 < NLAG2 - 1 ? lo + 4 : NLAG2 - 1;
-                const int m = (first < NLAG2 ? first : NLAG2 - 1) / PK_CKF;
-                float y = L.ckf[m][s], ev[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma nounroll
-                for (int st = 0; st < PK_CKF + 4; st++) {
-                    const int i = PK_CKF * m + st;
-                    if (i > last) break;
+                // the energy lags lo .. lo + 4 of window q saw: from the check point below the first of them, the scan's own
+                // steps (at most 7 + 5; every row is requested before the first step is taken)
+                const int lo = L.u.f.lo[q][s], first = lo > 0 ? lo : 0;
+                const int i0 = (first < NLAG2 ? first : NLAG2 - 1) & ~(PK_CKF - 1);
+                float y = L.ckf[i0 / PK_CKF][s], ev[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                float ra[PK_CKF + 4], rd[PK_CKF + 4];
 #pragma unroll
-                    for (int c = 0; c < 5; c++) ev[c] = (i == lo + c) ? y : ev[c];
-                    const float a = L.pb[pk_at(i + 480, s)], d = L.pb[pk_at(i, s)];
-                    y += a * a - d * d;
+                for (int st = 0; st < PK_CKF + 4; st++) {
+                    const int i = i0 + st < NLAG2 ? i0 + st : NLAG2 - 1;
+                    ra[st] = L.pb[pk_at(i + 480, s)];
+                    rd[st] = L.pb[pk_at(i, s)];
+                }
+#pragma unroll
+                for (int st = 0; st < PK_CKF + 4; st++) {
+#pragma unroll
+                    for (int c = 0; c < 5; c++) ev[c] = (i0 + st == lo + c) ? y : ev[c];
+                    y += ra[st] * ra[st] - rd[st] * rd[st];
                     y = fmaxf(y, 1.0f);
                 }
 #pragma unroll
@@ -859,8 +886,9 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         }
         if (wave == 0) {
             // yy_lookup at the candidate periods (ref: src/pitch.rs:138-142): lane (s, q) takes candidates q, q + 4, ..; from the
-            // check point below T, at most three of the scan's steps
+            // check point below T, at most four of the scan's steps
             wave_lds_sync();
+            float yv[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int e = q + 4 * i, T = L.u.f.cand[e][s], m = T / PK_CKY;
@@ -872,8 +900,10 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                     const float yn = y + (a * a - c * c);
                     y = j <= T ? yn : y;
                 }
-                L.u.f.yy[e][s] = fmaxf(y, 0.0f);
+                yv[i] = fmaxf(y, 0.0f);
             }
+#pragma unroll
+            for (int i = 0; i < 8; i++) L.u.f.yy[q + 4 * i][s] = yv[i];   // (after the last read: the reads travel together)
         }
         __syncthreads();
         NNN_STAMP(b, 53);
@@ -1392,7 +1422,10 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     }
 }
 
-__global__ void __launch_bounds__(64 * FFT_SPB) k_fft_xp(Buffers b, const StepParams *sp)
+#ifndef NNN_FFT_MINWAVES
+#define NNN_FFT_MINWAVES 4
+#endif
+__global__ void __launch_bounds__(64 * FFT_SPB, NNN_FFT_MINWAVES) k_fft_xp(Buffers b, const StepParams *sp)
 {
     __shared__ FftLds t;
     __shared__ float2 Z[FFT_SPB][NFFT_BUF];
@@ -2486,7 +2519,10 @@ __device__ __forceinline__ float interp_gain(const float *g, int k, const float 
 //     ref: src/features.rs:223-275, src/denoise.rs:103-114.  One wave per stream; the launch loops over the `g` frames of
 //     its group with the overlap memory in registers (read and written once per group, not per frame).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64 * FFT_SPB, 4) k_synth(Buffers b, const StepParams *sp0, int g)
+#ifndef NNN_SYN_MINWAVES
+#define NNN_SYN_MINWAVES 4
+#endif
+__global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffers b, const StepParams *sp0, int g)
 {
     __shared__ FftLds t;
     __shared__ float2 A_[FFT_SPB][NFFT_BUF];   // also the per-bin energies of the band renormalisation (before A is filled)

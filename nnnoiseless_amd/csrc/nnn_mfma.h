@@ -120,6 +120,8 @@ __device__ __forceinline__ int flag_read(const int *flag)
 {
     return __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
 }
+// true when the predicate holds on any active lane of the wave (wave-uniform)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 __device__ __forceinline__ void chain_pause() { __builtin_amdgcn_s_sleep(4); }
 
 }  // namespace nnn

@@ -76,6 +76,7 @@ static inline float sadd(float a, float b) { return a + b; }
 // (the interpreter runs the workgroups of a launch one after the other in index order: a flag is always set when it is read)
 static inline void flag_publish(int *flag, int value) { *flag = value; }
 static inline int flag_read(const int *flag) { return *flag; }
+static inline bool wave_any(bool) { return true; }   // (a skipped no-op update and an executed one leave the same state)
 static inline void chain_pause() {}
 static inline void __threadfence() {}
 
