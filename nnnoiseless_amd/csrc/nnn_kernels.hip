@@ -267,7 +267,10 @@ constexpr int PK_JB = 8;                         // taps per unrolled step of th
 constexpr int PK_NP = PK_LC / 2;                 // packed accumulators per lane (+ one single: PK_LC is odd)
 constexpr int PK_NT = PK_JB / 2 + PK_NP;         // window pairs per alignment
 static_assert((PK_NG - 1) * PK_LC + 239 + PK_JB + PK_LC < XLP / 2, "the window stays inside the even rows");
-constexpr int PK_NC = 36;                        // inner-product slots: 10 fine lags | 32 candidates of remove_doubling (+ 3 refinement)
+constexpr int PK_KMAX = 12;                      // largest divisor of remove_doubling that can pass its `t1 >= min_period` test
+constexpr int PK_NE = 1 + 2 * (PK_KMAX - 1);     // candidate periods of the decision loop: t0, then two per divisor k = 2 .. 12
+constexpr int PK_NSLOT = PK_NE + 2;              // + the two neighbours of t0
+constexpr int PK_NC = 36;                        // inner-product slots: 10 fine lags | 25 candidates of remove_doubling, 32 .. 34 the refinement
 
 constexpr int PK_HALF = (XLP / 2) * PK_SPB;      // floats of the even rows
 constexpr int PK_ODD = PK_HALF + 16;             // first odd row
@@ -382,7 +385,7 @@ __device__ __forceinline__ void pk_window_load(const Buffers &b, const StepParam
 template <int NCAND>
 __device__ __forceinline__ void pk_inner(const float *pb, int s, int q, const int (&yr)[NCAND], float (&acc)[NCAND])
 {
-    constexpr int U = NCAND >= 4 ? 2 : (NCAND == 2 ? 3 : 4);   // tap pairs per unrolled step
+    constexpr int U = NCAND >= 4 ? 2 : (NCAND >= 2 ? 3 : 4);   // tap pairs per unrolled step
     static_assert(120 % (2 * U) == 0, "");
     const float *xp = pb + pk_at(PITCH_MAX / 2 + q, s);
     const float *yp[NCAND];
@@ -860,16 +863,17 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             }
             const int psr = 2 * bp.best - offset;
             if (b.taps) NNN_TIF(b, psearch, 1, f, tile, sl)[0] = psr;
-            // ---- remove_doubling: 29 candidates of the decision loop + the two neighbours of t0 (slots 29, 30): if the
-            //      loop keeps t0 the final +-1 refinement needs no inner products of its own
+            // ---- remove_doubling: the candidates of the decision loop + the two neighbours of t0 (slots 23, 24): if the loop keeps
+            //      t0 the final +-1 refinement needs no inner products of its own.  Divisors k >= 13 never get past the loop's
+            //      `t1 < min_period` break (t0 <= 383: (2 t0 + 13) / 26 <= 29), so slots exist for k = 2 .. PK_KMAX = 12 only.
             NNN_STAMP(b, 60);
             t0 = (PITCH_MAX - psr) / 2;
             if (t0 > max_period - 1) t0 = max_period - 1;
             #pragma unroll
-            for (int e = 0; e < 32; e++) {   // (unrolled: k is a constant in every copy)
+            for (int e = 0; e < PK_NSLOT; e++) {   // (unrolled: k is a constant in every copy)
                 int t;
-                if (e == 0 || e == 31) t = t0;
-                else if (e >= 29) t = e == 29 ? t0 - 1 : t0 + 1;
+                if (e == 0) t = t0;
+                else if (e >= PK_NE) t = e == PK_NE ? t0 - 1 : t0 + 1;
                 else {
                     const int k = 2 + (e - 1) / 2;
                     const int t1 = (2 * t0 + k) / (2 * k);
@@ -888,9 +892,10 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             // yy_lookup at the candidate periods (ref: src/pitch.rs:138-142): lane (s, q) takes candidates q, q + 4, ..; from the
             // check point below T, at most four of the scan's steps
             wave_lds_sync();
-            float yv[8];
+            constexpr int NI = (PK_NE + 3) / 4;
+            float yv[NI];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < NI; i++) {
                 const int e = q + 4 * i, T = L.u.f.cand[e][s], m = T / PK_CKY;
                 float y = L.cky[m][s];
 #pragma unroll
@@ -903,19 +908,28 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 yv[i] = fmaxf(y, 0.0f);
             }
 #pragma unroll
-            for (int i = 0; i < 8; i++) L.u.f.yy[q + 4 * i][s] = yv[i];   // (after the last read: the reads travel together)
+            for (int i = 0; i < NI; i++) L.u.f.yy[q + 4 * i][s] = yv[i];   // (after the last read: the reads travel together)
         }
         __syncthreads();
         NNN_STAMP(b, 53);
-        // ---- the candidates' inner products against p[384 ..]: wave w takes slots w, w + 8, w + 16, w + 24
-        {
+        // ---- the candidates' inner products against p[384 ..]: wave w takes slots w, w + 8, w + 16 (wave 0 also slot 24)
+        static_assert(PK_NSLOT == 25, "three slots per wave and one more");
+        if (wave == 0) {
             int yr[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) yr[c] = max_period - L.u.f.cand[wave + 8 * c][s];
+            for (int c = 0; c < 4; c++) yr[c] = max_period - L.u.f.cand[8 * c][s];
             float acc[4];
             pk_inner<4>(L.pb, s, qi, yr, acc);
 #pragma unroll
-            for (int c = 0; c < 4; c++) L.u.f.part[wave + 8 * c][qi][s] = acc[c];
+            for (int c = 0; c < 4; c++) L.u.f.part[8 * c][qi][s] = acc[c];
+        } else {
+            int yr[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) yr[c] = max_period - L.u.f.cand[wave + 8 * c][s];
+            float acc[3];
+            pk_inner<3>(L.pb, s, qi, yr, acc);
+#pragma unroll
+            for (int c = 0; c < 3; c++) L.u.f.part[wave + 8 * c][qi][s] = acc[c];
         }
         if (dec_lane) {
             if (chain && f > 0) {
@@ -931,12 +945,12 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         __syncthreads();
         NNN_STAMP(b, 54);
         // ---- decision loop (ref: src/pitch.rs:150-206).  Whether divisor k replaces the best candidate depends on t0, the previous
-        //      frame and k's own inner products, not on the other divisors: lane (stream, k) judges k = 2 .. 15 on four waves, the
+        //      frame and k's own inner products, not on the other divisors: lane (stream, k) judges k = 2 .. 12 on three waves, the
         //      stream's lane then takes the last k that passed (the loop's break at the first t1 < min_period cuts a suffix: t1
         //      falls with k).
-        if (wave < 4) {
+        if (wave < 3) {
             const int k = 2 + 4 * wave + q;
-            if (k <= 15) {
+            if (k <= PK_KMAX) {
                 auto ipv = [&](int e) { return L.u.f.part[e][0][s] + L.u.f.part[e][1][s] + L.u.f.part[e][2][s] + L.u.f.part[e][3][s]; };
                 const int e1 = 1 + 2 * (k - 2), e2 = e1 + 1;
                 const int t1 = L.u.f.cand[e1][s], t0s = L.u.f.t0[s];
@@ -972,7 +986,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             gg = pitch_gain(best_xy, xx, best_yy);
             int kw = 0;
 #pragma unroll
-            for (int k = 2; k <= 15; k++) kw = L.u.f.kpass[k][s] ? k : kw;
+            for (int k = 2; k <= PK_KMAX; k++) kw = L.u.f.kpass[k][s] ? k : kw;
             if (kw) {
                 best_xy = L.u.f.kxy[kw][s];
                 best_yy = L.u.f.kyy[kw][s];
@@ -1001,7 +1015,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         if (dec_lane) {
             auto ipv = [&](int e) { return L.u.f.part[e][0][s] + L.u.f.part[e][1][s] + L.u.f.part[e][2][s] + L.u.f.part[e][3][s]; };
             float x3[3];
-            if (t == t0) { x3[0] = ipv(29); x3[1] = ipv(0); x3[2] = ipv(30); }
+            if (t == t0) { x3[0] = ipv(PK_NE); x3[1] = ipv(0); x3[2] = ipv(PK_NE + 1); }
             else { x3[0] = ipv(32); x3[1] = ipv(33); x3[2] = ipv(34); }
             int offset = 0;
             if (x3[2] - x3[0] > 0.7f * (x3[1] - x3[0])) offset = 1;
