@@ -705,6 +705,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             }
             lo1 = 2 * bp.best - 2;
             lo2 = 2 * bp.second - 2;
+            NNN_STAMP(b, 61);
         } else if (wave == 5 && lane < PK_SPB) {
             // the running energy every fine lag sees (ref: src/pitch.rs:97 -> :380-402): <= 10 lags can update the best pitch there,
             // and they are replayed below with the energy each of them saw
