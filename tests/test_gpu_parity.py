@@ -659,3 +659,29 @@ def test_long_calls_stay_inside_their_buffers():
     assert bool((xbuf[n:] == 12345.0).all()) and bool((ybuf[n:] == -777.0).all()) and bool((vbuf[T * S:] == -777.0).all())
     assert bool(torch.isfinite(ybuf[:n]).all()) and bool((vbuf[:T * S] >= 0).all())
     bd.close()
+
+
+@pytest.mark.gpu
+def test_pitch_frames_chained_and_looped_agree(nn, oracle_mod, weights_bytes, monkeypatch):
+    """k_pitch runs the frames of a group either side by side (one workgroup per frame and quarter tile, the previous frame's
+    pitch and gain handed over through a flag in device memory) or in a loop inside one workgroup (what large batches use):
+    the same bits either way, over several groups, every schedule of the host side; pitch equal to the oracle's."""
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T = 454, 43
+    x = make_streams(321, S, T)
+    res = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("NNN_PITCH_CHAIN", mode)
+        for pipe in (False, True):
+            bd = nn.BatchDenoiser(S)
+            bd.set_pipeline(pipe)
+            out, vad = bd.process(x)
+            res[mode, pipe] = (out, vad, bd.tap("pitch").copy(), bd.tap("pitch_gain").copy(), bd.tap("g").copy())
+            bd.close()
+    first = res["0", False]
+    for key, r in res.items():
+        for a, b in zip(first, r):
+            assert np.array_equal(a, b), key
+    n = 96
+    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x[:n], want=("pitch",))
+    assert np.array_equal(first[2][:n, 0], ref["pitch"][:, -1])

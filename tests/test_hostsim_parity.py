@@ -260,3 +260,23 @@ def test_quarter_tile_block_remap(hostsim_lib, oracle_mod, weights_bytes):
     o = out.reshape(32, 16, 2, 480)
     assert all(np.array_equal(o[0], o[i]) for i in range(1, 32))
     assert rel_rms(o[0][:, 1:], ref["out"][:, 1:]) < 1e-5
+
+
+def test_pitch_frames_chained_and_looped_agree(hostsim_lib, oracle_mod, weights_bytes, monkeypatch):
+    """k_pitch runs the frames of a group either side by side (one workgroup per frame and quarter tile, the previous frame's
+    pitch handed over through a flag) or in a loop inside one workgroup: the same bits either way, pitch equal to the oracle's."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T = 20, 11
+    x = make_streams(123, S, T)
+    res = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("NNN_PITCH_CHAIN", mode)
+        bd = nn.BatchDenoiser(S, lib=hostsim_lib)
+        out, vad = bd.process(x)
+        res[mode] = (out, vad, bd.tap("pitch").copy(), bd.tap("pitch_gain").copy())
+        bd.close()
+    for a, b in zip(res["0"], res["2"]):
+        assert np.array_equal(a, b)
+    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x)
+    assert np.array_equal(res["2"][2][:, 0], ref["pitch"][:, -1])
