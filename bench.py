@@ -48,8 +48,8 @@ BYTES_PER_FRAME_FUSED = 16948  # I/O + resident-state to
 FLOPS_PER_FRAME = 0.42e6
 
 # Algorithmic HBM bytes per stream-frame of each kernel (its own inputs + outputs, each counted once; per-group state traffic
-# divided by the 8 frames of a full group; derivation in DESIGN.md "Kernels")
-G = 8
+# divided by the 16 frames of a full group; derivation in DESIGN.md "Kernels")
+G = 16
 KERNEL_BYTES = {
     "k_hp": 1920 + 1920 + 960 + 960 // 5 + 4 + (16 + 8) // G,     # input, history slot, 240 decimated values (+ mirrored share), x_lp[0]; biquad state per group
     "k_pitch": 3456 + 4 + 8 + 16 // G,                              # decimated window + x_lp[0] in; pitch index + gain out; last pitch per group

@@ -23,10 +23,10 @@ constexpr int NFEAT = 42;         // src/lib.rs:53
 constexpr int CEPS_MEM = 8;       // src/lib.rs:50
 constexpr int HIST = 1728;        // PITCH_BUF_SIZE, src/lib.rs:46
 #ifndef NNN_GROUP
-#define NNN_GROUP 8
+#define NNN_GROUP 16
 #endif
 #ifndef NNN_DEPTH
-#define NNN_DEPTH 3
+#define NNN_DEPTH 2
 #endif
 constexpr int GROUP = NNN_GROUP;  // frames per launch: every kernel is launched once per group of up to GROUP consecutive frames (kernels
                                   // with a frame-to-frame recurrence loop over the group's frames inside the launch)

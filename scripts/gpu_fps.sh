@@ -1,8 +1,7 @@
 #!/bin/bash
-# frames-per-call sweep of the pipelined path
+# Frames-per-call sweep at the headline batch: how much of a call is pipeline fill and drain
 set -u
 mkdir -p gpurun_out
-for S in ${STREAMS:-4096}; do for F in ${FPS_LIST:-8 12 16 24 36 48 96}; do
-  timeout 300 python bench.py --streams $S --frames-per-step $F --steps $((1440 / F)) --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/fps_${S}_$F.json 2>gpurun_out/fps_${S}_$F.err
-  python -c "import json; d=json.load(open('gpurun_out/fps_${S}_$F.json')); print('S=$S frames/step=$F value=%.3e ms/step=%.3f' % (d['value'], d['ms_per_step']))"
-done; done
+for F in ${FPSS:-48 96 192 384}; do
+  timeout 300 python bench.py --frames-per-step $F --steps $((1920 / F)) --warmup 3 --no-cpu-baseline --no-roofline --no-also --no-tick ${BENCH_ARGS:-} 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('frames/step=$F: %.2f M  (%.3f ms per step)' % (d['value']/1e6, d['ms_per_step']))"
+done
