@@ -101,7 +101,7 @@ struct nnn_batch {
                                     // (measured at 4096 streams x 48 frames: 1: 28.5, 2: 37.1, 3: 32.9, 4: 32.2 M frames/s -- the default 4 hardware
                                     // queues are shared with the host's own streams)
     int pitch_chain = 1;            // k_pitch: one workgroup per (frame, quarter tile) instead of a frame loop: 1 = below 16384 streams, 0 = never, 2 = always (env NNN_PITCH_CHAIN)
-    bool ramp = false;              // pipelined calls start and end with smaller groups (env NNN_RAMP=1; round 2a's default: with the
+    int ramp = 0;                   // pipelined calls start and end with smaller groups (env NNN_RAMP=1; round 2a's default: with the
                                     // frames of a group side by side in k_pitch and 16-frame groups, full groups throughout measured 6 % faster)
     bool use_pipeline = true;
     bool profiling = false;
@@ -262,7 +262,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     for (int s = 0; s < ST_COUNT; s++)
         for (int i = 0; i < EVR; i++) HIPCHK(hipEventCreateWithFlags(&h->ev[s][i], hipEventDisableTiming));
     if (const char *e = getenv("NNN_PIPELINE")) h->use_pipeline = atoi(e) != 0;
-    if (const char *e = getenv("NNN_RAMP")) h->ramp = atoi(e) != 0;
+    if (const char *e = getenv("NNN_RAMP")) h->ramp = atoi(e);
     if (const char *e = getenv("NNN_PITCH_CHAIN")) h->pitch_chain = atoi(e);
     if (const char *e = getenv("NNN_SCHED")) {
         if (!strcmp(e, "seq")) h->sched = SCHED_SEQ;
@@ -662,10 +662,12 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     std::vector<int> sizes;
     for (int rem = n_frames, k = 0; rem > 0; k++) {
         int g = GROUP;
-        if (pipe && h->ramp) {
+        if (pipe && h->ramp == 1) {
             g = GROUP < k + 1 ? GROUP : k + 1;
             const int half = (rem + 1) / 2 > 1 ? (rem + 1) / 2 : 1;
             if (g > half) g = half;
+        } else if (pipe && h->ramp >= 2 && k == 0) {
+            g = GROUP / h->ramp;   // a short first group: the stages behind the high-pass start sooner
         }
         if (g > rem) g = rem;
         sizes.push_back(g);
