@@ -111,9 +111,10 @@ int nnn_batch_process_pcm_host(nnn_batch *b, const void *in, void *out, float *v
 int nnn_batch_synchronize(nnn_batch *b);
 
 /* Parity taps: intermediate quantities of the most recent frame, copied to the host as
- * [n_streams][len] (float32 or int32, see nnn_tap_info).  Test/diagnostic interface.  Four of them (XCORR1, XCORR2C, P
- * beyond bin 399, FEATURES) are quantities the kernels keep on chip: they are stored to device memory only after
- * nnn_batch_set_taps(batch, 1), and reading them without it is an error. */
+ * [n_streams][len] (float32 or int32, see nnn_tap_info).  Test/diagnostic interface.  Everything inside the pitch analysis
+ * (XLP, AC, LPC2, XCORR1, BEST1, XCORR2C, PITCH_SEARCH), P beyond bin 399 and FEATURES are quantities the kernels keep on
+ * chip: they are stored to device memory only after nnn_batch_set_taps(batch, 1) (which also allocates their arrays), and
+ * reading them without it is an error. */
 enum nnn_tap {
     NNN_TAP_FILTERED = 0, /* [480] f32  high-passed input (features.rs:97-104)           */
     NNN_TAP_XLP,          /* [864] f32  pitch_buf after pitch_downsample (pitch.rs:448)   */

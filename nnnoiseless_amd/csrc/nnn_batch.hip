@@ -103,6 +103,7 @@ struct nnn_batch {
     int pitch_chain = 1;            // k_pitch: one workgroup per (frame, quarter tile) instead of a frame loop: 1 = below 16384 streams, 0 = never, 2 = always (env NNN_PITCH_CHAIN)
     int ramp = 0;                   // pipelined calls start and end with smaller groups (env NNN_RAMP=1; round 2a's default: with the
                                     // frames of a group side by side in k_pitch and 16-frame groups, full groups throughout measured 6 % faster)
+    bool taps_alloc = false;        // the tap-only scratch arrays exist
     bool use_pipeline = true;
     bool profiling = false;
     std::vector<hipEvent_t> evp;    // pairs per launch while profiling
@@ -387,8 +388,9 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     }
     {   // per-frame scratch (doubles as parity taps): every array holds NSET sets back to back
         Buffers &q = h->b[0];
+        // (the arrays only the parity taps fill, 4.1 KB per stream and set, wait for nnn_batch_set_taps(1))
 #define NNN_F(name, len) HIPCHK(dalloc(h, &q.name, Sp * (size_t)(len) * NSET, false));
-        NNN_SCRATCH_FIELDS(NNN_F)
+        NNN_WORK_FIELDS(NNN_F)
 #undef NNN_F
         for (int set = 1; set < NSET; set++) h->b[set] = frame_view(h->b[0], set);
         h->state_bufs.push_back({(void *)q.pflag, Sp * NSET * sizeof(int)});   // frame numbers restart with reset / load_state
@@ -537,8 +539,10 @@ extern "C" nnn_batch *nnn_batch_clone(nnn_batch *h)
     c->n_lanes = h->n_lanes;
     c->use_pipeline = h->use_pipeline;
     c->pitch_chain = h->pitch_chain;
-    c->b[0].taps = h->b[0].taps;
-    for (int set = 1; set < NSET; set++) c->b[set].taps = h->b[0].taps;
+    if (h->b[0].taps && nnn_batch_set_taps(c, 1) != 0) {
+        nnn_batch_destroy(c);
+        return nullptr;
+    }
     return c;
 }
 
@@ -866,13 +870,13 @@ static bool tap_desc(const nnn_batch *h, int tap, TapDesc &d, const void **ptr)
 #define TP(field) (b ? (const void *)b->field : nullptr)
     switch (tap) {
     case NNN_TAP_FILTERED: d = {FRAME, 0, 3, 0, FRAME, 0}; *ptr = TP(hist); return true;
-    case NNN_TAP_XLP: d = {XLP, 0, 0, 0, XLP, 0}; *ptr = TP(xlp_ti); return true;
-    case NNN_TAP_AC: d = {5, 0, 0, 0, 10, 0}; *ptr = TP(lpc); return true;
-    case NNN_TAP_LPC2: d = {5, 0, 0, 5, 10, 0}; *ptr = TP(lpc); return true;
+    case NNN_TAP_XLP: d = {XLP, 0, 0, 0, XLP, 1}; *ptr = TP(xlp_ti); return true;
+    case NNN_TAP_AC: d = {5, 0, 0, 0, 10, 1}; *ptr = TP(lpc); return true;
+    case NNN_TAP_LPC2: d = {5, 0, 0, 5, 10, 1}; *ptr = TP(lpc); return true;
     case NNN_TAP_XCORR1: d = {NLAG1, 0, 0, 0, NLAG1, 1}; *ptr = TP(xc1); return true;
-    case NNN_TAP_BEST1: d = {2, 1, 0, 0, 2, 0}; *ptr = TP(best1); return true;
+    case NNN_TAP_BEST1: d = {2, 1, 0, 0, 2, 1}; *ptr = TP(best1); return true;
     case NNN_TAP_XCORR2C: d = {10, 0, 0, 0, 10, 1}; *ptr = TP(xc2); return true;
-    case NNN_TAP_PITCH_SEARCH: d = {1, 1, 0, 0, 1, 0}; *ptr = TP(psearch); return true;
+    case NNN_TAP_PITCH_SEARCH: d = {1, 1, 0, 0, 1, 1}; *ptr = TP(psearch); return true;
     case NNN_TAP_PITCH: d = {1, 1, 0, 0, 1, 0}; *ptr = TP(pitch); return true;
     case NNN_TAP_PITCH_GAIN: d = {1, 0, 0, 0, 1, 0}; *ptr = TP(pgain); return true;
     case NNN_TAP_X: d = {2 * FREQ, 0, 2, 0, 2 * FREQ, 0}; *ptr = TP(X); return true;
@@ -904,6 +908,17 @@ extern "C" int nnn_tap_info(int tap, int *len, int *is_int)
 extern "C" int nnn_batch_set_taps(nnn_batch *h, int on)
 {
     if (!h) return fail("null batch");
+    if (on && !h->taps_alloc) {   // first use: the tap-only arrays, NSET sets like every scratch array
+        NNN_RT_LOCK;
+        if (int rc = quiesce(h)) return rc;
+        const size_t Sp = (size_t)h->S_pad;
+        Buffers &q = h->b[0];
+#define NNN_F(name, len) HIPCHK(dalloc(h, &q.name, Sp * (size_t)(len) * NSET, false));
+        NNN_TAP_FIELDS(NNN_F)
+#undef NNN_F
+        for (int set = 1; set < NSET; set++) h->b[set] = frame_view(h->b[0], set);
+        h->taps_alloc = true;
+    }
     for (int set = 0; set < NSET; set++) h->b[set].taps = on != 0;
     return 0;
 }

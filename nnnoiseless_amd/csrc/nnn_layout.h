@@ -123,10 +123,13 @@ struct Buffers {
 
 // Per-frame scratch of set f lies f * S_pad * LEN elements after set 0 in every scratch array, so a launch that covers
 // several consecutive frames (block index = frame * blocks_per_frame + block) reaches its frame's set by offsetting.
-#define NNN_SCRATCH_FIELDS(F)                                                                                        \
-    F(lpc, 10) F(xlp_ti, XLP) F(xc1, NLAG1) F(best1, 2) F(xc2, 10) F(psearch, 1)  \
+// (the first six are written only while the parity taps are on -- everything they hold stays in LDS otherwise -- and are
+// allocated when the taps are first switched on)
+#define NNN_TAP_FIELDS(F) F(lpc, 10) F(xlp_ti, XLP) F(xc1, NLAG1) F(best1, 2) F(xc2, 10) F(psearch, 1)
+#define NNN_WORK_FIELDS(F)                                                                                           \
     F(pitch, 1) F(pflag, 1) F(pgain, 1) F(X, FSTR) F(P, FSTR) F(ex, NB) F(ep, NB) F(exp_, NB) F(cn, 28) F(feat, NFEAT)      \
     F(silence, 1) F(branch, 1) F(g_raw, NB) F(g, NB) F(vad, 1)
+#define NNN_SCRATCH_FIELDS(F) NNN_TAP_FIELDS(F) NNN_WORK_FIELDS(F)
 __host__ __device__ inline Buffers frame_view(Buffers b, int f)
 {
     const size_t sp = (size_t)b.S_pad * (size_t)f;

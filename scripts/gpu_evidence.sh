@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2b evidence session: full GPU parity suite, then scripts/gpu_final_profile.sh (driver-style default bench, rocprofv3 kernel
+# The evidence session of a round: full GPU parity suite, then scripts/gpu_final_profile.sh (driver-style default bench, rocprofv3 kernel
 # stats, PMC traffic at 4096 and 65536 streams, SQ counters at 65536, overlap trace, single-stream latency), k_pitch phase stamps.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
