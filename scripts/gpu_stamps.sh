@@ -5,7 +5,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 W=$R/nnnoiseless_amd/data/weights.rnn
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -DNNN_STAMPS -I nnnoiseless_amd/csrc -DNNN_WEIGHTS_PATH="\"$W\"" -x hip nnnoiseless_amd/csrc/nnn_batch.hip nnnoiseless_amd/csrc/nnn_model.cpp nnnoiseless_amd/csrc/rnnoise_capi.cpp -o /tmp/libnnn_stamps.so || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -DNNN_STAMPS -I nnnoiseless_amd/csrc -DNNN_WEIGHTS_PATH="\"$W\"" -x hip nnnoiseless_amd/csrc/nnn_batch.hip nnnoiseless_amd/csrc/nnn_resample.hip nnnoiseless_amd/csrc/nnn_model.cpp nnnoiseless_amd/csrc/rnnoise_capi.cpp -o /tmp/libnnn_stamps.so || exit 1
 python - <<'PY'
 import ctypes as C, numpy as np, sys, os
 sys.path.insert(0, '.')
@@ -31,6 +31,6 @@ for S, rows, T in ((4096, 0, 4), (4096, 32, 4), (65536, 0, 4)):
     for r, name in enumerate(("denoise unit", "noise unit", "vad + out + dense", "features")):
         o = 30 + 5 * r
         print("     ", name, d(o, o + 1), d(o + 1, o + 2), d(o + 2, o + 3), d(o + 3, o + 4), " tick", d(o, o + 4))
-    print("  k_hp total (last frame)", d(24, 25), " k_lpc: autocorr", d(0, 1), "lpc", d(1, 2), "fir", d(2, 3))
+    print("  k_hp total (last frame)", d(24, 25), " (k_pitch: scripts/gpu_stamps_pitch.sh)")
     bd.close()
 PY
