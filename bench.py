@@ -149,6 +149,9 @@ def parse_args(argv=None):
     ap.add_argument("--frames-per-step", type=int, default=48,
                     help="frames per stream per call (0.48 s of audio by default); the same JSON line also reports the one-frame-per-call rate (`tick`)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="do not tell the library that inputs are final at call time (nnn_batch_set_inputs_ready): every call then "
+                         "waits for the previous one to drain before it reads its input")
     ap.add_argument("--workload", choices=["denoise", "train"], default="denoise",
                     help="denoise = process_frame (the headline); train = 87-column training rows (SURVEY 8(f) #3)")
     ap.add_argument("--pcm", choices=["f32", "i16", "unit"], default="f32",
@@ -193,6 +196,10 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
     bd = nn.BatchDenoiser(S, model=model, device=0 if args.dry_run else local_rank)   # the interpreter build has one device
     if args.no_graph:
         bd.set_graph(False)
+    if not args.no_overlap:
+        # the input pool is resident and final before the timed region starts: consecutive calls may overlap at their boundary
+        # (the next call's high-pass chain starts while the previous call drains; outputs stay ordered on the stream)
+        bd.set_inputs_ready(True)
     stream = torch.cuda.current_stream().cuda_stream if dev.type == "cuda" else 0
 
     def run(f0, n):   # n frames of every stream starting at frame f0 of the pool: never past its end
@@ -414,6 +421,8 @@ def main():
                        "boundary_format": {"f32": "f32 planar (process_frame's own)", "i16": "packed int16",
                                            "unit": "unit-range f32"}[args.pcm] + (f", {args.channels} interleaved channels" if args.channels > 1 else ""),
                        "streams_per_gpu": S, "streams_total": S * world, "frames_per_step": fps,
+                       "inputs": "resident in HBM and final before the timed region" + ("" if args.no_overlap else "; declared to the library "
+                                 "(nnn_batch_set_inputs_ready): consecutive calls overlap at their boundary, outputs stay stream-ordered"),
                        "parallelism": f"streams sharded x{world}, one process per GPU, no data-path collective"},
             "ranks_seen": ranks_seen, "timed_s": res["timed_s"], "pool_frames": res["pool_frames"],
             "tick": res.get("tick"),

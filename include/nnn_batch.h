@@ -152,14 +152,21 @@ int nnn_batch_read_kernel_times(nnn_batch *b, double *total_ms, int64_t *launche
  * -DNNN_STAMPS). */
 int nnn_batch_read_stamps(nnn_batch *b, long long *dst64);
 
-/* Retained from the round-1 ABI, no effect: a frame group is seven kernel launches now and they are always eager. */
+/* Retained from the round-1 ABI, no effect: a frame group is five kernel launches now and they are always eager. */
 int nnn_batch_set_graph(nnn_batch *b, int on);
-/* 1 = calls of 8 frames or more spread their frame groups over the batch's internal HIP streams so that independent stages
+/* 1 = calls of 32 frames or more spread their frame groups over the batch's internal HIP streams so that independent stages
  * overlap (default), 0 = every call runs its groups back to back on the caller's stream.  Results are bit-identical. */
 int nnn_batch_set_pipeline(nnn_batch *b, int on);
+/* The caller's promise about INPUT buffers of the device-pointer entry points: 1 = a call's input is final when the call is
+ * made (uploaded and synchronised, or produced by work that has completed) -- not produced by work the caller enqueued on
+ * the call's stream after the previous call.  Consecutive pipelined calls on one stream may then overlap at the boundary:
+ * the next call's high-pass chain (the only stage that reads the input) starts while the previous call is still draining.
+ * Outputs stay ordered on the caller's stream exactly as without it; results are bit-identical.  0 (default): a call's
+ * input is read only after everything enqueued on its stream before the call. */
+int nnn_batch_set_inputs_ready(nnn_batch *b, int on);
 /* How a pipelined call uses the internal streams: mode 0 = not at all (as set_pipeline(0)); 1 = "lanes": the high-pass
- * chain on its own stream, the other six stages of group k on lane k mod `lanes` (1..4; default 2; lane 0 is the caller's stream);
- * 2 = "stages": one stream per stage pair, every stream a chain of groups.  Environment: NNN_SCHED=seq|lanes|stages,
+ * chain on its own stream, the other four stages of group k on lane k mod `lanes` (1..4; default 2; lane 0 is the caller's stream);
+ * 2 = "stages": one stream per stage, every stream a chain of groups.  Environment: NNN_SCHED=seq|lanes|stages,
  * NNN_LANES=n. */
 int nnn_batch_set_schedule(nnn_batch *b, int mode, int lanes);
 

@@ -198,6 +198,11 @@ class BatchDenoiser:
     def set_pipeline(self, on):
         self._lib.check(self._lib.L.nnn_batch_set_pipeline(self._h, int(on)))
 
+    def set_inputs_ready(self, on):
+        """Promise that the input of every process_device call is final when the call is made: consecutive calls may then
+        overlap at their boundary (include/nnn_batch.h).  Outputs stay ordered on the caller's stream; same bits."""
+        self._lib.check(self._lib.L.nnn_batch_set_inputs_ready(self._h, int(on)))
+
     def kernel_times(self):
         """{kernel: (total_ms, launches)} accumulated while profiling; resets the counters."""
         n = self._lib.L.nnn_batch_num_kernels()

@@ -16,7 +16,7 @@ BATCH_SYMBOLS = [
     "nnn_batch_create", "nnn_batch_create_grouped", "nnn_batch_destroy", "nnn_batch_num_streams", "nnn_batch_reset",
     "nnn_batch_process_device", "nnn_batch_process_host", "nnn_batch_process_pcm_device", "nnn_batch_process_pcm_host",
     "nnn_batch_synchronize", "nnn_batch_clone", "nnn_batch_state_bytes", "nnn_batch_save_state", "nnn_batch_load_state",
-    "nnn_batch_set_taps", "nnn_batch_set_schedule", "nnn_debug_activations",
+    "nnn_batch_set_taps", "nnn_batch_set_schedule", "nnn_batch_set_inputs_ready", "nnn_debug_activations",
     "nnn_tap_info", "nnn_batch_read_tap", "nnn_batch_set_profiling", "nnn_batch_num_kernels",
     "nnn_batch_kernel_name", "nnn_batch_read_kernel_times", "nnn_batch_set_graph", "nnn_batch_set_pipeline", "nnn_batch_read_stamps",
     "nnn_last_error",
@@ -93,6 +93,7 @@ class Library:
         L.nnn_batch_set_schedule.argtypes = [vp, i32, i32]
         L.nnn_debug_activations.argtypes = [i32, i32, vp, vp, i32]
         L.nnn_batch_set_pipeline.argtypes = [vp, i32]
+        L.nnn_batch_set_inputs_ready.argtypes = [vp, i32]
         L.nnn_train_create.restype = vp
         L.nnn_train_create.argtypes = [i32, i32]
         L.nnn_train_destroy.argtypes = [vp]

@@ -90,7 +90,17 @@ struct nnn_batch {
     hipStream_t stream = nullptr;   // default launch stream
     hipStream_t pool[NSTREAMS] = {};   // internal streams of pipelined calls
     uint64_t pool_call[NSTREAMS] = {}; // call in which each last waited for the caller's stream
-    hipEvent_t ev[ST_COUNT][EVR] = {}; // stage s of group (k mod EVR) of the current call done
+    hipEvent_t ev[2][ST_COUNT][EVR] = {}; // [call parity]: stage s of group (k mod EVR) of that call done
+    hipEvent_t ev_done[2] = {};     // [call parity]: that call complete, on the stream it was made on
+    bool have_done[2] = {false, false};
+    // the previous call, if it was a pipelined one: the next call's high-pass chain may be started before it has drained
+    // (nnn_batch_set_inputs_ready) and needs its synthesis events for the history rings
+    bool prev_pipe = false;
+    hipStream_t prev_st = nullptr;
+    uint64_t prev_frame0 = 0;
+    int prev_par = 0;
+    std::vector<int> prev_first;
+    bool inputs_ready = false;      // the caller's promise that a call's input is final when the call is made
     hipEvent_t ev_in = nullptr;     // the caller's stream at the start of a pipelined call
     hipEvent_t ev_last = nullptr;   // end of the most recent call, on the stream it was made on
     hipStream_t last_stream = nullptr;
@@ -183,9 +193,12 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
     NNN_RT_LOCK;
     hipSetDevice(h->device);
     hipDeviceSynchronize();
-    for (int s = 0; s < ST_COUNT; s++)
-        for (int i = 0; i < EVR; i++)
-            if (h->ev[s][i]) hipEventDestroy(h->ev[s][i]);
+    for (int p = 0; p < 2; p++) {
+        for (int s = 0; s < ST_COUNT; s++)
+            for (int i = 0; i < EVR; i++)
+                if (h->ev[p][s][i]) hipEventDestroy(h->ev[p][s][i]);
+        if (h->ev_done[p]) hipEventDestroy(h->ev_done[p]);
+    }
     if (h->ev_in) hipEventDestroy(h->ev_in);
     if (h->ev_last) hipEventDestroy(h->ev_last);
     for (hipEvent_t e : h->evp) hipEventDestroy(e);
@@ -260,8 +273,11 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     HIPCHK(hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming));
     // (the internal streams of pipelined calls are created on first use: HIP spreads streams over a few hardware queues in
     // creation order, and a stream that shares its queue with the caller's blocks behind the caller's waits)
-    for (int s = 0; s < ST_COUNT; s++)
-        for (int i = 0; i < EVR; i++) HIPCHK(hipEventCreateWithFlags(&h->ev[s][i], hipEventDisableTiming));
+    for (int p = 0; p < 2; p++) {
+        for (int s = 0; s < ST_COUNT; s++)
+            for (int i = 0; i < EVR; i++) HIPCHK(hipEventCreateWithFlags(&h->ev[p][s][i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_done[p], hipEventDisableTiming));
+    }
     if (const char *e = getenv("NNN_PIPELINE")) h->use_pipeline = atoi(e) != 0;
     if (const char *e = getenv("NNN_RAMP")) h->ramp = atoi(e);
     if (const char *e = getenv("NNN_PITCH_CHAIN")) h->pitch_chain = atoi(e);
@@ -348,7 +364,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     HIPCHK(dalloc(h, &b.gru_n, Sp * md.nn, true));
     HIPCHK(dalloc(h, &b.gru_dn, Sp * md.ndn, true));
     HIPCHK(dalloc(h, &b.stamps, 64, false));
-    HIPCHK(hipMalloc((void **)&h->sp_tab, 64 * sizeof(StepParams)));
+    HIPCHK(hipMalloc((void **)&h->sp_tab, 2 * 64 * sizeof(StepParams)));   // two tables: consecutive calls alternate
     h->sp_tab_cap = 64;
     // tables
     std::vector<float> window, dct, tansig, bin_frac;
@@ -460,6 +476,7 @@ extern "C" int nnn_batch_reset(nnn_batch *h)
     h->frame_count = 0;
     h->group_count = 0;
     h->last_set = 0;
+    h->prev_pipe = false;
     return 0;
 }
 
@@ -512,6 +529,7 @@ extern "C" int nnn_batch_load_state(nnn_batch *h, const void *host_src, size_t s
     HIPCHK(hipDeviceSynchronize());
     h->frame_count = hd.frame_count;
     h->group_count = hd.group_count;
+    h->prev_pipe = false;
     return 0;
 }
 
@@ -539,6 +557,7 @@ extern "C" nnn_batch *nnn_batch_clone(nnn_batch *h)
     c->n_lanes = h->n_lanes;
     c->use_pipeline = h->use_pipeline;
     c->pitch_chain = h->pitch_chain;
+    c->inputs_ready = h->inputs_ready;
     if (h->b[0].taps && nnn_batch_set_taps(c, 1) != 0) {
         nnn_batch_destroy(c);
         return nullptr;
@@ -656,10 +675,10 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
         h->sp_tab = nullptr;
         h->sp_tab_cap = 0;
         const int cap = n_frames < 64 ? 64 : n_frames;
-        HIPCHK(hipMalloc((void **)&h->sp_tab, (size_t)cap * sizeof(StepParams)));
+        HIPCHK(hipMalloc((void **)&h->sp_tab, (size_t)2 * cap * sizeof(StepParams)));
         h->sp_tab_cap = cap;
+        h->prev_pipe = false;
     }
-    hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, st, h->sp_tab, v0, n_frames);
     // group sizes: in pipelined calls they ramp up 1, 2, 3 at the start and down 3, 2, 1 at the end (shorter fill and
     // drain of the pipeline: the caller's stream waits for the last stage of the last group)
     const bool pipe = h->use_pipeline && h->sched != SCHED_SEQ && !h->profiling && n_frames >= 2 * GROUP;
@@ -679,17 +698,32 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     }
     const int n_groups = (int)sizes.size();
     h->call_count += 1;
+    const int par = (int)(h->call_count & 1);
+    StepParams *const tab = h->sp_tab + (size_t)par * h->sp_tab_cap;   // this call's parameter table
+    const uint64_t frame0 = h->frame_count;
     bool ok = true;
     auto chk = [&](hipError_t e) { ok = ok && e == hipSuccess; };
+    // The next call's high-pass chain may start before this stream has seen the previous call drain, when the caller has
+    // promised that inputs are final at call time (nnn_batch_set_inputs_ready): it depends on the previous call only through
+    // its own stream (biquad state) and the history-ring slots it overwrites (synthesis events of the groups that read them).
+    const bool early_hp = pipe && h->inputs_ready && h->prev_pipe && h->prev_st == st && h->sched == SCHED_LANES && h->pool[0];
+    if (early_hp) {
+        if (h->have_done[par]) chk(hipStreamWaitEvent(h->pool[0], h->ev_done[par], 0));   // the table's previous user (two calls back)
+        hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, h->pool[0], tab, v0, n_frames);
+        h->pool_call[0] = h->call_count;   // (no wait for the caller's stream on this one)
+    } else {
+        hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, st, tab, v0, n_frames);
+    }
     if (!pipe) {
         for (int k = 0, t = 0; k < n_groups; k++) {
             const int g = sizes[k], set0 = (int)(h->group_count % DEPTH) * GROUP;
-            for (int s = 0; s < ST_COUNT; s++) launch_stage(h, s, set0, g, h->sp_tab + t, st, h->profiling);
+            for (int s = 0; s < ST_COUNT; s++) launch_stage(h, s, set0, g, tab + t, st, h->profiling);
             h->group_count += 1;
             h->frame_count += g;
             h->last_set = set0 + g - 1;
             t += g;
         }
+        h->prev_pipe = false;
     } else {
         chk(hipEventRecord(h->ev_in, st));
         // index into h->pool; -1 = the caller's stream (lane 0 of the lanes schedule, the synthesis chain of the stages one)
@@ -719,7 +753,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
                 }
                 auto wait_for = [&](int ds, int dk) {
                     if (dk < 0 || dk < k - EVR + 1) return;   // before this call (ordered by ev_in) or long retired
-                    if (stream_of(ds, dk) != si) chk(hipStreamWaitEvent(ss, h->ev[ds][dk % EVR], 0));
+                    if (stream_of(ds, dk) != si) chk(hipStreamWaitEvent(ss, h->ev[par][ds][dk % EVR], 0));
                 };
                 if (s > 0) wait_for(s - 1, k);
                 if (s == ST_HP || s == ST_PITCH || s == ST_RNN || s == ST_SYN) wait_for(s, k - 1);
@@ -732,16 +766,32 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
                     for (int j = 0; j < k; j++)
                         if (first[j] <= need) dk = j;
                     wait_for(ST_SYN, dk);
+                    if (early_hp && need < 0) {
+                        // the frame lies in the previous call: the synthesis of its group there; older still: the call before that
+                        const long long pn = (long long)frame0 + need - (long long)h->prev_frame0;
+                        int pj = -1;
+                        for (int j = 0; j < (int)h->prev_first.size(); j++)
+                            if (h->prev_first[j] <= pn) pj = j;
+                        if (pn >= 0 && pj >= 0 && (int)h->prev_first.size() - pj < EVR) chk(hipStreamWaitEvent(ss, h->ev[h->prev_par][ST_SYN][pj % EVR], 0));
+                        else if (h->have_done[par]) chk(hipStreamWaitEvent(ss, h->ev_done[par], 0));   // (par = the call before the previous one)
+                    }
                 }
-                launch_stage(h, s, set0, g, h->sp_tab + first[k], ss, false);
-                if (consumers_elsewhere(s, k)) chk(hipEventRecord(h->ev[s][k % EVR], ss));
+                launch_stage(h, s, set0, g, tab + first[k], ss, false);
+                if (consumers_elsewhere(s, k)) chk(hipEventRecord(h->ev[par][s][k % EVR], ss));
             }
             h->group_count += 1;
             h->frame_count += g;
             h->last_set = set0 + g - 1;
         }
-        if (stream_of(ST_SYN, n_groups - 1) >= 0) chk(hipStreamWaitEvent(st, h->ev[ST_SYN][(n_groups - 1) % EVR], 0));
+        if (stream_of(ST_SYN, n_groups - 1) >= 0) chk(hipStreamWaitEvent(st, h->ev[par][ST_SYN][(n_groups - 1) % EVR], 0));
+        h->prev_pipe = true;
+        h->prev_st = st;
+        h->prev_frame0 = frame0;
+        h->prev_par = par;
+        h->prev_first = first;
     }
+    chk(hipEventRecord(h->ev_done[par], st));
+    h->have_done[par] = true;
     chk(hipEventRecord(h->ev_last, st));
     h->last_stream = st;
     h->have_last = true;
@@ -1017,6 +1067,12 @@ extern "C" int nnn_batch_set_graph(nnn_batch *h, int on)
     (void)on;
     if (!h) return fail("null batch");
     return 0;   // kept for callers of the round-1 ABI: a group is seven launches now and they are always eager
+}
+extern "C" int nnn_batch_set_inputs_ready(nnn_batch *h, int on)
+{
+    if (!h) return fail("null batch");
+    h->inputs_ready = on != 0;
+    return 0;
 }
 extern "C" int nnn_batch_set_pipeline(nnn_batch *h, int on)
 {

@@ -539,7 +539,7 @@ def _stress(nn, S, T, reps, schedules):
         mode, lanes = schedules[it % len(schedules)]
         bd = nn.BatchDenoiser(S)
         bd.set_schedule(mode, lanes)
-        cut = 8 + (5 * it) % (T - 16)                   # two calls of varying length: ramp phases, rotation phases
+        cut = 32 + (5 * it) % (T - 64)                  # two pipelined calls (>= 32 frames each) of varying length: every rotation phase
         out = np.concatenate([bd.process(x[:, :cut])[0], bd.process(x[:, cut:])[0]], axis=1)
         bd.close()
         bad = np.argwhere(np.abs(out - ref).max(axis=2) > 0)
@@ -554,7 +554,7 @@ def test_pipelined_runs_repeat_bit_identically(nn):
     the headline batch."""
     sched = [("lanes", 1), ("lanes", 2), ("lanes", 3), ("lanes", 4), ("stages", 0)]
     total = 0
-    for S, T, reps in ((63, 40, 70), (65, 40, 70), (454, 40, 70), (4096, 32, 30)):
+    for S, T, reps in ((63, 80, 70), (65, 80, 70), (454, 80, 70), (4096, 72, 30)):
         total += _stress(nn, S, T, reps, sched)
     assert total >= 200
 
@@ -564,7 +564,7 @@ def test_race_stress_other_queue_counts(queues):
     """The same stress under GPU_MAX_HW_QUEUES 2 and 8 (the variable is read when the HIP runtime starts: own process)."""
     env = dict(os.environ, GPU_MAX_HW_QUEUES=queues, NNN_STRESS_CHILD="1")
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import nnnoiseless_amd as nn; import test_gpu_parity as t; "
-            "n = sum(t._stress(nn, S, 40, 25, [('lanes', 3), ('stages', 0), ('lanes', 2)]) for S in (65, 454)); print('runs', n)"
+            "n = sum(t._stress(nn, S, 80, 25, [('lanes', 3), ('stages', 0), ('lanes', 2)]) for S in (65, 454)); print('runs', n)"
             % (ROOT, os.path.join(ROOT, "tests")))
     txt = subprocess.check_output([os.sys.executable, "-c", code], env=env, timeout=900).decode()
     assert "runs 50" in txt
@@ -685,3 +685,40 @@ def test_pitch_frames_chained_and_looped_agree(nn, oracle_mod, weights_bytes, mo
     n = 96
     ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x[:n], want=("pitch",))
     assert np.array_equal(first[2][:n, 0], ref["pitch"][:, -1])
+
+
+@pytest.mark.parametrize("S", [454, 4096])
+def test_calls_overlapping_at_their_boundary(nn, S):
+    """nnn_batch_set_inputs_ready: with the caller's promise that inputs are final at call time, the next call's high-pass chain
+    starts while the previous call is still draining.  Calls made back to back on one HIP stream with no host synchronisation
+    in between, lengths that put every group-rotation phase at a boundary (pipelined and short calls mixed): the same bits as
+    one sequential run, every time."""
+    import torch
+    from nnnoiseless_amd.synthetic import make_streams_device
+    dev = torch.device("cuda", 0)
+    T = 208
+    x = make_streams_device(torch, dev, S, T, seed=7)
+    ref_bd = nn.BatchDenoiser(S)
+    ref_bd.set_pipeline(False)
+    y_ref = torch.empty_like(x)
+    v_ref = torch.empty((T, S), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    ref_bd.process_device(x.data_ptr(), y_ref.data_ptr(), v_ref.data_ptr(), T, T * 480, 480, stream)
+    torch.cuda.synchronize()
+    ref_bd.close()
+    plans = [(48, 48, 48, 64), (32, 33, 47, 96), (64, 16, 48, 80), (35, 61, 112), (48, 160)]
+    for rep in range(15):
+        cuts = plans[rep % len(plans)]
+        assert sum(cuts) == T
+        bd = nn.BatchDenoiser(S)
+        bd.set_inputs_ready(True)
+        y = torch.zeros_like(x)
+        v = torch.zeros((T, S), dtype=torch.float32, device=dev)
+        pos = 0
+        for n in cuts:   # no synchronisation between the calls
+            bd.process_device(x.data_ptr() + pos * 480 * 4, y.data_ptr() + pos * 480 * 4, v.data_ptr() + pos * S * 4, n, T * 480, 480, stream)
+            pos += n
+        torch.cuda.synchronize()
+        bd.close()
+        assert torch.equal(y, y_ref), (S, rep, cuts)
+        assert torch.equal(v, v_ref), (S, rep, cuts)
