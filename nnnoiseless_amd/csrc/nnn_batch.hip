@@ -349,7 +349,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     b.S = h->S; b.S_pad = h->S_pad; b.NT = h->NT;
     b.gru_v_w = md.nv; b.gru_n_w = md.nn; b.gru_dn_w = md.ndn;
     // persistent state
-    HIPCHK(dalloc(h, &b.hist, Sp * RING, true));
+    HIPCHK(dalloc(h, &b.hist, Sp * HSTR, true));
     HIPCHK(dalloc(h, &b.hp_mem, Sp * 2, true));
     HIPCHK(dalloc(h, &b.hp_last, Sp, true));
     HIPCHK(dalloc(h, &b.dec, Sp * DEC_LEN, true));
@@ -997,10 +997,10 @@ extern "C" int nnn_batch_read_tap(nnn_batch *h, int tap, void *host_dst, size_t 
         HIPCHK(hipMemcpy(tmp.data(), p, tmp.size() * 4, hipMemcpyDeviceToHost));
         for (int s = 0; s < h->S; s++) memcpy(dst + (size_t)s * d.len, tmp.data() + (size_t)s * 2 * FSTR, (size_t)d.len * 4);
     } else {  // newest frame in the history ring
-        std::vector<uint32_t> tmp(Sp * RING);
+        std::vector<uint32_t> tmp(Sp * HSTR);
         HIPCHK(hipMemcpy(tmp.data(), p, tmp.size() * 4, hipMemcpyDeviceToHost));
         int slot = (int)((h->frame_count + NSLOT - 1) % NSLOT);  // slot of the most recent frame
-        for (int s = 0; s < h->S; s++) memcpy(dst + (size_t)s * FRAME, tmp.data() + (size_t)s * RING + slot * FRAME, FRAME * 4);
+        for (int s = 0; s < h->S; s++) memcpy(dst + (size_t)s * FRAME, tmp.data() + (size_t)s * HSTR + slot * FRAME, FRAME * 4);
     }
     return 0;
 }

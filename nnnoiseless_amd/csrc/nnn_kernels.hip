@@ -149,7 +149,7 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp,
     float m0 = st.m0, m1 = st.m1, prev = st.prev;
     NNN_STAMP(b, 24);
     float *ring = NNN_TI(b.dec, DEC_LEN, tile, lane);
-    float *h = b.hist + (size_t)s * RING;
+    float *h = b.hist + (size_t)s * HSTR;
     {   // x_lp[0] = (x[1] / 2 + x[0]) / 2 on the oldest two samples of this frame's 1728-sample history: kept beside
         // the ring, per slot (the ring position it replaces is still a regular value for the previous frame)
         const int rb = ring_base(slot);
@@ -176,6 +176,7 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp,
             }
 #pragma unroll
             for (int q = 0; q < HP_CH / 4; q++) hw[HP_CH / 4 * (c - 1) + q] = make_float4(ys[4 * q], ys[4 * q + 1], ys[4 * q + 2], ys[4 * q + 3]);
+            if (slot == 0 && c == 1) h[RING] = ys[0];   // the ring's first sample again behind its end (8-byte reads across the wrap)
         }
         if (c == FRAME / HP_CH) break;
         if (c + 1 < FRAME / HP_CH) nxt.load(in + (long long)(c + 1) * HP_CH * sstride, sstride);
@@ -1305,6 +1306,7 @@ __device__ __forceinline__ float dct_out(const float *x, const float *dct, int i
     return (float)((double)sum * 0.30151134457776363 /* sqrt(2/22) */);
 }
 
+struct __attribute__((packed, aligned(4))) SamplePair { float x, y; };   // two consecutive samples: one 8-byte load at 4-byte alignment
 // windowed 960 samples ending `lag` samples before the newest one -> Z (packed as 480 complex), transform in place,
 // spectrum bins into Y (lane owns bins lane + 64 u), scaled by wnorm
 __device__ __forceinline__ void window_rfft(const Buffers &b, const float *h, int rb, int lag, const float2 (&w)[8], const FftLds &t,
@@ -1316,10 +1318,10 @@ __device__ __forceinline__ void window_rfft(const Buffers &b, const float *h, in
     for (int u = 0; u < 8; u++) {
         const int n = lane + 64 * u;
         if (n < NFFT) {
-            int i0 = start + 2 * n, i1 = i0 + 1;
+            int i0 = start + 2 * n;
             if (i0 >= RING) i0 -= RING;
-            if (i1 >= RING) i1 -= RING;
-            Z[n] = make_float2(h[i0] * w[u].x, h[i1] * w[u].y);
+            const SamplePair v = *(const SamplePair *)(h + i0);   // (i0 + 1 = RING reads the copy of sample 0 kept there)
+            Z[n] = make_float2(v.x * w[u].x, v.y * w[u].y);
         }
     }
     if (first) __syncthreads();   // tables in place; from here on every wave is on its own
@@ -1351,7 +1353,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     }
     const int lag = WITH_P ? NNN_TI(b.pitch, 1, tile, sl)[0] : 0;
     fft_tables_load(t, b, false);
-    const float *h = b.hist + (size_t)s * RING;
+    const float *h = b.hist + (size_t)s * HSTR;
     float2 X[8];
     window_rfft(b, h, rb, 0, w, t, Z, X, lane, true);
     float2 *dx = b.X + (size_t)s * FSTR;

@@ -35,6 +35,8 @@ constexpr int NSET = DEPTH * GROUP;   // per-frame scratch sets
 constexpr int NSLOT = (DEPTH + 1) * GROUP + 4;   // history ring slots: the high-pass may run a group ahead of the DEPTH groups in flight,
                                   // whose oldest frame still reads a 1728-sample history (3 slots behind it)
 constexpr int RING = NSLOT * 480; // history ring instead of the reference's memmove
+constexpr int HSTR = RING + 32;   // a stream's stride in the history array (whole 128-byte lines): hist[RING] repeats hist[0], so a sample pair that starts on the
+                                  // ring's last sample is still one 8-byte read
 constexpr int XLP = 864;          // HIST / 2
 constexpr int PITCH_MIN = 60, PITCH_MAX = 768;
 constexpr int NLAG1 = 147;        // coarse lags  (PITCH_MAX - 3*PITCH_MIN) / 4
@@ -74,7 +76,7 @@ struct RnnPlan {
 
 struct Buffers {
     // ---- persistent per-stream state (src/denoise.rs:37-42, features.rs:18-46, pitch.rs:4-17, rnn.rs:65-70)
-    float *hist;         // SM [RING]   high-passed input history, ring of NSLOT frame slots
+    float *hist;         // SM [HSTR]   high-passed input history, ring of NSLOT frame slots (+ the wrap-around sample)
     float *hp_mem;       // TI [2]      biquad state
     float *hp_last;      // TI [1]      last filtered sample of the previous frame
     float *dec;          // TI [DEC_LEN]  2:1 decimated history: ring of NSLOT x 240 values whose first 960 are mirrored behind its end,
