@@ -280,3 +280,24 @@ def test_pitch_frames_chained_and_looped_agree(hostsim_lib, oracle_mod, weights_
         assert np.array_equal(a, b)
     ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x)
     assert np.array_equal(res["2"][2][:, 0], ref["pitch"][:, -1])
+
+
+def test_pitch_taps_exist_only_after_set_taps(hostsim_lib):
+    """Nothing inside the pitch analysis leaves LDS in production: its taps are an error until the taps are switched on (which
+    also allocates their arrays), and switching them on afterwards works mid-stream."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(5, 3, 3)
+    bd = nn.BatchDenoiser(3, lib=hostsim_lib)
+    bd.process(x[:, :1])
+    assert bd.tap("pitch").shape == (3, 1)            # the pitch index itself is always there (the transforms need it)
+    for name in ("xlp", "ac", "lpc2", "xcorr1", "best1", "xcorr2c", "pitch_search", "features"):
+        with pytest.raises(RuntimeError):
+            bd.tap(name)
+    bd.set_taps(True)
+    bd.process(x[:, 1:2])
+    assert bd.tap("xlp").shape == (3, 864) and np.isfinite(bd.tap("xlp")).all()
+    ref = nn.BatchDenoiser(3, lib=hostsim_lib, taps=True)
+    ref.process(x[:, :2])
+    for name in ("xlp", "ac", "xcorr1", "best1", "pitch_search", "pitch"):
+        assert np.array_equal(bd.tap(name), ref.tap(name)), name
