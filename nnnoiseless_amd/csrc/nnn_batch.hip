@@ -364,6 +364,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     HIPCHK(dalloc(h, &b.gru_n, Sp * md.nn, true));
     HIPCHK(dalloc(h, &b.gru_dn, Sp * md.ndn, true));
     HIPCHK(dalloc(h, &b.stamps, 64, false));
+    HIPCHK(dalloc(h, &b.fault, 1, false));
     HIPCHK(hipMalloc((void **)&h->sp_tab, 2 * 64 * sizeof(StepParams)));   // two tables: consecutive calls alternate
     h->sp_tab_cap = 64;
     // tables
@@ -452,6 +453,9 @@ extern "C" int nnn_batch_synchronize(nnn_batch *h)
     HIPCHK(hipSetDevice(h->device));
     if (h->have_last) HIPCHK(hipEventSynchronize(h->ev_last));   // the most recent call, whatever stream it was made on
     HIPCHK(hipStreamSynchronize(h->stream));
+    int fault = 0;
+    HIPCHK(hipMemcpy(&fault, h->b[0].fault, sizeof(int), hipMemcpyDeviceToHost));
+    if (fault) return fail("a pitch workgroup gave up waiting for the previous frame's result (frame hand-off flag never set): results of the affected streams are invalid");
     return 0;
 }
 
@@ -885,6 +889,7 @@ static int process_host_span(nnn_batch *h, const void *in, void *out, float *vad
                     memcpy((char *)out + o, tmp.data() + o, fr);
                 }
         if (err != hipSuccess) rc = fail("copy back failed: %s", hipGetErrorString(err));
+        if (!rc) rc = nnn_batch_synchronize(h);   // (also reports a frame hand-off that never arrived)
     } else {
         hipStreamSynchronize(h->stream);
     }

@@ -937,7 +937,9 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             if (chain && f > 0) {
                 // the previous frame of these streams is another workgroup's: wait for its flag, then take its pitch and gain
                 const int *flag = (const int *)NNN_TIF(b, pflag, 1, f - 1, tile, q0);
-                for (int spins = 0; flag_read(flag) != seq0 + f - 1 && spins < (1 << 22); spins++) chain_pause();
+                int spins = 0;
+                while (flag_read(flag) != seq0 + f - 1 && spins < (1 << 22)) { spins++; chain_pause(); }
+                if (spins >= (1 << 22)) *b.fault = 1;   // never seen: the predecessor is an earlier workgroup of this launch; reported, not hung on
                 last_period = NNN_TIF(b, pitch, 1, f - 1, tile, sl)[0];
                 last_gain = NNN_TIF(b, pgain, 1, f - 1, tile, sl)[0];
             }

@@ -117,6 +117,7 @@ struct Buffers {
     const float *bin_frac;   // [400]  j / band_size
     const int *bin_band;     // [400]
     long long *stamps;       // [64] optional phase time stamps of block 0 (built with -DNNN_STAMPS)
+    int *fault;              // [1]  set by a kernel that gave up waiting for another workgroup's flag (k_pitch); checked by the host
     const int *seg;          // [192] band-sum segments: k0[64], count[64], first segment[32], segments[32] per interval
     float wnorm;
     int S, S_pad, NT;
