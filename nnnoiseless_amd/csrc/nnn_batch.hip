@@ -1,5 +1,6 @@
 // nnn_batch.hip -- host side of the batched process_frame backend: the state slab in HBM, the
-// per-frame kernel pipeline (eager or as a replayed hipGraph), parity taps, per-kernel timing.
+// frame-group kernel pipeline (five launches per group, spread over a few HIP streams for long calls), parity taps,
+// per-kernel timing.
 // C ABI declared in include/nnn_batch.h.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -683,8 +684,8 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
         h->sp_tab_cap = cap;
         h->prev_pipe = false;
     }
-    // group sizes: in pipelined calls they ramp up 1, 2, 3 at the start and down 3, 2, 1 at the end (shorter fill and
-    // drain of the pipeline: the caller's stream waits for the last stage of the last group)
+    // group sizes: full groups of GROUP frames, the remainder last (NNN_RAMP keeps round 2a's smaller groups at the ends of a
+    // pipelined call for comparison)
     const bool pipe = h->use_pipeline && h->sched != SCHED_SEQ && !h->profiling && n_frames >= 2 * GROUP;
     std::vector<int> sizes;
     for (int rem = n_frames, k = 0; rem > 0; k++) {
@@ -1071,7 +1072,7 @@ extern "C" int nnn_batch_set_graph(nnn_batch *h, int on)
 {
     (void)on;
     if (!h) return fail("null batch");
-    return 0;   // kept for callers of the round-1 ABI: a group is seven launches now and they are always eager
+    return 0;   // kept for callers of the round-1 ABI: a group is five launches now and they are always eager
 }
 extern "C" int nnn_batch_set_inputs_ready(nnn_batch *h, int on)
 {

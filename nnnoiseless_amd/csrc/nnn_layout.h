@@ -142,8 +142,8 @@ __host__ __device__ inline Buffers frame_view(Buffers b, int f)
     return b;
 }
 
-// Per-frame launch parameters, resident in device memory so that one captured hipGraph can be
-// replayed for every frame: k_advance steps it at the end of each frame.
+// Per-frame launch parameters: a call's table (one entry per frame, filled on the device by k_fill_params) lives in device
+// memory, and a group's launches get a pointer to their first frame's entry.
 // PCM sample formats at the batch boundary (values match enum nnn_pcm_format in include/nnn_batch.h)
 enum { PCM_F32 = 0, PCM_I16 = 1, PCM_F32_UNIT = 2 };
 __host__ __device__ inline int pcm_elem_bytes(int fmt) { return fmt == PCM_I16 ? 2 : 4; }
