@@ -88,6 +88,9 @@ class BatchDenoiser {
     {
         check(nnn_batch_process_host(b_.get(), in, out, vad, n_frames, stream_stride, frame_stride));
     }
+    // promise that every process_device call's input is final when the call is made: consecutive calls may then overlap at
+    // their boundary (include/nnn_batch.h); outputs stay ordered on the call's stream
+    void set_inputs_ready(bool on) { check(nnn_batch_set_inputs_ready(b_.get(), on ? 1 : 0)); }
     // device buffers, asynchronous on `hip_stream` (nullptr = the batch's own stream)
     void process_device(const float *d_in, float *d_out, float *d_vad, int n_frames, size_t stream_stride, size_t frame_stride,
                         void *hip_stream = nullptr)
