@@ -2585,14 +2585,6 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
             b_graw = NNN_TIF(b, g_raw, NB, f, tile, sl)[(size_t)lane * TILE];
             b_g = NNN_TIF(b, g, NB, f, tile, sl)[(size_t)lane * TILE];
         }
-        float2 wlo[4], whi[4];   // the two window halves, as sample pairs
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int n = lane + 64 * u;
-            const bool on = n < FRAME / 2;
-            wlo[u] = on ? ((const float2 *)b.window)[n] : make_float2(0.0f, 0.0f);
-            whi[u] = on ? ((const float2 *)b.window)[FRAME / 2 + n] : make_float2(0.0f, 0.0f);
-        }
         const float vadv = NNN_TIF(b, vad, 1, f, tile, sl)[0];
         // this stream's first output sample; mono streams of matching alignment take one store per sample pair
         const int ch = sp->channels, grp = s / ch, elem = pcm_elem_bytes(fmt), sstride = ch * elem;
@@ -2683,6 +2675,16 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
             if (k < NFFT) A[k] = zin[u];
         }
         wave_lds_sync();
+        // (the window is requested here, not with the frame's other loads: its 16 registers would be live across the whole frame and
+        // spill; it travels behind the transform)
+        float2 wlo[4], whi[4];   // the two window halves, as sample pairs
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int n = lane + 64 * u;
+            const bool on = n < FRAME / 2;
+            wlo[u] = on ? ((const float2 *)b.window)[n] : make_float2(0.0f, 0.0f);
+            whi[u] = on ? ((const float2 *)b.window)[FRAME / 2 + n] : make_float2(0.0f, 0.0f);
+        }
         fft480(A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
         if (lane == 0 && vad_out && s < b.S) vad_out[s] = vadv;
 #pragma unroll
