@@ -162,7 +162,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-tick", action="store_true", help="skip the one-frame-per-call measurement")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs[2] / configs[4] measurements of the default run")
-    ap.add_argument("--pool-bytes", type=float, default=6e9, help="HBM budget for the resident input pool (and as much again for the output)")
+    ap.add_argument("--pool-bytes", type=float, default=6.5e9, help="HBM budget for the resident input pool (and as much again for the output)")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a GPU: gloo backend, CPU tensors, the library named by NNN_LIBRARY (the tests "
                          "point it at the SIMT-interpreter build), a few streams; the numbers mean nothing")
@@ -182,6 +182,8 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
     esz = 2 if fmt == 1 else 4
     # distinct audio for every step while it fits the pool budget, else cycle through a pool of frames
     pool = max(1, min(total_frames, int(args.pool_bytes // (S * 480 * esz))))
+    if pool >= fps:
+        pool -= pool % fps   # whole steps: a step never straddles the end of the pool (no call is cut in two)
     x = make_streams_device(torch, dev, S, pool, seed=rank)               # [S, pool, 480] f32, resident
     if fmt or Cc > 1:   # packed PCM: [groups][pool * 480][channels], channel-interleaved
         x = x.reshape(S // Cc, Cc, pool * 480).permute(0, 2, 1)
