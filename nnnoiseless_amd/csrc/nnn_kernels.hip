@@ -675,6 +675,33 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                         ysq = fmaxf(ysq, 1.0f);
                     }
                 }
+            } else if (wave == 7 && lane < PK_SPB) {
+                // the starting sums of the two long energy scans of the next phase (ref: src/pitch.rs:380-382, 133-136): these
+                // waves have nothing else to do while the cross-correlation runs, the scans are that phase's critical path
+                {
+                    float ysq = 1.0f;
+#pragma nounroll
+                    for (int m0 = 0; m0 < 240; m0 += 4) {
+                        float ve[4], vo[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { ve[i] = pE[(m0 + i) * PK_SPB]; vo[i] = pO[(m0 + i) * PK_SPB]; }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { ysq += ve[i] * ve[i]; ysq += vo[i] * vo[i]; }
+                    }
+                    L.ckf[0][s] = ysq;
+                }
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma nounroll
+                for (int m0 = 192; m0 < 432; m0 += 4) {
+                    float ve[4], vo[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { ve[i] = pE[(m0 + i) * PK_SPB]; vo[i] = pO[(m0 + i) * PK_SPB]; }
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {
+                        s0 += ve[i] * ve[i]; s1 += vo[i] * vo[i]; s2 += ve[i + 1] * ve[i + 1]; s3 += vo[i + 1] * vo[i + 1];
+                    }
+                }
+                L.cky[0][s] = s0 + s1 + s2 + s3;   // xx = yy_lookup[0]
             }
         }
         __syncthreads();
@@ -710,15 +737,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         } else if (wave == 5 && lane < PK_SPB) {
             // the running energy every fine lag sees (ref: src/pitch.rs:97 -> :380-402): <= 10 lags can update the best pitch there,
             // and they are replayed below with the energy each of them saw
-            float ysq = 1.0f;
-#pragma nounroll
-            for (int m0 = 0; m0 < 240; m0 += 4) {
-                float ve[4], vo[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) { ve[i] = pE[(m0 + i) * PK_SPB]; vo[i] = pO[(m0 + i) * PK_SPB]; }
-#pragma unroll
-                for (int i = 0; i < 4; i++) { ysq += ve[i] * ve[i]; ysq += vo[i] * vo[i]; }
-            }
+            float ysq = L.ckf[0][s];   // the sum over the first 480 rows, made beside the coarse cross-correlation
 #pragma nounroll
             for (int m = 0; m < PK_NCKF; m++) {   // lags 8 m .. 8 m + 7 (the last few past the table: computed, never looked up)
                 L.ckf[m][s] = ysq;
@@ -740,19 +759,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         } else if (wave == 6 && lane < PK_SPB) {
             // xx = |x|^2 over the analysis frame and the 384-step running energy yy_lookup of remove_doubling
             // (ref: src/pitch.rs:133-142)
-            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-#pragma nounroll
-            for (int m0 = 192; m0 < 432; m0 += 4) {
-                float ve[4], vo[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) { ve[i] = pE[(m0 + i) * PK_SPB]; vo[i] = pO[(m0 + i) * PK_SPB]; }
-#pragma unroll
-                for (int i = 0; i < 4; i += 2) {
-                    s0 += ve[i] * ve[i]; s1 += vo[i] * vo[i]; s2 += ve[i + 1] * ve[i + 1]; s3 += vo[i + 1] * vo[i + 1];
-                }
-            }
-            float yy = s0 + s1 + s2 + s3;
-            L.cky[0][s] = yy;   // xx = yy_lookup[0]
+            float yy = L.cky[0][s];   // xx = yy_lookup[0], made beside the coarse cross-correlation
 #pragma nounroll
             for (int bk = 0; bk < 38; bk++) {   // steps 10 bk + 1 .. 10 bk + 10 (380 steps: the last four are only ever replayed)
                 const int n0 = 5 * bk;          // steps 2n + 1, 2n + 2: rows 383 - 2n, 382 - 2n enter, rows 863 - 2n, 862 - 2n leave
