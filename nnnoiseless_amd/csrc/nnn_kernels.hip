@@ -796,12 +796,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             pk_inner<2>(L.pb, s, qi, yr, acc);
             L.u.f.part[wave][qi][s] = acc[0];
             L.u.f.part[5 + wave][qi][s] = acc[1];
-        }
-        __syncthreads();
-        NNN_STAMP(b, 7);
-        // ---- find_best_pitch over the fine lags: xcorr is zero outside the two 5-lag windows, so only they can update the
-        //      best pitch; replayed in increasing lag order with the energy each of them saw.  Then the candidate periods.
-        if (wave == 0) {
+        } else if (wave == 5) {   // (beside it, on a wave the cross-correlation leaves idle)
             if (q < 2) {
                 // the energy lags lo .. lo + 4 of window q saw: from the check point below the first of them, the scan's own
                 // steps (at most 7 + 5; every row is requested before the first step is taken)
@@ -825,8 +820,11 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
 #pragma unroll
                 for (int c = 0; c < 5; c++) L.u.f.ye[5 * q + c][s] = ev[c];
             }
-            wave_lds_sync();
         }
+        __syncthreads();
+        NNN_STAMP(b, 7);
+        // ---- find_best_pitch over the fine lags: xcorr is zero outside the two 5-lag windows, so only they can update the
+        //      best pitch; replayed in increasing lag order with the energy each of them saw.  Then the candidate periods.
         Xc2 xc;
         int t0 = 0;
         float xx = 0.0f;
@@ -897,30 +895,30 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             L.u.f.xx[s] = xx;
             L.u.f.t0[s] = t0;
         }
-        if (wave == 0) {
-            // yy_lookup at the candidate periods (ref: src/pitch.rs:138-142): lane (s, q) takes candidates q, q + 4, ..; from the
-            // check point below T, at most four of the scan's steps
-            wave_lds_sync();
-            constexpr int NI = (PK_NE + 3) / 4;
-            float yv[NI];
-#pragma unroll
-            for (int i = 0; i < NI; i++) {
-                const int e = q + 4 * i, T = L.u.f.cand[e][s], m = T / PK_CKY;
+        __syncthreads();
+        NNN_STAMP(b, 53);
+        // ---- yy_lookup at the candidate periods (ref: src/pitch.rs:138-142): one candidate per lane (s, q) of waves 0..5; from the
+        //      check point below T, at most four of the scan's steps.  (Read by the decision loop, behind the next barrier.)
+        {
+            const int e = 4 * wave + q;
+            if (e < PK_NE) {
+                const int T = L.u.f.cand[e][s], m = T / PK_CKY;
                 float y = L.cky[m][s];
+                float ra[PK_CKY - 1], rc[PK_CKY - 1];
 #pragma unroll
                 for (int st = 1; st < PK_CKY; st++) {
                     const int j = PK_CKY * m + st, jc = j <= 384 ? j : 384;   // step j: row 384 - j enters, row 864 - j leaves
-                    const float a = L.pb[pk_at(384 - jc, s)], c = L.pb[pk_at(864 - jc, s)];
-                    const float yn = y + (a * a - c * c);
-                    y = j <= T ? yn : y;
+                    ra[st - 1] = L.pb[pk_at(384 - jc, s)];
+                    rc[st - 1] = L.pb[pk_at(864 - jc, s)];
                 }
-                yv[i] = fmaxf(y, 0.0f);
-            }
 #pragma unroll
-            for (int i = 0; i < NI; i++) L.u.f.yy[q + 4 * i][s] = yv[i];   // (after the last read: the reads travel together)
+                for (int st = 1; st < PK_CKY; st++) {
+                    const float yn = y + (ra[st - 1] * ra[st - 1] - rc[st - 1] * rc[st - 1]);
+                    y = PK_CKY * m + st <= T ? yn : y;
+                }
+                L.u.f.yy[e][s] = fmaxf(y, 0.0f);
+            }
         }
-        __syncthreads();
-        NNN_STAMP(b, 53);
         // ---- the candidates' inner products against p[384 ..]: wave w takes slots w, w + 8, w + 16 (wave 0 also slot 24)
         static_assert(PK_NSLOT == 25, "three slots per wave and one more");
         if (wave == 0) {
