@@ -1135,31 +1135,35 @@ extern "C" int nnn_train_reset(nnn_train *t)
 // shift_and_filter_input + the part of compute_frame_features the row needs: everything up to the 42 features for the
 // mix, only the band energies of X for the clean and noise states (src/training.rs:129-131 computes their full
 // features and says itself that only the transform and band energies are needed; nothing else of them is read).
-static void enqueue_feature_frame(nnn_batch *h, hipStream_t st, StepParams *sp, const float *in, size_t stream_stride, bool full)
+static void enqueue_feature_group(nnn_batch *h, hipStream_t st, const float *in, size_t stream_stride, size_t frame_stride, int g, bool full)
 {
+    // `g` consecutive frames (<= GROUP) in scratch sets 0 .. g - 1, the same launches as the denoiser's front: the stateful
+    // kernels cover the group in one launch, the per-frame feature stage once per frame
     const Buffers &b = h->b[0];
-    const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad;
+    const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad, ug = (unsigned)g;
+    StepParams *sp = h->sp_tab;
     StepParams v;
     v.in = (const char *)in;
     v.out = nullptr;
     v.vad = nullptr;
     v.group_stride = (long long)stream_stride * 4;
-    v.frame_stride = 0;
+    v.frame_stride = (long long)frame_stride * 4;
     v.fmt = PCM_F32;
     v.channels = 1;
     v.discard = 0;
     v.slot = (int)(h->frame_count % NSLOT);
     v.n_streams = h->S;
-    hipLaunchKernelGGL(k_fill_params, dim3(1), dim3(64), 0, st, sp, v, 1);
-    hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, (const StepParams *)sp, 1);
+    hipLaunchKernelGGL(k_fill_params, dim3(1), dim3(64), 0, st, sp, v, g);
+    hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, (const StepParams *)sp, g);
     if (full) {
-        hipLaunchKernelGGL(k_pitch, dim3(Sp / PK_SPB), dim3(PK_T), 0, st, b, (const StepParams *)sp, 1, 0, 0);
-        hipLaunchKernelGGL(k_fft_xp, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp);
-        hipLaunchKernelGGL(k_features, dim3(NT), dim3(64 * FEAT_WAVES), 0, st, b);
+        const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
+        hipLaunchKernelGGL(k_pitch, dim3(Sp / PK_SPB * (chain ? ug : 1u)), dim3(PK_T), 0, st, b, (const StepParams *)sp, g, chain, seq0);
+        hipLaunchKernelGGL(k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp);
+        hipLaunchKernelGGL(k_features, dim3(NT), dim3(64 * FEAT_WAVES), 0, st, b, g);
     } else {
-        hipLaunchKernelGGL(k_fft_x, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp);
+        hipLaunchKernelGGL(k_fft_x, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp);
     }
-    h->frame_count += 1;
+    h->frame_count += g;
 }
 
 extern "C" int nnn_train_process_device(nnn_train *t, const float *d_signal, const float *d_noise, const float *d_combined,
@@ -1173,13 +1177,14 @@ extern "C" int nnn_train_process_device(nnn_train *t, const float *d_signal, con
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
     const size_t S = (size_t)h->S;
-    for (int f = 0; f < n_frames; f++) {
-        const size_t off = (size_t)f * frame_stride;
-        enqueue_feature_frame(t->comb, st, t->comb->sp_tab, d_combined + off, stream_stride, true);
-        enqueue_feature_frame(t->clean, st, t->clean->sp_tab, d_signal + off, stream_stride, false);
-        enqueue_feature_frame(t->noise, st, t->noise->sp_tab, d_noise + off, stream_stride, false);
-        hipLaunchKernelGGL(k_train_rows, dim3((unsigned)h->NT), dim3(64), 0, st, t->comb->b[0], t->clean->b[0], t->noise->b[0],
-                           (const int *)d_cutoff + f * S, d_vad + f * S, d_rows + f * S * TRAIN_COLS);
+    for (int f0 = 0; f0 < n_frames; f0 += GROUP) {
+        const int g = n_frames - f0 < GROUP ? n_frames - f0 : GROUP;
+        const size_t off = (size_t)f0 * frame_stride;
+        enqueue_feature_group(t->comb, st, d_combined + off, stream_stride, frame_stride, g, true);
+        enqueue_feature_group(t->clean, st, d_signal + off, stream_stride, frame_stride, g, false);
+        enqueue_feature_group(t->noise, st, d_noise + off, stream_stride, frame_stride, g, false);
+        hipLaunchKernelGGL(k_train_rows, dim3((unsigned)(h->NT * g)), dim3(64), 0, st, t->comb->b[0], t->clean->b[0], t->noise->b[0],
+                           (const int *)d_cutoff + (size_t)f0 * S, d_vad + (size_t)f0 * S, d_rows + (size_t)f0 * S * TRAIN_COLS);
     }
     HIPCHK(hipGetLastError());
     return 0;

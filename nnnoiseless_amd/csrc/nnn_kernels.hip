@@ -1594,11 +1594,16 @@ __device__ __forceinline__ float spectral_variability(const float *dists, int la
 //     features (training-data generation, ref: src/training.rs:113-160).  One 64-stream tile per block, 8 waves.
 // ---------------------------------------------------------------------------------------------
 constexpr int FEAT_WAVES = 8;
-__global__ void __launch_bounds__(64 * FEAT_WAVES) k_features(Buffers b)
+__global__ void __launch_bounds__(64 * FEAT_WAVES) k_features(Buffers b0, int g)
 {
     __shared__ float crs[CEPS_MEM * NB * TILE];   // staged cepstral ring
     __shared__ float dists[28 * TILE];            // new cepstrum / correlation DCT, then the pair distances
     const int wave = (int)(threadIdx.x >> 6), lane = threadIdx.x & 63, tile = blockIdx.x;
+    // the frames of a group one after the other (the cepstral ring is the tile's own state, carried through memory)
+#pragma unroll 1
+    for (int fr_i = 0; fr_i < g; fr_i++) {
+    const Buffers b = frame_view(b0, fr_i);
+    if (fr_i) __syncthreads();
     FeatHead fh;
     float fr[NFEAT];
     if (wave == 0) {
@@ -1618,6 +1623,7 @@ __global__ void __launch_bounds__(64 * FEAT_WAVES) k_features(Buffers b)
 #pragma unroll
         for (int k = 0; k < NFEAT; k++) f[(size_t)k * TILE] = fr[k];
     }
+    }
 }
 
 // One training row per stream (ref: src/training.rs:136-158): the combined signal's 42 features, 22 ideal band gains
@@ -1628,7 +1634,15 @@ __global__ void __launch_bounds__(64) k_train_rows(Buffers comb, Buffers clean, 
                                                    float *rows)
 {
     __shared__ float row[TILE][TRAIN_COLS + 1];
-    const int lane = threadIdx.x, tile = blockIdx.x, s = tile * TILE + lane;
+    // block index = frame * tiles + tile: the frames of a group in one launch, frame f's labels and rows f * S further on
+    const int NTl = comb.S_pad / TILE, frame = (int)blockIdx.x / NTl;
+    const int lane = threadIdx.x, tile = (int)blockIdx.x - frame * NTl, s = tile * TILE + lane;
+    comb = frame_view(comb, frame);
+    clean = frame_view(clean, frame);
+    noise = frame_view(noise, frame);
+    cutoff += (size_t)frame * comb.S;
+    vad += (size_t)frame * comb.S;
+    rows += (size_t)frame * comb.S * TRAIN_COLS;
     if (s < comb.S) {
         const bool silent = NNN_TI(comb.silence, 1, tile, lane)[0] != 0;
         const int cut = silent ? 0 : cutoff[s];
