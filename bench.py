@@ -30,6 +30,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                 (benches/sin.rs: 100 frames of a 440 Hz sine, fresh state per iteration, one thread).  The genuine Rust
                 reference cannot be built here (no cargo), hence kind "port".
   also          (default N=1 run only) the same measurement on configs[2] and configs[4], so the driver's line carries them
+  host_boundary (default N=1 run only) the headline workload through the host-buffer entry point: PCIe-inclusive, never `value`
 """
 import argparse
 import json
@@ -160,6 +161,7 @@ def parse_args(argv=None):
     ap.add_argument("--channels", type=int, default=1, help="interleaved channels per group (with --pcm i16/unit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-host", action="store_true", help="skip the PCIe-inclusive host-buffer measurement of the default run")
     ap.add_argument("--no-tick", action="store_true", help="skip the one-frame-per-call measurement")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs[2] / configs[4] measurements of the default run")
     ap.add_argument("--pool-bytes", type=float, default=6.5e9, help="HBM budget for the resident input pool (and as much again for the output)")
@@ -329,6 +331,36 @@ def config0():
                       "golden_metric": err}), flush=True)
 
 
+def host_boundary(S, fps, calls=4):
+    """The same workload through the host-buffer entry point (the shape of the reference's own process_frame: host slices in,
+    host slices out), every call shipping its audio over PCIe and bringing the result back -- never `value`, reported beside it.
+    Page-locked buffers (nnn_host_alloc), f32 and packed int16."""
+    import ctypes as C
+    import numpy as np
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd import _ffi
+    lib = nn.library()
+    out = {"unit": "frames/s", "frames_per_call": fps, "streams": S, "calls": calls,
+           "note": "PCIe-inclusive: upload + kernels + download per call, page-locked host buffers, chunks overlapped"}
+    rng = np.random.default_rng(0)
+    for fmt, name in ((0, "f32"), (1, "i16")):
+        bd = nn.BatchDenoiser(S)
+        dt = np.float32 if fmt == 0 else np.int16
+        px, po, pv = nn.pinned_empty((S, fps * 480), dt), nn.pinned_empty((S, fps * 480), dt), nn.pinned_empty((fps, S))
+        px[:] = (rng.standard_normal((S, fps * 480), dtype=np.float32) * 3000).astype(dt)
+        L = _ffi.PcmLayout(fmt, 1, 0, 0, fps * 480, 480)
+        call = lambda: lib.check(lib.L.nnn_batch_process_pcm_host(bd._h, _ffi.ptr(px), _ffi.ptr(po), _ffi.ptr(pv), fps, C.byref(L)))
+        call()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            call()
+        dt_s = (time.perf_counter() - t0) / calls
+        out[name] = {"value": S * fps / dt_s, "ms_per_call": dt_s * 1e3, "bus_GBps_both_ways": 2 * px.nbytes / dt_s / 1e9}
+        bd.close()
+        del px, po, pv
+    return out
+
+
 def main():
     args = parse_args()
     if args.config == 0:
@@ -405,6 +437,10 @@ def main():
                 "kernels_us_per_frame": {k: round(v["us_per_frame"], 2) for k, v in r.get("kernels", {}).items()},
                 "roofline": r.get("roofline")}
 
+    host = None
+    if default_run and rank == 0 and not args.no_host:
+        host = host_boundary(S, args.frames_per_step)
+
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and not args.dry_run:
         cpu = cpu_baseline()
@@ -431,6 +467,7 @@ def main():
             "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
             "outputs_finite": res["outputs_finite"],
             "roofline": res.get("roofline"), "cpu_baseline": cpu, "kernels": res.get("kernels", {}), "also": also,
+            "host_boundary": host,
         }
         if args.dry_run:
             line["dry_run"] = "gloo + CPU tensors + NNN_LIBRARY build: plumbing only, numbers meaningless"

@@ -39,6 +39,8 @@ extern "C" {
         frame_stride: usize,
         hip_stream: *mut c_void,
     ) -> c_int;
+    fn nnn_host_alloc(bytes: usize) -> *mut c_void;
+    fn nnn_host_free(p: *mut c_void);
     fn nnn_model_from_rnnoise_text(text: *const u8, len: usize) -> *mut RawModel;
     fn nnn_batch_create_grouped(
         models: *const *const RawModel,
@@ -197,3 +199,43 @@ impl DenoiseState {
         vad[0]
     }
 }
+
+/// Page-locked host memory (`nnn_host_alloc`): slices of it cross the bus by DMA in `BatchDenoiser::process`, uploads and
+/// downloads at the same time; ordinary slices work too, through the runtime's staging copies.
+pub struct PinnedBuf {
+    ptr: *mut c_float,
+    len: usize,
+}
+
+impl PinnedBuf {
+    pub fn new(len: usize) -> Option<PinnedBuf> {
+        let ptr = unsafe { nnn_host_alloc(len * std::mem::size_of::<c_float>()) } as *mut c_float;
+        if ptr.is_null() {
+            None
+        } else {
+            unsafe { std::ptr::write_bytes(ptr, 0, len) };
+            Some(PinnedBuf { ptr, len })
+        }
+    }
+}
+
+impl std::ops::Deref for PinnedBuf {
+    type Target = [f32];
+    fn deref(&self) -> &[f32] {
+        unsafe { std::slice::from_raw_parts(self.ptr, self.len) }
+    }
+}
+
+impl std::ops::DerefMut for PinnedBuf {
+    fn deref_mut(&mut self) -> &mut [f32] {
+        unsafe { std::slice::from_raw_parts_mut(self.ptr, self.len) }
+    }
+}
+
+impl Drop for PinnedBuf {
+    fn drop(&mut self) {
+        unsafe { nnn_host_free(self.ptr as *mut c_void) }
+    }
+}
+
+unsafe impl Send for PinnedBuf {}

@@ -53,6 +53,26 @@ class RnnModel {
 };
 
 // n independent DenoiseStates advanced in lock-step on one GPU
+// Page-locked host memory for the host-buffer calls (nnn_host_alloc): n elements of T.
+template <class T> class PinnedBuffer {
+  public:
+    explicit PinnedBuffer(size_t n) : p_((T *)nnn_host_alloc(n * sizeof(T))), n_(n)
+    {
+        if (!p_) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+    }
+    ~PinnedBuffer() { nnn_host_free(p_); }
+    PinnedBuffer(const PinnedBuffer &) = delete;
+    PinnedBuffer &operator=(const PinnedBuffer &) = delete;
+    T *data() { return p_; }
+    const T *data() const { return p_; }
+    size_t size() const { return n_; }
+    T &operator[](size_t i) { return p_[i]; }
+
+  private:
+    T *p_;
+    size_t n_;
+};
+
 class BatchDenoiser {
   public:
     BatchDenoiser(int n_streams, const RnnModel *model = nullptr, int device = 0)
@@ -84,6 +104,7 @@ class BatchDenoiser {
         check(nnn_batch_process_pcm_device(b_.get(), d_in, d_out, d_vad, n_frames, &layout, hip_stream));
     }
     // host buffers: sample i of frame t of stream s at [s * stream_stride + t * frame_stride + i]; vad[t * n_streams + s]
+    // (long calls cross the bus in chunks beside the kernels; PinnedBuffer memory goes by DMA, both directions at once)
     void process(const float *in, float *out, float *vad, int n_frames, size_t stream_stride, size_t frame_stride)
     {
         check(nnn_batch_process_host(b_.get(), in, out, vad, n_frames, stream_stride, frame_stride));

@@ -36,6 +36,33 @@ def library():
     return _lib
 
 
+class _Pinned:
+    """Owner of one nnn_host_alloc block (freed with the last array that views it)."""
+
+    def __init__(self, lib, nbytes):
+        self._lib, self.nbytes = lib, int(nbytes)
+        self.ptr = lib.L.nnn_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("nnnoiseless_amd: " + lib.error())
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self._lib.L.nnn_host_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_empty(shape, dtype=np.float32, lib=None):
+    """A numpy array in page-locked host memory (include/nnn_batch.h nnn_host_alloc): what BatchDenoiser.process /
+    process_pcm transfer by DMA, uploads and downloads at the same time."""
+    lib = lib or library()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape))
+    own = _Pinned(lib, max(1, n * dt.itemsize))
+    buf = (C.c_char * own.nbytes).from_address(own.ptr)
+    buf._owner = own   # the ctypes view is the array's base: the block lives as long as any view of the array
+    return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+
 class RnnModel:
     """Model parameters (reference: src/rnn.rs:54-62).  Constructors return None on malformed input
     exactly where the reference returns None."""
@@ -131,13 +158,16 @@ class BatchDenoiser:
         """mode: "seq" | "lanes" | "stages" (include/nnn_batch.h nnn_batch_set_schedule)."""
         self._lib.check(self._lib.L.nnn_batch_set_schedule(self._h, {"seq": 0, "lanes": 1, "stages": 2}[mode], int(lanes)))
 
-    def process(self, x):
-        """x: float32 [n_streams, n_frames, 480] on the host -> (out same shape, vad [n_frames, n_streams])."""
+    def process(self, x, out=None, vad=None):
+        """x: float32 [n_streams, n_frames, 480] on the host -> (out same shape, vad [n_frames, n_streams]).  Arrays from
+        pinned_empty (x, and out / vad handed in) cross the bus by DMA."""
         x = _ffi.as_f32(x)
         S, T, F = x.shape
         assert S == self.n_streams and F == FRAME_SIZE
-        out = np.empty_like(x)
-        vad = np.empty((T, S), np.float32)
+        out = np.empty_like(x) if out is None else out
+        vad = np.empty((T, S), np.float32) if vad is None else vad
+        assert out.shape == x.shape and out.dtype == np.float32 and out.flags.c_contiguous
+        assert vad.shape == (T, S) and vad.dtype == np.float32 and vad.flags.c_contiguous
         self._lib.check(self._lib.L.nnn_batch_process_host(self._h, _ffi.ptr(x), _ffi.ptr(out), _ffi.ptr(vad), T,
                                                            T * FRAME_SIZE, FRAME_SIZE))
         self.frames_done += T

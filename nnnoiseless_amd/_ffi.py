@@ -19,7 +19,7 @@ BATCH_SYMBOLS = [
     "nnn_batch_set_taps", "nnn_batch_set_schedule", "nnn_batch_set_inputs_ready", "nnn_debug_activations",
     "nnn_tap_info", "nnn_batch_read_tap", "nnn_batch_set_profiling", "nnn_batch_num_kernels",
     "nnn_batch_kernel_name", "nnn_batch_read_kernel_times", "nnn_batch_set_graph", "nnn_batch_set_pipeline", "nnn_batch_read_stamps",
-    "nnn_last_error",
+    "nnn_host_alloc", "nnn_host_free", "nnn_last_error",
 ]
 TRAIN_SYMBOLS = [
     "nnn_train_create", "nnn_train_destroy", "nnn_train_reset", "nnn_train_process_device", "nnn_train_process_host",
@@ -76,6 +76,10 @@ class Library:
         L.nnn_batch_process_pcm_device.argtypes = [vp, vp, vp, vp, i32, C.POINTER(PcmLayout), vp]
         L.nnn_batch_process_pcm_host.argtypes = [vp, vp, vp, vp, i32, C.POINTER(PcmLayout)]
         L.nnn_batch_synchronize.argtypes = [vp]
+        L.nnn_host_alloc.restype = vp
+        L.nnn_host_alloc.argtypes = [sz]
+        L.nnn_host_free.restype = None
+        L.nnn_host_free.argtypes = [vp]
         L.nnn_tap_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
         L.nnn_batch_read_tap.argtypes = [vp, i32, vp, sz]
         L.nnn_batch_set_profiling.argtypes = [vp, i32]

@@ -413,6 +413,39 @@ def test_interleaved_formats_match_planar(nn):
     assert np.abs(out - np.clip(want / np.float32(32768.0), -1, 1)).max() <= 1e-6
 
 
+def test_host_calls_in_chunks_and_pinned_buffers(nn, monkeypatch):
+    """Host-buffer calls of more than 16 frames cross the bus in chunks, uploads and downloads beside the kernels: same bits as
+    the one-piece call, from pageable and from page-locked arrays, planar f32 and packed int16 stereo with the dropped frame."""
+    from nnnoiseless_amd import _ffi
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T = 454, 40
+    x = make_streams(21, S, T)
+    inter = np.ascontiguousarray(np.round(x).astype(np.int16).reshape(S // 2, 2, T * 480).transpose(0, 2, 1))
+    monkeypatch.setenv("NNN_HOST_CHUNK", "0")
+    bd = nn.BatchDenoiser(S)
+    ref, vref = bd.process(x)
+    bd.reset()
+    iref, ivref = bd.process_pcm(inter, _ffi.PCM_I16, 2, discard_first=True)
+    for chunk in (None, "16", "8"):   # None: the library's own choice (4-frame chunks for a call of 40 frames)
+        if chunk is None:
+            monkeypatch.delenv("NNN_HOST_CHUNK")
+        else:
+            monkeypatch.setenv("NNN_HOST_CHUNK", chunk)
+        bd = nn.BatchDenoiser(S)
+        out, vad = bd.process(x)
+        assert np.array_equal(out, ref) and np.array_equal(vad, vref), chunk
+        px, po, pv = nn.pinned_empty(x.shape), nn.pinned_empty(x.shape), nn.pinned_empty((T, S))
+        px[:] = x
+        bd.reset()
+        bd.process(px, out=po, vad=pv)
+        assert np.array_equal(po, ref) and np.array_equal(pv, vref), chunk
+        bd.reset()
+        out, vad = bd.process_pcm(inter, _ffi.PCM_I16, 2, discard_first=True)
+        assert np.array_equal(out, iref) and np.array_equal(vad, ivref), chunk
+        out, vad = bd.process_pcm(inter, _ffi.PCM_I16, 2, discard_first=True)   # not fresh any more: nothing dropped
+        assert out.shape[1] == T * 480
+
+
 def test_denoise_signal(nn, oracle_mod, weights_bytes):
     from nnnoiseless_amd.pcm import DenoiseSignal
     model = oracle_mod.Model(weights_bytes)

@@ -70,3 +70,39 @@ def test_denoise_signal(hostsim_lib, oracle_mod, weights_bytes):
         assert out.shape == ref.shape, n
         assert np.abs(out - ref).max() <= 2e-5, n
     assert np.abs(out).max() <= 1.0
+
+
+def test_host_calls_in_chunks_are_bit_identical(hostsim_lib, monkeypatch):
+    """A long host-buffer call crosses the bus in chunks of frames (include/nnn_batch.h nnn_batch_process_host); the chunks must
+    not show: planar f32, and packed int16 stereo with the dropped first frame (outputs one frame ahead of their inputs)."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd import _ffi
+    pcm = _speech(7, 4)
+    planar = np.ascontiguousarray(pcm.T.reshape(4, 7, 480).astype(np.float32))
+    inter = np.ascontiguousarray(pcm.reshape(-1, 2, 2).transpose(1, 0, 2))   # 2 groups x 2 channels
+    res = {}
+    for chunk in ("0", "2", "3"):
+        monkeypatch.setenv("NNN_HOST_CHUNK", chunk)
+        bd = nn.BatchDenoiser(4, lib=hostsim_lib)
+        a, va = bd.process(planar)
+        bd.reset()
+        b, vb = bd.process_pcm(inter, _ffi.PCM_I16, 2, discard_first=True)
+        assert b.shape == (2, 6 * 480, 2)
+        res[chunk] = (a, va, b, vb)
+    for chunk in ("2", "3"):
+        for u, v in zip(res["0"], res[chunk]):
+            assert np.array_equal(u, v), chunk
+
+
+def test_pinned_host_arrays(hostsim_lib):
+    """pinned_empty arrays behave like any other numpy array (and free their block with their last view)."""
+    import nnnoiseless_amd as nn
+    x = nn.pinned_empty((3, 2, 480), lib=hostsim_lib)
+    x[:] = _speech(2, 3).T.reshape(3, 2, 480)
+    out, vad = nn.pinned_empty((3, 2, 480), lib=hostsim_lib), nn.pinned_empty((2, 3), lib=hostsim_lib)
+    ref, vref = nn.BatchDenoiser(3, lib=hostsim_lib).process(np.array(x))
+    o, v = nn.BatchDenoiser(3, lib=hostsim_lib).process(x, out=out, vad=vad)
+    assert o is out and v is vad and np.array_equal(out, ref) and np.array_equal(vad, vref)
+    view = out[1]
+    del out, o
+    assert np.array_equal(view, ref[1])
