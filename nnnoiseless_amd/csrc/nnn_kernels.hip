@@ -2133,7 +2133,7 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
 
 // ---------------------------------------------------------------------------------------------
 // K10w rnn, layer-pipelined ("wavefront"): the same computation as k_rnn for models of the built-in shape class (at most 2 / 2 /
-//     3 / 6 neuron blocks of 16 in the input dense, vad, noise and denoise layers), 16 stream rows per block, 10 waves.
+//     3 / 6 neuron blocks of 16 in the input dense, vad, noise and denoise layers), 16 stream rows per block, 12 waves.
 //     The chain of a frame -- dense, three GRUs of two phases each, output dense -- is eleven dependent phases of ~1-2 us of
 //     mostly latency; here the layers of DIFFERENT frames run side by side, each on its own waves: in tick t the vad GRU works
 //     on frame t, the noise GRU on frame t - 1, the denoise GRU on frame t - 2, the output layer on frame t - 3, the input
@@ -2143,8 +2143,11 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
 //     slot of that frame (noise: 2 slots, denoise: 3), so nothing is overwritten before its last reader has passed; all
 //     matrices use the column coordinates of the packed weights (k_rnn's single input matrix), each holding the window its
 //     layer reads.  Roles (every phase of every layer is a latency chain, so no wave carries two of the long ones): waves 0..5
-//     denoise neuron block w; waves 6..8 noise block w - 6; waves 9, 10 vad block w - 9 plus the output and input dense units
-//     (dealt alternately); wave 11 features (lane = row), vad output, feature fan-out.
+//     denoise neuron block w, the first two also an input dense unit each in the second phase (their shortest); waves 6..8
+//     noise block w - 6 and, between them, the feature fan-out; waves 9, 10 vad block w - 9 plus an output dense unit each;
+//     wave 11 the feature stage (lane = (row, part)) and the vad output.  Measured per tick at 65 536 streams
+//     (scripts/gpu_stamps_rnn.sh): first phase 3.7-3.9 us on every role, second 1.5-2.6 us (round 2a: 5.8 + 3.4, both set by
+//     the features wave and the vad waves, which then also carried the input dense layer and the fan-out).
 // ---------------------------------------------------------------------------------------------
 constexpr int WF_ROWS = 16, WF_WAVES = 12, WF_FS_W = 72;   // feature staging: the input dense layer's two k-steps wide + 8
 
@@ -2253,6 +2256,26 @@ __device__ __forceinline__ WfFeatIn wf_features_in(const WfWeights &w)
     in.silent = (int)w.h.f[0][0].x;
     return in;
 }
+// outputs kb + part of the feature stage, all of one kind (compile-time, so every address below is a base + a constant):
+// KIND 0: ceps + ring[-1] + ring[-2]; 1: the value itself; 2: ceps - ring[-2]; 3: ceps - 2 ring[-1] + ring[-2] -- each as
+// (v0 + a) + c with features_row's a and c, zeros included.  src_b / rb: first input of the kind / first ring band, for part 0.
+template <int KIND, int KB, int SRC_B, int RB, bool HALF>
+__device__ __forceinline__ void wf_feature_outputs(const Buffers &b, int f, int tile, int trow, int part, bool silent, const float *cnb_l,
+                                                   const float *r1_l, const float *r2_l, unsigned short *fs_l)
+{
+    constexpr int rm = WF_ROWS;
+    if (HALF && part >= 2) return;   // (the kind's last two outputs)
+    const float v0 = cnb_l[SRC_B * rm];
+    const float v1 = (KIND == 0 || KIND == 3) ? r1_l[RB * rm] : 0.0f;
+    const float v2 = (KIND == 0 || KIND == 2 || KIND == 3) ? r2_l[RB * rm] : 0.0f;
+    const float a = KIND == 0 ? v1 : (KIND == 3 ? -(2.0f * v1) : 0.0f);
+    const float c = (KIND == 0 || KIND == 3) ? v2 : (KIND == 2 ? -v2 : 0.0f);
+    float v = (v0 + a) + c;
+    v = silent ? 0.0f : v;
+    if (b.taps) NNN_TIF(b, feat, NFEAT, f, tile, trow)[(size_t)(KB + part) * TILE] = v;
+    store_split(fs_l, rm * WF_FS_W, KB, v);
+}
+
 __device__ __forceinline__ void wf_features(const Buffers &b, const WfFeatIn &in, int f, int tile, int r0, int lane, float *crs, float *dc,
                                             float *cnb, unsigned short *FS, int *live_f, int &mem_id)
 {
@@ -2260,12 +2283,14 @@ __device__ __forceinline__ void wf_features(const Buffers &b, const WfFeatIn &in
     const int row = lane & 15, part = lane >> 4, trow = r0 + row;
     const int pitch = in.pitch;
     const bool silent = in.silent != 0;
+    NNN_STAMPW(b, 8, f == 3);
 #pragma unroll
     for (int i = 0; i < 7; i++) cnb[(7 * part + i) * rm + row] = in.mine[i];
     wave_lds_sync();
     if (part == 0) live_f[row] = silent ? 0 : 1;
     const int c0 = mem_id, c1 = mem_id < 1 ? CEPS_MEM + mem_id - 1 : mem_id - 1;
     const int c2 = mem_id < 2 ? CEPS_MEM + mem_id - 2 : mem_id - 2;
+    NNN_STAMPW(b, 9, f == 3);
     if (!silent) {   // "if there's no audio, avoid messing up the state" (ref: src/features.rs:160-166)
         float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, trow);
         for (int k = part; k < NB; k += 4) {
@@ -2274,42 +2299,54 @@ __device__ __forceinline__ void wf_features(const Buffers &b, const WfFeatIn &in
             crs[(c0 * NB + k) * rm + row] = v;
         }
         mem_id = mem_id + 1 == CEPS_MEM ? 0 : mem_id + 1;
+        NNN_STAMPW(b, 10, f == 3);
         // the 7 distances the new row takes part in, each summed over the 22 bands in order (ref: src/features.rs:203-208);
-        // they read the new row from cnb and the others from the ring (rows j != c0 are not being written)
-        for (int i = part; i < CEPS_MEM - 1; i += 4) {
-            const int j = i < c0 ? i : i + 1;
-            float dist = 0.0f;
+        // they read the new row from cnb and the others from the ring (rows j != c0 are not being written).  A lane takes
+        // partners part and part + 4 together (the fourth part's second one is a shadow of its first, not stored): one read of
+        // the new row serves both sums and the two chains hide each other's latency.
+        const int ia = part, ib = part + 4 < CEPS_MEM - 1 ? part + 4 : part;
+        const int ja = ia < c0 ? ia : ia + 1, jb = ib < c0 ? ib : ib + 1;
+        const float *ra = crs + (ja * NB) * rm + row, *rb = crs + (jb * NB) * rm + row, *nw = cnb + row;
+        float da = 0.0f, db = 0.0f;
 #pragma unroll
-            for (int k = 0; k < NB; k++) {
-                const float d = cnb[k * rm + row] - crs[(j * NB + k) * rm + row];
-                dist += d * d;
-            }
-            dc[pair_index(j < c0 ? j : c0, j < c0 ? c0 : j) * rm + row] = dist;
+        for (int k = 0; k < NB; k++) {
+            const float x = nw[k * rm];
+            const float ea = x - ra[k * rm], eb = x - rb[k * rm];
+            da += ea * ea;
+            db += eb * eb;
         }
+        dc[pair_index(ja < c0 ? ja : c0, ja < c0 ? c0 : ja) * rm + row] = da;
+        if (part + 4 < CEPS_MEM - 1) dc[pair_index(jb < c0 ? jb : c0, jb < c0 ? c0 : jb) * rm + row] = db;
     }
+    NNN_STAMPW(b, 11, f == 3);
     wave_lds_sync();
-    // outputs k = part, part + 4, ...: 0..39 without a branch (every output is v0 [+ a v1] [+- v2] on the new cepstrum v0 and the
-    // two ring rows before it, the operations of features_row in its order; the LDS reads of several travel together)
-#pragma unroll 2
-    for (int j = 0; j < 10; j++) {
-        const int k = part + 4 * j;
-        const int type = k < 6 ? 0 : (k < NB ? 1 : (k < NB + 6 ? 2 : (k < NB + 12 ? 3 : 4)));
-        const int i0 = type == 2 ? k - NB : (type == 3 ? k - NB - 6 : (type == 4 ? k - 12 : k));   // type 4: cn[22 + (k - 34)]
-        const int i1 = (type == 0 || type == 2 || type == 3) ? i0 : 0;
-        const float v0 = cnb[i0 * rm + row], v1 = crs[(c1 * NB + i1) * rm + row], v2 = crs[(c2 * NB + i1) * rm + row];
-        const float a = type == 0 ? v1 : (type == 3 ? -(2.0f * v1) : 0.0f);
-        const float c = (type == 0 || type == 3) ? v2 : (type == 2 ? -v2 : 0.0f);
-        float v = (v0 + a) + c;
-        v = silent ? 0.0f : v;
-        if (b.taps) NNN_TIF(b, feat, NFEAT, f, tile, trow)[(size_t)k * TILE] = v;
-        store_split(FS, rm * WF_FS_W, row * WF_FS_W + k, v);
+    // outputs 0..39, four at a time (one per part) and one kind at a time: the operations of features_row in its order on the
+    // new cepstrum and the two ring rows before it
+    {
+        const float *cnb_l = cnb + part * rm + row;
+        const float *r1_l = crs + (c1 * NB + part) * rm + row, *r2_l = crs + (c2 * NB + part) * rm + row;
+        unsigned short *fs_l = FS + row * WF_FS_W + part;
+        wf_feature_outputs<0, 0, 0, 0, false>(b, f, tile, trow, part, silent, cnb_l, r1_l, r2_l, fs_l);
+        wf_feature_outputs<0, 4, 4, 4, true>(b, f, tile, trow, part, silent, cnb_l, r1_l, r2_l, fs_l);
+        wf_feature_outputs<1, 6, 6, 0, false>(b, f, tile, trow, part, silent, cnb_l, r1_l, r2_l, fs_l);
+        wf_feature_outputs<1, 10, 10, 0, false>(b, f, tile, trow, part, silent, cnb_l, r1_l, r2_l, fs_l);
+        wf_feature_outputs<1, 14, 14, 0, false>(b, f, tile, trow, part, silent, cnb_l, r1_l, r2_l, fs_l);
+        wf_feature_outputs<1, 18, 18, 0, false>(b, f, tile, trow, part, silent, cnb_l, r1_l, r2_l, fs_l);
+        wf_feature_outputs<2, NB, 0, 0, false>(b, f, tile, trow, part, silent, cnb_l, r1_l, r2_l, fs_l);
+        wf_feature_outputs<2, NB + 4, 4, 4, true>(b, f, tile, trow, part, silent, cnb_l, r1_l, r2_l, fs_l);
+        wf_feature_outputs<3, NB + 6, 0, 0, false>(b, f, tile, trow, part, silent, cnb_l, r1_l, r2_l, fs_l);
+        wf_feature_outputs<3, NB + 10, 4, 4, true>(b, f, tile, trow, part, silent, cnb_l, r1_l, r2_l, fs_l);
+        wf_feature_outputs<1, NB + 12, NB, 0, false>(b, f, tile, trow, part, silent, cnb_l, r1_l, r2_l, fs_l);       // cn[22 + ..]: the correlation DCT
+        wf_feature_outputs<1, NB + 16, NB + 4, 0, true>(b, f, tile, trow, part, silent, cnb_l, r1_l, r2_l, fs_l);
     }
+    NNN_STAMPW(b, 12, f == 3);
     if (part < 2) {   // k = 40 (pitch) on part 0, k = 41 (spectral variability) on part 1
         float v = part == 0 ? 0.01f * ((float)pitch - 300.0f) : spectral_variability(dc, row, rm);
         v = silent ? 0.0f : v;
         if (b.taps) NNN_TIF(b, feat, NFEAT, f, tile, trow)[(size_t)(40 + part) * TILE] = v;
         store_split(FS, rm * WF_FS_W, row * WF_FS_W + 40 + part, v);
     }
+    NNN_STAMPW(b, 13, f == 3);
 }
 
 // dense unit nbi of layer L on the 16 rows of the block; sink(row, neuron, value).  Its weights are requested by wf_dense_load,
@@ -2473,9 +2510,21 @@ __global__ void __launch_bounds__(64 * WF_WAVES) k_rnn_wf(Buffers b, RnnPlan pl,
         NNN_STAMPW(b, 32 + 5 * srole, t == 2 && srole >= 0);
         // ---------------- second phase
         if (wave < W_N) {
+            // the denoise units' second phase is the shortest of all: the first waves also take the input dense layer of
+            // frame ff (ref: src/rnn.rs:353-355) on the features staged in the first phase; two k-steps (42 features)
+            WfDenseW<2> dw;
+            const bool mine_d = on_f && wave < pl.dense.nb;
             if (on_d && wave < pl.dn.nb)
                 wf_gru_b(pl.dn, RSdn, wp.sw_dn, Wq, wts, tab, live + 16 * (fd & 7), wave, lane, ua,
                          [&](int row, int n, float v) { store_split(SPdn, rm * wp.sw_dn, row * wp.sw_dn + n, v); });
+            if (mine_d) {
+                unsigned short *Xnn = Xn + (ff & 1) * 3 * rm * wp.w_n;
+                wf_dense_load(dw, pl.dense, Wq, fpar, wave, lane);
+                wf_dense(pl.dense, FS - cF, WF_FS_W, Wq, dw, tab, wave, lane, [&](int row, int n, float v) {
+                    store_split(Xv, rm * wp.w_v, row * wp.w_v + n, v);                      // vad window starts at cD
+                    store_split(Xnn, rm * wp.w_n, row * wp.w_n + (cD - cV) + n, v);
+                });
+            }
         } else if (wave < W_V) {
             if (on_n && wave - W_N < pl.noise.nb) {
                 unsigned short *Xd = Xdn + (fn % 3) * 3 * rm * wp.w_dn;   // the denoise layer's input of the same frame
@@ -2484,9 +2533,18 @@ __global__ void __launch_bounds__(64 * WF_WAVES) k_rnn_wf(Buffers b, RnnPlan pl,
                     store_split(Xd, rm * wp.w_dn, row * wp.w_dn + n, v);
                 });
             }
+            if (on_f) {
+                // feature fan-out, dealt over the noise waves: the staged features of frame ff -> the noise and denoise inputs
+                // of that frame (48 columns)
+                unsigned short *Xnn = Xn + (ff & 1) * 3 * rm * wp.w_n, *Xd = Xdn + (ff % 3) * 3 * rm * wp.w_dn;
+                for (int i = 64 * (wave - W_N) + lane; i < 3 * rm * 6; i += 64 * (W_V - W_N)) {
+                    const int plx = i / (rm * 6), rem = i - plx * rm * 6, row = rem / 6, c8 = rem - row * 6;
+                    const uint4 v = *(const uint4 *)(FS + (size_t)plx * rm * WF_FS_W + row * WF_FS_W + 8 * c8);
+                    *(uint4 *)(Xnn + (size_t)plx * rm * wp.w_n + row * wp.w_n + (cF - cV) + 8 * c8) = v;
+                    *(uint4 *)(Xd + (size_t)plx * rm * wp.w_dn + row * wp.w_dn + cF + 8 * c8) = v;
+                }
+            }
         } else if (wave < W_F) {
-            WfDenseW<2> dw;   // the input dense layer reads the 42 features: two k-steps
-            const bool mine_d = on_f && wave - W_V < pl.dense.nb;
             if (on_v && wave - W_V < pl.vad.nb) {
                 unsigned short *Xnn = Xn + (fv & 1) * 3 * rm * wp.w_n, *Xd = Xdn + (fv % 3) * 3 * rm * wp.w_dn;
                 wf_gru_b(pl.vad, RSv, wp.sw_v, Wq, wts, tab, live + 16 * (fv & 7), wave - W_V, lane, ua, [&](int row, int n, float v) {
@@ -2495,25 +2553,7 @@ __global__ void __launch_bounds__(64 * WF_WAVES) k_rnn_wf(Buffers b, RnnPlan pl,
                     store_split(Xd, rm * wp.w_dn, row * wp.w_dn + cV + n, v);
                 });
             }
-            if (mine_d) {   // input dense of frame ff (ref: src/rnn.rs:353-355) on the features staged in the first phase
-                unsigned short *Xnn = Xn + (ff & 1) * 3 * rm * wp.w_n;
-                wf_dense_load(dw, pl.dense, Wq, fpar, wave - W_V, lane);
-                wf_dense(pl.dense, FS - cF, WF_FS_W, Wq, dw, tab, wave - W_V, lane, [&](int row, int n, float v) {
-                    store_split(Xv, rm * wp.w_v, row * wp.w_v + n, v);                      // vad window starts at cD
-                    store_split(Xnn, rm * wp.w_n, row * wp.w_n + (cD - cV) + n, v);
-                });
-            }
         } else {
-            if (on_f) {
-                // feature fan-out: the staged features of frame ff -> the noise and denoise inputs of that frame (48 columns)
-                unsigned short *Xnn = Xn + (ff & 1) * 3 * rm * wp.w_n, *Xd = Xdn + (ff % 3) * 3 * rm * wp.w_dn;
-                for (int i = lane; i < 3 * rm * 6; i += 64) {
-                    const int plx = i / (rm * 6), rem = i - plx * rm * 6, row = rem / 6, c8 = rem - row * 6;
-                    const uint4 v = *(const uint4 *)(FS + (size_t)plx * rm * WF_FS_W + row * WF_FS_W + 8 * c8);
-                    *(uint4 *)(Xnn + (size_t)plx * rm * wp.w_n + row * wp.w_n + (cF - cV) + 8 * c8) = v;
-                    *(uint4 *)(Xd + (size_t)plx * rm * wp.w_dn + row * wp.w_dn + cF + 8 * c8) = v;
-                }
-            }
             if (on_n && rowl) {
                 // vad output of frame fn, 1 x nv, lane = stream (ref: src/rnn.rs:359), from the copy of that frame's vad state in
                 // the noise layer's input (columns 0.. of its window; not rewritten before tick fn + 2)
