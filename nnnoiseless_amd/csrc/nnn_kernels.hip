@@ -35,6 +35,9 @@ namespace nnn {
 #define NNN_STAMP(b, i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) (b).stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 // the same from lane 0 of any wave of block 0, when `cond` holds (role-by-role breakdowns)
 #define NNN_STAMPW(b, i, cond) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (cond)) (b).stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#ifndef NNN_WFSTAMP_PHASE
+#define NNN_WFSTAMP_PHASE 1
+#endif
 #else
 #define NNN_STAMP(b, i) do { } while (0)
 #define NNN_STAMPW(b, i, cond) do { } while (0)
@@ -2506,6 +2509,9 @@ __global__ void __launch_bounds__(64 * WF_WAVES) k_rnn_wf(Buffers b, RnnPlan pl,
             if (ff + 1 >= 0 && ff + 1 < g) wf_features_load(wts, b, ff + 1, tile, r0, lane);   // the next tick's inputs start travelling
         }
         NNN_STAMPW(b, 31 + 5 * srole, t == 2 && srole >= 0);
+#if defined(NNN_STAMPS) && NNN_WFSTAMP_PHASE == 1
+        NNN_STAMPW(b, 14 + wave0, t == 2);   // every wave's end of the first phase (scripts/gpu_stamps_rnn.sh)
+#endif
         lds_barrier();
         NNN_STAMPW(b, 32 + 5 * srole, t == 2 && srole >= 0);
         // ---------------- second phase
@@ -2564,6 +2570,9 @@ __global__ void __launch_bounds__(64 * WF_WAVES) k_rnn_wf(Buffers b, RnnPlan pl,
             }
         }
         NNN_STAMPW(b, 33 + 5 * srole, t == 2 && srole >= 0);
+#if defined(NNN_STAMPS) && NNN_WFSTAMP_PHASE == 2
+        NNN_STAMPW(b, 14 + wave0, t == 2);   // ... or of the second
+#endif
         lds_barrier();
         NNN_STAMPW(b, 34 + 5 * srole, t == 2 && srole >= 0);
     }
