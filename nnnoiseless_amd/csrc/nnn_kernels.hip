@@ -1152,9 +1152,15 @@ template <int R> __device__ __forceinline__ void dftR(float2 *v)
 // ~100 cycles instead of a trip to L2.  After the tables are in place (one __syncthreads) the waves never meet again:
 // each synchronises only with itself (wave_lds_sync) on its own LDS region.
 constexpr int FFT_SPB = 4;
+// Per-bin arrays that the band sums read (lane = a segment of <= 8 consecutive bins: neighbouring lanes 8 floats apart, every
+// read 8-way bank-conflicted) are kept skewed, bin k at k + k / 8: neighbouring
+// lanes then sit 9 floats apart.  Lanes that walk the bins in order (k = lane + 64 u) pay nothing: the skew of their index is a
+// per-lane constant.  k_fft_xp 19.6 -> 18.9 us per frame at 4096 streams, 325 -> 321 at 65536 (same box).
+__device__ __forceinline__ int bsk(int k) { return k + (k >> 3); }
+constexpr int BSK_LEN = 400 + 400 / 8;
 struct FftLds {
     float2 tw[NFFT];           // exp(-2 pi i k / 960), k < 480; the other half of the circle is the negation
-    float frac[400];           // triangular band weights (ref: src/lib.rs:65-82)
+    float frac[BSK_LEN];       // triangular band weights (ref: src/lib.rs:65-82), skewed (bsk)
     unsigned char band[400];   // band of each bin
     short seg[192];            // band-sum segmentation (see band_sums_par)
 };
@@ -1164,7 +1170,7 @@ __device__ __forceinline__ void fft_tables_load(FftLds &t, const Buffers &b, boo
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int i = tid; i < NFFT; i += nt) t.tw[i] = b.tw960[i];
     for (int i = tid; i < 400; i += nt) {
-        t.frac[i] = b.bin_frac[i];
+        t.frac[bsk(i)] = b.bin_frac[i];
         if (want_band) t.band[i] = (unsigned char)b.bin_band[i];
     }
     for (int i = tid; i < 192; i += nt) t.seg[i] = (short)b.seg[i];
@@ -1266,10 +1272,11 @@ __device__ __forceinline__ void band_sums_par(const FftLds &t, const float *cons
 #pragma unroll
         for (int q = 0; q < NQ; q++) { pa[q] = 0.0f; pb[q] = 0.0f; }
         for (int k = k0; k < k0 + cnt; k++) {
-            const float fr = t.frac[k];
+            const int ks = bsk(k);
+            const float fr = t.frac[ks];
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
-                const float x = v[q][k];
+                const float x = v[q][ks];
                 pa[q] = fmaf(1.0f - fr, x, pa[q]);
                 pb[q] = fmaf(fr, x, pb[q]);
             }
@@ -1372,11 +1379,11 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
         const int k = lane + 64 * u;
         if (k < FREQ) dx[k] = X[u];
     }
-    float *vv = (float *)Z, *vc = vv + 400;
+    float *vv = (float *)Z, *vc = vv + BSK_LEN;   // per-bin quantities of the band sums, skewed (bsk)
 #pragma unroll
     for (int u = 0; u < 7; u++) {
         const int k = lane + 64 * u;
-        if (k < 400) vv[k] = X[u].x * X[u].x + X[u].y * X[u].y;
+        if (k < 400) vv[bsk(k)] = X[u].x * X[u].x + X[u].y * X[u].y;
     }
     wave_lds_sync();
     float exv;
@@ -1402,8 +1409,8 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     for (int u = 0; u < 7; u++) {
         const int k = lane + 64 * u;
         if (k < 400) {
-            vv[k] = Y[u].x * Y[u].x + Y[u].y * Y[u].y;
-            vc[k] = X[u].x * Y[u].x + X[u].y * Y[u].y;
+            vv[bsk(k)] = Y[u].x * Y[u].x + Y[u].y * Y[u].y;
+            vc[bsk(k)] = X[u].x * Y[u].x + X[u].y * Y[u].y;
         }
     }
     wave_lds_sync();
@@ -2597,7 +2604,7 @@ __device__ __forceinline__ float interp_gain(const float *g, int k, const float 
 {
     if (k >= 400) return 0.0f;
     int i = bin_band[k];
-    float frac = bin_frac[k];
+    float frac = bin_frac[bsk(k)];   // (the LDS table is skewed)
     return (1.0f - frac) * g[i] + frac * g[i + 1];
 }
 
@@ -2690,7 +2697,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
                     X.x = X.x + Pr[u].x * rf;
                     X.y = X.y + Pr[u].y * rf;
                     Xr[u] = X;
-                    if (k < 400) ebuf[k] = X.x * X.x + X.y * X.y;
+                    if (k < 400) ebuf[bsk(k)] = X.x * X.x + X.y * X.y;
                 }
             }
             wave_lds_sync();
