@@ -1171,11 +1171,16 @@ extern "C" int nnn_batch_set_schedule(nnn_batch *h, int mode, int lanes)
 // ---- training-feature rows (include/nnn_train.h) ---------------------------------------------------------------------
 struct nnn_train {
     nnn_batch *comb = nullptr, *clean = nullptr, *noise = nullptr;   // three sets of DenoiseFeatures state
+    float *stage = nullptr;          // device staging of the host entry point (grow-only): [signal | noise | combined | vad | rows]
+    int32_t *stage_cut = nullptr;
+    size_t stage_frames = 0;         // frames the staging holds
 };
 
 extern "C" void nnn_train_destroy(nnn_train *t)
 {
     if (!t) return;
+    if (t->stage) hipFree(t->stage);
+    if (t->stage_cut) hipFree(t->stage_cut);
     nnn_batch_destroy(t->comb);
     nnn_batch_destroy(t->clean);
     nnn_batch_destroy(t->noise);
@@ -1272,35 +1277,64 @@ extern "C" int nnn_train_process_host(nnn_train *t, const float *signal, const f
     nnn_batch *h = t->comb;
     HIPCHK(hipSetDevice(h->device));
     const size_t S = (size_t)h->S, na = S * n_frames * FRAME, nl = S * n_frames;
-    float *d = nullptr;   // [signal | noise | combined | vad | rows], cutoff apart
-    int32_t *dc = nullptr;
-    hipError_t e;
-    {
+    if ((size_t)n_frames > t->stage_frames) {   // the staging grows as needed and is kept (per-call hipMalloc / hipFree cost more than a group)
         NNN_RT_LOCK;
-        HIPCHK(hipMalloc((void **)&d, (3 * na + nl + nl * TRAIN_COLS) * sizeof(float)));
-        e = hipMalloc((void **)&dc, nl * sizeof(int32_t));
+        if (int rc = quiesce(h)) return rc;
+        if (t->stage) HIPCHK(hipFree(t->stage));
+        if (t->stage_cut) HIPCHK(hipFree(t->stage_cut));
+        t->stage = nullptr;
+        t->stage_cut = nullptr;
+        t->stage_frames = 0;
+        HIPCHK(hipMalloc((void **)&t->stage, (3 * na + nl + nl * TRAIN_COLS) * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&t->stage_cut, nl * sizeof(int32_t)));
+        t->stage_frames = (size_t)n_frames;
     }
-    float *dv = d + 3 * na, *dr = dv + nl;
-    if (e == hipSuccess) e = hipMemcpyAsync(d, signal, na * 4, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + na, noise, na * 4, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + 2 * na, combined, na * 4, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dv, vad, nl * 4, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dc, cutoff, nl * 4, hipMemcpyHostToDevice, h->stream);
-    int rc = e == hipSuccess ? 0 : fail("host staging failed: %s", hipGetErrorString(e));
-    if (!rc) rc = nnn_train_process_device(t, d, d + na, d + 2 * na, dc, dv, dr, n_frames, (size_t)n_frames * FRAME, FRAME, h->stream);
-    if (!rc) {
-        e = hipMemcpyAsync(rows, dr, nl * TRAIN_COLS * 4, hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        if (e != hipSuccess) rc = fail("copy back failed: %s", hipGetErrorString(e));
-    } else {
-        hipStreamSynchronize(h->stream);
+    float *d = t->stage, *dv = d + 3 * na, *dr = dv + nl;
+    int32_t *dc = t->stage_cut;
+    // Like the denoiser's host calls (process_host_chunked): chunk i + 1 crosses the bus while chunk i is turned into rows and
+    // chunk i - 1's rows return.  Audio is [stream][frame][480] (a chunk: 2-D copies, one row per stream), labels and rows are
+    // frame-major (a chunk: one run each).
+    int C = n_frames > 2 * GROUP && S * GROUP * FRAME * 4 >= ((size_t)1 << 20) ? GROUP : n_frames;
+    if (h->host_chunk >= 0) C = h->host_chunk > 0 && h->host_chunk < n_frames ? h->host_chunk : n_frames;   // NNN_HOST_CHUNK (tests)
+    const int nch = (n_frames + C - 1) / C;
+    if (!h->copy_in) {
+        HIPCHK(hipStreamCreateWithFlags(&h->copy_in, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&h->copy_out, hipStreamNonBlocking));
     }
-    {
-        NNN_RT_LOCK;
-        hipFree(d);
-        if (dc) hipFree(dc);
+    while ((int)h->ev_up.size() < nch) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        h->ev_up.push_back(a);
+        h->ev_run.push_back(b);
     }
-    return rc;
+    const size_t pitch = (size_t)n_frames * FRAME * 4;
+    const float *src[3] = {signal, noise, combined};
+    int rc = 0;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < nch && !rc && e == hipSuccess; i++) {
+        const int t0 = i * C, n = t0 + C < n_frames ? C : n_frames - t0;
+        const size_t off = (size_t)t0 * FRAME, lo = (size_t)t0 * S;
+        for (int k = 0; k < 3 && e == hipSuccess; k++)
+            e = hipMemcpy2DAsync(d + k * na + off, pitch, src[k] + off, pitch, (size_t)n * FRAME * 4, S, hipMemcpyHostToDevice, h->copy_in);
+        if (e == hipSuccess) e = hipMemcpyAsync(dv + lo, vad + lo, (size_t)n * S * 4, hipMemcpyHostToDevice, h->copy_in);
+        if (e == hipSuccess) e = hipMemcpyAsync(dc + lo, cutoff + lo, (size_t)n * S * 4, hipMemcpyHostToDevice, h->copy_in);
+        if (e == hipSuccess) e = hipEventRecord(h->ev_up[i], h->copy_in);
+        if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->ev_up[i], 0);
+        if (e != hipSuccess) break;
+        rc = nnn_train_process_device(t, d + off, d + na + off, d + 2 * na + off, dc + lo, dv + lo, dr + lo * TRAIN_COLS, n,
+                                      (size_t)n_frames * FRAME, FRAME, h->stream);
+        if (rc) break;
+        e = hipEventRecord(h->ev_run[i], h->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(h->copy_out, h->ev_run[i], 0);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(rows + lo * TRAIN_COLS, dr + lo * TRAIN_COLS, (size_t)n * S * TRAIN_COLS * 4, hipMemcpyDeviceToHost, h->copy_out);
+    }
+    const hipError_t e1 = hipStreamSynchronize(h->copy_in), e2 = hipStreamSynchronize(h->stream), e3 = hipStreamSynchronize(h->copy_out);
+    if (rc) return rc;
+    if (e == hipSuccess) e = e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3);
+    if (e != hipSuccess) return fail("host transfer failed: %s", hipGetErrorString(e));
+    return 0;
 }
 
 // ---- model entry points -------------------------------------------------------------------------

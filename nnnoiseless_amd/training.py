@@ -21,17 +21,20 @@ class TrainingFeatures:
         if not self._h:
             raise RuntimeError("nnnoiseless_amd: " + self._lib.error())
 
-    def process(self, signal, noise, combined, band_gain_cutoff, vad):
+    def process(self, signal, noise, combined, band_gain_cutoff, vad, rows=None):
         """signal / noise / combined: float32 [n_streams, n_frames, 480] (i16 range); band_gain_cutoff int32 and vad
         float32 [n_frames, n_streams].  Returns rows float32 [n_frames, n_streams, 87]:
-        42 features of the mix | 22 gains | 22 noise levels | vad."""
+        42 features of the mix | 22 gains | 22 noise levels | vad.  Long calls cross the bus in 16-frame chunks beside the
+        kernels; arrays from nnnoiseless_amd.pinned_empty (inputs, and `rows` handed in) go by DMA."""
         signal, noise, combined = (_ffi.as_f32(a) for a in (signal, noise, combined))
         S, T, F = signal.shape
         assert S == self.n_streams and F == FRAME_SIZE and noise.shape == signal.shape == combined.shape
         cut = np.ascontiguousarray(band_gain_cutoff, dtype=np.int32)
         vad = _ffi.as_f32(vad)
         assert cut.shape == (T, S) and vad.shape == (T, S)
-        rows = np.empty((T, S, ROW_WIDTH), np.float32)
+        if rows is None:
+            rows = np.empty((T, S, ROW_WIDTH), np.float32)
+        assert rows.shape == (T, S, ROW_WIDTH) and rows.dtype == np.float32 and rows.flags.c_contiguous
         self._lib.check(self._lib.L.nnn_train_process_host(self._h, _ffi.ptr(signal), _ffi.ptr(noise), _ffi.ptr(combined),
                                                            _ffi.ptr(cut), _ffi.ptr(vad), _ffi.ptr(rows), T))
         return rows

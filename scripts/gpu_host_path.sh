@@ -12,3 +12,7 @@ for cfg in "4096 48 6" "4096 192 3" "16384 48 4"; do
   echo "== chunked, $1 streams x $2 frames"; PYTHONPATH=. timeout 300 python scripts/host_path_rate.py $1 $2 $3 2>&1 | grep frames/s
 done
 } | tee gpurun_out/host_path.txt
+{
+echo "== training rows, one piece (NNN_HOST_CHUNK=0), 4096 triples x 48 frames"; NNN_HOST_CHUNK=0 PYTHONPATH=. timeout 300 python scripts/train_host_rate.py 4096 48 4 2>&1 | grep rows/s
+echo "== training rows, chunked, 4096 triples x 48 frames"; PYTHONPATH=. timeout 300 python scripts/train_host_rate.py 4096 48 4 2>&1 | grep rows/s
+} | tee -a gpurun_out/host_path.txt

@@ -510,6 +510,17 @@ def test_training_rows(nn, oracle_mod, weights_bytes):
     check_rows(rows, ref)
 
 
+def test_training_host_call_in_chunks(nn, monkeypatch):
+    """A long host call of the training-row path crosses the bus in 16-frame chunks beside the kernels: same rows as in one piece."""
+    from nnnoiseless_amd.training import TrainingFeatures
+    from train_fixtures import make_training_inputs
+    sig, noise, comb, cutoff, vad = make_training_inputs(10, 600, 40)
+    rows = TrainingFeatures(600).process(sig, noise, comb, cutoff, vad)            # chunks of 16, 16, 8 frames
+    monkeypatch.setenv("NNN_HOST_CHUNK", "0")
+    ref = TrainingFeatures(600).process(sig, noise, comb, cutoff, vad)
+    assert np.array_equal(rows, ref)
+
+
 def test_states_on_concurrent_threads(nn, golden_io):
     """SURVEY 8(b) threading: rnnoise-style states are independent and may be driven from different threads at once
     (the reference's DenoiseState is Send + Sync, src/denoise.rs:125); each thread's output equals a lone run."""

@@ -30,3 +30,16 @@ def test_training_rows(hostsim_lib, oracle_mod, weights_bytes):
     tf.reset()
     again = tf.process(sig[:, :5], noise[:, :5], comb[:, :5], cutoff[:5], vad[:5])
     assert np.array_equal(again, rows[:5])
+
+
+def test_training_host_call_in_chunks(hostsim_lib, monkeypatch):
+    """The host entry point ships a long call in chunks of frames (uploads, kernels and downloads side by side on the GPU):
+    the chunks must not show."""
+    from nnnoiseless_amd.training import TrainingFeatures
+    from train_fixtures import make_training_inputs
+    sig, noise, comb, cutoff, vad = make_training_inputs(6, 9, 7)
+    res = []
+    for chunk in ("0", "3"):
+        monkeypatch.setenv("NNN_HOST_CHUNK", chunk)
+        res.append(TrainingFeatures(9, lib=hostsim_lib).process(sig, noise, comb, cutoff, vad))
+    assert np.array_equal(res[0], res[1])
