@@ -88,6 +88,7 @@ struct nnn_batch {
     std::vector<char> stage_host;   // host side of the copy back
     hipStream_t copy_in = nullptr, copy_out = nullptr;   // host-buffer calls in chunks: uploads, downloads (created on first use)
     std::vector<hipEvent_t> ev_up, ev_run;               // per chunk: uploaded, processed
+    int wf_min_g = 0;               // groups shorter than this run k_rnn instead of the layer-pipelined kernel (env NNN_RNN_WF_MIN_G; 0 = by batch size)
     int host_chunk = -1;            // frames per chunk of a host-buffer call (env NNN_HOST_CHUNK): -1 = by call length and size,
                                     // 0 = the whole call in one piece
     StepParams *sp_tab = nullptr;   // device, per-frame parameter table of a call
@@ -290,6 +291,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     if (const char *e = getenv("NNN_PIPELINE")) h->use_pipeline = atoi(e) != 0;
     if (const char *e = getenv("NNN_RAMP")) h->ramp = atoi(e);
     if (const char *e = getenv("NNN_HOST_CHUNK")) h->host_chunk = atoi(e);
+    if (const char *e = getenv("NNN_RNN_WF_MIN_G")) h->wf_min_g = atoi(e);
     if (const char *e = getenv("NNN_PITCH_CHAIN")) h->pitch_chain = atoi(e);
     if (const char *e = getenv("NNN_SCHED")) {
         if (!strcmp(e, "seq")) h->sched = SCHED_SEQ;
@@ -623,7 +625,11 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
     case ST_FFT: L.go(K_FFT_XP, k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0); break;
     case ST_RNN:
         for (const nnn_batch::ModelGroup &G : h->groups) {   // one launch per resident model (a run of whole tiles)
-            if (G.wf)
+            // the layer-pipelined kernel spends g + 4 ticks on g frames: for a lone frame on a batch of many block rounds the
+            // plain kernel's eleven phases are shorter (one frame per call at 16 384 / 32 768 / 65 536 streams: +6 / +7 / +7 %;
+            // at 4096 streams, one round of blocks, the pipelined kernel stays 8 % ahead).  Same bits either way.
+            const int min_g = h->wf_min_g > 0 ? h->wf_min_g : (G.ntiles * (TILE / WF_ROWS) >= 1024 ? 2 : 1);
+            if (G.wf && g >= min_g)
                 L.go(K_RNN, k_rnn_wf, dim3((unsigned)(G.ntiles * (TILE / WF_ROWS))), dim3(64 * WF_WAVES), G.wf_lds, b, G.plan, G.wp, G.wq,
                      G.fpar, G.tile0, g);
             else

@@ -498,6 +498,20 @@ def test_rnn_rows_per_block_variants(nn, oracle_mod, weights_bytes, rows, monkey
 
 # ---- batched training-feature rows -----------------------------------------------------------------
 
+def test_rnn_kernels_agree_bit_for_bit(nn, monkeypatch):
+    """One-frame groups on large batches run k_rnn, longer groups k_rnn_wf (nnn_batch.hip launch_stage): streams that change
+    kernel from call to call must not notice."""
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(32, 454, 9)
+    monkeypatch.setenv("NNN_RNN_WF_MIN_G", "1")
+    ref, vref = nn.BatchDenoiser(454).process(x)
+    monkeypatch.setenv("NNN_RNN_WF_MIN_G", "3")
+    bd = nn.BatchDenoiser(454)
+    parts = [bd.process(x[:, a:b]) for a, b in ((0, 1), (1, 5), (5, 7), (7, 8), (8, 9))]
+    assert np.array_equal(np.concatenate([p[0] for p in parts], axis=1), ref)
+    assert np.array_equal(np.concatenate([p[1] for p in parts], axis=0), vref)
+
+
 def test_training_rows(nn, oracle_mod, weights_bytes):
     """1000 (clean, noise, mix) triples x 30 frames, in two calls, against the oracle's src/training.rs:113-160."""
     from nnnoiseless_amd.training import TrainingFeatures

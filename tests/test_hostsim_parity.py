@@ -301,3 +301,18 @@ def test_pitch_taps_exist_only_after_set_taps(hostsim_lib):
     ref.process(x[:, :2])
     for name in ("xlp", "ac", "xcorr1", "best1", "pitch_search", "pitch"):
         assert np.array_equal(bd.tap(name), ref.tap(name)), name
+
+
+def test_rnn_kernels_agree_bit_for_bit(hostsim_lib, monkeypatch):
+    """One-frame groups on large batches run k_rnn, longer groups the layer-pipelined k_rnn_wf: a stream that changes kernel from
+    call to call (forced here through NNN_RNN_WF_MIN_G) must not notice."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    x = make_streams(31, 5, 7)
+    monkeypatch.setenv("NNN_RNN_WF_MIN_G", "1")
+    ref, vref = nn.BatchDenoiser(5, lib=hostsim_lib).process(x)
+    monkeypatch.setenv("NNN_RNN_WF_MIN_G", "3")
+    bd = nn.BatchDenoiser(5, lib=hostsim_lib)
+    parts = [bd.process(x[:, a:b]) for a, b in ((0, 1), (1, 4), (4, 6), (6, 7))]   # k_rnn, k_rnn_wf, k_rnn, k_rnn
+    assert np.array_equal(np.concatenate([p[0] for p in parts], axis=1), ref)
+    assert np.array_equal(np.concatenate([p[1] for p in parts], axis=0), vref)
