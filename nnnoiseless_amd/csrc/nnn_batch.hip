@@ -857,6 +857,25 @@ extern "C" int nnn_batch_process_pcm_device(nnn_batch *h, const void *d_in, void
                           (long long)L->frame_stride * e, drop, hip_stream);
 }
 
+// the two copy streams of chunked host calls and an (uploaded, processed) event pair per chunk, made on first use
+static int host_copy_streams(nnn_batch *h, int n_chunks)
+{
+    if (h->copy_in && (int)h->ev_up.size() >= n_chunks) return 0;
+    NNN_RT_LOCK;
+    if (!h->copy_in) {
+        HIPCHK(hipStreamCreateWithFlags(&h->copy_in, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&h->copy_out, hipStreamNonBlocking));
+    }
+    while ((int)h->ev_up.size() < n_chunks) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        h->ev_up.push_back(a);
+        h->ev_run.push_back(b);
+    }
+    return 0;
+}
+
 // A long host-buffer call with gap-free frames runs in chunks of C frames: chunk i + 1 crosses the bus on one copy
 // stream while chunk i is processed and chunk i - 1 returns on another (PCIe is full duplex), every transfer a 2-D copy of
 // groups x chunk-bytes straight between the caller's buffers and the device staging (DMA when they are page-locked --
@@ -867,17 +886,7 @@ static int process_host_chunked(nnn_batch *h, const char *in, char *out, float *
     const size_t e = (size_t)pcm_elem_bytes(L->format), groups = (size_t)(h->S / L->channels), fr = (size_t)FRAME * L->channels * e;
     const size_t pitch = groups > 1 ? L->group_stride * e : (size_t)n_frames * fr;
     const int nch = (n_frames + C - 1) / C;
-    if (!h->copy_in) {
-        HIPCHK(hipStreamCreateWithFlags(&h->copy_in, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&h->copy_out, hipStreamNonBlocking));
-    }
-    while ((int)h->ev_up.size() < nch) {
-        hipEvent_t a, b;
-        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-        h->ev_up.push_back(a);
-        h->ev_run.push_back(b);
-    }
+    if (int rc = host_copy_streams(h, nch)) return rc;
     // (the previous call ended with every stream drained, so the staging is free)
     nnn_pcm_layout Lc = *L;
     int rc = 0;
@@ -1303,17 +1312,7 @@ extern "C" int nnn_train_process_host(nnn_train *t, const float *signal, const f
     int C = n_frames > 2 * GROUP && S * GROUP * FRAME * 4 >= ((size_t)1 << 20) ? GROUP : n_frames;
     if (h->host_chunk >= 0) C = h->host_chunk > 0 && h->host_chunk < n_frames ? h->host_chunk : n_frames;   // NNN_HOST_CHUNK (tests)
     const int nch = (n_frames + C - 1) / C;
-    if (!h->copy_in) {
-        HIPCHK(hipStreamCreateWithFlags(&h->copy_in, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&h->copy_out, hipStreamNonBlocking));
-    }
-    while ((int)h->ev_up.size() < nch) {
-        hipEvent_t a, b;
-        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-        h->ev_up.push_back(a);
-        h->ev_run.push_back(b);
-    }
+    if (int rc = host_copy_streams(h, nch)) return rc;
     const size_t pitch = (size_t)n_frames * FRAME * 4;
     const float *src[3] = {signal, noise, combined};
     int rc = 0;
