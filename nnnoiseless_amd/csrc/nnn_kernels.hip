@@ -1232,6 +1232,21 @@ __device__ __forceinline__ void fft480(float2 *buf, const float2 *tw, int lane)
     fft_pass<6, 8, true, false>(buf, tw, lane);
     fft_pass<10, 48, false, false>(buf, tw, lane);
 }
+// The same with the input handed over in registers in the first pass's own order -- lane j < 60 holds elements j + 60 r, r < 8
+// (lanes 60..63 hold anything) -- instead of staged in buf: both callers can produce their input in that order, which saves the
+// staging store, the first pass's reads and a synchronisation per transform.  Every earlier reader of buf must be done.
+__device__ __forceinline__ void fft480_regs(float2 (&v)[8], float2 *buf, const float2 *tw, int lane)
+{
+    dft8(v);
+    if (lane < NFFT / 8) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) buf[9 * lane + r] = v[r];   // skewed, as fft_pass<8, 1, false, true> leaves it
+    }
+    wave_lds_sync();
+    fft_pass<6, 8, true, false>(buf, tw, lane);
+    fft_pass<10, 48, false, false>(buf, tw, lane);
+}
+constexpr int FFT_P1 = NFFT / 8;   // butterflies (= lanes at work) of the first pass
 
 // bin k (0..480) of the real 960-point spectrum from Z = FFT480(x[2n] + i x[2n+1])
 __device__ __forceinline__ float2 rfft_bin(const float2 *Z, const float2 *tw, int k)
@@ -1331,19 +1346,18 @@ __device__ __forceinline__ void window_rfft(const Buffers &b, const float *h, in
 {
     int start = rb + (HIST - WINDOW) - lag;   // in (0, 2 RING)
     if (start >= RING) start -= RING;
+    // sample pairs n = j + 60 r straight into the first pass's registers (w holds the window in the same order)
+    const int j = lane < FFT_P1 ? lane : FFT_P1 - 1;   // (lanes 60..63 shadow lane 59 and store nothing)
+    float2 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const int n = lane + 64 * u;
-        if (n < NFFT) {
-            int i0 = start + 2 * n;
-            if (i0 >= RING) i0 -= RING;
-            const SamplePair v = *(const SamplePair *)(h + i0);   // (i0 + 1 = RING reads the copy of sample 0 kept there)
-            Z[n] = make_float2(v.x * w[u].x, v.y * w[u].y);
-        }
+    for (int r = 0; r < 8; r++) {
+        int i0 = start + 2 * (j + FFT_P1 * r);
+        if (i0 >= RING) i0 -= RING;
+        const SamplePair s = *(const SamplePair *)(h + i0);   // (i0 + 1 = RING reads the copy of sample 0 kept there)
+        v[r] = make_float2(s.x * w[r].x, s.y * w[r].y);
     }
     if (first) __syncthreads();   // tables in place; from here on every wave is on its own
-    else wave_lds_sync();
-    fft480(Z, t.tw, lane);
+    fft480_regs(v, Z, t.tw, lane);
     const float wn = b.wnorm;
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -1362,12 +1376,9 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
 {
     const int lane = threadIdx.x & 63, s = bx * FFT_SPB + (int)(threadIdx.x >> 6), tile = s >> 6, sl = s & 63;
     const int rb = ring_base(sp->slot);
-    float2 w[8];
+    float2 w[8];   // the window at sample pairs j + 60 r: the order of the transforms' first pass (window_rfft)
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const int n = lane + 64 * u;
-        w[u] = n < NFFT ? ((const float2 *)b.window)[n] : make_float2(0.0f, 0.0f);
-    }
+    for (int r = 0; r < 8; r++) w[r] = ((const float2 *)b.window)[(lane < FFT_P1 ? lane : FFT_P1 - 1) + FFT_P1 * r];
     const int lag = WITH_P ? NNN_TI(b.pitch, 1, tile, sl)[0] : 0;
     fft_tables_load(t, b, false);
     const float *h = b.hist + (size_t)s * HSTR;
@@ -2729,27 +2740,23 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
         wave_lds_sync();
         // complex-to-real 960-point inverse as a 480-point complex inverse: Zin[k] = (X[k] + conj X[480-k])
         // + i e^{+2 pi i k/960} (X[k] - conj X[480-k]); stored re/im-swapped so the forward FFT inverts.
+        // (element k = j + 60 r on lane j: the order the transform's first pass wants its input in, see fft480_regs)
         float2 zin[8];
+        {
+            const int j = lane < FFT_P1 ? lane : FFT_P1 - 1;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = lane + 64 * u;
-            if (k < NFFT) {
+            for (int r = 0; r < 8; r++) {
+                const int k = j + FFT_P1 * r;
                 float2 a = A[k], c = A[NFFT - k];
                 float2 e2 = make_float2(a.x + c.x, a.y - c.y);
                 float2 d = make_float2(a.x - c.x, a.y + c.y);
                 float2 w = t.tw[k];
                 w.y = -w.y;
                 float2 o2 = cmulf(d, w);
-                zin[u] = make_float2(e2.y + o2.x, e2.x - o2.y);
+                zin[r] = make_float2(e2.y + o2.x, e2.x - o2.y);
             }
         }
-        wave_lds_sync();
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = lane + 64 * u;
-            if (k < NFFT) A[k] = zin[u];
-        }
-        wave_lds_sync();
+        wave_lds_sync();   // the spectrum has been read: the transform takes its buffer
         // (the window is requested here, not with the frame's other loads: its 16 registers would be live across the whole frame and
         // spill; it travels behind the transform)
         float2 wlo[4], whi[4];   // the two window halves, as sample pairs
@@ -2760,7 +2767,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
             wlo[u] = on ? ((const float2 *)b.window)[n] : make_float2(0.0f, 0.0f);
             whi[u] = on ? ((const float2 *)b.window)[FRAME / 2 + n] : make_float2(0.0f, 0.0f);
         }
-        fft480(A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
+        fft480_regs(zin, A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
         if (lane == 0 && vad_out && s < b.S) vad_out[s] = vadv;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
