@@ -1248,16 +1248,6 @@ __device__ __forceinline__ void fft480_regs(float2 (&v)[8], float2 *buf, const f
 }
 constexpr int FFT_P1 = NFFT / 8;   // butterflies (= lanes at work) of the first pass
 
-// bin k (0..480) of the real 960-point spectrum from Z = FFT480(x[2n] + i x[2n+1])
-__device__ __forceinline__ float2 rfft_bin(const float2 *Z, const float2 *tw, int k)
-{
-    float2 zk = Z[k % NFFT], zn = Z[(NFFT - k) % NFFT];
-    float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-    float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));   // (zk - conj zn) / (2i)
-    float2 wo = cmulf(o, tw960_at(tw, k));
-    return cadd(e, wo);
-}
-
 // band sums in the reference's accumulation order (ref: src/lib.rs:65-82): out[b] first receives
 // the frac-weighted terms of interval b-1, then the (1-frac)-weighted terms of interval b.
 __device__ __forceinline__ float band_sum(const float *v, int bnd, const float *bin_frac)
@@ -1358,17 +1348,30 @@ __device__ __forceinline__ void window_rfft(const Buffers &b, const float *h, in
     }
     if (first) __syncthreads();   // tables in place; from here on every wave is on its own
     fft480_regs(v, Z, t.tw, lane);
+    // Bins k and 480 - k come from the same two transform outputs (E[480 - k] = conj E[k], O[480 - k] = conj O[k], the twiddle
+    // of 480 - k is -conj of k's): a lane takes them as a pair -- one read of each output, one twiddle, one complex product for
+    // both -- and owns bins rfft_slot_bin(lane, u): k = lane + 64 u in slots u < 4 (k <= 240), 480 - k in slot 4 + u (k < 240).
     const float wn = b.wnorm;
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < 4; u++) {
         const int k = lane + 64 * u;
-        if (k < FREQ) {
-            Y[u] = rfft_bin(Z, t.tw, k);
-            Y[u].x *= wn;
-            Y[u].y *= wn;
+        if (k <= NFFT / 2) {
+            const float2 zk = Z[k], zn = Z[k ? NFFT - k : 0];
+            const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+            const float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));   // (zk - conj zn) / (2i)
+            const float2 wo = cmulf(o, t.tw[k]);
+            Y[u] = make_float2((e.x + wo.x) * wn, (e.y + wo.y) * wn);
+            Y[4 + u] = make_float2((e.x - wo.x) * wn, -(e.y - wo.y) * wn);   // conj(E - W O)
         }
     }
     wave_lds_sync();   // the transform has been read: its buffer now takes the per-bin products for the band sums
+}
+// bin of slot u of a lane's spectrum registers (see window_rfft); -1: an empty slot
+__device__ __forceinline__ int rfft_slot_bin(int lane, int u)
+{
+    const int k = lane + 64 * (u & 3);
+    if (u < 4) return k <= NFFT / 2 ? k : -1;
+    return k < NFFT / 2 ? NFFT - k : -1;
 }
 
 template <bool WITH_P>
@@ -1387,14 +1390,14 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     float2 *dx = b.X + (size_t)s * FSTR;
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-        const int k = lane + 64 * u;
-        if (k < FREQ) dx[k] = X[u];
+        const int k = rfft_slot_bin(lane, u);
+        if (k >= 0) dx[k] = X[u];
     }
     float *vv = (float *)Z, *vc = vv + BSK_LEN;   // per-bin quantities of the band sums, skewed (bsk)
 #pragma unroll
-    for (int u = 0; u < 7; u++) {
-        const int k = lane + 64 * u;
-        if (k < 400) vv[bsk(k)] = X[u].x * X[u].x + X[u].y * X[u].y;
+    for (int u = 0; u < 8; u++) {
+        const int k = rfft_slot_bin(lane, u);
+        if (k >= 0 && k < 400) vv[bsk(k)] = X[u].x * X[u].x + X[u].y * X[u].y;
     }
     wave_lds_sync();
     float exv;
@@ -1413,13 +1416,13 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     const int np = b.taps ? FREQ : 400;   // the pitch filter reads bins 0..399 only
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-        const int k = lane + 64 * u;
-        if (k < np) dp[k] = Y[u];
+        const int k = rfft_slot_bin(lane, u);
+        if (k >= 0 && k < np) dp[k] = Y[u];
     }
 #pragma unroll
-    for (int u = 0; u < 7; u++) {
-        const int k = lane + 64 * u;
-        if (k < 400) {
+    for (int u = 0; u < 8; u++) {
+        const int k = rfft_slot_bin(lane, u);
+        if (k >= 0 && k < 400) {
             vv[bsk(k)] = Y[u].x * Y[u].x + Y[u].y * Y[u].y;
             vc[bsk(k)] = X[u].x * Y[u].x + X[u].y * Y[u].y;
         }
