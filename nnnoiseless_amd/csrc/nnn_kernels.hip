@@ -217,6 +217,7 @@ __device__ __forceinline__ void hp_group(const Buffers &b, const StepParams *sp,
 __global__ void __launch_bounds__(64, HP_CH <= 16 ? 3 : 1) k_hp(Buffers b, const StepParams *sp, int g)
 {
     const int lane = threadIdx.x, tile = blockIdx.x, fmt = sp->fmt;
+    wf_setprio_high();   // a lone wave on a serial chain that shares its SIMD with another kernel's wave (+1 % at 4096 streams)
     const bool vec = sp->channels == 1 && ((((size_t)sp->in) | (size_t)sp->group_stride | (size_t)sp->frame_stride) & 15) == 0;
     if (fmt == PCM_F32) { if (vec) hp_group<PCM_F32, true>(b, sp, g, tile, lane); else hp_group<PCM_F32, false>(b, sp, g, tile, lane); }
     else if (fmt == PCM_I16) { if (vec) hp_group<PCM_I16, true>(b, sp, g, tile, lane); else hp_group<PCM_I16, false>(b, sp, g, tile, lane); }
