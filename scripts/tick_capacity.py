@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One 10 ms frame per call, the way a real-time server is driven: H independent batches (handles) of S streams each, every batch
 on its own HIP stream, called round-robin.  Calls of different batches overlap on the GPU; a single batch called back to back
-(bench.py's `tick`) cannot overlap with itself.  usage: tick_capacity.py [streams_per_batch] [batches] [rounds]"""
+(bench.py's `tick`) cannot overlap with itself.  usage: tick_capacity.py [streams_per_batch] [batches] [rounds] [host_threads]"""
 import sys, time
 import torch
 import nnnoiseless_amd as nn
@@ -28,11 +28,29 @@ def rounds(n, f0):
             bds[h].process_device(xs[h].data_ptr() + off, ys[h].data_ptr() + off, vs[h].data_ptr() + f * S * 4, 1, pool * 480, 480,
                                   streams[h].cuda_stream)
 
-rounds(10, 0)
+NT = int(sys.argv[4]) if len(sys.argv) > 4 else 1   # host threads, each driving its share of the batches (ctypes calls release the GIL)
+
+def rounds_threaded(n, f0):
+    import threading
+    def work(t):
+        for r in range(n):
+            f = (f0 + r) % pool
+            for h in range(t, H, NT):
+                off = f * 480 * 4
+                bds[h].process_device(xs[h].data_ptr() + off, ys[h].data_ptr() + off, vs[h].data_ptr() + f * S * 4, 1, pool * 480, 480,
+                                      streams[h].cuda_stream)
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(NT)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+
+run = rounds if NT == 1 else rounds_threaded
+run(10, 0)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-rounds(R, 10)
+run(R, 10)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(f"{H} batches x {S} streams, one frame per call: {H * S * R / dt / 1e6:.2f} M frames/s "
+print(f"{NT} host thread(s), {H} batches x {S} streams, one frame per call: {H * S * R / dt / 1e6:.2f} M frames/s "
       f"({dt / R * 1e6:.0f} us per round of {H} calls = {H * S} streams served; {dt / R / H * 1e6:.0f} us per call)", flush=True)
