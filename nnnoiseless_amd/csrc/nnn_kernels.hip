@@ -138,8 +138,13 @@ template <int FMT, bool VEC> struct HpChunk {
 // ---------------------------------------------------------------------------------------------
 struct HpState { float m0, m1, prev; };
 
+// The history ring is stored in rows: a lane's own 32 results are 128 contiguous bytes of ITS stream, so storing them directly
+// makes every store instruction touch 64 cache lines with 16 bytes each -- measured (same box, stores left out) at 5 % of the whole
+// pipeline's throughput at 4096 streams, more than the kernel's share of anything.  The results of a chunk therefore cross LDS
+// (row stride 33 floats: conflict-free both ways) and leave as 8 stores of 8 streams x 128 contiguous bytes.
+constexpr int HP_LD = HP_CH + 1;
 template <int FMT, bool VEC>
-__device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp, int tile, int lane, HpState &st)
+__device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp, int tile, int lane, HpState &st, float *Ly)
 {
     const int slot = sp->slot;
     const int elem = pcm_elem_bytes(FMT), ch = sp->channels, sstride = ch * elem;
@@ -177,8 +182,22 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp,
 #pragma unroll
                 for (int t = 0; t < HP_CH / 2; t++) dec[(size_t)(DEC_RING + HP_CH / 2 * (c - 1) + t) * TILE] = dvs[t];
             }
+            if (HP_CH == 32) {
+                wave_lds_sync();   // (the previous chunk's rows have been read)
 #pragma unroll
-            for (int q = 0; q < HP_CH / 4; q++) hw[HP_CH / 4 * (c - 1) + q] = make_float4(ys[4 * q], ys[4 * q + 1], ys[4 * q + 2], ys[4 * q + 3]);
+                for (int j = 0; j < HP_CH; j++) Ly[lane * HP_LD + j] = ys[j];
+                wave_lds_sync();
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const int r = 8 * it + (lane >> 3);
+                    const float *y = Ly + r * HP_LD + 4 * (lane & 7);
+                    float4 *hr = (float4 *)(b.hist + (size_t)(tile * TILE + r) * HSTR + slot * FRAME + (c - 1) * HP_CH) + (lane & 7);
+                    *hr = make_float4(y[0], y[1], y[2], y[3]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < HP_CH / 4; q++) hw[HP_CH / 4 * (c - 1) + q] = make_float4(ys[4 * q], ys[4 * q + 1], ys[4 * q + 2], ys[4 * q + 3]);
+            }
             if (slot == 0 && c == 1) h[RING] = ys[0];   // the ring's first sample again behind its end (8-byte reads across the wrap)
         }
         if (c == FRAME / HP_CH) break;
@@ -203,12 +222,12 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp,
 }
 
 template <int FMT, bool VEC>
-__device__ __forceinline__ void hp_group(const Buffers &b, const StepParams *sp, int g, int tile, int lane)
+__device__ __forceinline__ void hp_group(const Buffers &b, const StepParams *sp, int g, int tile, int lane, float *Ly)
 {
     float *hp = NNN_TI(b.hp_mem, 2, tile, lane);
     float *hl = NNN_TI(b.hp_last, 1, tile, lane);
     HpState st{hp[0], hp[TILE], hl[0]};
-    for (int f = 0; f < g; f++) hp_frame<FMT, VEC>(b, sp + f, tile, lane, st);
+    for (int f = 0; f < g; f++) hp_frame<FMT, VEC>(b, sp + f, tile, lane, st, Ly);
     hp[0] = st.m0;
     hp[TILE] = st.m1;
     hl[0] = st.prev;
@@ -219,9 +238,10 @@ __global__ void __launch_bounds__(64, HP_CH <= 16 ? 3 : 1) k_hp(Buffers b, const
     const int lane = threadIdx.x, tile = blockIdx.x, fmt = sp->fmt;
     wf_setprio_high();   // a lone wave on a serial chain that shares its SIMD with another kernel's wave (+1 % at 4096 streams)
     const bool vec = sp->channels == 1 && ((((size_t)sp->in) | (size_t)sp->group_stride | (size_t)sp->frame_stride) & 15) == 0;
-    if (fmt == PCM_F32) { if (vec) hp_group<PCM_F32, true>(b, sp, g, tile, lane); else hp_group<PCM_F32, false>(b, sp, g, tile, lane); }
-    else if (fmt == PCM_I16) { if (vec) hp_group<PCM_I16, true>(b, sp, g, tile, lane); else hp_group<PCM_I16, false>(b, sp, g, tile, lane); }
-    else { if (vec) hp_group<PCM_F32_UNIT, true>(b, sp, g, tile, lane); else hp_group<PCM_F32_UNIT, false>(b, sp, g, tile, lane); }
+    __shared__ float Ly[TILE * HP_LD];
+    if (fmt == PCM_F32) { if (vec) hp_group<PCM_F32, true>(b, sp, g, tile, lane, Ly); else hp_group<PCM_F32, false>(b, sp, g, tile, lane, Ly); }
+    else if (fmt == PCM_I16) { if (vec) hp_group<PCM_I16, true>(b, sp, g, tile, lane, Ly); else hp_group<PCM_I16, false>(b, sp, g, tile, lane, Ly); }
+    else { if (vec) hp_group<PCM_F32_UNIT, true>(b, sp, g, tile, lane, Ly); else hp_group<PCM_F32_UNIT, false>(b, sp, g, tile, lane, Ly); }
 }
 
 // ---------------------------------------------------------------------------------------------
