@@ -12,8 +12,9 @@ from --gpus.
 A "step" is one pass of the hot path over one batch: every stream of this rank's shard advances by `--frames-per-step`
 frames (default 48 = 0.48 s of audio per stream per call).  Workloads are BASELINE.json's configs (0-based index):
 
-  --config 1  (default)  4096 concurrent mono streams per GPU, built-in model          (configs[1], the headline)
-  --config 2             65536 concurrent streams on one GPU, built-in model            (configs[2])
+  --config 2  (default)  65536 concurrent streams on one GPU, built-in model, GRU as batched MFMA GEMM
+                         (configs[2]: the largest single-GPU configuration, the headline `value`)
+  --config 1             4096 concurrent mono streams per GPU, built-in model           (configs[1])
   --config 3             262144 streams sharded over the node = 32768 per GPU at 8 GPUs (configs[3]; per-GPU share fixed)
   --config 4             65536 streams, custom model (--model, default tests/golden/sh.rnn: GregorR's rnnoise-models
                          "sh" converted to .rnn)                                        (configs[4])
@@ -29,7 +30,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                 several thread counts (best reported, scaling table alongside) and the reference's own bench shape
                 (benches/sin.rs: 100 frames of a 440 Hz sine, fresh state per iteration, one thread).  The genuine Rust
                 reference cannot be built here (no cargo), hence kind "port".
-  also          (default N=1 run only) the same measurement on configs[2] and configs[4], so the driver's line carries them
+  also          (default N=1 run only) the same measurement on configs[1] and configs[4], so the driver's line carries them
+                (each timed for at least 0.5 s)
   host_boundary (default N=1 run only) the headline workload through the host-buffer entry point: PCIe-inclusive, never `value`
 """
 import argparse
@@ -54,12 +56,21 @@ G = 16
 KERNEL_BYTES = {
     "k_hp": 1920 + 1920 + 960 + 960 // 5 + 4 + (16 + 8) // G,     # input, history slot, 240 decimated values (+ mirrored share), x_lp[0]; biquad state per group
     "k_pitch": 3456 + 4 + 8 + 16 // G,                              # decimated window + x_lp[0] in; pitch index + gain out; last pitch per group
-                                                                   # (pitch_buf, coarse xcorr and energies never leave LDS; the two energy tables
-                                                                   # that go through global scratch, 2.7 KB, are the design's own and not counted)
+                                                                   # (pitch_buf, coarse xcorr, the running energies and their check points never leave LDS)
     "k_fft_xp": 3840 + 1200 + 4 + 3848 + 3200 + 264 + 112 + 4,     # 960 + (mean lag 300) history samples; X (481 bins), P (400 bins), band energies, cepstrum head out
     "k_rnn": 120 + 88 + 4 + 2 * 88 + 2 * 88 + (704 + 2 * 672 + 8) // G,   # features head in; ring row, vad, gains, last gains; ring + GRU states per group
     "k_synth": 3848 + 3200 + 440 + 8 + 1920 + 8 + 3840 // G,       # X, P, band quantities in; audio, vad, branch out; overlap memory per group
 }
+
+# Useful arithmetic per stream-frame of each kernel (SURVEY.md 8(d)'s break-down of the 0.42 MFLOP) and the roof that applies to
+# it (TFLOP/s): the pitch analysis may not fuse a multiply with an add (bit-exact sums in the reference's order), so its roof
+# is half the FP32 vector peak; the transforms run at the full FP32 vector peak; the RNN's products run as three bf16 planes
+# per f32 activation on the matrix cores (dense bf16 peak / 3); the biquad is an f64 chain.
+KERNEL_FLOPS = {"k_hp": 480 * 13, "k_pitch": 135e3, "k_fft_xp": 66e3, "k_rnn": 174e3, "k_synth": 42e3}
+KERNEL_ROOF_TFLOPS = {"k_hp": FP32_PEAK_TFLOPS / 2, "k_pitch": FP32_PEAK_TFLOPS / 2, "k_fft_xp": FP32_PEAK_TFLOPS, "k_synth": FP32_PEAK_TFLOPS,
+                      "k_rnn": 2500.0 / 3}
+KERNEL_ROOF_NAME = {"k_hp": "f64 vector, serial chain", "k_pitch": "FP32 vector without FMA (exact sums)", "k_fft_xp": "FP32 vector",
+                    "k_synth": "FP32 vector", "k_rnn": "bf16 MFMA / 3 planes"}
 
 CONFIGS = {
     1: {"streams": 4096, "model": None, "name": "configs[1]: 4096 concurrent mono streams per GPU, built-in weights.rnn"},
@@ -144,7 +155,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--config", type=int, default=1, choices=[0, 1, 2, 3, 4], help="BASELINE.json configs[i] (see the module docstring)")
+    ap.add_argument("--config", type=int, default=2, choices=[0, 1, 2, 3, 4], help="BASELINE.json configs[i] (see the module docstring)")
     ap.add_argument("--streams", type=int, default=None, help="concurrent streams PER GPU (overrides the config's)")
     ap.add_argument("--model", default=None, help=".rnn model file (configs[4]; default for --config 4: tests/golden/sh.rnn)")
     ap.add_argument("--frames-per-step", type=int, default=48,
@@ -163,7 +174,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host", action="store_true", help="skip the PCIe-inclusive host-buffer measurement of the default run")
     ap.add_argument("--no-tick", action="store_true", help="skip the one-frame-per-call measurement")
-    ap.add_argument("--no-also", action="store_true", help="skip the extra configs[2] / configs[4] measurements of the default run")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] / configs[4] measurements of the default run")
+    ap.add_argument("--min-timed-s", type=float, default=0.5, help="the `also` entries run enough steps to be timed for at least this long")
     ap.add_argument("--pool-bytes", type=float, default=6.5e9, help="HBM budget for the resident input pool (and as much again for the output)")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a GPU: gloo backend, CPU tensors, the library named by NNN_LIBRARY (the tests "
@@ -171,19 +183,29 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want_tick=True, want_roofline=True):
-    """One workload on this rank's device: returns the dict of measured quantities (aggregated over ranks)."""
+def pmc_profile(kind, S):
+    """A committed rocprofv3 --pmc summary for this stream count (profiles/pmc_<kind>_<S>streams.json) or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", f"pmc_{kind}_{S}streams.json")))
+        return d if d.get("streams") == S else None
+    except Exception:
+        return None
+
+
+def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want_tick=True, want_roofline=True, min_timed_s=0.0):
+    """One workload on this rank's device.  Returns (dict of measured quantities aggregated over ranks, roofline pass): the
+    second is a callable (or None) that runs the event-instrumented pass on this rank and returns the extra fields -- rank 0
+    calls it after the ranks have parted, so that nobody idles behind it."""
     import nnnoiseless_amd as nn
     from nnnoiseless_amd.shard import aggregate
     from nnnoiseless_amd.synthetic import make_streams_device
     fps, K, W = args.frames_per_step, args.steps, args.warmup
-    total_frames = (K + W) * fps
     fmt = {"f32": 0, "i16": 1, "unit": 2}[args.pcm]
     Cc = args.channels
     assert S % Cc == 0
     esz = 2 if fmt == 1 else 4
     # distinct audio for every step while it fits the pool budget, else cycle through a pool of frames
-    pool = max(1, min(total_frames, int(args.pool_bytes // (S * 480 * esz))))
+    pool = max(1, min((K + W) * fps, int(args.pool_bytes // (S * 480 * esz))))
     if pool >= fps:
         pool -= pool % fps   # whole steps: a step never straddles the end of the pool (no call is cut in two)
     x = make_streams_device(torch, dev, S, pool, seed=rank)               # [S, pool, 480] f32, resident
@@ -235,20 +257,28 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
             dist.barrier()
         sync()
 
+    barrier()
+    tw = time.perf_counter()
     for i in range(W):
         run_span(i * fps, fps)
     barrier()
+    tw = time.perf_counter() - tw
+    if min_timed_s > 0 and W > 0 and world == 1:
+        # an `also` entry: enough steps for the timed region to last min_timed_s (the warm-up's own rate is the estimate)
+        K = max(K, int(np_ceil(1.2 * min_timed_s / max(tw / W, 1e-6))))
     t0 = time.perf_counter()
     for i in range(W, W + K):
         run_span(i * fps, fps)
     t_enq = time.perf_counter() - t0          # host time to enqueue everything (the calls are asynchronous)
     barrier()
     elapsed = time.perf_counter() - t0
+    if bd.fault():                            # (a caller that synchronises its own stream has to ask: nnn_batch_fault)
+        raise SystemExit("bench: the library reports a frame hand-off fault (nnn_batch_fault): results invalid")
     d = dist if world > 1 else None
     frames_done, elapsed_max = aggregate(d, S * fps * K, elapsed, dev)
     if os.environ.get("NNN_PMC_CALIB"):   # a kernel of known traffic (reads N bytes, writes N bytes) for the PMC passes' calibration
         torch.abs(x)
-    res = {"value": frames_done / elapsed_max, "ms_per_step": elapsed_max * 1e3 / K, "timed_s": elapsed_max,
+    res = {"value": frames_done / elapsed_max, "ms_per_step": elapsed_max * 1e3 / K, "timed_s": elapsed_max, "steps": K,
            "host_enqueue_ms_per_step": t_enq * 1e3 / K, "pool_frames": pool,
            "outputs_finite": bool(torch.isfinite(y.float()).all().item())}
 
@@ -267,7 +297,19 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
         tf, tmax = aggregate(d, S * kt, tt, dev)
         res["tick"] = {"frames_per_step": 1, "value": tf / tmax, "unit": "frames/s", "ms_per_step": tmax * 1e3 / kt, "steps": kt}
 
-    if want_roofline and rank == 0 and dev.type == "cuda":
+    def close():
+        nonlocal x, y, vad
+        bd.close()
+        del x, y, vad
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
+
+    if not (want_roofline and rank == 0 and dev.type == "cuda"):
+        close()
+        return res, None
+    per_gpu = res["value"] / world
+
+    def roofline_pass():
         # second pass over the same workload with HIP events around every launch, on the stream they are launched on
         bd.set_profiling(True)
         kp = min(K, 12)
@@ -276,9 +318,17 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
         sync()
         times = bd.kernel_times()
         bd.set_profiling(False)
+        close()
         frames_prof = kp * fps
         kern = {k: {"avg_us": 1e3 * ms / max(n, 1), "launches": n, "us_per_frame": 1e3 * ms / frames_prof}
                 for k, (ms, n) in times.items() if n}
+        for k, v in kern.items():   # each kernel's useful arithmetic against the roof that applies to it, and its algorithmic bytes against HBM
+            sec_per_stream_frame = v["us_per_frame"] * 1e-6 / S
+            v["useful_tflops"] = KERNEL_FLOPS.get(k, 0) / sec_per_stream_frame / 1e12
+            v["roof_tflops"] = KERNEL_ROOF_TFLOPS.get(k)
+            v["roof"] = KERNEL_ROOF_NAME.get(k)
+            v["frac_of_roof"] = v["useful_tflops"] / KERNEL_ROOF_TFLOPS[k] if k in KERNEL_ROOF_TFLOPS else None
+            v["hbm_frac"] = KERNEL_BYTES.get(k, 0) / sec_per_stream_frame / 1e9 / HBM_PEAK_GBS
         dom = max(kern, key=lambda k: kern[k]["us_per_frame"])
         # one launch of the dominant kernel covers frames_prof / launches frames of every stream
         frames_per_launch = frames_prof / kern[dom]["launches"]
@@ -286,28 +336,40 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
         bytes_per_launch = KERNEL_BYTES.get(dom, 0) * S * frames_per_launch
         achieved = bytes_per_launch / avg_s / 1e9
         traffic = None
-        try:   # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes (same workload only)
-            pm = json.load(open(os.path.join(ROOT, "profiles", f"pmc_traffic_{S}streams.json")))
-            if pm.get("streams") == S and dom in pm["kernels"]:
-                traffic = pm["kernels"][dom]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
-        per_gpu = res["value"] / world
-        res["kernels"] = kern
-        res["roofline"] = {
+        pm = pmc_profile("traffic", S)   # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (same workload only)
+        if pm and dom in pm["kernels"]:
+            traffic = pm["kernels"][dom]["hbm_bytes_per_launch"]
+        # what binds the dominant kernel: the busiest on-chip resource of the committed SQ counter pass at this stream count
+        binding = None
+        sq = pmc_profile("sq", S)
+        if sq and dom in sq.get("kernels", {}):
+            q = sq["kernels"][dom]
+            cand = {"vector ALU issue": q.get("valu_busy"), "LDS": q.get("lds_busy")}
+            cand = {k: v for k, v in cand.items() if v is not None}
+            if cand:
+                top = max(cand, key=cand.get)
+                binding = {"resource": top, "busy": cand[top], "valu_busy": q.get("valu_busy"), "lds_busy": q.get("lds_busy"),
+                           "lds_conflict_share": q.get("lds_conflict_share"), "source": f"profiles/pmc_sq_{S}streams.json (rocprofv3 --pmc SQ_* passes)"}
+        return {"kernels": kern, "roofline": {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "avg_kernel_us": avg_s * 1e6, "frames_per_launch": frames_per_launch, "bytes_per_launch": bytes_per_launch,
+            "binding": binding,
+            "useful_tflops": kern[dom]["useful_tflops"], "roof_tflops": kern[dom]["roof_tflops"], "roof": kern[dom]["roof"],
+            "frac_of_applicable_roof": kern[dom]["frac_of_roof"],
             "sum_kernel_us_per_frame": sum(v["us_per_frame"] for v in kern.values()),
             "pipeline_fused_bytes_GBs": per_gpu * BYTES_PER_FRAME_FUSED / 1e9,
             "pipeline_hbm_frac": per_gpu * BYTES_PER_FRAME_FUSED / 1e9 / HBM_PEAK_GBS,
             "pipeline_fp32_frac": per_gpu * FLOPS_PER_FRAME / 1e12 / FP32_PEAK_TFLOPS,
-            "note": "path is FP32-VALU/latency bound (23-100 FLOP/B, SURVEY 8d); HBM fraction reported as north_star asks"}
-    bd.close()
-    del x, y, vad
-    if dev.type == "cuda":
-        torch.cuda.empty_cache()
-    return res
+            "note": "the HBM fraction is reported because north_star asks for it; the path sits at 23-100 FLOP/B (SURVEY 8d) and its "
+                    "dominant kernel hardly touches HBM: `binding` names the on-chip resource the SQ counters show busiest and "
+                    "`frac_of_applicable_roof` the kernel's useful arithmetic against the roof that applies to it"}}
+    return res, roofline_pass
+
+
+def np_ceil(v):
+    import math
+    return math.ceil(v)
 
 
 def config0():
@@ -416,65 +478,88 @@ def main():
         args.frames_per_step = min(args.frames_per_step, 3)
         args.steps, args.warmup = min(args.steps, 2), min(args.warmup, 1)
     model_path = args.model or cfg["model"]
-    res = measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want_tick=not args.no_tick, want_roofline=not args.no_roofline)
+    res, roof = measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want_tick=not args.no_tick, want_roofline=not args.no_roofline)
+    # Every collective of the run is behind us (the aggregation inside measure): the ranks part here, and what only rank 0
+    # reports -- the event-instrumented pass, the other configurations, the host-buffer rates, the CPU baseline -- runs with no
+    # other rank waiting behind a barrier for it.
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    if roof:
+        res.update(roof())
 
+    default_run = (args.config == 2 and args.streams is None and args.model is None and world == 1 and args.pcm == "f32"
+                   and args.channels == 1 and not args.dry_run)
     also = None
-    default_run = (args.config == 1 and args.streams is None and args.model is None and world == 1 and args.pcm == "f32"
-                   and args.channels == 1 and not args.dry_run and not args.no_also)
-    if default_run:
-        # the other single-GPU configurations of BASELINE.json, measured the same way, so the driver's line carries them
+    if default_run and not args.no_also:
+        # the other single-GPU configurations of BASELINE.json, measured the same way (each for at least --min-timed-s), so the
+        # driver's line carries them
         also = {}
-        for c in (2, 4):
+        for c in (1, 4):
             a = argparse.Namespace(**vars(args))
-            a.steps, a.warmup = min(args.steps, 12), min(args.warmup, 2)
-            r = measure(a, CONFIGS[c]["streams"], CONFIGS[c]["model"], rank, world, dev, local_rank, dist, torch, want_tick=False,
-                        want_roofline=not args.no_roofline)
+            a.steps, a.warmup = min(args.steps, 12), max(2, min(args.warmup, 6))
+            r, rf = measure(a, CONFIGS[c]["streams"], CONFIGS[c]["model"], rank, world, dev, local_rank, dist, torch, want_tick=(c == 1 and not args.no_tick),
+                            want_roofline=not args.no_roofline, min_timed_s=args.min_timed_s)
+            if rf:
+                r.update(rf())
             also[f"configs[{c}]"] = {
-                "workload": CONFIGS[c]["name"], "value": r["value"], "unit": "frames/s", "steps": a.steps, "warmup": a.warmup,
+                "workload": CONFIGS[c]["name"], "value": r["value"], "unit": "frames/s", "steps": r["steps"], "warmup": a.warmup,
                 "ms_per_step": r["ms_per_step"], "timed_s": r["timed_s"], "frames_per_step": args.frames_per_step,
-                "outputs_finite": r["outputs_finite"], "pool_frames": r["pool_frames"],
+                "outputs_finite": r["outputs_finite"], "pool_frames": r["pool_frames"], "tick": r.get("tick"),
                 "pipeline_hbm_frac": r["value"] * BYTES_PER_FRAME_FUSED / 1e9 / HBM_PEAK_GBS,
                 "kernels_us_per_frame": {k: round(v["us_per_frame"], 2) for k, v in r.get("kernels", {}).items()},
                 "roofline": r.get("roofline")}
 
+    default_semantics = None
+    if default_run and not args.no_overlap and not args.no_also:
+        # the same headline workload under the library's default call ordering (no promise about the inputs: every call waits for
+        # the previous one to drain before it reads its input), quoted beside the headline
+        a = argparse.Namespace(**vars(args))
+        a.no_overlap = True
+        a.steps, a.warmup = min(args.steps, 12), min(args.warmup, 2)
+        r, _ = measure(a, S, model_path, rank, world, dev, local_rank, dist, torch, want_tick=False, want_roofline=False, min_timed_s=args.min_timed_s)
+        default_semantics = {"inputs_ready": False, "value": r["value"], "unit": "frames/s", "steps": r["steps"], "ms_per_step": r["ms_per_step"],
+                             "timed_s": r["timed_s"]}
+
     host = None
-    if default_run and rank == 0 and not args.no_host:
-        host = host_boundary(S, args.frames_per_step)
+    if default_run and not args.no_host:
+        host = host_boundary(CONFIGS[1]["streams"], args.frames_per_step)
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline and not args.dry_run:
+    if not args.no_cpu_baseline and not args.dry_run:
         cpu = cpu_baseline()
 
-    if rank == 0:
-        fps = args.frames_per_step
-        line = {
-            "metric": "480-sample frames/sec (whole node) at N concurrent streams", "value": res["value"], "unit": "frames/s",
-            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{cfg['name'] if S == cfg['streams'] else f'{S} concurrent mono streams per GPU (custom --streams)'}"
-                                   f"{'' if model_path == cfg['model'] else ', model ' + os.path.basename(model_path or 'built-in')}, "
-                                   f"synthetic 48 kHz sine+noise, {fps} frame(s) per stream per step",
-                       "baseline_config_index": args.config,
-                       "model": os.path.basename(model_path) if model_path else "built-in weights.rnn",
-                       "boundary_format": {"f32": "f32 planar (process_frame's own)", "i16": "packed int16",
-                                           "unit": "unit-range f32"}[args.pcm] + (f", {args.channels} interleaved channels" if args.channels > 1 else ""),
-                       "streams_per_gpu": S, "streams_total": S * world, "frames_per_step": fps,
-                       "inputs": "resident in HBM and final before the timed region" + ("" if args.no_overlap else "; declared to the library "
-                                 "(nnn_batch_set_inputs_ready): consecutive calls overlap at their boundary, outputs stay stream-ordered"),
-                       "parallelism": f"streams sharded x{world}, one process per GPU, no data-path collective"},
-            "ranks_seen": ranks_seen, "timed_s": res["timed_s"], "pool_frames": res["pool_frames"],
-            "tick": res.get("tick"),
-            "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
-            "outputs_finite": res["outputs_finite"],
-            "roofline": res.get("roofline"), "cpu_baseline": cpu, "kernels": res.get("kernels", {}), "also": also,
-            "host_boundary": host,
-        }
-        if args.dry_run:
-            line["dry_run"] = "gloo + CPU tensors + NNN_LIBRARY build: plumbing only, numbers meaningless"
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    fps = args.frames_per_step
+    line = {
+        "metric": "480-sample frames/sec (whole node) at N concurrent streams", "value": res["value"], "unit": "frames/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{cfg['name'] if S == cfg['streams'] else f'{S} concurrent mono streams per GPU (custom --streams)'}"
+                               f"{'' if model_path == cfg['model'] else ', model ' + os.path.basename(model_path or 'built-in')}, "
+                               f"synthetic 48 kHz sine+noise, {fps} frame(s) per stream per step",
+                   "baseline_config_index": args.config,
+                   "model": os.path.basename(model_path) if model_path else "built-in weights.rnn",
+                   "boundary_format": {"f32": "f32 planar (process_frame's own)", "i16": "packed int16",
+                                       "unit": "unit-range f32"}[args.pcm] + (f", {args.channels} interleaved channels" if args.channels > 1 else ""),
+                   "streams_per_gpu": S, "streams_total": S * world, "frames_per_step": fps,
+                   "inputs_ready": not args.no_overlap,
+                   "schedule": os.environ.get("NNN_SCHED", "lanes"), "lanes": int(os.environ.get("NNN_LANES", "2")),
+                   "pipeline": os.environ.get("NNN_PIPELINE", "1") != "0",
+                   "inputs": "resident in HBM and final before the timed region" + ("" if args.no_overlap else "; declared to the library "
+                             "(nnn_batch_set_inputs_ready): consecutive calls overlap at their boundary, outputs stay stream-ordered"),
+                   "parallelism": f"streams sharded x{world}, one process per GPU, no data-path collective"},
+        "ranks_seen": ranks_seen, "timed_s": res["timed_s"], "pool_frames": res["pool_frames"],
+        "tick": res.get("tick"),
+        "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
+        "outputs_finite": res["outputs_finite"],
+        "roofline": res.get("roofline"), "cpu_baseline": cpu, "kernels": res.get("kernels", {}), "also": also,
+        "default_semantics": default_semantics, "host_boundary": host,
+    }
+    if args.dry_run:
+        line["dry_run"] = "gloo + CPU tensors + NNN_LIBRARY build: plumbing only, numbers meaningless"
+    print(json.dumps(line), flush=True)
 
 
 def bench_train(args, rank, world, dev, local_rank, dist):

@@ -116,6 +116,15 @@ int nnn_batch_process_pcm_device(nnn_batch *b, const void *d_in, void *d_out, fl
 int nnn_batch_process_pcm_host(nnn_batch *b, const void *in, void *out, float *vad, int n_frames,
                                const nnn_pcm_layout *layout);
 int nnn_batch_synchronize(nnn_batch *b);
+/* 1 if a pitch workgroup of an earlier call ran out of patience waiting for the previous frame's result (the frames of a group
+ * run side by side below 16 384 streams and hand the last pitch from workgroup to workgroup): the state of the affected streams
+ * is invalid from that frame on.  Work items are handed out in the order workgroups start, so the wait cannot deadlock whatever
+ * order the hardware dispatches them in; the condition exists as a safety net.  It is sticky: every later process call and
+ * nnn_batch_synchronize fail with it until nnn_batch_reset or nnn_batch_load_state.  Cheap (a read of page-locked host memory the
+ * device writes into): callers that synchronise their own stream instead of calling nnn_batch_synchronize can poll it. */
+int nnn_batch_fault(const nnn_batch *b);
+/* Test hook for the above: withhold the hand-off flag of the frame `frames_ahead` frames from now (negative: off). */
+int nnn_batch_debug_withhold_flag(nnn_batch *b, int frames_ahead);
 
 /* Parity taps: intermediate quantities of the most recent frame, copied to the host as
  * [n_streams][len] (float32 or int32, see nnn_tap_info).  Test/diagnostic interface.  Everything inside the pitch analysis
@@ -147,6 +156,13 @@ enum nnn_tap {
 int nnn_tap_info(int tap, int *len, int *is_int);
 int nnn_batch_set_taps(nnn_batch *b, int on);
 int nnn_batch_read_tap(nnn_batch *b, int tap, void *host_dst, size_t dst_bytes);
+
+/* Parity-test record of whole calls (the taps above hold the most recent frame only): from this call on, every processed frame
+ * t = 0, 1, ... writes d_log[(t * n_streams + s) * NNN_FRAME_LOG_WORDS + i] for stream s -- word 0: pitch index (int32), word 1: the
+ * BRANCH tap (int32), words 2..23: the 22 smoothed band gains (float32; zero on silent frames) -- until `frames` frames have
+ * been recorded.  d_log is device memory owned by the caller; NULL or 0 frames switches the record off. */
+#define NNN_FRAME_LOG_WORDS 24
+int nnn_batch_set_frame_log(nnn_batch *b, void *d_log, size_t frames);
 
 /* Per-kernel timing with HIP events on the launch stream (off by default: it adds two event
  * records per launch).  Times accumulate until read; reading resets them. */

@@ -38,6 +38,8 @@ long nnn_resampler_max_output(const nnn_resampler *r, long n_in);
  * (d_out[s * out_stride + m], m < *n_out <= cap_out; the same count for every stream).  An output sample whose
  * source samples have not all arrived is produced by the next call: any chunking of the input gives the same output
  * as one call.  Buffers resident in device memory; asynchronous on hip_stream (NULL = the resampler's own stream).
+ * cap_out must be at least nnn_resampler_max_output(r, n_in): every source sample of a call is consumed by it, so a
+ * smaller buffer would drop outputs -- such a call is refused (non-zero return, nothing consumed).
  */
 int nnn_resampler_process_device(nnn_resampler *r, const float *d_in, long n_in, size_t in_stride, float *d_out, long cap_out,
                                  size_t out_stride, long *n_out, void *hip_stream);

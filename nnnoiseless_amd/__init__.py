@@ -162,12 +162,16 @@ class BatchDenoiser:
         """x: float32 [n_streams, n_frames, 480] on the host -> (out same shape, vad [n_frames, n_streams]).  Arrays from
         pinned_empty (x, and out / vad handed in) cross the bus by DMA."""
         x = _ffi.as_f32(x)
+        if x.ndim != 3 or x.shape[0] != self.n_streams or x.shape[2] != FRAME_SIZE:
+            raise ValueError(f"process needs x of shape [{self.n_streams}, n_frames, {FRAME_SIZE}], got {x.shape}")
         S, T, F = x.shape
-        assert S == self.n_streams and F == FRAME_SIZE
         out = np.empty_like(x) if out is None else out
         vad = np.empty((T, S), np.float32) if vad is None else vad
-        assert out.shape == x.shape and out.dtype == np.float32 and out.flags.c_contiguous
-        assert vad.shape == (T, S) and vad.dtype == np.float32 and vad.flags.c_contiguous
+        # caller-supplied buffers are written by the C library: a wrong size or layout must never get that far
+        if not (isinstance(out, np.ndarray) and out.shape == x.shape and out.dtype == np.float32 and out.flags.c_contiguous and out.flags.writeable):
+            raise ValueError("process: `out` must be a writable C-contiguous float32 array of x's shape")
+        if not (isinstance(vad, np.ndarray) and vad.shape == (T, S) and vad.dtype == np.float32 and vad.flags.c_contiguous and vad.flags.writeable):
+            raise ValueError("process: `vad` must be a writable C-contiguous float32 array of shape [n_frames, n_streams]")
         self._lib.check(self._lib.L.nnn_batch_process_host(self._h, _ffi.ptr(x), _ffi.ptr(out), _ffi.ptr(vad), T,
                                                            T * FRAME_SIZE, FRAME_SIZE))
         self.frames_done += T
@@ -178,8 +182,9 @@ class BatchDenoiser:
         float32 otherwise), n_groups * channels == n_streams.  Returns (out [n_groups, n_out_frames * 480, channels],
         vad [n_frames, n_streams]); n_out_frames = n_frames - 1 if discard_first drops the first frame after a reset."""
         x = np.ascontiguousarray(x, dtype=_ffi.PCM_DTYPE[fmt])
+        if x.ndim != 3 or x.shape[2] != channels or x.shape[0] * channels != self.n_streams or x.shape[1] % FRAME_SIZE:
+            raise ValueError(f"process_pcm needs x of shape [n_streams / channels, n_frames * {FRAME_SIZE}, channels], got {x.shape}")
         G, N, Cc = x.shape
-        assert Cc == channels and G * channels == self.n_streams and N % FRAME_SIZE == 0
         T = N // FRAME_SIZE
         out = np.zeros_like(x)
         vad = np.empty((T, self.n_streams), np.float32)
@@ -232,6 +237,17 @@ class BatchDenoiser:
         """Promise that the input of every process_device call is final when the call is made: consecutive calls may then
         overlap at their boundary (include/nnn_batch.h).  Outputs stay ordered on the caller's stream; same bits."""
         self._lib.check(self._lib.L.nnn_batch_set_inputs_ready(self._h, int(on)))
+
+    def set_frame_log(self, d_log, frames):
+        """Record (pitch index, branch mask, 22 smoothed gains) of the next `frames` frames into device memory at `d_log`
+        (an int: [frames][n_streams][24] 32-bit words; include/nnn_batch.h nnn_batch_set_frame_log).  Parity tests."""
+        self._lib.check(self._lib.L.nnn_batch_set_frame_log(self._h, d_log, int(frames)))
+
+    def fault(self):
+        """True once a pitch workgroup has given up waiting for the previous frame's hand-off (include/nnn_batch.h nnn_batch_fault):
+        sticky until reset() / load_state().  A cheap host-memory read; no synchronisation."""
+        fn = getattr(self._lib.L, "nnn_batch_fault", None)   # (absent from experimental builds of older sources: NNN_LIBRARY)
+        return bool(fn(self._h)) if fn else False
 
     def kernel_times(self):
         """{kernel: (total_ms, launches)} accumulated while profiling; resets the counters."""

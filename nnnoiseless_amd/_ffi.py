@@ -19,7 +19,7 @@ BATCH_SYMBOLS = [
     "nnn_batch_set_taps", "nnn_batch_set_schedule", "nnn_batch_set_inputs_ready", "nnn_debug_activations",
     "nnn_tap_info", "nnn_batch_read_tap", "nnn_batch_set_profiling", "nnn_batch_num_kernels",
     "nnn_batch_kernel_name", "nnn_batch_read_kernel_times", "nnn_batch_set_graph", "nnn_batch_set_pipeline", "nnn_batch_read_stamps",
-    "nnn_host_alloc", "nnn_host_free", "nnn_last_error",
+    "nnn_host_alloc", "nnn_host_free", "nnn_last_error", "nnn_batch_fault", "nnn_batch_debug_withhold_flag", "nnn_batch_set_frame_log",
 ]
 TRAIN_SYMBOLS = [
     "nnn_train_create", "nnn_train_destroy", "nnn_train_reset", "nnn_train_process_device", "nnn_train_process_host",
@@ -98,6 +98,9 @@ class Library:
         L.nnn_debug_activations.argtypes = [i32, i32, vp, vp, i32]
         L.nnn_batch_set_pipeline.argtypes = [vp, i32]
         L.nnn_batch_set_inputs_ready.argtypes = [vp, i32]
+        for name, at in (("nnn_batch_set_frame_log", [vp, vp, sz]), ("nnn_batch_fault", [vp]), ("nnn_batch_debug_withhold_flag", [vp, i32])):
+            if hasattr(L, name):   # (experimental builds of older sources, loaded through NNN_LIBRARY, lack the newest entry points)
+                getattr(L, name).argtypes = at
         L.nnn_train_create.restype = vp
         L.nnn_train_create.argtypes = [i32, i32]
         L.nnn_train_destroy.argtypes = [vp]

@@ -107,6 +107,11 @@ struct nnn_batch {
     int prev_par = 0;
     std::vector<int> prev_first;
     bool inputs_ready = false;      // the caller's promise that a call's input is final when the call is made
+    volatile int *fault_host = nullptr;   // host view of Buffers::fault (page-locked, mapped): a hand-off that never arrived
+    unsigned tickets = 0;           // work items handed out so far by chained k_pitch launches (Buffers::ticket never restarts)
+    unsigned *frame_log = nullptr;  // nnn_batch_set_frame_log: the next frame's record (device), and the frames that still have room
+    size_t frame_log_left = 0;
+    bool host_call = false;         // inside a host-buffer entry point: the input is an upload enqueued by this library, final only in stream order
     hipEvent_t ev_in = nullptr;     // the caller's stream at the start of a pipelined call
     hipEvent_t ev_last = nullptr;   // end of the most recent call, on the stream it was made on
     hipStream_t last_stream = nullptr;
@@ -209,6 +214,7 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
     if (h->ev_last) hipEventDestroy(h->ev_last);
     for (hipEvent_t e : h->evp) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
+    if (h->fault_host) hipHostFree((void *)h->fault_host);
     if (h->sp_tab) hipFree(h->sp_tab);
     for (hipEvent_t e : h->ev_up) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_run) hipEventDestroy(e);
@@ -376,7 +382,15 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     HIPCHK(dalloc(h, &b.gru_n, Sp * md.nn, true));
     HIPCHK(dalloc(h, &b.gru_dn, Sp * md.ndn, true));
     HIPCHK(dalloc(h, &b.stamps, 64, false));
-    HIPCHK(dalloc(h, &b.fault, 1, false));
+    {   // the fault word lives in page-locked host memory the device writes straight into: the host reads it at every call
+        void *hp = nullptr, *dp = nullptr;
+        HIPCHK(hipHostMalloc(&hp, sizeof(int), hipHostMallocMapped));
+        *(volatile int *)hp = 0;
+        HIPCHK(hipHostGetDevicePointer(&dp, hp, 0));
+        h->fault_host = (volatile int *)hp;
+        b.fault = (int *)dp;
+    }
+    HIPCHK(dalloc(h, &b.ticket, 1, false));
     HIPCHK(hipMalloc((void **)&h->sp_tab, 2 * 64 * sizeof(StepParams)));   // two tables: consecutive calls alternate
     h->sp_tab_cap = 64;
     // tables
@@ -408,6 +422,12 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
         }
         if (ns > 64) return fail("band segmentation overflow");
         HIPCHK(upload(h, &b.seg, seg));
+        // the transform kernels' LDS tables, built once in their LDS layout
+        std::vector<FftLds> img(1);
+        fft_tables_image(img[0], tw.data(), bin_frac.data(), bin_band.data(), seg.data());
+        const FftLds *dimg = nullptr;
+        HIPCHK(upload(h, &dimg, img));
+        b.fft_img = dimg;
     }
     for (int g = 0; g < n_groups; g++) {
         const uint16_t *dq = nullptr;
@@ -459,16 +479,24 @@ extern "C" nnn_batch *nnn_batch_create(const RNNModel *model, int n_streams, int
 
 extern "C" int nnn_batch_num_streams(const nnn_batch *h) { return h ? h->S : 0; }
 
+// A pitch workgroup that never saw its predecessor's hand-off flag went on with a stale pitch: the streams' state is invalid from
+// that frame on.  Sticky: every later call and nnn_batch_synchronize report it until nnn_batch_reset / nnn_batch_load_state.
+extern "C" int nnn_batch_fault(const nnn_batch *h) { return h && h->fault_host && *h->fault_host ? 1 : 0; }
+static int report_fault(const nnn_batch *h)
+{
+    if (!nnn_batch_fault(h)) return 0;
+    return fail("a pitch workgroup gave up waiting for the previous frame's result (frame hand-off flag never set): the state of the "
+                "affected streams is invalid from that frame on; nnn_batch_reset or nnn_batch_load_state clears the condition "
+                "(NNN_PITCH_CHAIN=0 runs the frames of a group in a loop instead of side by side)");
+}
+
 extern "C" int nnn_batch_synchronize(nnn_batch *h)
 {
     if (!h) return fail("null batch");
     HIPCHK(hipSetDevice(h->device));
     if (h->have_last) HIPCHK(hipEventSynchronize(h->ev_last));   // the most recent call, whatever stream it was made on
     HIPCHK(hipStreamSynchronize(h->stream));
-    int fault = 0;
-    HIPCHK(hipMemcpy(&fault, h->b[0].fault, sizeof(int), hipMemcpyDeviceToHost));
-    if (fault) return fail("a pitch workgroup gave up waiting for the previous frame's result (frame hand-off flag never set): results of the affected streams are invalid");
-    return 0;
+    return report_fault(h);
 }
 
 // everything this batch has enqueued anywhere is complete
@@ -489,6 +517,7 @@ extern "C" int nnn_batch_reset(nnn_batch *h)
     if (int rc = quiesce(h)) return rc;
     for (auto &sb : h->state_bufs) HIPCHK(hipMemset(sb.first, 0, sb.second));
     HIPCHK(hipDeviceSynchronize());
+    *h->fault_host = 0;
     h->frame_count = 0;
     h->group_count = 0;
     h->last_set = 0;
@@ -543,6 +572,7 @@ extern "C" int nnn_batch_load_state(nnn_batch *h, const void *host_src, size_t s
         p += sb.second;
     }
     HIPCHK(hipDeviceSynchronize());
+    *h->fault_host = 0;
     h->frame_count = hd.frame_count;
     h->group_count = hd.group_count;
     h->prev_pipe = false;
@@ -619,7 +649,9 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
         // streams; measured at 4096: 46.8 -> 32.8 us per frame; at 65536, where the frame loop's prefetch of the next window
         // matters instead: 468 -> 515); flag values are frame numbers (> 0)
         const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
-        L.go(K_PITCH, k_pitch, dim3(Sp / PK_SPB * (chain ? ug : 1u)), dim3(PK_T), 0, b, sp0, g, chain, seq0);
+        const unsigned grid = Sp / PK_SPB * (chain ? ug : 1u);
+        L.go(K_PITCH, k_pitch, dim3(grid), dim3(PK_T), 0, b, sp0, g, chain, seq0, h->tickets);
+        if (chain) h->tickets += grid;   // (launches of one batch's pitch stage are ordered among themselves: a stateful stage)
         break;
     }
     case ST_FFT: L.go(K_FFT_XP, k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0); break;
@@ -674,6 +706,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
                           long long group_stride, long long frame_stride, int drop, void *hip_stream)
 {
     HIPCHK(hipSetDevice(h->device));
+    if (int rc = report_fault(h)) return rc;   // an earlier call's hand-off failure (seen as soon as the device has written it)
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
     // calls are ordered even when consecutive ones arrive on different streams
     if (h->have_last && h->last_stream != st) HIPCHK(hipStreamWaitEvent(st, h->ev_last, 0));
@@ -688,6 +721,12 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     v0.discard = drop;
     v0.slot = (int)(h->frame_count % NSLOT);
     v0.n_streams = h->S;
+    v0.log = h->frame_log_left ? h->frame_log : nullptr;
+    v0.log_frames = (int)(h->frame_log_left < (size_t)n_frames ? h->frame_log_left : (size_t)n_frames);
+    if (v0.log) {
+        h->frame_log += (size_t)v0.log_frames * h->S * FRAME_LOG_WORDS;
+        h->frame_log_left -= (size_t)v0.log_frames;
+    }
     if (n_frames > h->sp_tab_cap) {
         NNN_RT_LOCK;
         if (int rc = quiesce(h)) return rc;
@@ -726,7 +765,9 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     // The next call's high-pass chain may start before this stream has seen the previous call drain, when the caller has
     // promised that inputs are final at call time (nnn_batch_set_inputs_ready): it depends on the previous call only through
     // its own stream (biquad state) and the history-ring slots it overwrites (synthesis events of the groups that read them).
-    const bool early_hp = pipe && h->inputs_ready && h->prev_pipe && h->prev_st == st && h->sched == SCHED_LANES && h->pool[0];
+    // (never for the library's own host-buffer calls: their input is an upload enqueued just before on the caller's stream or on
+    // a copy stream, final only in that stream's order -- the promise is about buffers the CALLER filled)
+    const bool early_hp = pipe && h->inputs_ready && !h->host_call && h->prev_pipe && h->prev_st == st && h->sched == SCHED_LANES && h->pool[0];
     if (early_hp) {
         if (h->have_done[par]) chk(hipStreamWaitEvent(h->pool[0], h->ev_done[par], 0));   // the table's previous user (two calls back)
         hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, h->pool[0], tab, v0, n_frames);
@@ -920,7 +961,15 @@ static int process_host_chunked(nnn_batch *h, const char *in, char *out, float *
 }
 
 // Host buffers: ship the bounding span of the (possibly strided) layout, run, bring the written frames back.
+static int process_host_span_impl(nnn_batch *h, const void *in, void *out, float *vad, int n_frames, const nnn_pcm_layout *L);
 static int process_host_span(nnn_batch *h, const void *in, void *out, float *vad, int n_frames, const nnn_pcm_layout *L)
+{
+    h->host_call = true;
+    const int rc = process_host_span_impl(h, in, out, vad, n_frames, L);
+    h->host_call = false;
+    return rc;
+}
+static int process_host_span_impl(nnn_batch *h, const void *in, void *out, float *vad, int n_frames, const nnn_pcm_layout *L)
 {
     HIPCHK(hipSetDevice(h->device));
     const size_t e = (size_t)pcm_elem_bytes(L->format), groups = (size_t)(h->S / L->channels), fr = (size_t)FRAME * L->channels * e;
@@ -1168,6 +1217,23 @@ extern "C" int nnn_batch_set_inputs_ready(nnn_batch *h, int on)
     h->inputs_ready = on != 0;
     return 0;
 }
+// Parity-test record of every frame processed from now on (include/nnn_batch.h): device memory for `frames` frames.
+extern "C" int nnn_batch_set_frame_log(nnn_batch *h, void *d_log, size_t frames)
+{
+    if (!h) return fail("null batch");
+    h->frame_log = (unsigned *)d_log;
+    h->frame_log_left = d_log ? frames : 0;
+    return 0;
+}
+// Test hook: the hand-off flag of the frame `frames_ahead` frames from now (0 = the next one) is never published, so the workgroups
+// waiting for it run into their timeout and raise the fault.  A negative value switches the hook off.
+extern "C" int nnn_batch_debug_withhold_flag(nnn_batch *h, int frames_ahead)
+{
+    if (!h) return fail("null batch");
+    const int seq = frames_ahead < 0 ? 0 : (int)((h->frame_count + (uint64_t)frames_ahead) & 0x3fffffffu) + 1;
+    for (int set = 0; set < NSET; set++) h->b[set].dbg_withhold = seq;
+    return 0;
+}
 extern "C" int nnn_batch_set_pipeline(nnn_batch *h, int on)
 {
     if (!h) return fail("null batch");
@@ -1246,11 +1312,15 @@ static void enqueue_feature_group(nnn_batch *h, hipStream_t st, const float *in,
     v.discard = 0;
     v.slot = (int)(h->frame_count % NSLOT);
     v.n_streams = h->S;
+    v.log = nullptr;
+    v.log_frames = 0;
     hipLaunchKernelGGL(k_fill_params, dim3(1), dim3(64), 0, st, sp, v, g);
     hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, (const StepParams *)sp, g);
     if (full) {
         const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
-        hipLaunchKernelGGL(k_pitch, dim3(Sp / PK_SPB * (chain ? ug : 1u)), dim3(PK_T), 0, st, b, (const StepParams *)sp, g, chain, seq0);
+        const unsigned grid = Sp / PK_SPB * (chain ? ug : 1u);
+        hipLaunchKernelGGL(k_pitch, dim3(grid), dim3(PK_T), 0, st, b, (const StepParams *)sp, g, chain, seq0, h->tickets);
+        if (chain) h->tickets += grid;
         hipLaunchKernelGGL(k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp);
         hipLaunchKernelGGL(k_features, dim3(NT), dim3(64 * FEAT_WAVES), 0, st, b, g);
     } else {

@@ -440,22 +440,33 @@ __device__ __forceinline__ void pk_inner(const float *pb, int s, int q, const in
 #ifndef NNN_PK_MINWAVES
 #define NNN_PK_MINWAVES 4   // waves per SIMD: two blocks of 8 waves per CU, <= 128 registers
 #endif
-// `chain` != 0: one workgroup per (frame, quarter tile), block index = frame * blocks_per_frame + quarter tile.  Everything but the
+// `chain` != 0: one workgroup per (frame, quarter tile), work item = frame * blocks_per_frame + quarter tile.  Everything but the
 // decision loop of remove_doubling is independent from frame to frame, so the frames of a group run side by side and a workgroup
-// waits -- just before that loop -- for the flag its predecessor (same streams, previous frame: a lower block index, dispatched
-// earlier) sets once its pitch and gain are in memory.  `seq0` numbers the group's first frame; flag values are frame numbers, so a
-// flag left by an earlier use of the scratch set never matches.  `chain` == 0: one workgroup per quarter tile loops over the frames.
-__global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, const StepParams *sp0, int g, int chain, int seq0)
+// waits -- just before that loop -- for the flag its predecessor (same streams, previous frame: a lower work item) sets once its
+// pitch and gain are in memory.  A workgroup takes its work item from a device-wide ticket counter when it STARTS (`tbase` = the
+// counter's value before this launch), not from its block index: the holder of item i then knows that every item below i has been
+// taken by a workgroup that is already running, so the wait always ends -- whatever order the hardware dispatches workgroups in
+// (HIP promises none; in the observed in-order dispatch ticket and block index coincide).  `seq0` numbers the group's first frame;
+// flag values are frame numbers, so a flag left by an earlier use of the scratch set never matches.  `chain` == 0: one workgroup
+// per quarter tile loops over the frames.
+__global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, const StepParams *sp0, int g, int chain, int seq0, unsigned tbase)
 {
     __shared__ PkLds L;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane0 = threadIdx.x & 63;
     int lane = lane0, s = lane & 15, q = lane >> 4;  // lane = (stream, chain)
+    int item = (int)blockIdx.x;
+    if (chain) {
+        if (threadIdx.x == 0) L.u.f.any_refine = (int)(ticket_take(b.ticket) - tbase);
+        __syncthreads();
+        item = __builtin_amdgcn_readfirstlane(L.u.f.any_refine);
+        __syncthreads();   // (the field is written again further down)
+    }
     // Workgroup b runs on XCD b mod 8 (observed dispatch order; a speed matter only).  The four quarter-tile blocks of tile t are
     // sent to XCD t mod 8 -- the one whose L2 holds the tile's decimated history, written there by k_hp's block t: consecutive
     // block indices would spread them over four XCDs, each fetching the same lines.
     const int per = b.S_pad / PK_SPB;   // blocks per frame
-    const int f_begin = chain ? (int)blockIdx.x / per : 0, f_end = chain ? f_begin + 1 : g;
-    int blk = (int)blockIdx.x - f_begin * per;
+    const int f_begin = chain ? item / per : 0, f_end = chain ? f_begin + 1 : g;
+    int blk = item - f_begin * per;
     if ((per & 31) == 0) {
         const int xcd = blk & 7, i = blk >> 3;
         blk = 4 * (8 * (i >> 2) + xcd) + (i & 3);
@@ -968,7 +979,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 const int *flag = (const int *)NNN_TIF(b, pflag, 1, f - 1, tile, q0);
                 int spins = 0;
                 while (flag_read(flag) != seq0 + f - 1 && spins < (1 << 22)) { spins++; chain_pause(); }
-                if (spins >= (1 << 22)) *b.fault = 1;   // never seen: the predecessor is an earlier workgroup of this launch; reported, not hung on
+                if (spins >= (1 << 22)) *b.fault = 1;   // never seen (cannot happen, see the ticket order above): reported to the host, not hung on
                 last_period = NNN_TIF(b, pitch, 1, f - 1, tile, sl)[0];
                 last_gain = NNN_TIF(b, pgain, 1, f - 1, tile, sl)[0];
             }
@@ -1062,7 +1073,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             last_gain = pg;
             if (chain) {
                 __threadfence();   // every stream's pitch and gain before the flag
-                if (lane0 == 0) flag_publish((int *)NNN_TIF(b, pflag, 1, f, tile, q0), seq0 + f);
+                if (lane0 == 0 && seq0 + f != b.dbg_withhold) flag_publish((int *)NNN_TIF(b, pflag, 1, f, tile, q0), seq0 + f);
             }
         }
         NNN_STAMP(b, 57);
@@ -1080,6 +1091,17 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
 // (easyfft 0.4.2 -> realfft 3.5.0 -> rustfft 6.4.1; call sites src/features.rs:264,290),
 // un-normalised in both directions.
 // ---------------------------------------------------------------------------------------------
+// Everything from here to the end of k_fft_x, and k_synth further down, is downstream of an FFT: the reference itself is only
+// defined to f32 rounding there (its FFT picks AVX / SSE / scalar code at run time), parity is a tolerance, and these kernels
+// are bound by vector-instruction issue -- so a multiply may fuse with the add that follows it (v_fma_f32 / v_pk_fma_f32),
+// which the translation unit's -ffp-contract=off forbids everywhere else (the pitch path rounds like the scalar reference, the
+// activation functions are compared bit for bit).  NNN_FFT_CONTRACT=0 builds the unfused variant for A/B runs.
+#ifndef NNN_FFT_CONTRACT
+#define NNN_FFT_CONTRACT 1
+#endif
+#if NNN_FFT_CONTRACT
+#pragma clang fp contract(fast)
+#endif
 constexpr int NFFT = 480;
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 w)
@@ -1179,22 +1201,34 @@ constexpr int FFT_SPB = 4;
 // per-lane constant.  k_fft_xp 19.6 -> 18.9 us per frame at 4096 streams, 325 -> 321 at 65536 (same box).
 __device__ __forceinline__ int bsk(int k) { return k + (k >> 3); }
 constexpr int BSK_LEN = 400 + 400 / 8;
-struct FftLds {
+struct alignas(16) FftLds {
     float2 tw[NFFT];           // exp(-2 pi i k / 960), k < 480; the other half of the circle is the negation
     float frac[BSK_LEN];       // triangular band weights (ref: src/lib.rs:65-82), skewed (bsk)
     unsigned char band[400];   // band of each bin
     short seg[192];            // band-sum segmentation (see band_sums_par)
 };
-// fills the block's tables; every thread of the block calls it, the caller synchronises
-__device__ __forceinline__ void fft_tables_load(FftLds &t, const Buffers &b, bool want_band)
+static_assert(sizeof(FftLds) % 16 == 0, "copied as 16-byte pieces");
+// Fills the block's tables from the image the host built in exactly this layout (Buffers::fft_img): a straight copy of 16-byte
+// pieces.  (Building them in the kernel from the plain tables -- skewed index, byte and short conversions, scattered narrow LDS
+// stores -- cost k_fft_xp 190 of its 1530 vector instructions per stream-frame.)  Every thread of the block calls it, the caller
+// synchronises.
+__device__ __forceinline__ void fft_tables_load(FftLds &t, const Buffers &b)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
-    for (int i = tid; i < NFFT; i += nt) t.tw[i] = b.tw960[i];
-    for (int i = tid; i < 400; i += nt) {
-        t.frac[bsk(i)] = b.bin_frac[i];
-        if (want_band) t.band[i] = (unsigned char)b.bin_band[i];
+    const uint4 *src = (const uint4 *)b.fft_img;
+    uint4 *dst = (uint4 *)&t;
+    for (int i = tid; i < (int)(sizeof(FftLds) / 16); i += nt) dst[i] = src[i];
+}
+// the host's side of it
+__host__ inline void fft_tables_image(FftLds &t, const float2 *tw960, const float *bin_frac, const int *bin_band, const int *seg)
+{
+    memset(&t, 0, sizeof(t));
+    for (int i = 0; i < NFFT; i++) t.tw[i] = tw960[i];
+    for (int i = 0; i < 400; i++) {
+        t.frac[i + (i >> 3)] = bin_frac[i];
+        t.band[i] = (unsigned char)bin_band[i];
     }
-    for (int i = tid; i < 192; i += nt) t.seg[i] = (short)b.seg[i];
+    for (int i = 0; i < 192; i++) t.seg[i] = (short)seg[i];
 }
 __device__ __forceinline__ float2 tw960_at(const float2 *tw, int k)   // k in [0, 960)
 {
@@ -1404,7 +1438,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
 #pragma unroll
     for (int r = 0; r < 8; r++) w[r] = ((const float2 *)b.window)[(lane < FFT_P1 ? lane : FFT_P1 - 1) + FFT_P1 * r];
     const int lag = WITH_P ? NNN_TI(b.pitch, 1, tile, sl)[0] : 0;
-    fft_tables_load(t, b, false);
+    fft_tables_load(t, b);
     const float *h = b.hist + (size_t)s * HSTR;
     float2 X[8];
     window_rfft(b, h, rb, 0, w, t, Z, X, lane, true);
@@ -1515,6 +1549,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB) k_fft_x(Buffers b, const StepPar
     transform_inputs<false>(b, sp + frame, bx, t, Z[wave], part[wave]);
 }
 
+#pragma clang fp contract(off)
 // ---------------------------------------------------------------------------------------------
 // K9  features: the 42 RNN inputs from band energies, pitch and the cepstral history.
 //     ref: src/features.rs:135-219, src/lib.rs:139-148.  lane = stream; runs on wave 0 of the RNN kernel.
@@ -2634,6 +2669,9 @@ __global__ void __launch_bounds__(64 * WF_WAVES) k_rnn_wf(Buffers b, RnnPlan pl,
     NNN_STAMP(b, 52);
 }
 
+#if NNN_FFT_CONTRACT
+#pragma clang fp contract(fast)   // (k_synth: downstream of the transforms, see the note above them)
+#endif
 // interpolated band gain at bin k (ref: src/lib.rs:84-97): zero for k >= 400
 __device__ __forceinline__ float interp_gain(const float *g, int k, const float *bin_frac, const unsigned char *bin_band)
 {
@@ -2641,6 +2679,18 @@ __device__ __forceinline__ float interp_gain(const float *g, int k, const float 
     int i = bin_band[k];
     float frac = bin_frac[bsk(k)];   // (the LDS table is skewed)
     return (1.0f - frac) * g[i] + frac * g[i + 1];
+}
+// the same for two gain vectors at once (one look-up of the bin's band and weight serves both)
+__device__ __forceinline__ void interp_gain2(const float *ga, const float *gb, int k, const float *bin_frac, const unsigned char *bin_band,
+                                             float &ra, float &rb)
+{
+    ra = 0.0f;
+    rb = 0.0f;
+    if (k >= 400) return;
+    const int i = bin_band[k];
+    const float frac = bin_frac[bsk(k)], om = 1.0f - frac;
+    ra = om * ga[i] + frac * ga[i + 1];
+    rb = om * gb[i] + frac * gb[i + 1];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2662,7 +2712,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
     float *ebuf = (float *)A, *r = r_[wave], *r2 = r + NB, *gg = r + 2 * NB, *part = part_[wave];
     const int lane0 = threadIdx.x & 63, s = blockIdx.x * FFT_SPB + wave, tile = s >> 6, sl = s & 63;
     int lane = lane0;
-    fft_tables_load(t, b, true);
+    fft_tables_load(t, b);
     float *sm = b.synth_mem + (size_t)s * FRAME;
     float2 smv[4];   // overlap memory as sample pairs, carried from frame to frame in registers
 #pragma unroll
@@ -2701,10 +2751,11 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
         char *o = sp->out + (long long)grp * sp->group_stride + (long long)(s - grp * ch) * elem;
         const bool store = s < b.S && !sp->discard;
         const bool pair_ok = ch == 1 && (((size_t)o) & (size_t)(2 * elem - 1)) == 0;
+        int bmask = 1 << NB;             // lane 0: this frame's branch mask (bit 22: silent)
         if (live) {
             const bool up = b_xp > b_graw;   // the branch the parity tests compare (ref: src/features.rs:227)
+            const int mask = (int)(wave_ballot(up && lane < NB) & ((1ull << NB) - 1));   // bit i: band i took `exp > g`
             if (lane < NB) {
-                part[lane] = up ? 1.0f : 0.0f;
                 float v;
                 if (up) v = 1.0f;
                 else {
@@ -2718,10 +2769,8 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
             }
             wave_lds_sync();
             if (lane == 0) {
-                int mask = 0;
-#pragma unroll
-                for (int i = 0; i < NB; i++) mask |= part[i] != 0.0f ? 1 << i : 0;
                 NNN_TIF(b, branch, 1, f, tile, sl)[0] = mask;
+                bmask = mask;
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -2747,14 +2796,22 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
             for (int u = 0; u < 8; u++) {
                 const int k = lane + 64 * u;
                 if (k < FREQ) {
-                    const float rf = interp_gain(r2, k, t.frac, t.band);
+                    float rf, gf;
+                    interp_gain2(r2, gg, k, t.frac, t.band, rf, gf);
                     Xr[u].x *= rf; Xr[u].y *= rf;
-                    const float gf = interp_gain(gg, k, t.frac, t.band);
                     Xr[u].x *= gf; Xr[u].y *= gf;
                 }
             }
         } else if (lane == 0) {
             NNN_TIF(b, branch, 1, f, tile, sl)[0] = 1 << NB;
+        }
+        if (sp->log && s < b.S) {   // parity-test record of this frame: pitch index, branch mask, smoothed gains
+            unsigned *lg = sp->log + (size_t)s * FRAME_LOG_WORDS;
+            if (lane < NB) lg[2 + lane] = __float_as_uint(live ? b_g : 0.0f);
+            if (lane == 0) {
+                lg[0] = (unsigned)NNN_TIF(b, pitch, 1, f, tile, sl)[0];
+                lg[1] = (unsigned)bmask;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -2823,6 +2880,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
     }
 }
 
+#pragma clang fp contract(off)
 // the activation functions on their own, for the direct known-answer sweep of the parity tests (ref: src/util.rs:29-53)
 __global__ void k_activation_kat(const float *tansig, const float *x, float *y, int act, int n)
 {
@@ -2844,6 +2902,7 @@ __global__ void k_fill_params(StepParams *tab, StepParams v, int n)
     p.discard = t < v.discard;
     p.vad = v.vad ? v.vad + (size_t)t * v.n_streams : nullptr;
     p.slot = (v.slot + t) % NSLOT;
+    p.log = (v.log && t < v.log_frames) ? v.log + (size_t)t * v.n_streams * FRAME_LOG_WORDS : nullptr;
     tab[t] = p;
 }
 

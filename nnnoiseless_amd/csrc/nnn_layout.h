@@ -117,8 +117,12 @@ struct Buffers {
     const float *bin_frac;   // [400]  j / band_size
     const int *bin_band;     // [400]
     long long *stamps;       // [64] optional phase time stamps of block 0 (built with -DNNN_STAMPS)
-    int *fault;              // [1]  set by a kernel that gave up waiting for another workgroup's flag (k_pitch); checked by the host
+    int *fault;              // [1]  set by a kernel that gave up waiting for another workgroup's flag (k_pitch); page-locked host memory
+                             //      mapped into the device, so the host sees it without a copy (checked at every call, sticky until reset)
+    unsigned *ticket;        // [1]  chained k_pitch launches: workgroups take their work item in the order they START (see k_pitch)
+    int dbg_withhold;        // test hook: the frame number whose hand-off flag is never published (0 = none)
     const int *seg;          // [192] band-sum segments: k0[64], count[64], first segment[32], segments[32] per interval
+    const void *fft_img;     // the transform kernels' LDS tables (twiddles, band weights, bands, segments) in their LDS layout (FftLds)
     float wnorm;
     int S, S_pad, NT;
     int taps;                // != 0: kernels also store the quantities only parity tests look at (xc1, xc2, P from bin 400 up)
@@ -159,7 +163,12 @@ struct StepParams {
     int discard;       // frame tables: != 0 = this frame's audio is not written; call parameters: frames to drop
     int slot;          // history ring slot that receives this frame (frame index mod NSLOT)
     int n_streams;
+    // optional per-frame record for parity tests (nnn_batch_set_frame_log): [n_streams][FRAME_LOG_WORDS] words, or null.
+    // Frame tables: this frame's record; call parameters: the first frame's record and the frames that still have room.
+    unsigned *log;
+    int log_frames;
 };
+constexpr int FRAME_LOG_WORDS = 2 + NB;   // pitch index, branch mask, the 22 smoothed band gains (f32 bits)
 
 // ring position of logical input_mem[0] when the newest frame sits in slot `slot`
 __host__ __device__ inline int ring_base(int slot) { return (FRAME * slot + RING - (HIST - FRAME)) % RING; }

@@ -120,8 +120,15 @@ __device__ __forceinline__ int flag_read(const int *flag)
 {
     return __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
 }
+// next value of a device-wide counter (one lane calls it)
+__device__ __forceinline__ unsigned ticket_take(unsigned *ctr)
+{
+    return __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // true when the predicate holds on any active lane of the wave (wave-uniform)
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+// bit l: the predicate on lane l (wave-uniform)
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ void chain_pause() { __builtin_amdgcn_s_sleep(4); }
 
 }  // namespace nnn

@@ -132,6 +132,9 @@ extern "C" int nnn_resampler_process_device(nnn_resampler *r, const float *d_in,
     if (!r || !n_out) return rfail("null argument");
     *n_out = 0;
     if (n_in < 0 || cap_out < 0 || (n_in > 0 && !d_in) || (cap_out > 0 && !d_out)) return rfail("resampler: bad buffer");
+    // every source sample of a call is consumed by it (the ring moves past all of them), so every output they complete must
+    // have room: a smaller cap_out would silently drop outputs and leave the bookkeeping behind the ring
+    if (cap_out < nnn_resampler_max_output(r, n_in)) return rfail("resampler: cap_out smaller than nnn_resampler_max_output(r, n_in)");
     if (hipSetDevice(r->device) != hipSuccess) return rfail("resampler: no such HIP device");
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : r->stream;
     // ---- the position sequence of Resample::next_sample (src/nnnoiseless.rs:107-120) and the weights of Sinc::interpolate

@@ -11,8 +11,9 @@ def shard_range(n_streams, rank, world):
 
 def aggregate(dist, frames_done, elapsed_s, device=None):
     """(total frames over all ranks, max elapsed over ranks).  `dist` = torch.distributed or None."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return frames_done, elapsed_s
+    # (an initialised group of one rank still runs the two all-reduces: the 1-rank RCCL test exercises exactly this path)
     import torch
     f = torch.tensor([float(frames_done)], dtype=torch.float64, device=device)
     t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)

@@ -27,14 +27,18 @@ class TrainingFeatures:
         42 features of the mix | 22 gains | 22 noise levels | vad.  Long calls cross the bus in 16-frame chunks beside the
         kernels; arrays from nnnoiseless_amd.pinned_empty (inputs, and `rows` handed in) go by DMA."""
         signal, noise, combined = (_ffi.as_f32(a) for a in (signal, noise, combined))
+        if signal.ndim != 3 or signal.shape[0] != self.n_streams or signal.shape[2] != FRAME_SIZE or not (noise.shape == signal.shape == combined.shape):
+            raise ValueError(f"process needs three arrays of shape [{self.n_streams}, n_frames, {FRAME_SIZE}]")
         S, T, F = signal.shape
-        assert S == self.n_streams and F == FRAME_SIZE and noise.shape == signal.shape == combined.shape
         cut = np.ascontiguousarray(band_gain_cutoff, dtype=np.int32)
         vad = _ffi.as_f32(vad)
-        assert cut.shape == (T, S) and vad.shape == (T, S)
+        if cut.shape != (T, S) or vad.shape != (T, S):
+            raise ValueError("band_gain_cutoff and vad must have shape [n_frames, n_streams]")
         if rows is None:
             rows = np.empty((T, S, ROW_WIDTH), np.float32)
-        assert rows.shape == (T, S, ROW_WIDTH) and rows.dtype == np.float32 and rows.flags.c_contiguous
+        # a caller-supplied row buffer is written by the C library: a wrong size or layout must never get that far
+        if not (isinstance(rows, np.ndarray) and rows.shape == (T, S, ROW_WIDTH) and rows.dtype == np.float32 and rows.flags.c_contiguous and rows.flags.writeable):
+            raise ValueError(f"rows must be a writable C-contiguous float32 array of shape [n_frames, n_streams, {ROW_WIDTH}]")
         self._lib.check(self._lib.L.nnn_train_process_host(self._h, _ffi.ptr(signal), _ffi.ptr(noise), _ffi.ptr(combined),
                                                            _ffi.ptr(cut), _ffi.ptr(vad), _ffi.ptr(rows), T))
         return rows

@@ -101,7 +101,8 @@ static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 1; }
 template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
-enum { hipHostMallocDefault = 0 };
+enum { hipHostMallocDefault = 0, hipHostMallocMapped = 2 };
+static inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 1; }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }

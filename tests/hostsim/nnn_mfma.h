@@ -76,6 +76,21 @@ static inline float sadd(float a, float b) { return a + b; }
 // (the interpreter runs the workgroups of a launch one after the other in index order: a flag is always set when it is read)
 static inline void flag_publish(int *flag, int value) { *flag = value; }
 static inline int flag_read(const int *flag) { return *flag; }
+static inline unsigned ticket_take(unsigned *ctr) { return (*ctr)++; }
+namespace detail {
+static inline void ballot_fn(const void *const *ins, void *const *outs, int nl)
+{
+    unsigned long long m = 0;
+    for (int l = 0; l < nl; l++) if (ins[l] && *(const bool *)ins[l]) m |= 1ull << l;
+    for (int l = 0; l < nl; l++) if (outs[l]) *(unsigned long long *)outs[l] = m;
+}
+}  // namespace detail
+static inline unsigned long long wave_ballot(bool p)
+{
+    unsigned long long m = 0;
+    hostsim::wave_collective(&p, &m, detail::ballot_fn);
+    return m;
+}
 static inline bool wave_any(bool) { return true; }   // (a skipped no-op update and an executed one leave the same state)
 static inline void chain_pause() {}
 static inline void __threadfence() {}

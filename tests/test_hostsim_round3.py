@@ -1,0 +1,97 @@
+"""Round-3 host logic under the test-only SIMT interpreter (no GPU): the per-frame parity record, the hand-off fault and its
+test hook, the resampler's output-capacity precondition, argument validation of caller-supplied buffers."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from nnnoiseless_amd import _ffi
+
+
+def test_frame_log_records_every_frame(hostsim_lib):
+    """nnn_batch_set_frame_log: (pitch, branch, 22 gains) of every frame of multi-frame calls equal the taps of the same frames
+    processed one at a time; frames beyond the record's capacity are not written."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T = 9, 7
+    x = make_streams(3, S, T)
+    ref = nn.BatchDenoiser(S, lib=hostsim_lib)
+    want = np.zeros((T, S, 24), np.uint32)
+    for t in range(T):
+        ref.process(x[:, t:t + 1])
+        want[t, :, 0] = ref.tap("pitch")[:, 0].view(np.uint32)
+        want[t, :, 1] = ref.tap("branch")[:, 0].view(np.uint32)
+        want[t, :, 2:] = ref.tap("g").view(np.uint32)
+    bd = nn.BatchDenoiser(S, lib=hostsim_lib)
+    log = np.full((T, S, 24), 0xDEADBEEF, np.uint32)
+    bd.set_frame_log(log.ctypes.data, T - 1)          # room for all frames but the last
+    bd.process(x[:, :4])
+    bd.process(x[:, 4:])
+    assert np.array_equal(log[:T - 1], want[:T - 1])
+    assert (log[T - 1] == 0xDEADBEEF).all()
+    silent = want[:, :, 1] == 1 << 22
+    assert silent[:, 7 - 3].all() and not want[:, :, 2:][silent].any()   # stream 7 of the synthetic mix is silence
+
+
+def test_withheld_handoff_flag_raises_a_sticky_fault(hostsim_lib):
+    """The frames of a group run side by side in k_pitch and hand the last pitch from workgroup to workgroup; a flag that never
+    arrives must not hang and must not pass silently: the waiting workgroup times out, the batch reports the fault from
+    synchronize() and from every later call, and reset() clears it."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T = 5, 6
+    x = make_streams(0, S, T)
+    bd = nn.BatchDenoiser(S, lib=hostsim_lib)
+    clean, _ = bd.process(x)
+    assert not bd.fault()
+    bd.reset()
+    hostsim_lib.check(hostsim_lib.L.nnn_batch_debug_withhold_flag(bd._h, 2))    # frame 2's flag is never published
+    with pytest.raises(RuntimeError, match="hand-off"):
+        bd.process(x)                                                            # (the host call ends in a synchronize)
+    assert bd.fault()
+    with pytest.raises(RuntimeError, match="hand-off"):
+        bd.process(x[:, :1])
+    with pytest.raises(RuntimeError, match="hand-off"):
+        bd.synchronize()
+    bd.reset()
+    hostsim_lib.check(hostsim_lib.L.nnn_batch_debug_withhold_flag(bd._h, -1))
+    assert not bd.fault()
+    again, _ = bd.process(x)
+    assert np.array_equal(again, clean)
+
+
+def test_resampler_refuses_a_short_output_buffer(hostsim_lib):
+    """cap_out below nnn_resampler_max_output would drop outputs while the ring moves on: refused, nothing consumed."""
+    L = hostsim_lib.L
+    r = L.nnn_resampler_create(2, 44100.0 / 48000.0, 0)
+    assert r
+    x = np.random.default_rng(0).standard_normal((2, 500)).astype(np.float32)
+    cap = L.nnn_resampler_max_output(r, 500)
+    out = np.zeros((2, cap), np.float32)
+    n = C.c_long(-1)
+    assert L.nnn_resampler_process_host(r, _ffi.ptr(x), 500, _ffi.ptr(out), cap - 200, C.byref(n)) != 0
+    assert "cap_out" in hostsim_lib.error() and n.value == 0
+    assert L.nnn_resampler_process_host(r, _ffi.ptr(x), 500, _ffi.ptr(out), cap, C.byref(n)) == 0 and n.value > 500
+    L.nnn_resampler_destroy(r)
+
+
+def test_caller_supplied_buffers_are_validated(hostsim_lib):
+    """Wrong-sized `out` / `vad` / `rows` never reach the C library (explicit ValueError, also under python -O)."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.training import ROW_WIDTH, TrainingFeatures
+    bd = nn.BatchDenoiser(3, lib=hostsim_lib)
+    x = np.zeros((3, 2, 480), np.float32)
+    with pytest.raises(ValueError):
+        bd.process(x, out=np.zeros((3, 1, 480), np.float32))
+    with pytest.raises(ValueError):
+        bd.process(x, vad=np.zeros((3, 2), np.float32))
+    with pytest.raises(ValueError):
+        bd.process(x, out=np.zeros((3, 2, 480), np.float64))
+    with pytest.raises(ValueError):
+        bd.process(np.zeros((2, 2, 480), np.float32))
+    tf = TrainingFeatures(3, lib=hostsim_lib)
+    cut, vad = np.zeros((2, 3), np.int32), np.zeros((2, 3), np.float32)
+    with pytest.raises(ValueError):
+        tf.process(x, x, x, cut, vad, rows=np.zeros((2, 3, ROW_WIDTH - 1), np.float32))
+    with pytest.raises(ValueError):
+        tf.process(x, x, x, cut[:1], vad)
