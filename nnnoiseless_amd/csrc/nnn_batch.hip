@@ -45,8 +45,8 @@ int nnn_set_error(const char *msg) { return fail("%s", msg); }   // for the libr
         if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));  \
     } while (0)
 
-enum KernelId { K_HP, K_PITCH, K_FFT_XP, K_RNN, K_SYNTH, K_COUNT };
-static const char *kKernelNames[K_COUNT] = {"k_hp", "k_pitch", "k_fft_xp", "k_rnn", "k_synth"};
+enum KernelId { K_HP, K_LPC, K_PITCH, K_FFT_XP, K_RNN, K_SYNTH, K_COUNT };
+static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_pitch", "k_fft_xp", "k_rnn", "k_synth"};
 
 // The five stages of a frame group, one kernel launch each (k_rnn: one per resident model).  hp, pitch, rnn and synth carry
 // state from frame to frame and loop over the group's frames inside the launch; fft_xp covers all frames of the group
@@ -643,7 +643,11 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
     const Buffers &b = h->b[set0];
     Launcher L{h, st, prof};
     switch (s) {
-    case ST_HP: L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g); break;
+    case ST_HP:
+        L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g);
+        // the LPC analysis of the group's frames (lane = stream, frames side by side) rides on the same stream, ahead of the pitch stage
+        L.go(K_LPC, k_lpc, dim3(NT * ug), dim3(64), 0, b, sp0, g);
+        break;
     case ST_PITCH: {
         // frames side by side, chained through flags (k_pitch), while one frame's workgroups cannot fill the GPU (below 16384
         // streams; measured at 4096: 46.8 -> 32.8 us per frame; at 65536, where the frame loop's prefetch of the next window
@@ -1064,8 +1068,8 @@ static bool tap_desc(const nnn_batch *h, int tap, TapDesc &d, const void **ptr)
     switch (tap) {
     case NNN_TAP_FILTERED: d = {FRAME, 0, 3, 0, FRAME, 0}; *ptr = TP(hist); return true;
     case NNN_TAP_XLP: d = {XLP, 0, 0, 0, XLP, 1}; *ptr = TP(xlp_ti); return true;
-    case NNN_TAP_AC: d = {5, 0, 0, 0, 10, 1}; *ptr = TP(lpc); return true;
-    case NNN_TAP_LPC2: d = {5, 0, 0, 5, 10, 1}; *ptr = TP(lpc); return true;
+    case NNN_TAP_AC: d = {5, 0, 0, 0, 10, 0}; *ptr = TP(lpc); return true;
+    case NNN_TAP_LPC2: d = {5, 0, 0, 5, 10, 0}; *ptr = TP(lpc); return true;
     case NNN_TAP_XCORR1: d = {NLAG1, 0, 0, 0, NLAG1, 1}; *ptr = TP(xc1); return true;
     case NNN_TAP_BEST1: d = {2, 1, 0, 0, 2, 1}; *ptr = TP(best1); return true;
     case NNN_TAP_XCORR2C: d = {10, 0, 0, 0, 10, 1}; *ptr = TP(xc2); return true;
@@ -1317,6 +1321,7 @@ static void enqueue_feature_group(nnn_batch *h, hipStream_t st, const float *in,
     hipLaunchKernelGGL(k_fill_params, dim3(1), dim3(64), 0, st, sp, v, g);
     hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, (const StepParams *)sp, g);
     if (full) {
+        hipLaunchKernelGGL(k_lpc, dim3(NT * ug), dim3(64), 0, st, b, (const StepParams *)sp, g);
         const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
         const unsigned grid = Sp / PK_SPB * (chain ? ug : 1u);
         hipLaunchKernelGGL(k_pitch, dim3(grid), dim3(PK_T), 0, st, b, (const StepParams *)sp, g, chain, seq0, h->tickets);

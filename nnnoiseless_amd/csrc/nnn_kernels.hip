@@ -245,6 +245,113 @@ __global__ void __launch_bounds__(64, HP_CH <= 16 ? 3 : 1) k_hp(Buffers b, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// K2  lpc: the part of pitch_downsample between the decimation and the FIR -- 5-lag autocorrelation of the 864-value window,
+//     lag window, order-4 Levinson recursion, bandwidth expansion and the extra zero (ref: src/pitch.rs:433-446, 460-480,
+//     257-292) -- lane = stream on the tile-interleaved decimated ring, one wave per (tile, frame).
+//     Each of the five sums is a serial chain of 860 steps in the reference's order; inside k_pitch (one block per 16
+//     streams) they occupied two waves for 8.7 of the block's 44 us with the other six waiting behind a barrier.  Here every lane
+//     carries its own stream's five chains (independent of each other: five-way instruction-level parallelism on full waves), the
+//     frames of a group run side by side (nothing here carries over from frame to frame), every load is a whole 256-byte row,
+//     and the launch rides on the high-pass stream, ahead of the pitch stage.  Output: ac[5], FIR taps[5] per stream-frame.
+// ---------------------------------------------------------------------------------------------
+constexpr int LPC_CH = 20;   // rows per unrolled chunk: 860 = 43 x 20
+static_assert((XLP - 4) % LPC_CH == 0, "");
+__global__ void __launch_bounds__(64) k_lpc(Buffers b, const StepParams *sp0, int g)
+{
+    const int lane = threadIdx.x;
+    // block -> (tile, frame).  Workgroup i runs on XCD i mod 8 (observed; a speed matter only): the g frames of a tile read
+    // overlapping windows (624 of 864 rows shared by neighbours), so they go to one XCD -- tile t's to XCD t mod 8, where k_hp's
+    // block t wrote the ring.
+    int tile, f;
+    {
+        const int blk = (int)blockIdx.x;
+        if ((b.NT & 7) == 0) {
+            const int xcd = blk & 7, i = blk >> 3;
+            tile = xcd + 8 * (i / g);
+            f = i % g;
+        } else {
+            tile = blk / g;
+            f = blk % g;
+        }
+    }
+    const int slot = sp0[f].slot;
+    const float *base = b.dec + ((size_t)tile * DEC_LEN + (size_t)dec_base(slot)) * TILE + lane;
+    float cur[LPC_CH + 4], nxt[LPC_CH];
+#pragma unroll
+    for (int i = 0; i < LPC_CH + 4; i++) cur[i] = base[(size_t)i * TILE];
+    cur[0] = NNN_TI(b.xlp0, NSLOT, tile, lane)[(size_t)slot * TILE];   // x_lp[0] is special (ref: src/pitch.rs:458)
+    float c[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int NCH = (XLP - 4) / LPC_CH;
+#pragma nounroll
+    for (int ch = 0; ch < NCH; ch++) {
+        // rows 20 (ch + 1) + 4 .. + 23 travel while this chunk is summed (the last chunk re-reads its own rows: in range, unused)
+        const float *nb = base + (size_t)((ch + 1 < NCH ? ch + 1 : ch) * LPC_CH + 4) * TILE;
+#pragma unroll
+        for (int i = 0; i < LPC_CH; i++) nxt[i] = nb[(size_t)i * TILE];
+        // ac[k] += x[i] * x[i + k], i ascending: the reference's sequential sum per lag (pitch_xcorr's unrolling keeps that order)
+#pragma unroll
+        for (int j = 0; j < LPC_CH; j++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) c[k] += cur[j] * cur[j + k];
+        if (ch + 1 < NCH) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) cur[i] = cur[LPC_CH + i];
+#pragma unroll
+            for (int i = 0; i < LPC_CH; i++) cur[4 + i] = nxt[i];
+        }
+    }
+    // tail d_k = sum_{i = k + 860}^{863} x[i] x[i - k], added after the main sum; cur[] holds rows 840 .. 863
+    float ac[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        float d = 0.0f;
+#pragma unroll
+        for (int i = k + XLP - 4; i < XLP; i++) d += cur[i - (XLP - LPC_CH - 4)] * cur[i - k - (XLP - LPC_CH - 4)];
+        ac[k] = c[k] + d;
+    }
+    // lag window, Levinson, bandwidth expansion, extra zero (ref: src/pitch.rs:460-480, 257-292)
+    ac[0] *= 1.0001f;
+#pragma unroll
+    for (int i = 1; i < 5; i++) ac[i] -= ac[i] * (0.008f * (float)i) * (0.008f * (float)i);
+    float lpc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (ac[0] != 0.0f) {
+        float error = ac[0];
+        bool done = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (!done) {
+                float rr = 0.0f;
+#pragma unroll
+                for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
+                rr += ac[i + 1];
+                float r = -rr / error;
+                lpc[i] = r;
+#pragma unroll
+                for (int j = 0; j < (i + 1) / 2; j++) {
+                    float t1 = lpc[j], t2 = lpc[i - 1 - j];
+                    lpc[j] = t1 + r * t2;
+                    lpc[i - 1 - j] = t2 + r * t1;
+                }
+                error = error - r * r * error;
+                if (error < 0.001f * ac[0]) done = true;
+            }
+        }
+    }
+    float tmp = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { tmp *= 0.9f; lpc[i] *= tmp; }
+    float l2[5];
+    l2[0] = lpc[0] + 0.8f;
+    l2[1] = lpc[1] + 0.8f * lpc[0];
+    l2[2] = lpc[2] + 0.8f * lpc[1];
+    l2[3] = lpc[3] + 0.8f * lpc[2];
+    l2[4] = 0.8f * lpc[3];
+    float *o = NNN_TIF(b, lpc, 10, f, tile, lane);
+#pragma unroll
+    for (int i = 0; i < 5; i++) { o[(size_t)i * TILE] = ac[i]; o[(size_t)(5 + i) * TILE] = l2[i]; }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K3  pitch: the whole pitch analysis of a frame in ONE launch, one block per 16 consecutive streams (a quarter tile):
 //       pitch_downsample's LPC part  5-lag autocorrelation, lag window, order-4 Levinson, bandwidth expansion + the extra
 //                                    zero, FIR5 -> pitch_buf (ref: src/pitch.rs:433-446, 460-480, 257-292, 407-429)
@@ -367,7 +474,6 @@ struct PkLds {
     float ckf[PK_NCKF][PK_SPB];                  // running energy of the fine lags before lag 8 m (find_best_pitch, ref: src/pitch.rs:380-402)
     float cky[PK_NCKY][PK_SPB];                  // running energy yy of remove_doubling after step 5 m (ref: src/pitch.rs:133-142); [0] = xx
     union {
-        struct { float acs[5][PK_SPB], coef[5][PK_SPB]; } a;         // LPC analysis: autocorrelation, FIR taps
         struct { float xc[NLAG1][PK_SPB], ysq[NLAG1][PK_SPB]; } c;   // coarse search: squared positive cross-correlation (else NaN), running energy per lag
         struct {                                                       // from the fine search on
             float part[PK_NC][4][PK_SPB];        // inner-product partials [slot][q][stream] (ref: src/pitch.rs:225-244)
@@ -390,12 +496,19 @@ struct PkLds {
 constexpr int PK_CH = 32, PK_NCH = XLP / PK_CH;
 static_assert(PK_NCH * PK_CH == XLP && PK_NCH * PK_SPB <= PK_T, "");
 
-// a frame's window from the decimated-history ring: 16 lanes share a 64-byte segment of a tile row
-__device__ __forceinline__ void pk_window_load(const Buffers &b, const StepParams *sp, int tile, int q0, int tid, float (&v)[PK_CH])
+// a frame's window from the decimated-history ring: 16 lanes share a 64-byte segment of a tile row; with it the frame's five FIR
+// taps (k_lpc's output, scratch set `f` of the group)
+__device__ __forceinline__ void pk_window_load(const Buffers &b, const StepParams *sp, int f, int tile, int q0, int tid, float (&v)[PK_CH],
+                                               float (&fir)[5])
 {
     const int col = tid & 15, ch = tid >> 4;
     if (ch >= PK_NCH) return;
     const int slot = sp->slot;
+    {
+        const float *lp = NNN_TIF(b, lpc, 10, f, tile, q0 + col);
+#pragma unroll
+        for (int i = 0; i < 5; i++) fir[i] = lp[(size_t)(5 + i) * TILE];
+    }
     const float *base = b.dec + ((size_t)tile * DEC_LEN + (size_t)dec_base(slot)) * TILE + q0;   // uniform
     const unsigned off = (unsigned)(ch * PK_CH) * TILE + (unsigned)col;
 #pragma unroll
@@ -480,8 +593,8 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         last_period = NNN_TI(b.last_period, 1, tile, q0 + s)[0];
         last_gain = NNN_TI(b.last_gain, 1, tile, q0 + s)[0];
     }
-    float win[PK_CH];
-    pk_window_load(b, sp0 + f_begin, tile, q0, (int)threadIdx.x, win);
+    float win[PK_CH], fir[5];
+    pk_window_load(b, sp0 + f_begin, f_begin, tile, q0, (int)threadIdx.x, win, fir);
     for (int f = f_begin; f < f_end; f++) {
         lane = launder_v(lane0);   // keep the frame loop's addresses inside the loop (see launder_v)
         s = lane & 15;
@@ -499,100 +612,8 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         }
         __syncthreads();
         NNN_STAMP(b, 1);
-        // ---- autocorrelation: lags 0..3 on wave 0, lag 4 on the first 16 lanes of wave 1 (ref: src/pitch.rs:433-446)
-        if (wave == 0 || (wave == 1 && lane < PK_SPB)) {
-            const int k = wave == 0 ? q : 4;
-            const int fast_n = XLP - 4;
-            // rows i0 .. i0 + 3 (i0 a multiple of 4) are E[a0], O[a0], E[a0 + 1], O[a0 + 1] with a0 = i0 / 2; rows i0 + k + u
-            // the same pattern started k rows later.  Pairs (u = 0, 2) and (u = 1, 3) come as one ds_read2_b32 each.
-            const float *aE = L.pb + s, *aO = aE + PK_ODD;
-            const float *bA = L.pb + ((k & 1) ? PK_ODD : 0) + (k >> 1) * PK_SPB + s;
-            const float *bB = L.pb + ((k & 1) ? 0 : PK_ODD) + ((k + 1) >> 1) * PK_SPB + s;
-            // a ring of four 4-step groups: a lone wave issues an instruction every four cycles, so group g + 3 is requested
-            // before group g is summed and the LDS round trip stays off the chain
-            constexpr int NGRP = (XLP - 4) / 4;   // 215
-            v2f ra[4][2], rb[4][2];
-            auto fetch = [&](int slot, int grp) {
-                const int o = (2 * grp) * PK_SPB;
-                ra[slot][0] = mk2(aE[o], aE[o + PK_SPB]); ra[slot][1] = mk2(aO[o], aO[o + PK_SPB]);
-                rb[slot][0] = mk2(bA[o], bA[o + PK_SPB]); rb[slot][1] = mk2(bB[o], bB[o + PK_SPB]);
-            };
-            float c = 0.0f;
-            auto sum = [&](int slot) {
-                const v2f p02 = ra[slot][0] * rb[slot][0], p13 = ra[slot][1] * rb[slot][1];
-                c += p02.x;
-                c += p13.x;
-                c += p02.y;
-                c += p13.y;
-            };
-            fetch(0, 0); fetch(1, 1); fetch(2, 2);
-#pragma nounroll
-            for (int g4 = 0; g4 + 4 <= NGRP; g4 += 4) {   // 212 groups
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int nx = g4 + u + 3;
-                    fetch((u + 3) & 3, nx < NGRP ? nx : NGRP - 1);
-                    sum(u);
-                }
-            }
-            sum(0); sum(1); sum(2);   // groups 212, 213, 214 (the ring slots they were fetched into)
-            float d = 0.0f;   // tail d_k = sum_{i = k+860}^{863} x[i] x[i-k], added after the main sum
-            for (int i = k + fast_n; i < XLP; i++) d += L.pb[pk_at(i, s)] * L.pb[pk_at(i - k, s)];
-            L.u.a.acs[k][s] = c + d;
-        }
-        __syncthreads();
-        NNN_STAMP(b, 2);
-        // ---- lag window, Levinson, bandwidth expansion, extra zero (ref: src/pitch.rs:460-480, 257-292)
-        if (dec_lane) {
-            float ac[5];
-#pragma unroll
-            for (int i = 0; i < 5; i++) ac[i] = L.u.a.acs[i][s];
-            ac[0] *= 1.0001f;
-#pragma unroll
-            for (int i = 1; i < 5; i++) ac[i] -= ac[i] * (0.008f * (float)i) * (0.008f * (float)i);
-            float lpc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (ac[0] != 0.0f) {
-                float error = ac[0];
-                bool done = false;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if (!done) {
-                        float rr = 0.0f;
-#pragma unroll
-                        for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
-                        rr += ac[i + 1];
-                        float r = -rr / error;
-                        lpc[i] = r;
-#pragma unroll
-                        for (int j = 0; j < (i + 1) / 2; j++) {
-                            float t1 = lpc[j], t2 = lpc[i - 1 - j];
-                            lpc[j] = t1 + r * t2;
-                            lpc[i - 1 - j] = t2 + r * t1;
-                        }
-                        error = error - r * r * error;
-                        if (error < 0.001f * ac[0]) done = true;
-                    }
-                }
-            }
-            float tmp = 1.0f;
-#pragma unroll
-            for (int i = 0; i < 4; i++) { tmp *= 0.9f; lpc[i] *= tmp; }
-            float l2[5];
-            l2[0] = lpc[0] + 0.8f;
-            l2[1] = lpc[1] + 0.8f * lpc[0];
-            l2[2] = lpc[2] + 0.8f * lpc[1];
-            l2[3] = lpc[3] + 0.8f * lpc[2];
-            l2[4] = 0.8f * lpc[3];
-#pragma unroll
-            for (int i = 0; i < 5; i++) L.u.a.coef[i][s] = l2[i];
-            if (b.taps) {
-                float *o = NNN_TIF(b, lpc, 10, f, tile, sl);
-#pragma unroll
-                for (int i = 0; i < 5; i++) { o[(size_t)i * TILE] = ac[i]; o[(size_t)(5 + i) * TILE] = l2[i]; }
-            }
-        }
-        __syncthreads();
-        NNN_STAMP(b, 3);
+        // (the autocorrelation and the Levinson recursion that stood here -- two waves busy for a fifth of the block's time, six waiting
+        // -- are k_lpc's now: lane = stream, ahead of this launch; the FIR taps arrive with the window)
         // ---- FIR5 with zero initial memory, in place (ref: src/pitch.rs:407-429): the chunk's inputs are still in the
         //      thread's registers, the five rows before it come from LDS before anyone overwrites them
         {
@@ -608,7 +629,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             }
             __syncthreads();   // every chunk has its inputs
             if (ch < PK_NCH) {
-                const float n0 = L.u.a.coef[0][col], n1 = L.u.a.coef[1][col], n2 = L.u.a.coef[2][col], n3 = L.u.a.coef[3][col], n4 = L.u.a.coef[4][col];
+                const float n0 = fir[0], n1 = fir[1], n2 = fir[2], n3 = fir[3], n4 = fir[4];
                 float *tap = b.taps ? NNN_TIF(b, xlp_ti, XLP, f, tile, q0 + col) + (size_t)(ch * PK_CH) * TILE : nullptr;
 #pragma unroll
                 for (int m = 0; m < PK_CH / 2; m++) {
@@ -625,7 +646,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 }
             }
         }
-        if (f + 1 < f_end) pk_window_load(b, sp0 + f + 1, tile, q0, tid, win);   // the next frame's window travels behind this frame's work
+        if (f + 1 < f_end) pk_window_load(b, sp0 + f + 1, f + 1, tile, q0, tid, win, fir);   // the next frame's window travels behind this frame's work
         __syncthreads();
         NNN_STAMP(b, 4);
         // ---- coarse search: the cross-correlation on waves 0..2, the running energy of the coarse lags on wave 3
@@ -1443,11 +1464,16 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     float2 X[8];
     window_rfft(b, h, rb, 0, w, t, Z, X, lane, true);
     float2 *dx = b.X + (size_t)s * FSTR;
+    // NNN_PROBE_XP (developer probe, wrong audio, timing only): the spectra are not stored here and k_synth reads them from a
+    // region small enough to stay in the XCD's L2 -- an upper bound on what keeping X and P on chip between the transforms
+    // and the synthesis (a fused back end) could gain from the removed HBM round trip.
+#ifndef NNN_PROBE_XP
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         const int k = rfft_slot_bin(lane, u);
         if (k >= 0) dx[k] = X[u];
     }
+#endif
     float *vv = (float *)Z, *vc = vv + BSK_LEN;   // per-bin quantities of the band sums, skewed (bsk)
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -1469,11 +1495,13 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     window_rfft(b, h, rb, lag, w, t, Z, Y, lane, false);
     float2 *dp = b.P + (size_t)s * FSTR;
     const int np = b.taps ? FREQ : 400;   // the pitch filter reads bins 0..399 only
+#ifndef NNN_PROBE_XP
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         const int k = rfft_slot_bin(lane, u);
         if (k >= 0 && k < np) dp[k] = Y[u];
     }
+#endif
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         const int k = rfft_slot_bin(lane, u);
@@ -2727,7 +2755,11 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
         const StepParams *sp = sp0 + f;
         float *vad_out = sp->vad;
         const int fmt = sp->fmt;
+#ifdef NNN_PROBE_XP
+        const float2 *Xg = b.X + (size_t)(s & 255) * FSTR, *Pg = b.P + (size_t)(s & 255) * FSTR;
+#else
         const float2 *Xg = b.X + (fo + s) * FSTR, *Pg = b.P + (fo + s) * FSTR;
+#endif
         // every global load of this frame is independent of its own results: issue them all now
         const bool live = NNN_TIF(b, silence, 1, f, tile, sl)[0] == 0;
         float2 Xr[8], Pr[8];

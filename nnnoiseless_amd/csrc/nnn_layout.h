@@ -91,7 +91,7 @@ struct Buffers {
     float *gru_v, *gru_n, *gru_dn;  // SM, tile t at t * 64 * gru_*_w (the widest resident model), rows of the tile's own width
     int gru_v_w, gru_n_w, gru_dn_w;
     // ---- per-frame scratch (doubles as the parity taps)
-    float *lpc;          // TI [10]     ac[5], lpc2[5]
+    float *lpc;          // TI [10]     ac[5], lpc2[5]: k_lpc -> k_pitch (the FIR taps)
     float *xlp_ti;       // TI [864]    pitch_buf
     float *xc1;          // TI [147]    coarse cross-correlation (stored only while taps are on: it lives in LDS otherwise)
     int *best1;          // TI [2]
@@ -132,9 +132,9 @@ struct Buffers {
 // several consecutive frames (block index = frame * blocks_per_frame + block) reaches its frame's set by offsetting.
 // (the first six are written only while the parity taps are on -- everything they hold stays in LDS otherwise -- and are
 // allocated when the taps are first switched on)
-#define NNN_TAP_FIELDS(F) F(lpc, 10) F(xlp_ti, XLP) F(xc1, NLAG1) F(best1, 2) F(xc2, 10) F(psearch, 1)
+#define NNN_TAP_FIELDS(F) F(xlp_ti, XLP) F(xc1, NLAG1) F(best1, 2) F(xc2, 10) F(psearch, 1)
 #define NNN_WORK_FIELDS(F)                                                                                           \
-    F(pitch, 1) F(pflag, 1) F(pgain, 1) F(X, FSTR) F(P, FSTR) F(ex, NB) F(ep, NB) F(exp_, NB) F(cn, 28) F(feat, NFEAT)      \
+    F(lpc, 10) F(pitch, 1) F(pflag, 1) F(pgain, 1) F(X, FSTR) F(P, FSTR) F(ex, NB) F(ep, NB) F(exp_, NB) F(cn, 28) F(feat, NFEAT)      \
     F(silence, 1) F(branch, 1) F(g_raw, NB) F(g, NB) F(vad, 1)
 #define NNN_SCRATCH_FIELDS(F) NNN_TAP_FIELDS(F) NNN_WORK_FIELDS(F)
 __host__ __device__ inline Buffers frame_view(Buffers b, int f)

@@ -582,7 +582,11 @@ def test_nonfinite_inputs_stay_contained(nn, oracle_mod, weights_bytes):
     assert np.array_equal(bd.tap("pitch")[:, 0], ref["pitch"][:, -1])
     assert np.array_equal(np.isnan(out), np.isnan(ref["out"]))
     ok = np.isfinite(out) & np.isfinite(ref["out"])
-    assert np.allclose(out[ok], ref["out"][ok], rtol=1e-4, atol=1e-2)
+    # finite samples agree to 1e-4 of their frame's peak (streams driven to 1e30 keep finite samples whose rounding noise scales
+    # with that peak, not with the sample)
+    peak = np.where(np.isfinite(ref["out"]), np.abs(ref["out"]), 0.0).max(axis=2, keepdims=True)
+    err = np.where(ok, np.abs(out - ref["out"]), 0.0)
+    assert (err <= 1e-4 * peak + 1e-2).all(), np.argwhere(err > 1e-4 * peak + 1e-2)[:8]
 
 
 def _stress(nn, S, T, reps, schedules):
