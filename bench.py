@@ -55,7 +55,8 @@ FLOPS_PER_FRAME = 0.42e6
 G = 16
 KERNEL_BYTES = {
     "k_hp": 1920 + 1920 + 960 + 960 // 5 + 4 + (16 + 8) // G,     # input, history slot, 240 decimated values (+ mirrored share), x_lp[0]; biquad state per group
-    "k_pitch": 3456 + 4 + 8 + 16 // G,                              # decimated window + x_lp[0] in; pitch index + gain out; last pitch per group
+    "k_lpc": 3456 + 4 + 40,                                         # decimated window + x_lp[0] in; autocorrelation and FIR taps out
+    "k_pitch": 3456 + 4 + 20 + 8 + 16 // G,                         # decimated window + x_lp[0] + FIR taps in; pitch index + gain out; last pitch per group
                                                                    # (pitch_buf, coarse xcorr, the running energies and their check points never leave LDS)
     "k_fft_xp": 3840 + 1200 + 4 + 3848 + 3200 + 264 + 112 + 4,     # 960 + (mean lag 300) history samples; X (481 bins), P (400 bins), band energies, cepstrum head out
     "k_rnn": 120 + 88 + 4 + 2 * 88 + 2 * 88 + (704 + 2 * 672 + 8) // G,   # features head in; ring row, vad, gains, last gains; ring + GRU states per group
@@ -66,10 +67,10 @@ KERNEL_BYTES = {
 # it (TFLOP/s): the pitch analysis may not fuse a multiply with an add (bit-exact sums in the reference's order), so its roof
 # is half the FP32 vector peak; the transforms run at the full FP32 vector peak; the RNN's products run as three bf16 planes
 # per f32 activation on the matrix cores (dense bf16 peak / 3); the biquad is an f64 chain.
-KERNEL_FLOPS = {"k_hp": 480 * 13, "k_pitch": 135e3, "k_fft_xp": 66e3, "k_rnn": 174e3, "k_synth": 42e3}
-KERNEL_ROOF_TFLOPS = {"k_hp": FP32_PEAK_TFLOPS / 2, "k_pitch": FP32_PEAK_TFLOPS / 2, "k_fft_xp": FP32_PEAK_TFLOPS, "k_synth": FP32_PEAK_TFLOPS,
+KERNEL_FLOPS = {"k_hp": 480 * 13, "k_lpc": 8.7e3, "k_pitch": 126e3, "k_fft_xp": 66e3, "k_rnn": 174e3, "k_synth": 42e3}
+KERNEL_ROOF_TFLOPS = {"k_hp": FP32_PEAK_TFLOPS / 2, "k_lpc": FP32_PEAK_TFLOPS / 2, "k_pitch": FP32_PEAK_TFLOPS / 2, "k_fft_xp": FP32_PEAK_TFLOPS, "k_synth": FP32_PEAK_TFLOPS,
                       "k_rnn": 2500.0 / 3}
-KERNEL_ROOF_NAME = {"k_hp": "f64 vector, serial chain", "k_pitch": "FP32 vector without FMA (exact sums)", "k_fft_xp": "FP32 vector",
+KERNEL_ROOF_NAME = {"k_hp": "f64 vector, serial chain", "k_lpc": "FP32 vector without FMA (exact sums)", "k_pitch": "FP32 vector without FMA (exact sums)", "k_fft_xp": "FP32 vector",
                     "k_synth": "FP32 vector", "k_rnn": "bf16 MFMA / 3 planes"}
 
 CONFIGS = {

@@ -372,6 +372,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     HIPCHK(dalloc(h, &b.hp_last, Sp, true));
     HIPCHK(dalloc(h, &b.dec, Sp * DEC_LEN, true));
     HIPCHK(dalloc(h, &b.xlp0, Sp * NSLOT, true));
+    HIPCHK(dalloc(h, &b.lpc, Sp * NSLOT * 10, false));   // (remade for every frame before it is read: not part of a snapshot)
     HIPCHK(dalloc(h, &b.ceps_mem, Sp * CEPS_MEM * NB, true));
     HIPCHK(dalloc(h, &b.mem_id, Sp, true));
     HIPCHK(dalloc(h, &b.synth_mem, Sp * FRAME, true));
@@ -1061,6 +1062,7 @@ extern "C" int nnn_batch_process_pcm_host(nnn_batch *h, const void *in, void *ou
 
 // ---- taps ---------------------------------------------------------------------------------------
 struct TapDesc { int len; int is_int; int layout; /* 0 TI, 2 SM float2 rows of FSTR, 3 hist ring */ int sub_ofs; int sub_len; int needs_taps; };
+static int last_slot(const nnn_batch *h) { return h ? (int)((h->frame_count + NSLOT - 1) % NSLOT) : 0; }   // ring slot of the most recent frame
 static bool tap_desc(const nnn_batch *h, int tap, TapDesc &d, const void **ptr)
 {
     const Buffers *b = h ? &h->b[h->last_set] : nullptr;   // scratch set of the most recent frame
@@ -1068,8 +1070,8 @@ static bool tap_desc(const nnn_batch *h, int tap, TapDesc &d, const void **ptr)
     switch (tap) {
     case NNN_TAP_FILTERED: d = {FRAME, 0, 3, 0, FRAME, 0}; *ptr = TP(hist); return true;
     case NNN_TAP_XLP: d = {XLP, 0, 0, 0, XLP, 1}; *ptr = TP(xlp_ti); return true;
-    case NNN_TAP_AC: d = {5, 0, 0, 0, 10, 0}; *ptr = TP(lpc); return true;
-    case NNN_TAP_LPC2: d = {5, 0, 0, 5, 10, 0}; *ptr = TP(lpc); return true;
+    case NNN_TAP_AC: d = {5, 0, 0, last_slot(h) * 10, NSLOT * 10, 0}; *ptr = TP(lpc); return true;
+    case NNN_TAP_LPC2: d = {5, 0, 0, last_slot(h) * 10 + 5, NSLOT * 10, 0}; *ptr = TP(lpc); return true;
     case NNN_TAP_XCORR1: d = {NLAG1, 0, 0, 0, NLAG1, 1}; *ptr = TP(xc1); return true;
     case NNN_TAP_BEST1: d = {2, 1, 0, 0, 2, 1}; *ptr = TP(best1); return true;
     case NNN_TAP_XCORR2C: d = {10, 0, 0, 0, 10, 1}; *ptr = TP(xc2); return true;

@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(64) k_lpc(Buffers b, const StepParams *sp0, in
     l2[2] = lpc[2] + 0.8f * lpc[1];
     l2[3] = lpc[3] + 0.8f * lpc[2];
     l2[4] = 0.8f * lpc[3];
-    float *o = NNN_TIF(b, lpc, 10, f, tile, lane);
+    float *o = NNN_TI(b.lpc, NSLOT * 10, tile, lane) + (size_t)(slot * 10) * TILE;
 #pragma unroll
     for (int i = 0; i < 5; i++) { o[(size_t)i * TILE] = ac[i]; o[(size_t)(5 + i) * TILE] = l2[i]; }
 }
@@ -497,15 +497,15 @@ constexpr int PK_CH = 32, PK_NCH = XLP / PK_CH;
 static_assert(PK_NCH * PK_CH == XLP && PK_NCH * PK_SPB <= PK_T, "");
 
 // a frame's window from the decimated-history ring: 16 lanes share a 64-byte segment of a tile row; with it the frame's five FIR
-// taps (k_lpc's output, scratch set `f` of the group)
-__device__ __forceinline__ void pk_window_load(const Buffers &b, const StepParams *sp, int f, int tile, int q0, int tid, float (&v)[PK_CH],
+// taps (k_lpc's output, kept by ring slot)
+__device__ __forceinline__ void pk_window_load(const Buffers &b, const StepParams *sp, int tile, int q0, int tid, float (&v)[PK_CH],
                                                float (&fir)[5])
 {
     const int col = tid & 15, ch = tid >> 4;
     if (ch >= PK_NCH) return;
     const int slot = sp->slot;
     {
-        const float *lp = NNN_TIF(b, lpc, 10, f, tile, q0 + col);
+        const float *lp = NNN_TI(b.lpc, NSLOT * 10, tile, q0 + col) + (size_t)(slot * 10) * TILE;
 #pragma unroll
         for (int i = 0; i < 5; i++) fir[i] = lp[(size_t)(5 + i) * TILE];
     }
@@ -594,7 +594,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         last_gain = NNN_TI(b.last_gain, 1, tile, q0 + s)[0];
     }
     float win[PK_CH], fir[5];
-    pk_window_load(b, sp0 + f_begin, f_begin, tile, q0, (int)threadIdx.x, win, fir);
+    pk_window_load(b, sp0 + f_begin, tile, q0, (int)threadIdx.x, win, fir);
     for (int f = f_begin; f < f_end; f++) {
         lane = launder_v(lane0);   // keep the frame loop's addresses inside the loop (see launder_v)
         s = lane & 15;
@@ -646,7 +646,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 }
             }
         }
-        if (f + 1 < f_end) pk_window_load(b, sp0 + f + 1, f + 1, tile, q0, tid, win, fir);   // the next frame's window travels behind this frame's work
+        if (f + 1 < f_end) pk_window_load(b, sp0 + f + 1, tile, q0, tid, win, fir);   // the next frame's window travels behind this frame's work
         __syncthreads();
         NNN_STAMP(b, 4);
         // ---- coarse search: the cross-correlation on waves 0..2, the running energy of the coarse lags on wave 3
@@ -1407,21 +1407,26 @@ __device__ __forceinline__ float dct_out(const float *x, const float *dct, int i
 struct __attribute__((packed, aligned(4))) SamplePair { float x, y; };   // two consecutive samples: one 8-byte load at 4-byte alignment
 // windowed 960 samples ending `lag` samples before the newest one -> Z (packed as 480 complex), transform in place,
 // spectrum bins into Y (lane owns bins lane + 64 u), scaled by wnorm
-__device__ __forceinline__ void window_rfft(const Buffers &b, const float *h, int rb, int lag, const float2 (&w)[8], const FftLds &t,
-                                            float2 *Z, float2 (&Y)[8], int lane, bool first)
+// the 960 samples ending `lag` samples before the newest one, as the sample pairs n = j + 60 r of the transform's first pass
+__device__ __forceinline__ void window_load(const float *h, int rb, int lag, int lane, SamplePair (&sm)[8])
 {
     int start = rb + (HIST - WINDOW) - lag;   // in (0, 2 RING)
     if (start >= RING) start -= RING;
-    // sample pairs n = j + 60 r straight into the first pass's registers (w holds the window in the same order)
     const int j = lane < FFT_P1 ? lane : FFT_P1 - 1;   // (lanes 60..63 shadow lane 59 and store nothing)
-    float2 v[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         int i0 = start + 2 * (j + FFT_P1 * r);
         if (i0 >= RING) i0 -= RING;
-        const SamplePair s = *(const SamplePair *)(h + i0);   // (i0 + 1 = RING reads the copy of sample 0 kept there)
-        v[r] = make_float2(s.x * w[r].x, s.y * w[r].y);
+        sm[r] = *(const SamplePair *)(h + i0);   // (i0 + 1 = RING reads the copy of sample 0 kept there)
     }
+}
+__device__ __forceinline__ void window_rfft(const Buffers &b, const SamplePair (&sm)[8], const float2 (&w)[8], const FftLds &t,
+                                            float2 *Z, float2 (&Y)[8], int lane, bool first)
+{
+    // sample pairs n = j + 60 r straight into the first pass's registers (w holds the window in the same order)
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = make_float2(sm[r].x * w[r].x, sm[r].y * w[r].y);
     if (first) __syncthreads();   // tables in place; from here on every wave is on its own
     fft480_regs(v, Z, t.tw, lane);
     // Bins k and 480 - k come from the same two transform outputs (E[480 - k] = conj E[k], O[480 - k] = conj O[k], the twiddle
@@ -1461,8 +1466,15 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     const int lag = WITH_P ? NNN_TI(b.pitch, 1, tile, sl)[0] : 0;
     fft_tables_load(t, b);
     const float *h = b.hist + (size_t)s * HSTR;
+    // both windows' samples are requested now: the second transform's used to be requested when it started, a trip to memory on
+    // the wave's critical path per stream-frame (these kernels move enough bytes for that to show)
+    SamplePair sx[8], spw[8];
+    window_load(h, rb, 0, lane, sx);
+#ifndef NNN_FFT_LATE_P   // (A/B knob: the second window requested where its transform starts, as before)
+    if (WITH_P) window_load(h, rb, lag, lane, spw);
+#endif
     float2 X[8];
-    window_rfft(b, h, rb, 0, w, t, Z, X, lane, true);
+    window_rfft(b, sx, w, t, Z, X, lane, true);
     float2 *dx = b.X + (size_t)s * FSTR;
     // NNN_PROBE_XP (developer probe, wrong audio, timing only): the spectra are not stored here and k_synth reads them from a
     // region small enough to stay in the XCD's L2 -- an upper bound on what keeping X and P on chip between the transforms
@@ -1492,7 +1504,10 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     if (!WITH_P) return;
     wave_lds_sync();
     float2 Y[8];
-    window_rfft(b, h, rb, lag, w, t, Z, Y, lane, false);
+#ifdef NNN_FFT_LATE_P
+    window_load(h, rb, lag, lane, spw);
+#endif
+    window_rfft(b, spw, w, t, Z, Y, lane, false);
     float2 *dp = b.P + (size_t)s * FSTR;
     const int np = b.taps ? FREQ : 400;   // the pitch filter reads bins 0..399 only
 #ifndef NNN_PROBE_XP

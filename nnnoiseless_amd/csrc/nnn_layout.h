@@ -82,6 +82,9 @@ struct Buffers {
     float *dec;          // TI [DEC_LEN]  2:1 decimated history: ring of NSLOT x 240 values whose first 960 are mirrored behind its end,
                          //             so that the 864-value window of any frame is one contiguous run (240 values are new per frame)
     float *xlp0;         // TI [NSLOT]  per ring slot: pitch_downsample's special first element (x[1]/2 + x[0])/2 of that frame
+    float *lpc;          // TI [NSLOT * 10]  per ring slot: that frame's windowed autocorrelation ac[5] and FIR taps lpc2[5], k_lpc -> k_pitch.
+                         //             Kept by ring slot, not by scratch set: k_lpc rides on the high-pass stream, which runs ahead of the
+                         //             groups in flight, and the ring's slots are what that stream already waits for
     float *ceps_mem;     // TI [8*22]
     int *mem_id;         // TI [1]
     float *synth_mem;    // SM [480]
@@ -91,7 +94,6 @@ struct Buffers {
     float *gru_v, *gru_n, *gru_dn;  // SM, tile t at t * 64 * gru_*_w (the widest resident model), rows of the tile's own width
     int gru_v_w, gru_n_w, gru_dn_w;
     // ---- per-frame scratch (doubles as the parity taps)
-    float *lpc;          // TI [10]     ac[5], lpc2[5]: k_lpc -> k_pitch (the FIR taps)
     float *xlp_ti;       // TI [864]    pitch_buf
     float *xc1;          // TI [147]    coarse cross-correlation (stored only while taps are on: it lives in LDS otherwise)
     int *best1;          // TI [2]
@@ -134,7 +136,7 @@ struct Buffers {
 // allocated when the taps are first switched on)
 #define NNN_TAP_FIELDS(F) F(xlp_ti, XLP) F(xc1, NLAG1) F(best1, 2) F(xc2, 10) F(psearch, 1)
 #define NNN_WORK_FIELDS(F)                                                                                           \
-    F(lpc, 10) F(pitch, 1) F(pflag, 1) F(pgain, 1) F(X, FSTR) F(P, FSTR) F(ex, NB) F(ep, NB) F(exp_, NB) F(cn, 28) F(feat, NFEAT)      \
+    F(pitch, 1) F(pflag, 1) F(pgain, 1) F(X, FSTR) F(P, FSTR) F(ex, NB) F(ep, NB) F(exp_, NB) F(cn, 28) F(feat, NFEAT)      \
     F(silence, 1) F(branch, 1) F(g_raw, NB) F(g, NB) F(vad, 1)
 #define NNN_SCRATCH_FIELDS(F) NNN_TAP_FIELDS(F) NNN_WORK_FIELDS(F)
 __host__ __device__ inline Buffers frame_view(Buffers b, int f)
