@@ -425,7 +425,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
         HIPCHK(upload(h, &b.seg, seg));
         // the transform kernels' LDS tables, built once in their LDS layout
         std::vector<FftLds> img(1);
-        fft_tables_image(img[0], tw.data(), bin_frac.data(), bin_band.data(), seg.data());
+        fft_tables_image(img[0], tw.data(), bin_frac.data(), bin_band.data(), seg.data(), dct.data());
         const FftLds *dimg = nullptr;
         HIPCHK(upload(h, &dimg, img));
         b.fft_img = dimg;

@@ -1227,6 +1227,9 @@ struct alignas(16) FftLds {
     float frac[BSK_LEN];       // triangular band weights (ref: src/lib.rs:65-82), skewed (bsk)
     unsigned char band[400];   // band of each bin
     short seg[192];            // band-sum segmentation (see band_sums_par)
+    float dct[NB * NB];        // DCT table (ref: src/lib.rs:118-127): the feature head's two transforms read 44 of its rows per stream-frame
+                               // (from global memory they were half of k_fft_xp's vector-memory instructions; same time either way)
+    float pad_[2];
 };
 static_assert(sizeof(FftLds) % 16 == 0, "copied as 16-byte pieces");
 // Fills the block's tables from the image the host built in exactly this layout (Buffers::fft_img): a straight copy of 16-byte
@@ -1241,9 +1244,10 @@ __device__ __forceinline__ void fft_tables_load(FftLds &t, const Buffers &b)
     for (int i = tid; i < (int)(sizeof(FftLds) / 16); i += nt) dst[i] = src[i];
 }
 // the host's side of it
-__host__ inline void fft_tables_image(FftLds &t, const float2 *tw960, const float *bin_frac, const int *bin_band, const int *seg)
+__host__ inline void fft_tables_image(FftLds &t, const float2 *tw960, const float *bin_frac, const int *bin_band, const int *seg, const float *dct)
 {
     memset(&t, 0, sizeof(t));
+    for (int i = 0; i < NB * NB; i++) t.dct[i] = dct[i];
     for (int i = 0; i < NFFT; i++) t.tw[i] = tw960[i];
     for (int i = 0; i < 400; i++) {
         t.frac[i + (i >> 3)] = bin_frac[i];
@@ -1557,11 +1561,11 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     wave_lds_sync();
     if (lane < NB) {
         float *cn = NNN_TI(b.cn, 28, tile, sl);
-        float c = dct_out(ly, b.dct, lane);
+        float c = dct_out(ly, t.dct, lane);
         c -= lane == 0 ? 12.0f : (lane == 1 ? 4.0f : 0.0f);
         cn[(size_t)lane * TILE] = c;
         if (lane < 6) {
-            float d = dct_out(xc, b.dct, lane);
+            float d = dct_out(xc, t.dct, lane);
             d -= lane == 0 ? 1.3f : (lane == 1 ? 0.9f : 0.0f);
             cn[(size_t)(NB + lane) * TILE] = d;
         }
