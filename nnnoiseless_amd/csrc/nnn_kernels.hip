@@ -1226,7 +1226,8 @@ struct alignas(16) FftLds {
     float2 tw[NFFT];           // exp(-2 pi i k / 960), k < 480; the other half of the circle is the negation
     float frac[BSK_LEN];       // triangular band weights (ref: src/lib.rs:65-82), skewed (bsk)
     unsigned char band[400];   // band of each bin
-    short seg[192];            // band-sum segmentation (see band_sums_par)
+    short seg[256];            // band-sum segmentation (see band_sums_par): k0[64], count[64], first segment[32] and segments[32] per
+                               // interval, [192 + s]: segments behind segment s in its interval
     float dct[NB * NB];        // DCT table (ref: src/lib.rs:118-127): the feature head's two transforms read 44 of its rows per stream-frame
                                // (from global memory they were half of k_fft_xp's vector-memory instructions; same time either way)
     float pad_[2];
@@ -1254,6 +1255,8 @@ __host__ inline void fft_tables_image(FftLds &t, const float2 *tw960, const floa
         t.band[i] = (unsigned char)bin_band[i];
     }
     for (int i = 0; i < 192; i++) t.seg[i] = (short)seg[i];
+    for (int iv = 0; iv < NB - 1; iv++)
+        for (int i = 0; i < seg[160 + iv]; i++) t.seg[192 + seg[128 + iv] + i] = (short)(seg[160 + iv] - 1 - i);
 }
 __device__ __forceinline__ float2 tw960_at(const float2 *tw, int k)   // k in [0, 960)
 {
@@ -1342,53 +1345,54 @@ __device__ __forceinline__ float band_sum(const float *v, int bnd, const float *
     return acc;
 }
 
-// Parallel band sums for tolerance-only quantities (every band energy is downstream of an FFT):
-// the 21 band intervals are cut into 54 segments of <= 8 bins (table b.seg: k0, count, interval per
-// segment; first segment and segment count per interval); lane = segment forms the two triangularly
-// weighted partial sums of up to NQ quantities, then lane = band adds its partials.
+// Parallel band sums for tolerance-only quantities (every band energy is downstream of an FFT): the 21 band intervals are cut
+// into 54 segments of 4 or 8 bins (table t.seg; an 8-bin segment starts on a multiple of 8, so a segment's bins are contiguous
+// in the skewed arrays too).  Lane = segment forms the two triangularly weighted partial sums of its bins for up to NQ
+// quantities -- eight unrolled steps, the shorter segments masked; the segments of an interval sit on consecutive lanes and are
+// summed across lanes by a segmented suffix sum (four shuffle rounds: intervals have at most 11 segments); lane = band then takes
+// the frac-weighted total of the interval below it and the (1 - frac)-weighted total of its own (ref: src/lib.rs:65-82).
+// (Until round 3 the partial sums went through LDS and lane = band looped over up to 11 of them, twice: with the per-bin loop
+// that was a third of k_fft_xp's vector instructions, issued for 22 or 54 of 64 lanes.)  Every lane of the wave must call it.
 template <int NQ>
-__device__ __forceinline__ void band_sums_par(const FftLds &t, const float *const (&v)[NQ], float *part /* [2 * NQ][64] */,
-                                              float (&out)[NQ], int lane)
+__device__ __forceinline__ void band_sums_par(const FftLds &t, const float *const (&v)[NQ], float (&out)[NQ], int lane)
 {
     const short *seg = t.seg;
-    if (lane < 54) {
-        const int k0 = seg[lane], cnt = seg[64 + lane];
-        float pa[NQ], pb[NQ];
+    const int ls = lane < 54 ? lane : 53;   // (lanes past the last segment shadow it and contribute nothing)
+    const int k0 = seg[ls], cnt = lane < 54 ? seg[64 + ls] : 0, rem = lane < 54 ? seg[192 + ls] : 0;
+    const int ks0 = bsk(k0);
+    float pa[NQ], pb[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; q++) { pa[q] = 0.0f; pb[q] = 0.0f; }
-        for (int k = k0; k < k0 + cnt; k++) {
-            const int ks = bsk(k);
-            const float fr = t.frac[ks];
+    for (int q = 0; q < NQ; q++) { pa[q] = 0.0f; pb[q] = 0.0f; }
 #pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                const float x = v[q][ks];
-                pa[q] = fmaf(1.0f - fr, x, pa[q]);
-                pb[q] = fmaf(fr, x, pb[q]);
-            }
+    for (int u = 0; u < 8; u++) {
+        const float fr = t.frac[ks0 + u], om = 1.0f - fr;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            float x = v[q][ks0 + u];
+            x = u < cnt ? x : 0.0f;
+            pa[q] = fmaf(om, x, pa[q]);
+            pb[q] = fmaf(fr, x, pb[q]);
         }
-#pragma unroll
-        for (int q = 0; q < NQ; q++) { part[(2 * q) * 64 + lane] = pa[q]; part[(2 * q + 1) * 64 + lane] = pb[q]; }
     }
-    wave_lds_sync();
+    // segmented suffix sum: afterwards the first segment of every interval holds the interval's totals
 #pragma unroll
-    for (int q = 0; q < NQ; q++) out[q] = 0.0f;
-    if (lane < NB) {
-        if (lane >= 1) {
-            const int s0 = seg[128 + lane - 1], ns = seg[160 + lane - 1];
-            for (int i = s0; i < s0 + ns; i++)
+    for (int d = 1; d < 16; d *= 2) {
 #pragma unroll
-                for (int q = 0; q < NQ; q++) out[q] += part[(2 * q + 1) * 64 + i];
+        for (int q = 0; q < NQ; q++) {
+            const float ta = __shfl_down(pa[q], d), tb = __shfl_down(pb[q], d);
+            pa[q] += rem >= d ? ta : 0.0f;
+            pb[q] += rem >= d ? tb : 0.0f;
         }
-        if (lane < NB - 1) {
-            const int s0 = seg[128 + lane], ns = seg[160 + lane];
-            for (int i = s0; i < s0 + ns; i++)
+    }
+    // lane = band: interval `lane - 1` from below, interval `lane` above
+    const int bnd = lane < NB ? lane : 0;
+    const int lo = seg[128 + (bnd >= 1 ? bnd - 1 : 0)], hi = seg[128 + (bnd < NB - 1 ? bnd : 0)];
 #pragma unroll
-                for (int q = 0; q < NQ; q++) out[q] += part[(2 * q) * 64 + i];
-        }
-        if (lane == 0 || lane == NB - 1) {
-#pragma unroll
-            for (int q = 0; q < NQ; q++) out[q] *= 2.0f;
-        }
+    for (int q = 0; q < NQ; q++) {
+        const float fb = __shfl(pb[q], lo), fa = __shfl(pa[q], hi);
+        float o = (bnd >= 1 ? fb : 0.0f) + (bnd < NB - 1 ? fa : 0.0f);
+        if (bnd == 0 || bnd == NB - 1) o *= 2.0f;
+        out[q] = lane < NB ? o : 0.0f;
     }
 }
 
@@ -1501,7 +1505,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     {
         const float *const v[1] = {vv};
         float o[1];
-        band_sums_par<1>(t, v, part, o, lane);
+        band_sums_par<1>(t, v, o, lane);
         exv = o[0];
         if (lane < NB) NNN_TI(b.ex, NB, tile, sl)[(size_t)lane * TILE] = exv;
     }
@@ -1532,42 +1536,63 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     wave_lds_sync();
     const float *const v[2] = {vv, vc};
     float o[2];
-    band_sums_par<2>(t, v, part, o, lane);
+    band_sums_par<2>(t, v, o, lane);
     // Head of the feature stage (ref: src/features.rs:135-170), here because everything it needs is at hand and this
     // launch covers a whole frame group: the correlation normalised by the band energies, the floored log energies,
     // the silence test, and the two DCTs -- lane = band.  Same operations in the same order as when one lane did it all.
     wave_lds_sync();
     float *xc = part, *ly = part + 64, *exl = part + 128;
+    float lyv = -2.0f;
     if (lane < NB) {
         const float xn = o[1] / sqrtf(0.001f + exv * o[0]);
         NNN_TI(b.ep, NB, tile, sl)[(size_t)lane * TILE] = o[0];
         NNN_TI(b.exp_, NB, tile, sl)[(size_t)lane * TILE] = xn;
         xc[lane] = xn;
         exl[lane] = exv;
-        ly[lane] = log10f(1e-2f + exv);
+        lyv = log10f(1e-2f + exv);
     }
-    wave_lds_sync();
-    if (lane == 0) {
-        float log_max = -2.0f, follow = -2.0f, e = 0.0f;
-        for (int i = 0; i < NB; i++) {
-            const float l = fmaxf(fmaxf(ly[i], log_max - 7.0f), follow - 1.5f);
-            ly[i] = l;
-            log_max = fmaxf(log_max, l);
-            follow = fmaxf(follow - 1.5f, l);
-            e += exl[i];
+    // The floors of the log energies (ref: src/features.rs:150-158) are a 22-step recurrence -- l_i = max(ly_i, max_{j<i} l_j - 7,
+    // follow_i - 1.5) with follow decaying by 1.5 per band -- that one lane used to walk while the wave waited.  Unrolled it is
+    // l_i = max over j <= i of ly_j - c(i - j) with c(0) = 0, c(d) = min(7, 1.5 d) (c is subadditive, so floors of floors add
+    // nothing), plus the two start values; and since c(d) = 7 from d = 5 on: four neighbours and a prefix maximum five bands
+    // back, lane = band, through shuffles.  Same values up to the rounding of the decay (one multiply instead of repeated
+    // subtraction); a NaN energy is ignored by the max exactly as in the recurrence.  (Every lane takes part in the shuffles.)
+    float lfl;
+    {
+        float pm = lyv;   // inclusive prefix maximum over the bands below (lanes past the bands hold -2: never above a log energy)
+#pragma unroll
+        for (int d = 1; d < 32; d *= 2) {
+            const float tt = __shfl_up(pm, d);
+            pm = lane >= d ? fmaxf(pm, tt) : pm;
         }
+        float m = fmaxf(fmaxf(lyv, -2.0f - 7.0f), -2.0f - 1.5f * (float)(lane + 1));
+#pragma unroll
+        for (int d = 1; d <= 4; d++) {
+            const float tt = __shfl_up(lyv, d) - 1.5f * (float)d;
+            m = lane >= d ? fmaxf(m, tt) : m;
+        }
+        const float t5 = __shfl_up(pm, 5) - 7.0f;
+        lfl = lane >= 5 ? fmaxf(m, t5) : m;
+    }
+    if (lane < NB) ly[lane] = lfl;
+    wave_lds_sync();
+    if (lane == 0) {   // the silence test on the band energies summed in band order (ref: src/features.rs:160)
+        float e = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NB; i++) e += exl[i];
         NNN_TI(b.silence, 1, tile, sl)[0] = e < 0.04f ? 1 : 0;
     }
-    wave_lds_sync();
-    if (lane < NB) {
-        float *cn = NNN_TI(b.cn, 28, tile, sl);
-        float c = dct_out(ly, t.dct, lane);
-        c -= lane == 0 ? 12.0f : (lane == 1 ? 4.0f : 0.0f);
-        cn[(size_t)lane * TILE] = c;
-        if (lane < 6) {
-            float d = dct_out(xc, t.dct, lane);
-            d -= lane == 0 ? 1.3f : (lane == 1 ? 0.9f : 0.0f);
-            cn[(size_t)(NB + lane) * TILE] = d;
+    // the two DCTs side by side: lanes 0..21 the cepstrum of the floored log energies, lanes 32..37 the first six coefficients
+    // of the pitch correlation (ref: src/features.rs:141-147, 167-169; src/lib.rs:139-148)
+    {
+        const bool second = lane >= 32;
+        const int i = second ? lane - 32 : lane;
+        if (i < (second ? 6 : NB)) {
+            float *cn = NNN_TI(b.cn, 28, tile, sl);
+            float c = dct_out(second ? xc : ly, t.dct, i);
+            if (second) c -= i == 0 ? 1.3f : (i == 1 ? 0.9f : 0.0f);
+            else c -= i == 0 ? 12.0f : (i == 1 ? 4.0f : 0.0f);
+            cn[(size_t)((second ? NB : 0) + i) * TILE] = c;
         }
     }
 }
@@ -1579,7 +1604,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_FFT_MINWAVES) k_fft_xp(Buffe
 {
     __shared__ FftLds t;
     __shared__ float2 Z[FFT_SPB][NFFT_BUF];
-    __shared__ float part[FFT_SPB][4 * 64];
+    __shared__ float part[FFT_SPB][3 * 64];   // the feature head's staging: correlation, log energies, band energies
     NNN_FRAME_SPLIT(b.S_pad / FFT_SPB)
     const int wave = threadIdx.x >> 6;
     transform_inputs<true>(b, sp + frame, bx, t, Z[wave], part[wave]);
@@ -1590,7 +1615,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB) k_fft_x(Buffers b, const StepPar
 {
     __shared__ FftLds t;
     __shared__ float2 Z[FFT_SPB][NFFT_BUF];
-    __shared__ float part[FFT_SPB][2 * 64];
+    __shared__ float part[FFT_SPB][4];   // (the feature head's staging: unused without the second transform)
     NNN_FRAME_SPLIT(b.S_pad / FFT_SPB)
     const int wave = threadIdx.x >> 6;
     transform_inputs<false>(b, sp + frame, bx, t, Z[wave], part[wave]);
@@ -2753,10 +2778,9 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
     __shared__ FftLds t;
     __shared__ float2 A_[FFT_SPB][NFFT_BUF];   // also the per-bin energies of the band renormalisation (before A is filled)
     __shared__ float r_[FFT_SPB][3 * NB];
-    __shared__ float part_[FFT_SPB][2 * 64];
     const int wave = threadIdx.x >> 6;
     float2 *A = A_[wave];
-    float *ebuf = (float *)A, *r = r_[wave], *r2 = r + NB, *gg = r + 2 * NB, *part = part_[wave];
+    float *ebuf = (float *)A, *r = r_[wave], *r2 = r + NB, *gg = r + 2 * NB;
     const int lane0 = threadIdx.x & 63, s = blockIdx.x * FFT_SPB + wave, tile = s >> 6, sl = s & 63;
     int lane = lane0;
     fft_tables_load(t, b);
@@ -2839,7 +2863,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
             {
                 const float *const v[1] = {ebuf};
                 float ne[1];
-                band_sums_par<1>(t, v, part, ne, lane);
+                band_sums_par<1>(t, v, ne, lane);
                 if (lane < NB) r2[lane] = sqrtf(b_ex / (1e-8f + ne[0]));
             }
             wave_lds_sync();
