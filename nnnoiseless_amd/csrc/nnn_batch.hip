@@ -400,6 +400,12 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     std::vector<int> bin_band;
     make_tables(window, dct, tw, tansig, bin_frac, bin_band, b.wnorm);
     HIPCHK(upload(h, &b.window, window));
+    {
+        std::vector<float> wa(WINDOW), ws(WINDOW);
+        for (int i = 0; i < WINDOW; i++) { wa[i] = window[i] * (b.wnorm * 0.5f); ws[i] = window[i] * 0.5f; }
+        HIPCHK(upload(h, &b.window_a, wa));
+        HIPCHK(upload(h, &b.window_s, ws));
+    }
     HIPCHK(upload(h, &b.dct, dct));
     HIPCHK(upload(h, &b.tw960, tw));
     HIPCHK(upload(h, &b.tansig, tansig));

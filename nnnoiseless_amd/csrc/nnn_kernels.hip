@@ -1440,17 +1440,17 @@ __device__ __forceinline__ void window_rfft(const Buffers &b, const SamplePair (
     // Bins k and 480 - k come from the same two transform outputs (E[480 - k] = conj E[k], O[480 - k] = conj O[k], the twiddle
     // of 480 - k is -conj of k's): a lane takes them as a pair -- one read of each output, one twiddle, one complex product for
     // both -- and owns bins rfft_slot_bin(lane, u): k = lane + 64 u in slots u < 4 (k <= 240), 480 - k in slot 4 + u (k < 240).
-    const float wn = b.wnorm;
+    // (the normalisation 1 / 480 and the split step's factor 1/2 ride on the analysis window, Buffers::window_a: nothing to scale here)
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int k = lane + 64 * u;
         if (k <= NFFT / 2) {
             const float2 zk = Z[k], zn = Z[k ? NFFT - k : 0];
-            const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-            const float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));   // (zk - conj zn) / (2i)
+            const float2 e = make_float2(zk.x + zn.x, zk.y - zn.y);
+            const float2 o = make_float2(zk.y + zn.y, -(zk.x - zn.x));   // (zk - conj zn) / i
             const float2 wo = cmulf(o, t.tw[k]);
-            Y[u] = make_float2((e.x + wo.x) * wn, (e.y + wo.y) * wn);
-            Y[4 + u] = make_float2((e.x - wo.x) * wn, -(e.y - wo.y) * wn);   // conj(E - W O)
+            Y[u] = make_float2(e.x + wo.x, e.y + wo.y);
+            Y[4 + u] = make_float2(e.x - wo.x, -(e.y - wo.y));   // conj(E - W O)
         }
     }
     wave_lds_sync();   // the transform has been read: its buffer now takes the per-bin products for the band sums
@@ -1470,7 +1470,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     const int rb = ring_base(sp->slot);
     float2 w[8];   // the window at sample pairs j + 60 r: the order of the transforms' first pass (window_rfft)
 #pragma unroll
-    for (int r = 0; r < 8; r++) w[r] = ((const float2 *)b.window)[(lane < FFT_P1 ? lane : FFT_P1 - 1) + FFT_P1 * r];
+    for (int r = 0; r < 8; r++) w[r] = ((const float2 *)b.window_a)[(lane < FFT_P1 ? lane : FFT_P1 - 1) + FFT_P1 * r];
     const int lag = WITH_P ? NNN_TI(b.pitch, 1, tile, sl)[0] : 0;
     fft_tables_load(t, b);
     const float *h = b.hist + (size_t)s * HSTR;
@@ -2920,8 +2920,8 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
         for (int u = 0; u < 4; u++) {
             const int n = lane + 64 * u;
             const bool on = n < FRAME / 2;
-            wlo[u] = on ? ((const float2 *)b.window)[n] : make_float2(0.0f, 0.0f);
-            whi[u] = on ? ((const float2 *)b.window)[FRAME / 2 + n] : make_float2(0.0f, 0.0f);
+            wlo[u] = on ? ((const float2 *)b.window_s)[n] : make_float2(0.0f, 0.0f);   // (window / 2: the inverse transform's halving rides on it)
+            whi[u] = on ? ((const float2 *)b.window_s)[FRAME / 2 + n] : make_float2(0.0f, 0.0f);
         }
         fft480_regs(zin, A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
         if (lane == 0 && vad_out && s < b.S) vad_out[s] = vadv;
@@ -2930,8 +2930,8 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
             const int n = lane + 64 * u;
             if (n < FRAME / 2) {
                 float2 lo = A[n], hi = A[n + FRAME / 2];
-                float v0 = lo.y / 2.0f * wlo[u].x, v1 = lo.x / 2.0f * wlo[u].y;
-                float u0 = hi.y / 2.0f * whi[u].x, u1 = hi.x / 2.0f * whi[u].y;
+                float v0 = lo.y * wlo[u].x, v1 = lo.x * wlo[u].y;   // (x / 2) * w and x * (w / 2) are the same float
+                float u0 = hi.y * whi[u].x, u1 = hi.x * whi[u].y;
                 if (store) {
                     const float y0 = v0 + smv[u].x, y1 = v1 + smv[u].y;
                     if (pair_ok && fmt == PCM_F32) ((float2 *)o)[n] = make_float2(y0, y1);
