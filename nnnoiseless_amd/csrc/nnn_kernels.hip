@@ -256,9 +256,56 @@ __global__ void __launch_bounds__(64, HP_CH <= 16 ? 3 : 1) k_hp(Buffers b, const
 // ---------------------------------------------------------------------------------------------
 constexpr int LPC_CH = 20;   // rows per unrolled chunk: 860 = 43 x 20
 static_assert((XLP - 4) % LPC_CH == 0, "");
-__global__ void __launch_bounds__(64) k_lpc(Buffers b, const StepParams *sp0, int g)
+// lags K0 .. K0 + NK - 1 of the autocorrelation of the 864 rows at base[i * TILE] (row 0 replaced by x0): the reference's
+// sequential sum per lag, then its tail (ref: src/pitch.rs:433-446)
+template <int K0, int NK>
+__device__ __forceinline__ void lpc_chains(const float *base, float x0, float (&ac)[NK])
 {
-    const int lane = threadIdx.x;
+    float cur[LPC_CH + 4], nxt[LPC_CH];
+#pragma unroll
+    for (int i = 0; i < LPC_CH + 4; i++) cur[i] = base[(size_t)i * TILE];
+    cur[0] = x0;
+    float c[NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++) c[k] = 0.0f;
+    constexpr int NCH = (XLP - 4) / LPC_CH;
+#pragma nounroll
+    for (int ch = 0; ch < NCH; ch++) {
+        // rows 20 (ch + 1) + 4 .. + 23 travel while this chunk is summed (the last chunk re-reads its own rows: in range, unused)
+        const float *nb = base + (size_t)((ch + 1 < NCH ? ch + 1 : ch) * LPC_CH + 4) * TILE;
+#pragma unroll
+        for (int i = 0; i < LPC_CH; i++) nxt[i] = nb[(size_t)i * TILE];
+        // ac[k] += x[i] * x[i + k], i ascending: the reference's sequential sum per lag (pitch_xcorr's unrolling keeps that order)
+#pragma unroll
+        for (int j = 0; j < LPC_CH; j++)
+#pragma unroll
+            for (int k = 0; k < NK; k++) c[k] += cur[j] * cur[j + K0 + k];
+        if (ch + 1 < NCH) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) cur[i] = cur[LPC_CH + i];
+#pragma unroll
+            for (int i = 0; i < LPC_CH; i++) cur[4 + i] = nxt[i];
+        }
+    }
+    // tail d_k = sum_{i = k + 860}^{863} x[i] x[i - k], added after the main sum; cur[] holds rows 840 .. 863
+#pragma unroll
+    for (int kk = 0; kk < NK; kk++) {
+        constexpr int O = XLP - LPC_CH - 4;
+        const int k = K0 + kk;
+        float d = 0.0f;
+#pragma unroll
+        for (int i = k + XLP - 4; i < XLP; i++) d += cur[i - O] * cur[i - k - O];
+        ac[kk] = c[kk] + d;
+    }
+}
+
+// WIDE = false: one wave per (tile, frame), every lane carries its stream's five chains.  WIDE = true, for launches too small to
+// fill the GPU (a one-frame call on a few thousand streams is 64 waves walking five 860-step chains each): five waves per (tile,
+// frame), one lag each, the five sums meeting in LDS.
+template <bool WIDE>
+__device__ __forceinline__ void lpc_body(const Buffers &b, const StepParams *sp0, int g, float (*acs)[TILE])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // block -> (tile, frame).  Workgroup i runs on XCD i mod 8 (observed; a speed matter only): the g frames of a tile read
     // overlapping windows (624 of 864 rows shared by neighbours), so they go to one XCD -- tile t's to XCD t mod 8, where k_hp's
     // block t wrote the ring.
@@ -276,38 +323,22 @@ __global__ void __launch_bounds__(64) k_lpc(Buffers b, const StepParams *sp0, in
     }
     const int slot = sp0[f].slot;
     const float *base = b.dec + ((size_t)tile * DEC_LEN + (size_t)dec_base(slot)) * TILE + lane;
-    float cur[LPC_CH + 4], nxt[LPC_CH];
-#pragma unroll
-    for (int i = 0; i < LPC_CH + 4; i++) cur[i] = base[(size_t)i * TILE];
-    cur[0] = NNN_TI(b.xlp0, NSLOT, tile, lane)[(size_t)slot * TILE];   // x_lp[0] is special (ref: src/pitch.rs:458)
-    float c[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    constexpr int NCH = (XLP - 4) / LPC_CH;
-#pragma nounroll
-    for (int ch = 0; ch < NCH; ch++) {
-        // rows 20 (ch + 1) + 4 .. + 23 travel while this chunk is summed (the last chunk re-reads its own rows: in range, unused)
-        const float *nb = base + (size_t)((ch + 1 < NCH ? ch + 1 : ch) * LPC_CH + 4) * TILE;
-#pragma unroll
-        for (int i = 0; i < LPC_CH; i++) nxt[i] = nb[(size_t)i * TILE];
-        // ac[k] += x[i] * x[i + k], i ascending: the reference's sequential sum per lag (pitch_xcorr's unrolling keeps that order)
-#pragma unroll
-        for (int j = 0; j < LPC_CH; j++)
-#pragma unroll
-            for (int k = 0; k < 5; k++) c[k] += cur[j] * cur[j + k];
-        if (ch + 1 < NCH) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) cur[i] = cur[LPC_CH + i];
-#pragma unroll
-            for (int i = 0; i < LPC_CH; i++) cur[4 + i] = nxt[i];
-        }
-    }
-    // tail d_k = sum_{i = k + 860}^{863} x[i] x[i - k], added after the main sum; cur[] holds rows 840 .. 863
+    const float x0 = NNN_TI(b.xlp0, NSLOT, tile, lane)[(size_t)slot * TILE];   // x_lp[0] is special (ref: src/pitch.rs:458)
     float ac[5];
+    if (WIDE) {
+        float a1[1];
+        if (wave == 0) lpc_chains<0, 1>(base, x0, a1);
+        else if (wave == 1) lpc_chains<1, 1>(base, x0, a1);
+        else if (wave == 2) lpc_chains<2, 1>(base, x0, a1);
+        else if (wave == 3) lpc_chains<3, 1>(base, x0, a1);
+        else lpc_chains<4, 1>(base, x0, a1);
+        acs[wave][lane] = a1[0];
+        __syncthreads();
+        if (wave != 0) return;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        float d = 0.0f;
-#pragma unroll
-        for (int i = k + XLP - 4; i < XLP; i++) d += cur[i - (XLP - LPC_CH - 4)] * cur[i - k - (XLP - LPC_CH - 4)];
-        ac[k] = c[k] + d;
+        for (int k = 0; k < 5; k++) ac[k] = acs[k][lane];
+    } else {
+        lpc_chains<0, 5>(base, x0, ac);
     }
     // lag window, Levinson, bandwidth expansion, extra zero (ref: src/pitch.rs:460-480, 257-292)
     ac[0] *= 1.0001f;
@@ -349,6 +380,12 @@ __global__ void __launch_bounds__(64) k_lpc(Buffers b, const StepParams *sp0, in
     float *o = NNN_TI(b.lpc, NSLOT * 10, tile, lane) + (size_t)(slot * 10) * TILE;
 #pragma unroll
     for (int i = 0; i < 5; i++) { o[(size_t)i * TILE] = ac[i]; o[(size_t)(5 + i) * TILE] = l2[i]; }
+}
+__global__ void __launch_bounds__(64) k_lpc(Buffers b, const StepParams *sp0, int g) { lpc_body<false>(b, sp0, g, nullptr); }
+__global__ void __launch_bounds__(320) k_lpc_wide(Buffers b, const StepParams *sp0, int g)
+{
+    __shared__ float acs[5][TILE];
+    lpc_body<true>(b, sp0, g, acs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1440,7 +1477,11 @@ __device__ __forceinline__ void window_rfft(const Buffers &b, const SamplePair (
     // Bins k and 480 - k come from the same two transform outputs (E[480 - k] = conj E[k], O[480 - k] = conj O[k], the twiddle
     // of 480 - k is -conj of k's): a lane takes them as a pair -- one read of each output, one twiddle, one complex product for
     // both -- and owns bins rfft_slot_bin(lane, u): k = lane + 64 u in slots u < 4 (k <= 240), 480 - k in slot 4 + u (k < 240).
-    // (the normalisation 1 / 480 and the split step's factor 1/2 ride on the analysis window, Buffers::window_a: nothing to scale here)
+    // (the split step's factor 1/2 rides on the analysis window, Buffers::window_a -- an exact scaling.  The normalisation 1 / 480
+    // stays here: folded into the window as well it rounds every coefficient a second time, a window that is no longer the
+    // reference's bit for bit, and on a signal with a huge slowly decaying component -- the high-passed DC step of the edge-case
+    // set -- the leakage of that component differs enough to move the gains by three times the reference's own f32 / f64 spread.)
+    const float wn = b.wnorm;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int k = lane + 64 * u;
@@ -1449,8 +1490,8 @@ __device__ __forceinline__ void window_rfft(const Buffers &b, const SamplePair (
             const float2 e = make_float2(zk.x + zn.x, zk.y - zn.y);
             const float2 o = make_float2(zk.y + zn.y, -(zk.x - zn.x));   // (zk - conj zn) / i
             const float2 wo = cmulf(o, t.tw[k]);
-            Y[u] = make_float2(e.x + wo.x, e.y + wo.y);
-            Y[4 + u] = make_float2(e.x - wo.x, -(e.y - wo.y));   // conj(E - W O)
+            Y[u] = make_float2((e.x + wo.x) * wn, (e.y + wo.y) * wn);
+            Y[4 + u] = make_float2((e.x - wo.x) * wn, -(e.y - wo.y) * wn);   // conj(E - W O)
         }
     }
     wave_lds_sync();   // the transform has been read: its buffer now takes the per-bin products for the band sums

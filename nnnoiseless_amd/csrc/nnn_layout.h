@@ -113,8 +113,8 @@ struct Buffers {
     float *vad;          // TI [1]
     // ---- read-only tables
     const float *window;     // [960]
-    const float *window_a;   // [960]  window * wnorm / 2 for the analysis transforms: the normalisation (ref: src/features.rs:295) and the
-                             //        real-transform split step's 1/2 folded into the multiply every sample gets anyway
+    const float *window_a;   // [960]  window / 2 for the analysis transforms: the real-transform split step's 1/2 folded (exactly) into the
+                             //        multiply every sample gets anyway
     const float *window_s;   // [960]  window / 2 for the synthesis (ref: src/features.rs:263-275 halves the inverse transform)
     const float *dct;        // [22*22]
     const float2 *tw960;     // [960]  exp(-2 pi i k / 960)
