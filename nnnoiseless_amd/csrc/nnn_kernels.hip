@@ -2571,12 +2571,15 @@ __device__ __forceinline__ void wf_dense(const LayerDesc &L, const unsigned shor
     }
 }
 
+#ifndef NNN_WF_MINWAVES
+#define NNN_WF_MINWAVES 3   // waves per SIMD the register allocation must allow (12 waves = 3 per SIMD at <= 168 registers)
+#endif
 struct WfPlan {   // LDS strides (bf16 elements) of the per-layer matrices, set by the host from the model
     int w_v, w_n, w_dn;         // input windows: vad [cD ..], noise [cV ..], denoise [0 ..]
     int sw_v, sw_n, sw_dn;      // state / r * state matrices
 };
 
-__global__ void __launch_bounds__(64 * WF_WAVES) k_rnn_wf(Buffers b, RnnPlan pl, WfPlan wp, const uint4 *__restrict__ Wq,
+__global__ void __launch_bounds__(64 * WF_WAVES, NNN_WF_MINWAVES) k_rnn_wf(Buffers b, RnnPlan pl, WfPlan wp, const uint4 *__restrict__ Wq,
                                                             const float *__restrict__ fpar, int tile0, int g)
 {
     HIP_DYNAMIC_SHARED(float, lds_raw)
