@@ -654,7 +654,7 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
         L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g);
         // the LPC analysis of the group's frames (lane = stream, frames side by side) rides on the same stream, ahead of the pitch stage
         // (launches too small to fill the GPU spread the five lags of a stream over five waves)
-        if (NT * ug < 2048u) L.go(K_LPC, k_lpc_wide, dim3(NT * ug), dim3(320), 0, b, sp0, g);
+        if (NT * ug < 512u) L.go(K_LPC, k_lpc_wide, dim3(NT * ug), dim3(320), 0, b, sp0, g);
         else L.go(K_LPC, k_lpc, dim3(NT * ug), dim3(64), 0, b, sp0, g);
         break;
     case ST_PITCH: {
@@ -1331,7 +1331,7 @@ static void enqueue_feature_group(nnn_batch *h, hipStream_t st, const float *in,
     hipLaunchKernelGGL(k_fill_params, dim3(1), dim3(64), 0, st, sp, v, g);
     hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, (const StepParams *)sp, g);
     if (full) {
-        if (NT * ug < 2048u) hipLaunchKernelGGL(k_lpc_wide, dim3(NT * ug), dim3(320), 0, st, b, (const StepParams *)sp, g);
+        if (NT * ug < 512u) hipLaunchKernelGGL(k_lpc_wide, dim3(NT * ug), dim3(320), 0, st, b, (const StepParams *)sp, g);
         else hipLaunchKernelGGL(k_lpc, dim3(NT * ug), dim3(64), 0, st, b, (const StepParams *)sp, g);
         const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
         const unsigned grid = Sp / PK_SPB * (chain ? ug : 1u);
