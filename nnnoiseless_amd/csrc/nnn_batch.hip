@@ -1,5 +1,5 @@
 // nnn_batch.hip -- host side of the batched process_frame backend: the state slab in HBM, the
-// frame-group kernel pipeline (five launches per group, spread over a few HIP streams for long calls), parity taps,
+// frame-group kernel pipeline (five stages, six launches per group, spread over a few HIP streams for long calls), parity taps,
 // per-kernel timing.
 // C ABI declared in include/nnn_batch.h.
 #include <hip/hip_runtime.h>
@@ -48,7 +48,7 @@ int nnn_set_error(const char *msg) { return fail("%s", msg); }   // for the libr
 enum KernelId { K_HP, K_LPC, K_PITCH, K_FFT_XP, K_RNN, K_SYNTH, K_COUNT };
 static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_pitch", "k_fft_xp", "k_rnn", "k_synth"};
 
-// The five stages of a frame group, one kernel launch each (k_rnn: one per resident model).  hp, pitch, rnn and synth carry
+// The five stages of a frame group, one kernel launch each (hp: k_hp + k_lpc; k_rnn: one per resident model).  hp, pitch, rnn and synth carry
 // state from frame to frame and loop over the group's frames inside the launch; fft_xp covers all frames of the group
 // side by side (block index = frame * blocks_per_frame + block).
 enum Stage { ST_HP, ST_PITCH, ST_FFT, ST_RNN, ST_SYN, ST_COUNT };
@@ -1223,7 +1223,7 @@ extern "C" int nnn_batch_set_graph(nnn_batch *h, int on)
 {
     (void)on;
     if (!h) return fail("null batch");
-    return 0;   // kept for callers of the round-1 ABI: a group is five launches now and they are always eager
+    return 0;   // kept for callers of the round-1 ABI: a group is six launches now and they are always eager
 }
 extern "C" int nnn_batch_set_inputs_ready(nnn_batch *h, int on)
 {

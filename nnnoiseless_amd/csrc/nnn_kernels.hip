@@ -389,23 +389,21 @@ __global__ void __launch_bounds__(320) k_lpc_wide(Buffers b, const StepParams *s
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3  pitch: the whole pitch analysis of a frame in ONE launch, one block per 16 consecutive streams (a quarter tile):
-//       pitch_downsample's LPC part  5-lag autocorrelation, lag window, order-4 Levinson, bandwidth expansion + the extra
-//                                    zero, FIR5 -> pitch_buf (ref: src/pitch.rs:433-446, 460-480, 257-292, 407-429)
+// K3  pitch: the pitch analysis of a frame from the FIR on, one block per 16 consecutive streams (a quarter tile):
+//       pitch_downsample's last step FIR5 with k_lpc's taps -> pitch_buf (ref: src/pitch.rs:407-429)
 //       pitch_search                 coarse cross-correlation 147 lags x 240 taps on the 4x-decimated signal, find_best_pitch,
 //                                    fine cross-correlation within +-2 of 2*best / 2*second, find_best_pitch, pseudo-
 //                                    interpolation (ref: src/pitch.rs:63-115, 296-405)
 //       remove_doubling              (ref: src/pitch.rs:118-221)
 //     pitch_buf (864 values per stream) lives in LDS from the FIR that makes it to the last inner product that reads it and
 //     never travels to HBM (round 2a: written once and read by two more launches, 17 KB per stream-frame); so do the coarse
-//     cross-correlation and the coarse-lag energies.  Only the two long energy tables that are looked up at data-dependent
-//     lags later in the frame (fine-lag energies, yy_lookup) go through global scratch.
+//     cross-correlation, the coarse-lag energies and the check points of the two long energy scans (fine-lag energies,
+//     yy_lookup) that are looked up at data-dependent lags later in the frame.
 //
 //     Every sum that feeds the integer pitch index keeps the reference's order (sequential per lag / per partial), so the
 //     parallelism is over streams x independent chains, lane = (stream, chain):
-//       autocorrelation      (stream, lag)                  5 chains of 860 steps
-//       FIR                  (stream, 27-row chunk)         elementwise
-//       coarse xcorr         (stream, group of 7 lags)      21 groups; 8 x-rows + 8 y-rows from LDS per 56 multiply-adds
+//       FIR                  (stream, 32-row chunk)         elementwise
+//       coarse xcorr         (stream, group of 13 lags)     12 groups on three waves, packed accumulators (see the phase)
 //       energy scans         (stream) on three waves        serial running sums with their clamps
 //       inner products       (stream, partial q of 4), the wave picks the candidate lags: 2 (fine) or 4 (remove_doubling)
 //                            candidates share every read of the fixed operand
@@ -413,9 +411,9 @@ __global__ void __launch_bounds__(320) k_lpc_wide(Buffers b, const StepParams *s
 //     LDS layout of pitch_buf: even rows and odd rows apart, element (r, s) at (r & 1 ? ODD : 0) + (r >> 1) * 16 + s with ODD =
 //     432 * 16 + 16.  ds_read_b32 / ds_read2_b32 bank modulo 32, a 32-lane group is 16 streams x 2 chains: chains reading rows r
 //     and r + 2 (the inner-product partials, dealt to the lanes as q = 0, 2 | 1, 3) sit on neighbouring rows of one half,
-//     chains reading rows r and r + 1 (lags of the autocorrelation) on the same row index of the two halves, which the pad
+//     chains reading rows r and r + 1 on the same row index of the two halves, which the pad
 //     of 16 puts on different banks; the coarse cross-correlation reads the even half only -- the 4x-decimated signal,
-//     compact -- and its two lag groups per 32 lanes start 7 rows apart: all conflict-free (round 2a: 31 % of k_pitch2's LDS
+//     compact -- and its two lag groups per 32 lanes start 13 rows apart: all conflict-free (round 2a: 31 % of k_pitch2's LDS
 //     cycles were conflicts).  Rows 2 apart (consecutive taps of one partial, of the decimated signal, of the window pairs)
 //     are 16 or 32 floats apart at any parity: one ds_read2_b32 fetches two of them into a register pair, which is what
 //     v_pk_mul_f32 wants.
