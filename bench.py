@@ -171,6 +171,9 @@ def parse_args(argv=None):
                     help="boundary sample format (SURVEY 8(f) #1): f32 = process_frame's own (headline), i16 = the CLI's "
                          "packed int16, unit = DenoiseSignal's [-1, 1] floats")
     ap.add_argument("--channels", type=int, default=1, help="interleaved channels per group (with --pcm i16/unit)")
+    ap.add_argument("--layout", choices=["stream-major", "frame-major"], default="stream-major",
+                    help="resident buffers as [stream][frame][480] (one stream's audio contiguous, the reference's per-stream slices side by "
+                         "side) or [frame][stream][480] (the batch's frames interleaved); f32 mono only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host", action="store_true", help="skip the PCIe-inclusive host-buffer measurement of the default run")
@@ -213,6 +216,9 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
     if fmt or Cc > 1:   # packed PCM: [groups][pool * 480][channels], channel-interleaved
         x = x.reshape(S // Cc, Cc, pool * 480).permute(0, 2, 1)
         x = (x.to(torch.int16) if fmt == 1 else (x / 32768.0 if fmt == 2 else x)).contiguous()
+    fm = args.layout == "frame-major" and not fmt and Cc == 1
+    if fm:
+        x = x.permute(1, 0, 2).contiguous()   # [pool, S, 480]
     y = torch.empty_like(x)
     vad = torch.empty((pool, S), dtype=torch.float32, device=dev)
     model = None
@@ -235,6 +241,9 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
         if fmt or Cc > 1:
             bd.process_pcm_device(x.data_ptr() + off, y.data_ptr() + off, vad.data_ptr() + f0 * S * 4, n, fmt, Cc,
                                   pool * 480 * Cc, 480 * Cc, False, stream)
+        elif fm:
+            offm = f0 * S * 480 * 4
+            bd.process_device(x.data_ptr() + offm, y.data_ptr() + offm, vad.data_ptr() + f0 * S * 4, n, 480, S * 480, stream)
         else:
             bd.process_device(x.data_ptr() + off, y.data_ptr() + off, vad.data_ptr() + f0 * S * 4, n, pool * 480, 480, stream)
 

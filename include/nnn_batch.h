@@ -127,8 +127,8 @@ int nnn_batch_fault(const nnn_batch *b);
 int nnn_batch_debug_withhold_flag(nnn_batch *b, int frames_ahead);
 
 /* Parity taps: intermediate quantities of the most recent frame, copied to the host as
- * [n_streams][len] (float32 or int32, see nnn_tap_info).  Test/diagnostic interface.  Everything inside the pitch analysis
- * (XLP, AC, LPC2, XCORR1, BEST1, XCORR2C, PITCH_SEARCH), P beyond bin 399 and FEATURES are quantities the kernels keep on
+ * [n_streams][len] (float32 or int32, see nnn_tap_info).  Test/diagnostic interface.  Everything inside the pitch kernel
+ * (XLP, XCORR1, BEST1, XCORR2C, PITCH_SEARCH), P beyond bin 399 and FEATURES are quantities the kernels keep on
  * chip: they are stored to device memory only after nnn_batch_set_taps(batch, 1) (which also allocates their arrays), and
  * reading them without it is an error. */
 enum nnn_tap {

@@ -109,8 +109,8 @@ class BatchDenoiser:
     def __init__(self, n_streams, model=None, device=0, lib=None, groups=None, taps=False, _handle=None):
         """groups: [(model_or_None, n_streams), ...] keeps several models resident, one per run of streams (every run
         but the last a multiple of 64); it replaces `model` and must add up to n_streams.  taps=True also stores the
-        intermediate quantities the kernels otherwise keep on chip (parity tests: everything inside the pitch analysis -- tap("xlp"),
-        "ac", "lpc2", "xcorr1", "best1", "xcorr2c", "pitch_search" --, "P" beyond bin 399, "features")."""
+        intermediate quantities the kernels otherwise keep on chip (parity tests: everything inside the pitch kernel -- tap("xlp"),
+        "xcorr1", "best1", "xcorr2c", "pitch_search" --, "P" beyond bin 399, "features")."""
         self._lib = lib or library()
         self._model = model
         self.n_streams = int(n_streams)

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -26,6 +27,12 @@ static thread_local std::string g_err;
 // on another: the HIP runtime rejects those ("would make the legacy stream depend on a capturing blocking stream").
 // Those short sections -- never the per-frame launches -- take this lock.
 static std::recursive_mutex g_rt_mu;
+// Batches alive in this process.  With more than one -- the real-time serving pattern: independent batches ticking one frame per
+// call, each on its own HIP stream -- one-frame groups take k_rnn, which does not hold every compute unit for the pipelined
+// kernel's five ticks.  (Also tried for that pattern: running short calls on the batch's own stream so that two batches would not
+// depend on the hardware queue their callers' streams share -- 2 x 4096 streams 23.5 -> 19.0 M frames/s, 8 x 4096 43.2 -> 36.4:
+// the extra event hops cost more than they free; with GPU_MAX_HW_QUEUES=8 in the environment two batches do overlap, 33.5 M.)
+static std::atomic<int> g_live_batches{0};
 #define NNN_RT_LOCK std::lock_guard<std::recursive_mutex> rt_lock_(g_rt_mu)
 extern "C" const char *nnn_last_error(void) { return g_err.c_str(); }
 static int fail(const char *fmt, ...)
@@ -111,6 +118,7 @@ struct nnn_batch {
     unsigned tickets = 0;           // work items handed out so far by chained k_pitch launches (Buffers::ticket never restarts)
     unsigned *frame_log = nullptr;  // nnn_batch_set_frame_log: the next frame's record (device), and the frames that still have room
     size_t frame_log_left = 0;
+    bool counted = false;           // in g_live_batches
     bool host_call = false;         // inside a host-buffer entry point: the input is an upload enqueued by this library, final only in stream order
     hipEvent_t ev_in = nullptr;     // the caller's stream at the start of a pipelined call
     hipEvent_t ev_last = nullptr;   // end of the most recent call, on the stream it was made on
@@ -211,6 +219,7 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
         if (h->ev_done[p]) hipEventDestroy(h->ev_done[p]);
     }
     if (h->ev_in) hipEventDestroy(h->ev_in);
+    if (h->counted) g_live_batches.fetch_sub(1);
     if (h->ev_last) hipEventDestroy(h->ev_last);
     for (hipEvent_t e : h->evp) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
@@ -286,6 +295,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     h->device = device;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+
     HIPCHK(hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming));
     // (the internal streams of pipelined calls are created on first use: HIP spreads streams over a few hardware queues in
     // creation order, and a stream that shares its queue with the caller's blocks behind the caller's waits)
@@ -455,6 +465,8 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     HIPCHK(hipFuncSetAttribute((const void *)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     HIPCHK(hipFuncSetAttribute((const void *)k_rnn_wf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     HIPCHK(hipDeviceSynchronize());
+    g_live_batches.fetch_add(1);
+    h->counted = true;
     return 0;
 }
 
@@ -673,7 +685,9 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
             // the layer-pipelined kernel spends g + 4 ticks on g frames: for a lone frame on a batch of many block rounds the
             // plain kernel's eleven phases are shorter (one frame per call at 16 384 / 32 768 / 65 536 streams: +6 / +7 / +7 %;
             // at 4096 streams, one round of blocks, the pipelined kernel stays 8 % ahead).  Same bits either way.
-            const int min_g = h->wf_min_g > 0 ? h->wf_min_g : (G.ntiles * (TILE / WF_ROWS) >= 1024 ? 2 : 1);
+            // ... and with other batches alive the lone frame's kernel is chosen for their sake too (k_rnn_wf holds every compute unit
+            // for its five ticks: eight 4096-stream batches ticking side by side 40.2 -> 43.4 M frames/s with k_rnn, a lone batch -8 %)
+            const int min_g = h->wf_min_g > 0 ? h->wf_min_g : ((G.ntiles * (TILE / WF_ROWS) >= 1024 || g_live_batches.load() > 1) ? 2 : 1);
             if (G.wf && g >= min_g)
                 L.go(K_RNN, k_rnn_wf, dim3((unsigned)(G.ntiles * (TILE / WF_ROWS))), dim3(64 * WF_WAVES), G.wf_lds, b, G.plan, G.wp, G.wq,
                      G.fpar, G.tile0, g);

@@ -291,7 +291,8 @@ def test_pitch_taps_exist_only_after_set_taps(hostsim_lib):
     bd = nn.BatchDenoiser(3, lib=hostsim_lib)
     bd.process(x[:, :1])
     assert bd.tap("pitch").shape == (3, 1)            # the pitch index itself is always there (the transforms need it)
-    for name in ("xlp", "ac", "lpc2", "xcorr1", "best1", "xcorr2c", "pitch_search", "features"):
+    assert bd.tap("ac").shape == (3, 5) and bd.tap("lpc2").shape == (3, 5)   # k_lpc's results travel through memory: always there
+    for name in ("xlp", "xcorr1", "best1", "xcorr2c", "pitch_search", "features"):
         with pytest.raises(RuntimeError):
             bd.tap(name)
     bd.set_taps(True)
