@@ -165,8 +165,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-overlap", action="store_true",
                     help="do not tell the library that inputs are final at call time (nnn_batch_set_inputs_ready): every call then "
                          "waits for the previous one to drain before it reads its input")
-    ap.add_argument("--workload", choices=["denoise", "train"], default="denoise",
-                    help="denoise = process_frame (the headline); train = 87-column training rows (SURVEY 8(f) #3)")
+    ap.add_argument("--workload", choices=["denoise", "train", "resample"], default="denoise",
+                    help="denoise = process_frame (the headline); train = 87-column training rows (SURVEY 8(f) #3); "
+                         "resample = the CLI's 16-tap sinc resampler 44.1 -> 48 kHz (SURVEY 8(f) #4)")
     ap.add_argument("--pcm", choices=["f32", "i16", "unit"], default="f32",
                     help="boundary sample format (SURVEY 8(f) #1): f32 = process_frame's own (headline), i16 = the CLI's "
                          "packed int16, unit = DenoiseSignal's [-1, 1] floats")
@@ -481,6 +482,8 @@ def main():
 
     if args.workload == "train":
         return bench_train(args, rank, world, dev, local_rank, dist)
+    if args.workload == "resample":
+        return bench_resample(args, rank, world, dev, local_rank, dist)
     cfg = CONFIGS[args.config]
     S = args.streams or cfg["streams"]
     if args.dry_run:
@@ -623,3 +626,61 @@ def bench_train(args, rank, world, dev, local_rank, dist):
 
 if __name__ == "__main__":
     main()
+
+
+def bench_resample(args, rank, world, dev, local_rank, dist):
+    """Output samples per second of the batched 16-tap sinc resampler (src/nnnoiseless.rs:106-131), 44.1 kHz -> 48 kHz, device
+    buffers: one step = every stream fed 0.48 s of source audio (21 168 samples).  Per output sample the kernel reads 16 taps
+    (from L1 / L2: 4 new source bytes per output from HBM) and 16 f64 weights shared by all streams, and writes 4 bytes."""
+    import ctypes as C
+    import torch
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.shard import aggregate
+    lib = nn.library()
+    S, K, W = args.streams or 4096, args.steps, args.warmup
+    n_in = 21168
+    r = lib.L.nnn_resampler_create(S, 44100.0 / 48000.0, local_rank)
+    if not r:
+        raise SystemExit("bench: " + lib.error())
+    cap = lib.L.nnn_resampler_max_output(r, n_in)
+    x = torch.randn((S, n_in), device=dev) * 3000.0
+    y = torch.empty((S, cap), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    n_out = C.c_long(0)
+
+    def step():
+        lib.check(lib.L.nnn_resampler_process_device(r, x.data_ptr(), n_in, n_in, y.data_ptr(), cap, cap, C.byref(n_out), stream))
+        return n_out.value
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(W):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    produced = sum(step() for _ in range(K))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    done, tmax = aggregate(dist if world > 1 else None, S * produced, elapsed, dev)
+    lib.L.nnn_resampler_destroy(r)
+    if rank == 0:
+        bytes_per_out = 4 + 4 * 44100.0 / 48000.0      # one output written, 0.92 new source samples read
+        print(json.dumps({
+            "metric": "resampler output samples/sec (44.1 kHz -> 48 kHz, 16-tap sinc)", "value": done / tmax, "unit": "samples/s",
+            "n_gpus": args.gpus, "steps": K, "warmup": W, "ms_per_step": tmax * 1e3 / K, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 tap weights)", "data": "synthetic",
+            "config": {"workload": f"{S} mono streams per GPU, {n_in} source samples (0.48 s) per stream per step (src/nnnoiseless.rs:106-131)",
+                       "streams_per_gpu": S},
+            "equivalent_frames_per_s": done / tmax / 480.0,
+            "roofline": {"bound": "hbm", "achieved": done / tmax * bytes_per_out / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": done / tmax * bytes_per_out / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "note": "algorithmic bytes: 4 written + 3.7 read per output sample; the position schedule and tap weights of a call "
+                                 "are computed on the host (f64) and uploaded per call"},
+            "outputs_finite": bool(torch.isfinite(y[:, :n_out.value]).all().item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()

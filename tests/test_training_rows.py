@@ -25,7 +25,8 @@ def test_training_rows(hostsim_lib, oracle_mod, weights_bytes):
     rows = np.concatenate([tf.process(sig[:, :5], noise[:, :5], comb[:, :5], cutoff[:5], vad[:5]),
                            tf.process(sig[:, 5:], noise[:, 5:], comb[:, 5:], cutoff[5:], vad[5:])])
     assert ROW_WIDTH == 87
-    check_rows(rows, ref)
+    ref32 = oracle_mod.training_rows(oracle_mod.Model(weights_bytes, f32_fft=True), sig, noise, comb, cutoff, vad)
+    check_rows(rows, ref, ref32)
     assert (ref[..., 42:64] == -1.0).any() and (ref[..., :42] == 0).all(axis=-1).any()   # both special cases occur
     tf.reset()
     again = tf.process(sig[:, :5], noise[:, :5], comb[:, :5], cutoff[:5], vad[:5])

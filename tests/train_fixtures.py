@@ -21,18 +21,27 @@ def make_training_inputs(seed, n_streams, n_frames):
     return sig, noise, comb, cutoff, vad
 
 
-def check_rows(rows, ref):
+def check_rows(rows, ref, ref32=None):
     """Cepstral / delta / variability features within 2e-4 absolute (values of order 1..20; the oracle's own f32-FFT and
     f64-FFT builds differ by up to 4e-5 on them).  The six pitch-correlation features (columns 34..39: band correlation /
     sqrt(.001 + Ex Ep)) are ill-conditioned on bands that hold only rounding noise -- the two oracle builds differ by up
-    to 1.1e-2 there, 8e-5 rms -- so they get 4e-2 worst case and 5e-4 rms.  Gains and log levels within 1e-4; the -1
-    markers, zeroed silent rows and the vad column exactly."""
+    to 1.1e-2 there, 8e-5 rms.  With `ref32` (the oracle's f32-FFT build on the same inputs) they are judged row by row like
+    the band gains of the denoiser tests: 2e-4, or three times the distance between the two oracle builds on that row where
+    that is larger; without it, 4e-2 worst case.  5e-4 rms either way.  Gains and log levels within 1e-4; the -1 markers,
+    zeroed silent rows and the vad column exactly."""
     assert rows.shape == ref.shape
     assert np.array_equal(rows[..., 86], ref[..., 86])
     assert np.array_equal(rows[..., 42:64] == -1.0, ref[..., 42:64] == -1.0)
     assert np.array_equal((rows[..., :42] == 0).all(axis=-1), (ref[..., :42] == 0).all(axis=-1))
     d = np.abs(rows[..., :42] - ref[..., :42]).max(axis=tuple(range(rows.ndim - 1)))
     assert np.delete(d, slice(34, 40)).max() < 2e-4, d
-    assert d[34:40].max() < 4e-2, d
+    if ref32 is not None:
+        err = np.abs(rows[..., 34:40] - ref[..., 34:40]).max(axis=-1)
+        tol = np.maximum(2e-4, 3.0 * np.abs(ref32[..., 34:40] - ref[..., 34:40]).max(axis=-1))
+        bad = np.argwhere(err > tol)
+        assert not len(bad), (len(bad), bad[:8], err[tuple(bad[0])], tol[tuple(bad[0])])
+        print(f"pitch-correlation features: worst error {err.max():.2e}; rows with a tolerance above 2e-4: {int((tol > 2e-4).sum())} of {tol.size}")
+    else:
+        assert d[34:40].max() < 4e-2, d
     assert np.sqrt(((rows[..., 34:40] - ref[..., 34:40]) ** 2).mean()) < 5e-4
     assert np.abs(rows[..., 42:86] - ref[..., 42:86]).max() < 1e-4
