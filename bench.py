@@ -624,8 +624,6 @@ def bench_train(args, rank, world, dev, local_rank, dist):
         dist.destroy_process_group()
 
 
-if __name__ == "__main__":
-    main()
 
 
 def bench_resample(args, rank, world, dev, local_rank, dist):
@@ -684,3 +682,6 @@ def bench_resample(args, rank, world, dev, local_rank, dist):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+if __name__ == "__main__":
+    main()

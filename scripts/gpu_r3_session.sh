@@ -1,14 +1,14 @@
 #!/bin/bash
 # Round-3 evidence session (one gpurun call): the GPU parity suite (incl. the bench-style / real-audio / wav parity tests), the
 # driver-style default bench line, same-box A/B of library variants (nnnoiseless_amd/lib/variants/*.so), rocprofv3 kernel stats
-# (pipelined and sequential), PMC traffic and SQ counter passes at 65536 and 4096 streams.  Sections: PARTS="tests bench ab stats pmc"
+# (pipelined and sequential), PMC traffic and SQ counter passes at 65536 and 4096 streams.  Sections: PARTS="tests bench ab stats pmc rows"
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=$R/gpurun_out
 mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-PARTS=${PARTS:-"tests bench ab stats pmc"}
+PARTS=${PARTS:-"tests bench ab stats pmc rows"}
 TAG=${TAG:-r3_a}
 for P in $PARTS; do
 case $P in
@@ -67,6 +67,18 @@ stats)
     grep -o '"avg_kernel_us": [0-9.]*' $O/prof_seq_c$C.log | head -1
   done
   cd $R
+  ;;
+rows)
+  for A in "--workload train --streams 4096" "--workload train --streams 16384" "--workload resample --streams 4096" "--pcm i16" "--pcm i16 --channels 2" "--config 1 --streams 16384"; do
+    timeout 300 python bench.py $A --config 1 --steps 20 --warmup 3 --no-cpu-baseline --no-also --no-tick --no-host --no-roofline > $O/${TAG}_row.json 2>$O/${TAG}_row.err
+    python - <<PY
+import json
+try:
+    d = json.load(open('$O/${TAG}_row.json')); print('$A:', '%.2f M %s' % (d['value'] / 1e6, d['unit']), (d.get('roofline') or {}).get('frac'))
+    open('$O/${TAG}_rows.jsonl', 'a').write(json.dumps({'args': '$A', 'line': d}) + chr(10))
+except Exception as e: print('$A: parse fail', e); print(open('$O/${TAG}_row.err').read()[-600:])
+PY
+  done
   ;;
 pmc)
   for S in ${PMC_SIZES:-65536 4096}; do

@@ -522,7 +522,7 @@ def test_training_rows(nn, oracle_mod, weights_bytes):
     rows = np.concatenate([tf.process(sig[:, :11], noise[:, :11], comb[:, :11], cutoff[:11], vad[:11]),
                            tf.process(sig[:, 11:], noise[:, 11:], comb[:, 11:], cutoff[11:], vad[11:])])
     ref32 = oracle_mod.training_rows(oracle_mod.Model(weights_bytes, f32_fft=True), sig, noise, comb, cutoff, vad, n_threads=os.cpu_count() or 1)
-    check_rows(rows, ref, ref32)   # the six pitch-correlation columns row by row against the oracle's own f32 / f64 spread
+    check_rows(rows, ref, ref32)   # the six pitch-correlation columns stream by stream against the oracle's own f32 / f64 spread
 
 
 def test_training_host_call_in_chunks(nn, monkeypatch):
