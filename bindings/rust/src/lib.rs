@@ -39,6 +39,7 @@ extern "C" {
         frame_stride: usize,
         hip_stream: *mut c_void,
     ) -> c_int;
+    fn nnn_batch_fault(b: *const RawBatch) -> c_int;
     fn nnn_host_alloc(bytes: usize) -> *mut c_void;
     fn nnn_host_free(p: *mut c_void);
     fn nnn_model_from_rnnoise_text(text: *const u8, len: usize) -> *mut RawModel;
@@ -157,6 +158,12 @@ impl BatchDenoiser {
         let rc = nnn_batch_process_device(self.raw, d_in, d_out, d_vad, n_frames as c_int, stream_stride, frame_stride, hip_stream);
         assert_eq!(rc, 0, "nnnoiseless-mi355x: backend error");
     }
+    /// True once a frame hand-off inside the pitch stage has failed (sticky until `reset`): for hosts that drive
+    /// `nnn_batch_process_device` on their own HIP stream and synchronise that stream themselves.
+    pub fn fault(&self) -> bool {
+        unsafe { nnn_batch_fault(self.raw) != 0 }
+    }
+
     pub fn reset(&mut self) {
         unsafe { nnn_batch_reset(self.raw) };
     }

@@ -119,6 +119,9 @@ class BatchDenoiser {
         check(nnn_batch_process_device(b_.get(), d_in, d_out, d_vad, n_frames, stream_stride, frame_stride, hip_stream));
     }
     void synchronize() { check(nnn_batch_synchronize(b_.get())); }
+    // true once a frame hand-off inside the pitch stage has failed (nnn_batch_fault): sticky until reset() / load_state(); for hosts
+    // that synchronise their own HIP stream instead of calling synchronize()
+    bool fault() const { return nnn_batch_fault(b_.get()) != 0; }
     void reset() { check(nnn_batch_reset(b_.get())); }
     // a second batch with the same models and a copy of every stream's state (DenoiseState: Clone)
     BatchDenoiser clone() const
