@@ -118,6 +118,7 @@ struct nnn_batch {
     unsigned tickets = 0;           // work items handed out so far by chained k_pitch launches (Buffers::ticket never restarts)
     unsigned *frame_log = nullptr;  // nnn_batch_set_frame_log: the next frame's record (device), and the frames that still have room
     size_t frame_log_left = 0;
+    int lpc_wide = -1;              // k_lpc_wide (one lag per wave): -1 = for launches below 512 waves, 0 / 1 = never / always (env NNN_LPC_WIDE; tests)
     bool counted = false;           // in g_live_batches
     bool host_call = false;         // inside a host-buffer entry point: the input is an upload enqueued by this library, final only in stream order
     hipEvent_t ev_in = nullptr;     // the caller's stream at the start of a pipelined call
@@ -309,6 +310,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     if (const char *e = getenv("NNN_HOST_CHUNK")) h->host_chunk = atoi(e);
     if (const char *e = getenv("NNN_RNN_WF_MIN_G")) h->wf_min_g = atoi(e);
     if (const char *e = getenv("NNN_PITCH_CHAIN")) h->pitch_chain = atoi(e);
+    if (const char *e = getenv("NNN_LPC_WIDE")) h->lpc_wide = atoi(e);
     if (const char *e = getenv("NNN_SCHED")) {
         if (!strcmp(e, "seq")) h->sched = SCHED_SEQ;
         else if (!strcmp(e, "lanes")) h->sched = SCHED_LANES;
@@ -622,6 +624,7 @@ extern "C" nnn_batch *nnn_batch_clone(nnn_batch *h)
     c->n_lanes = h->n_lanes;
     c->use_pipeline = h->use_pipeline;
     c->pitch_chain = h->pitch_chain;
+    c->lpc_wide = h->lpc_wide;
     c->inputs_ready = h->inputs_ready;
     if (h->b[0].taps && nnn_batch_set_taps(c, 1) != 0) {
         nnn_batch_destroy(c);
@@ -666,7 +669,7 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
         L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g);
         // the LPC analysis of the group's frames (lane = stream, frames side by side) rides on the same stream, ahead of the pitch stage
         // (launches too small to fill the GPU spread the five lags of a stream over five waves)
-        if (NT * ug < 512u) L.go(K_LPC, k_lpc_wide, dim3(NT * ug), dim3(320), 0, b, sp0, g);
+        if (h->lpc_wide >= 0 ? h->lpc_wide != 0 : NT * ug < 512u) L.go(K_LPC, k_lpc_wide, dim3(NT * ug), dim3(320), 0, b, sp0, g);
         else L.go(K_LPC, k_lpc, dim3(NT * ug), dim3(64), 0, b, sp0, g);
         break;
     case ST_PITCH: {
@@ -1345,7 +1348,7 @@ static void enqueue_feature_group(nnn_batch *h, hipStream_t st, const float *in,
     hipLaunchKernelGGL(k_fill_params, dim3(1), dim3(64), 0, st, sp, v, g);
     hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, (const StepParams *)sp, g);
     if (full) {
-        if (NT * ug < 512u) hipLaunchKernelGGL(k_lpc_wide, dim3(NT * ug), dim3(320), 0, st, b, (const StepParams *)sp, g);
+        if (h->lpc_wide >= 0 ? h->lpc_wide != 0 : NT * ug < 512u) hipLaunchKernelGGL(k_lpc_wide, dim3(NT * ug), dim3(320), 0, st, b, (const StepParams *)sp, g);
         else hipLaunchKernelGGL(k_lpc, dim3(NT * ug), dim3(64), 0, st, b, (const StepParams *)sp, g);
         const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
         const unsigned grid = Sp / PK_SPB * (chain ? ug : 1u);

@@ -95,3 +95,28 @@ def test_caller_supplied_buffers_are_validated(hostsim_lib):
         tf.process(x, x, x, cut, vad, rows=np.zeros((2, 3, ROW_WIDTH - 1), np.float32))
     with pytest.raises(ValueError):
         tf.process(x, x, x, cut[:1], vad)
+
+
+def test_lpc_kernel_variants_agree_bit_for_bit(hostsim_lib, oracle_mod, weights_bytes, monkeypatch):
+    """k_lpc (every lane carries its stream's five autocorrelation chains) and k_lpc_wide (one lag per wave, what launches too small
+    to fill the GPU use) give the same bits, and both the oracle's: autocorrelation, FIR taps and everything downstream."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T = 7, 4
+    x = make_streams(40, S, T)
+    res = {}
+    for wide in ("0", "1"):
+        monkeypatch.setenv("NNN_LPC_WIDE", wide)
+        bd = nn.BatchDenoiser(S, lib=hostsim_lib, taps=True)
+        out, vad = bd.process(x)
+        res[wide] = (out, vad, bd.tap("ac").copy(), bd.tap("lpc2").copy(), bd.tap("xlp").copy(), bd.tap("pitch").copy())
+    for a, b in zip(res["0"], res["1"]):
+        assert np.array_equal(a, b)
+    om = oracle_mod.Model(weights_bytes)
+    for s in range(S):
+        st = oracle_mod.State(om)
+        for t in range(T):
+            st.process_frame(x[s, t])
+        ot = st.taps()
+        for k, i in (("ac", 2), ("lpc2", 3), ("xlp", 4)):
+            assert np.array_equal(res["0"][i][s].view(np.uint32), np.atleast_1d(ot[k]).astype(np.float32).view(np.uint32)), (k, s)
