@@ -52,7 +52,7 @@ FLOPS_PER_FRAME = 0.42e6
 
 # Algorithmic HBM bytes per stream-frame of each kernel (its own inputs + outputs, each counted once; per-group state traffic
 # divided by the 16 frames of a full group; derivation in DESIGN.md "Kernels")
-G = 16
+G = 24   # frames of a full group (a 48-frame call is two of them)
 KERNEL_BYTES = {
     "k_hp": 1920 + 1920 + 960 + 960 // 5 + 4 + (16 + 8) // G,     # input, history slot, 240 decimated values (+ mirrored share), x_lp[0]; biquad state per group
     "k_lpc": 3456 + 4 + 40,                                         # decimated window + x_lp[0] in; autocorrelation and FIR taps out

@@ -768,11 +768,19 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
         h->sp_tab_cap = cap;
         h->prev_pipe = false;
     }
-    // group sizes: full groups of GROUP frames, the remainder last (NNN_RAMP keeps round 2a's smaller groups at the ends of a
-    // pipelined call for comparison)
-    const bool pipe = h->use_pipeline && h->sched != SCHED_SEQ && !h->profiling && n_frames >= 2 * GROUP;
+    // group sizes.  A pipelined call (32 frames or more) is cut into an even number of near-equal groups of at most GROUP frames --
+    // its groups alternate between two lanes, so an odd count leaves one lane a group short (three groups of 16 for the bench's
+    // 48-frame call: 55.5 M frames/s at 4096 streams; two of 24: 57.2 M) -- everything else into full groups of GROUP frames, the
+    // remainder last (NNN_RAMP keeps round 2a's smaller groups at the ends of a pipelined call for comparison).
+    constexpr int PIPE_MIN = 32;
+    const bool pipe = h->use_pipeline && h->sched != SCHED_SEQ && !h->profiling && n_frames >= PIPE_MIN;
     std::vector<int> sizes;
-    for (int rem = n_frames, k = 0; rem > 0; k++) {
+    if (pipe && h->ramp == 0) {
+        int k = 2;
+        while ((n_frames + k - 1) / k > GROUP) k += 2;
+        for (int i = 0; i < k; i++) sizes.push_back(n_frames / k + (i < n_frames % k ? 1 : 0));
+    }
+    for (int rem = sizes.empty() ? n_frames : 0, k = 0; rem > 0; k++) {
         int g = GROUP;
         if (pipe && h->ramp == 1) {
             g = GROUP < k + 1 ? GROUP : k + 1;
@@ -1033,8 +1041,9 @@ static int process_host_span_impl(nnn_batch *h, const void *in, void *out, float
     // long calls the kernels' own group length; chunks under a megabyte are not worth their launches.
     int chunk = h->host_chunk;
     if (chunk < 0) {
-        chunk = n_frames >= 128 ? GROUP : (n_frames >= 48 ? 8 : 4);
-        while (chunk < GROUP && (size_t)chunk * fr * groups < ((size_t)1 << 20)) chunk *= 2;
+        constexpr int HC = 16;   // longest chunk (tuned on the bus, not tied to the kernels' group length)
+        chunk = n_frames >= 128 ? HC : (n_frames >= 48 ? 8 : 4);
+        while (chunk < HC && (size_t)chunk * fr * groups < ((size_t)1 << 20)) chunk *= 2;
         if ((size_t)chunk * fr * groups < ((size_t)1 << 20)) chunk = 0;
     }
     if (chunk > 0 && n_frames > chunk && L->frame_stride == (size_t)FRAME * L->channels)
@@ -1412,7 +1421,8 @@ extern "C" int nnn_train_process_host(nnn_train *t, const float *signal, const f
     // Like the denoiser's host calls (process_host_chunked): chunk i + 1 crosses the bus while chunk i is turned into rows and
     // chunk i - 1's rows return.  Audio is [stream][frame][480] (a chunk: 2-D copies, one row per stream), labels and rows are
     // frame-major (a chunk: one run each).
-    int C = n_frames > 2 * GROUP && S * GROUP * FRAME * 4 >= ((size_t)1 << 20) ? GROUP : n_frames;
+    constexpr int HC = 16;   // frames per chunk (tuned on the bus, not tied to the kernels' group length)
+    int C = n_frames > 2 * HC && S * HC * FRAME * 4 >= ((size_t)1 << 20) ? HC : n_frames;
     if (h->host_chunk >= 0) C = h->host_chunk > 0 && h->host_chunk < n_frames ? h->host_chunk : n_frames;   // NNN_HOST_CHUNK (tests)
     const int nch = (n_frames + C - 1) / C;
     if (int rc = host_copy_streams(h, nch)) return rc;

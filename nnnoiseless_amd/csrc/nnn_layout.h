@@ -23,13 +23,17 @@ constexpr int NFEAT = 42;         // src/lib.rs:53
 constexpr int CEPS_MEM = 8;       // src/lib.rs:50
 constexpr int HIST = 1728;        // PITCH_BUF_SIZE, src/lib.rs:46
 #ifndef NNN_GROUP
-#define NNN_GROUP 16
+#define NNN_GROUP 24
 #endif
 #ifndef NNN_DEPTH
 #define NNN_DEPTH 2
 #endif
 constexpr int GROUP = NNN_GROUP;  // frames per launch: every kernel is launched once per group of up to GROUP consecutive frames (kernels
-                                  // with a frame-to-frame recurrence loop over the group's frames inside the launch)
+                                  // with a frame-to-frame recurrence loop over the group's frames inside the launch).  24 since round 3
+                                  // (16 before): a pipelined call is cut into an even number of near-equal groups, so the bench's
+                                  // 48-frame call is 2 x 24 instead of 3 x 16 -- one group per lane, fewer pipeline ticks and
+                                  // prologues per frame: 55.5 -> 57.2 M frames/s at 4096 streams, same at 65536; 64-frame calls stay
+                                  // 4 x 16.  The price is memory: 48 scratch sets and 76 ring slots per stream instead of 32 / 52.
 constexpr int DEPTH = NNN_DEPTH;  // groups in flight (blocks of GROUP scratch sets in rotation)
 constexpr int NSET = DEPTH * GROUP;   // per-frame scratch sets
 constexpr int NSLOT = (DEPTH + 1) * GROUP + 4;   // history ring slots: the high-pass may run a group ahead of the DEPTH groups in flight,
