@@ -5,7 +5,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 W=$R/nnnoiseless_amd/data/weights.rnn
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -DNNN_STAMPS -I nnnoiseless_amd/csrc -DNNN_WEIGHTS_PATH="\"$W\"" -x hip nnnoiseless_amd/csrc/nnn_batch.hip nnnoiseless_amd/csrc/nnn_resample.hip nnnoiseless_amd/csrc/nnn_model.cpp nnnoiseless_amd/csrc/rnnoise_capi.cpp -o /tmp/libnnn_stamps.so || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -DNNN_STAMPS ${STAMP_FLAGS:-} -I nnnoiseless_amd/csrc -DNNN_WEIGHTS_PATH="\"$W\"" -x hip nnnoiseless_amd/csrc/nnn_batch.hip nnnoiseless_amd/csrc/nnn_resample.hip nnnoiseless_amd/csrc/nnn_model.cpp nnnoiseless_amd/csrc/rnnoise_capi.cpp -o /tmp/libnnn_stamps.so || exit 1
 python - <<'PY'
 import ctypes as C, numpy as np, sys, os
 sys.path.insert(0, '.')
@@ -21,11 +21,12 @@ for S, T in ((4096, 4), (65536, 4)):
     bd.process(x[:, :T]); bd.process(x[:, T:])
     st = np.zeros(64, np.int64)
     lib.L.nnn_batch_read_stamps(bd._h, st.ctypes.data_as(C.c_void_p))
-    names = ["window->lds", "autocorr", "lpc", "fir", "coarse xcorr+scans", "find_best coarse", "fine xcorr", "combine+energies", "replay", "candidates", "cand inner", "judge k", "pick", "refine", "final"]
-    idx = [0, 1, 2, 3, 4, 5, 6, 7, 59, 60, 53, 54, 58, 55, 56, 57]
+    names = ["window->lds", "fir", "coarse xcorr+scans", "find_best coarse", "fine xcorr", "combine+energies", "replay", "candidates", "cand inner", "judge k", "pick", "refine", "final"]
+    idx = [0, 1, 4, 5, 6, 7, 59, 60, 53, 54, 58, 55, 56, 57]
     d = [(st[idx[i + 1]] - st[idx[i]]) / 2100.0 for i in range(len(names))]   # shader-clock cycles at ~2.1 GHz -> us (approximate)
     print(f"S={S} k_pitch last frame of block 0 [us, approximate]: total {sum(d):.1f}")
     print("   " + "  ".join(f"{n} {v:.2f}" for n, v in zip(names, d)))
-    print(f"   (find_best coarse: wave 0's own scan {(st[61] - st[5]) / 2100.0:.2f}, then waiting for the energy scans {(st[6] - st[61]) / 2100.0:.2f})")
+    print(f"   (find_best coarse: wave 0's own scan {(st[61] - st[5]) / 2100.0:.2f}, then the barrier {(st[6] - st[61]) / 2100.0:.2f})")
+    print("   coarse phase, from its start: " + "  ".join(f"{n} {(st[i] - st[4]) / 2100.0:.2f}" for n, i in (("xcorr wave 0 done", 2), ("wave 1", 40), ("wave 2", 41), ("coarse-lag energies", 3), ("fine-lag energies", 62), ("yy_lookup", 63))))
     bd.close()
 PY
