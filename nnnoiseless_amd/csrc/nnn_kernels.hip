@@ -430,14 +430,6 @@ constexpr int PK_LC = NNN_PK_LC;                 // coarse lags per lane: 12 gro
 constexpr int PK_NG = (NLAG1 + PK_LC - 1) / PK_LC;
 static_assert((PK_LC & 1) && PK_NG <= 4 * 8, "odd group size: neighbouring groups start on different row parities");
 constexpr int PK_XW = (PK_NG + 3) / 4;           // waves of the coarse cross-correlation
-#ifndef NNN_PK_YW
-#define NNN_PK_YW 6
-#endif
-#ifndef NNN_PK_SCAN_PRIO
-#define NNN_PK_SCAN_PRIO 1
-#endif
-constexpr int PK_FW = 7, PK_YW = NNN_PK_YW;      // the waves that scan the fine-lag energies / yy_lookup beside it (wave PK_XW: the coarse-lag energies)
-static_assert(PK_XW == 3 && PK_YW > PK_XW && PK_YW < PK_FW, "");
 constexpr int PK_JB = 8;                         // taps per unrolled step of the coarse cross-correlation (240 = 30 x 8)
 constexpr int PK_NP = PK_LC / 2;                 // packed accumulators per lane (+ one single: PK_LC is odd)
 constexpr int PK_NT = PK_JB / 2 + PK_NP;         // window pairs per alignment
@@ -475,6 +467,7 @@ struct BestPitch {
     // squares its 147 correlations on the lanes that made them
     __device__ __forceinline__ void update_sq(int i, float num, float y_sq_norm) {
         const bool in = num * second_den > second_num * y_sq_norm;
+        if (!wave_any(in)) return;   // none of the wave's streams takes this lag: nothing changes
         const bool top = in && num * best_den > best_num * y_sq_norm;
         const bool mid = in && !top;
         second_num = top ? best_num : (mid ? num : second_num);
@@ -506,15 +499,15 @@ struct Xc2 {   // xcorr[] of the fine search: zero except within 2 of 2*best / 2
 __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1.0f + xx * yy); }
 
 // The two long energy scans run once per frame, serially, and are looked up at a few data-dependent lags later in the frame.
-// They leave check points in LDS (every 8th fine lag, every 8th step of yy); a lookup replays the few steps from the check
+// They leave check points in LDS (every 8th fine lag, every 5th step of yy); a lookup replays the few steps from the check
 // point below it -- the same additions in the same order.  (Whole tables would be 43 KB per block; through global scratch the
 // scans were bound by the depth of a wave's store queue.)
 constexpr int PK_CKF = 8, PK_NCKF = (NLAG2 + PK_CKF - 1) / PK_CKF;    // 37
-constexpr int PK_CKY = 8, PK_NCKY = 384 / PK_CKY + 1;                  // 49
+constexpr int PK_CKY = 5, PK_NCKY = 384 / PK_CKY + 1;                  // 77
 struct PkLds {
     float pb[PK_ODD + PK_HALF];                  // the decimated window, then (in place) pitch_buf
     float ckf[PK_NCKF][PK_SPB];                  // running energy of the fine lags before lag 8 m (find_best_pitch, ref: src/pitch.rs:380-402)
-    float cky[PK_NCKY][PK_SPB];                  // running energy yy of remove_doubling after step 8 m (ref: src/pitch.rs:133-142); [0] = xx
+    float cky[PK_NCKY][PK_SPB];                  // running energy yy of remove_doubling after step 5 m (ref: src/pitch.rs:133-142); [0] = xx
     union {
         struct { float xc[NLAG1][PK_SPB], ysq[NLAG1][PK_SPB]; } c;   // coarse search: squared positive cross-correlation (else NaN), running energy per lag
         struct {                                                       // from the fine search on
@@ -750,298 +743,131 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                         if (L0 + i < NLAG1) o[(size_t)(L0 + i) * TILE] = acc[i];
                 }
             }
-            NNN_STAMPW(b, 2, wave == 0);
-            NNN_STAMPW(b, 40, wave == 1);
-            NNN_STAMPW(b, 41, wave == 2);
-            // Three serial scans beside the cross-correlation (they need nothing of it), one lane per stream: chains of dependent
-            // additions in the reference's order.  Such a wave is paced by how many instructions it issues next to the busy waves of its
-            // SIMD, not by the chain: the squares and differences that feed the chains are formed two steps at a time (rows r, r + 1 of
-            // a half arrive as a register pair from one ds_read2_b32; v_pk_mul_f32 / v_pk_add_f32 round like the scalar instructions),
-            // operands are fetched a chunk ahead, and the chunks alternate between two register sets so that nothing is moved.
-            // (What paces these waves is the trip to LDS and back while the cross-correlation keeps the LDS pipeline full -- some 300
-            // cycles -- so a chunk is as many rows as the registers hold, and the waves ask for issue priority.)
-            const bool scan_wave = NNN_PK_SCAN_PRIO && (wave == PK_XW || wave == PK_FW || wave == PK_YW);
-            if (scan_wave) wf_setprio_high();
             if (wave == PK_XW && lane < PK_SPB) {
                 // the running energy every coarse lag sees in find_best_pitch (ref: src/pitch.rs:83 -> :380-402): even rows only
                 float ysq = 1.0f;
-                {
-                    v2f A[8], B[8];
-                    auto ld = [&](v2f (&v)[8], int j0) {
-#pragma unroll
-                        for (int k = 0; k < 8; k++) v[k] = mk2(pE[(j0 + 2 * k) * PK_SPB], pE[(j0 + 2 * k + 1) * PK_SPB]);
-                    };
-                    auto sum = [&](const v2f (&v)[8]) {
-#pragma unroll
-                        for (int k = 0; k < 8; k++) { const v2f sq = pk_mul(v[k], v[k]); ysq += sq.x; ysq += sq.y; }
-                    };
-                    ld(A, 0);
 #pragma nounroll
-                    for (int j0 = 0; j0 < 240; j0 += 32) {   // 15 chunks of 16 rows
-                        ld(B, j0 + 16 < 240 ? j0 + 16 : j0);
-                        sum(A);
-                        if (j0 + 16 < 240) {
-                            ld(A, j0 + 32 < 240 ? j0 + 32 : j0);
-                            sum(B);
-                        }
+                for (int j0 = 0; j0 < 240; j0 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] = pE[(j0 + i) * PK_SPB];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) ysq += v[i] * v[i];
+                }
+#pragma nounroll
+                for (int i0 = 0; i0 < NLAG1; i0 += 7) {
+                    float a[7], d[7];
+#pragma unroll
+                    for (int i = 0; i < 7; i++) { a[i] = pE[(i0 + i + 240) * PK_SPB]; d[i] = pE[(i0 + i) * PK_SPB]; }
+#pragma unroll
+                    for (int i = 0; i < 7; i++) {
+                        L.u.c.ysq[i0 + i][s] = ysq;
+                        ysq += a[i] * a[i] - d[i] * d[i];
+                        ysq = fmaxf(ysq, 1.0f);
                     }
                 }
+            } else if (wave == 7 && lane < PK_SPB) {
+                // the starting sums of the two long energy scans of the next phase (ref: src/pitch.rs:380-382, 133-136): these
+                // waves have nothing else to do while the cross-correlation runs, the scans are that phase's critical path
                 {
-                    constexpr int CL = 16, NCH = (NLAG1 + CL - 1) / CL;   // 10 chunks of 16 lags; the last computes 13 lags too many and stores none of them
-                    v2f A[2][CL / 2], B[2][CL / 2];        // [0]: the rows that enter (lag + 240), [1]: the rows that leave (lag)
-                    auto ld = [&](v2f (&v)[2][CL / 2], int i0) {
-#pragma unroll
-                        for (int k = 0; k < CL / 2; k++) {
-                            v[0][k] = mk2(pE[(i0 + 2 * k + 240) * PK_SPB], pE[(i0 + 2 * k + 241) * PK_SPB]);
-                            v[1][k] = mk2(pE[(i0 + 2 * k) * PK_SPB], pE[(i0 + 2 * k + 1) * PK_SPB]);
-                        }
-                    };
-                    auto run = [&](const v2f (&v)[2][CL / 2], int i0) {
-#pragma unroll
-                        for (int k = 0; k < CL / 2; k++) {
-                            const v2f t = pk_sub(pk_mul(v[0][k], v[0][k]), pk_mul(v[1][k], v[1][k]));
-                            if (i0 + 2 * k < NLAG1) L.u.c.ysq[i0 + 2 * k][s] = ysq;
-                            ysq += t.x;
-                            ysq = fmaxf(ysq, 1.0f);
-                            if (i0 + 2 * k + 1 < NLAG1) L.u.c.ysq[i0 + 2 * k + 1][s] = ysq;
-                            ysq += t.y;
-                            ysq = fmaxf(ysq, 1.0f);
-                        }
-                    };
-                    static_assert(NCH % 2 == 0 && (NCH - 1) * CL + CL + 241 <= XLP / 2, "");
-                    ld(A, 0);
+                    float ysq = 1.0f;
 #pragma nounroll
-                    for (int c = 0; c < NCH; c += 2) {
-                        ld(B, CL * (c + 1));
-                        run(A, CL * c);
-                        ld(A, CL * (c + 2 < NCH ? c + 2 : c + 1));
-                        run(B, CL * (c + 1));
+                    for (int m0 = 0; m0 < 240; m0 += 4) {
+                        float ve[4], vo[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { ve[i] = pE[(m0 + i) * PK_SPB]; vo[i] = pO[(m0 + i) * PK_SPB]; }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { ysq += ve[i] * ve[i]; ysq += vo[i] * vo[i]; }
+                    }
+                    L.ckf[0][s] = ysq;
+                }
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma nounroll
+                for (int m0 = 192; m0 < 432; m0 += 4) {
+                    float ve[4], vo[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { ve[i] = pE[(m0 + i) * PK_SPB]; vo[i] = pO[(m0 + i) * PK_SPB]; }
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {
+                        s0 += ve[i] * ve[i]; s1 += vo[i] * vo[i]; s2 += ve[i + 1] * ve[i + 1]; s3 += vo[i + 1] * vo[i + 1];
                     }
                 }
-                NNN_STAMPW(b, 3, true);
-            } else if (wave == PK_FW && lane < PK_SPB) {
-                // the running energy every fine lag sees (ref: src/pitch.rs:97 -> :380-402): <= 10 lags can update the best pitch there,
-                // and they are replayed below with the energy each of them saw
-                float ysq = 1.0f;
-                {
-                    v2f A[2][8], B[2][8];                  // [0]: even rows 2i, 2i + 2, [1]: odd rows 2i + 1, 2i + 3
-                    auto ld = [&](v2f (&v)[2][8], int m0) {
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            v[0][k] = mk2(pE[(m0 + 2 * k) * PK_SPB], pE[(m0 + 2 * k + 1) * PK_SPB]);
-                            v[1][k] = mk2(pO[(m0 + 2 * k) * PK_SPB], pO[(m0 + 2 * k + 1) * PK_SPB]);
-                        }
-                    };
-                    auto sum = [&](const v2f (&v)[2][8]) {
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            const v2f e = pk_mul(v[0][k], v[0][k]), o = pk_mul(v[1][k], v[1][k]);
-                            ysq += e.x; ysq += o.x; ysq += e.y; ysq += o.y;
-                        }
-                    };
-                    ld(A, 0);
-#pragma nounroll
-                    for (int m0 = 0; m0 < 240; m0 += 32) {   // 15 chunks of 16 row pairs
-                        ld(B, m0 + 16 < 240 ? m0 + 16 : m0);
-                        sum(A);
-                        if (m0 + 16 < 240) {
-                            ld(A, m0 + 32 < 240 ? m0 + 32 : m0);
-                            sum(B);
-                        }
-                    }
-                }
-                {
-                    // lags 2n, 2n + 1: rows (2n, 2n + 1) leave, rows (2n + 480, 2n + 481) enter.  A chunk is two check points (16 lags,
-                    // n0 .. n0 + 7); [0] / [1]: entering even / odd rows, [2] / [3]: leaving even / odd rows, two n per register pair
-                    v2f A[4][4], B[4][4];
-                    auto ld = [&](v2f (&v)[4][4], int n0) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            v[0][k] = mk2(pE[(n0 + 2 * k + 240) * PK_SPB], pE[(n0 + 2 * k + 241) * PK_SPB]);
-                            v[1][k] = mk2(pO[(n0 + 2 * k + 240) * PK_SPB], pO[(n0 + 2 * k + 241) * PK_SPB]);
-                            v[2][k] = mk2(pE[(n0 + 2 * k) * PK_SPB], pE[(n0 + 2 * k + 1) * PK_SPB]);
-                            v[3][k] = mk2(pO[(n0 + 2 * k) * PK_SPB], pO[(n0 + 2 * k + 1) * PK_SPB]);
-                        }
-                    };
-                    auto run = [&](const v2f (&v)[4][4], int m) {   // m: first check point of the chunk
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            if (k % 2 == 0 && m + k / 2 < PK_NCKF) L.ckf[m + k / 2][s] = ysq;
-                            const v2f te = pk_sub(pk_mul(v[0][k], v[0][k]), pk_mul(v[2][k], v[2][k]));
-                            const v2f to = pk_sub(pk_mul(v[1][k], v[1][k]), pk_mul(v[3][k], v[3][k]));
-                            ysq += te.x; ysq = fmaxf(ysq, 1.0f);
-                            ysq += to.x; ysq = fmaxf(ysq, 1.0f);
-                            ysq += te.y; ysq = fmaxf(ysq, 1.0f);
-                            ysq += to.y; ysq = fmaxf(ysq, 1.0f);
-                        }
-                    };
-                    constexpr int NCH = (PK_NCKF + 1) / 2;   // 19 chunks: lags 0 .. 303 (the last few past the table: computed, never looked up)
-                    static_assert(PK_CKF == 8 && 8 * (NCH - 1) + 6 + 241 < XLP / 2, "");
-                    ld(A, 0);
-#pragma nounroll
-                    for (int c = 0; c < NCH; c += 2) {
-                        ld(B, 8 * (c + 1 < NCH ? c + 1 : c));
-                        run(A, 2 * c);
-                        if (c + 1 < NCH) {
-                            ld(A, 8 * (c + 2 < NCH ? c + 2 : c + 1));
-                            run(B, 2 * c + 2);
-                        }
-                    }
-                }
-                NNN_STAMPW(b, 62, true);
-            } else if (wave == PK_YW && lane < PK_SPB) {
-                // xx = |x|^2 over the analysis frame and the 384-step running energy yy_lookup of remove_doubling
-                // (ref: src/pitch.rs:133-142)
-                float yy;
-                {
-                    v2f s02 = mk2(0.0f, 0.0f), s13 = mk2(0.0f, 0.0f);   // the four interleaved partial sums: rows 4j, 4j + 2 | 4j + 1, 4j + 3
-                    v2f A[2][8], B[2][8];
-                    auto ld = [&](v2f (&v)[2][8], int m0) {
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            v[0][k] = mk2(pE[(m0 + 2 * k) * PK_SPB], pE[(m0 + 2 * k + 1) * PK_SPB]);
-                            v[1][k] = mk2(pO[(m0 + 2 * k) * PK_SPB], pO[(m0 + 2 * k + 1) * PK_SPB]);
-                        }
-                    };
-                    auto sum = [&](const v2f (&v)[2][8]) {
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            s02 = pk_add(s02, pk_mul(v[0][k], v[0][k]));
-                            s13 = pk_add(s13, pk_mul(v[1][k], v[1][k]));
-                        }
-                    };
-                    ld(A, 192);
-#pragma nounroll
-                    for (int m0 = 192; m0 < 432; m0 += 32) {   // 15 chunks of 16 row pairs
-                        ld(B, m0 + 16 < 432 ? m0 + 16 : m0);
-                        sum(A);
-                        if (m0 + 16 < 432) {
-                            ld(A, m0 + 32 < 432 ? m0 + 32 : m0);
-                            sum(B);
-                        }
-                    }
-                    yy = s02.x + s13.x + s02.y + s13.y;   // xx = yy_lookup[0]
-                }
-                L.cky[0][s] = yy;
-                {
-                    // steps 2n + 1, 2n + 2: rows 383 - 2n, 382 - 2n enter, rows 863 - 2n, 862 - 2n leave.  A chunk is eight n (two check
-                    // points, four n apart); [0] / [1]: entering odd / even rows, [2] / [3]: leaving odd / even rows, two n per pair
-                    static_assert(PK_CKY == 8 && 384 % 32 == 0, "");
-                    v2f A[4][4], B[4][4];
-                    auto ld = [&](v2f (&v)[4][4], int n0) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            v[0][k] = mk2(pO[(191 - (n0 + 2 * k)) * PK_SPB], pO[(190 - (n0 + 2 * k)) * PK_SPB]);
-                            v[1][k] = mk2(pE[(191 - (n0 + 2 * k)) * PK_SPB], pE[(190 - (n0 + 2 * k)) * PK_SPB]);
-                            v[2][k] = mk2(pO[(431 - (n0 + 2 * k)) * PK_SPB], pO[(430 - (n0 + 2 * k)) * PK_SPB]);
-                            v[3][k] = mk2(pE[(431 - (n0 + 2 * k)) * PK_SPB], pE[(430 - (n0 + 2 * k)) * PK_SPB]);
-                        }
-                    };
-                    auto run = [&](const v2f (&v)[4][4], int ck) {   // ck: first check point this chunk writes
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const v2f o = pk_sub(pk_mul(v[0][k], v[0][k]), pk_mul(v[2][k], v[2][k]));
-                            const v2f e = pk_sub(pk_mul(v[1][k], v[1][k]), pk_mul(v[3][k], v[3][k]));
-                            yy += o.x;
-                            yy += e.x;
-                            yy += o.y;
-                            yy += e.y;
-                            if (k % 2 == 1) L.cky[ck + k / 2][s] = yy;   // after steps 16 c + 8, 16 c + 16
-                        }
-                    };
-                    ld(A, 0);
-#pragma nounroll
-                    for (int c = 0; c < 24; c += 2) {   // all 384 steps
-                        ld(B, 8 * (c + 1));
-                        run(A, 2 * c + 1);
-                        ld(A, 8 * (c + 2 < 24 ? c + 2 : c + 1));
-                        run(B, 2 * c + 3);
-                    }
-                }
-                NNN_STAMPW(b, 63, true);
+                L.cky[0][s] = s0 + s1 + s2 + s3;   // xx = yy_lookup[0]
             }
-            if (scan_wave) wf_setprio_normal();
         }
         __syncthreads();
         NNN_STAMP(b, 5);
-        // ---- find_best_pitch over the coarse lags (ref: src/pitch.rs:372-405, call site :83-84), wave 0.  The reference walks the 147
-        //      lags in order keeping (best, second) under the comparison a > b  <=>  num_a den_b > num_b den_a in f32 -- a serial scan,
-        //      one lane per stream, with the other seven waves waiting: a fifth of the block's time when every lag was walked.
-        //      The walk is shortened without changing its result.  Call rho = num / den a lag's ratio and rho2 the second-largest one.
-        //      Among the <= 147 ratios inside the band [rho2 (1 - 2^-12), rho2] two neighbours (or the band's foot and the lowest of
-        //      them) are at least 2^-12 / 148 = 1.6e-6 apart, relatively: ten times what the rounding of the two products can do to a
-        //      comparison.  U = the lags above that gap (the top two are among them), W = those below: a W lag loses every comparison
-        //      against a U lag and a U lag wins every comparison against a W lag or the initial state, whatever the rounding.  Walk all
-        //      lags, or only a subset M that contains U, in order: until the first U lag arrives both slots hold W lags or the
-        //      initial state; it takes `best` in either walk; W lags after it can at most take `second`; the second U lag beats
-        //      whatever holds `second` and meets the first in the same comparison on the same values in either walk; from then on both
-        //      slots hold U lags, identical in the two walks, W lags change nothing, U lags meet identical states.  M = the lags
-        //      whose ratio, computed with a reciprocal (a few ulp), is within 2^-12 of the second-largest such ratio: every lane
-        //      (stream, quarter of the lags) takes the ratios of its 37 lags, the four quarters agree on the second-largest, every
-        //      lane marks its lags, and lane = stream walks the marked lags in order with the reference's comparisons -- a handful
-        //      of steps instead of 147.  Where the products could be denormal or overflow (not with samples in the i16 range), or
-        //      fewer than two correlations are positive, every lag with a positive correlation is marked: the full walk.
+        // ---- find_best_pitch over the coarse lags (ref: src/pitch.rs:372-405, call site :83-84) on wave 0, a serial scan; beside it,
+        //      on waves 5 and 6 (other SIMDs), the two serial energy scans whose results are looked up later in the frame
         int lo1 = 0, lo2 = 0;
-        if (wave == 0) {
-            constexpr int NQL = (NLAG1 + 3) / 4;   // 37 lags per quarter
-            static_assert(NQL > 32 && NQL <= 64, "");
-            float r[NQL];
-            float m1 = -1.0f, m2 = -1.0f, nmax = 0.0f, dmax = 1.0f;
-            {
-                const float *xcp = &L.u.c.xc[q * NQL][s], *ysp = &L.u.c.ysq[q * NQL][s];
-#pragma unroll
-                for (int t = 0; t < NQL; t++) {
-                    const bool inr = (NQL * 3 + t < NLAG1) || q < 3;
-                    const float c = xcp[t * PK_SPB], e = ysp[t * PK_SPB];       // (one row past the table for the last lane: in the block, unused)
-                    const float rt = c * fast_rcp(e);
-                    const bool ok = inr && rt >= 0.0f;                          // a NaN stands for "correlation not positive"
-                    r[t] = ok ? rt : -1.0f;
-                    m2 = fmaxf(m2, fminf(m1, r[t]));
-                    m1 = fmaxf(m1, r[t]);
-                    nmax = fmaxf(nmax, ok ? c : 0.0f);
-                    dmax = fmaxf(dmax, ok ? e : 1.0f);
-                }
-            }
-#pragma unroll
-            for (int d = 16; d <= 32; d <<= 1) {
-                const float o1 = __shfl_xor(m1, d), o2 = __shfl_xor(m2, d);
-                m2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
-                m1 = fmaxf(m1, o1);
-                nmax = fmaxf(nmax, __shfl_xor(nmax, d));
-                dmax = fmaxf(dmax, __shfl_xor(dmax, d));
-            }
-            const bool tame = m2 > 1e-30f && nmax * dmax < 1e37f;
-            const float thr = tame ? m2 * (1.0f - 1.0f / 4096.0f) : 0.0f;
-            unsigned mlo = 0, mhi = 0;
-#pragma unroll
-            for (int t = 0; t < 32; t++) mlo |= r[t] >= thr ? 1u << t : 0u;
-#pragma unroll
-            for (int t = 32; t < NQL; t++) mhi |= r[t] >= thr ? 1u << (t - 32) : 0u;
+        if (dec_lane) {
             BestPitch bp;
             bp.init();
-#pragma unroll 1
-            for (int qq = 0; qq < 4; qq++) {
-                unsigned lo = __shfl(mlo, s + 16 * qq), hi = __shfl(mhi, s + 16 * qq);
-                if (q != 0) { lo = 0; hi = 0; }
-                while (wave_ballot((lo | hi) != 0) != 0) {
-                    const bool act = (lo | hi) != 0;
-                    const int t = lo ? __builtin_ctz(lo) : (hi ? 32 + __builtin_ctz(hi) : 0);
-                    const int i = qq * NQL + t;
-                    const float num = L.u.c.xc[act ? i : 0][s], e = L.u.c.ysq[act ? i : 0][s];
-                    if (act) bp.update_sq(i, num, e);
-                    if (lo) lo &= lo - 1; else hi &= hi - 1;
-                }
+            float c[7], e[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) { c[i] = L.u.c.xc[i][s]; e[i] = L.u.c.ysq[i][s]; }
+#pragma nounroll
+            for (int i0 = 0; i0 < NLAG1; i0 += 7) {
+                float cn[7], en[7];   // the next seven lags travel while these are judged
+                const int i1 = i0 + 7 < NLAG1 ? i0 + 7 : i0;
+#pragma unroll
+                for (int i = 0; i < 7; i++) { cn[i] = L.u.c.xc[i1 + i][s]; en[i] = L.u.c.ysq[i1 + i][s]; }
+#pragma unroll
+                for (int i = 0; i < 7; i++) bp.update_sq(i0 + i, c[i], e[i]);
+#pragma unroll
+                for (int i = 0; i < 7; i++) { c[i] = cn[i]; e[i] = en[i]; }
             }
-            if (dec_lane) {
-                if (b.taps) {
-                    int *o = (int *)NNN_TIF(b, best1, 2, f, tile, sl);
-                    o[0] = bp.best;
-                    o[TILE] = bp.second;
-                }
-                lo1 = 2 * bp.best - 2;
-                lo2 = 2 * bp.second - 2;
+            if (b.taps) {
+                int *o = (int *)NNN_TIF(b, best1, 2, f, tile, sl);
+                o[0] = bp.best;
+                o[TILE] = bp.second;
             }
+            lo1 = 2 * bp.best - 2;
+            lo2 = 2 * bp.second - 2;
             NNN_STAMP(b, 61);
+        } else if (wave == 5 && lane < PK_SPB) {
+            // the running energy every fine lag sees (ref: src/pitch.rs:97 -> :380-402): <= 10 lags can update the best pitch there,
+            // and they are replayed below with the energy each of them saw
+            float ysq = L.ckf[0][s];   // the sum over the first 480 rows, made beside the coarse cross-correlation
+#pragma nounroll
+            for (int m = 0; m < PK_NCKF; m++) {   // lags 8 m .. 8 m + 7 (the last few past the table: computed, never looked up)
+                L.ckf[m][s] = ysq;
+                const int n0 = m * (PK_CKF / 2);
+                float ae[4], ao[4], de[4], dd[4];   // lags 2n, 2n + 1: rows (2n, 2n + 1) leave, rows (2n + 480, 2n + 481) enter
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    ae[i] = pE[(n0 + i + 240) * PK_SPB]; ao[i] = pO[(n0 + i + 240) * PK_SPB];
+                    de[i] = pE[(n0 + i) * PK_SPB]; dd[i] = pO[(n0 + i) * PK_SPB];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    ysq += ae[i] * ae[i] - de[i] * de[i];
+                    ysq = fmaxf(ysq, 1.0f);
+                    ysq += ao[i] * ao[i] - dd[i] * dd[i];
+                    ysq = fmaxf(ysq, 1.0f);
+                }
+            }
+        } else if (wave == 6 && lane < PK_SPB) {
+            // xx = |x|^2 over the analysis frame and the 384-step running energy yy_lookup of remove_doubling
+            // (ref: src/pitch.rs:133-142)
+            float yy = L.cky[0][s];   // xx = yy_lookup[0], made beside the coarse cross-correlation
+#pragma nounroll
+            for (int bk = 0; bk < 38; bk++) {   // steps 10 bk + 1 .. 10 bk + 10 (380 steps: the last four are only ever replayed)
+                const int n0 = 5 * bk;          // steps 2n + 1, 2n + 2: rows 383 - 2n, 382 - 2n enter, rows 863 - 2n, 862 - 2n leave
+                float ae[5], ao[5], ce[5], co[5];
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    ae[i] = pE[(191 - (n0 + i)) * PK_SPB]; ao[i] = pO[(191 - (n0 + i)) * PK_SPB];
+                    ce[i] = pE[(431 - (n0 + i)) * PK_SPB]; co[i] = pO[(431 - (n0 + i)) * PK_SPB];
+                }
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    yy += ao[i] * ao[i] - co[i] * co[i];
+                    if (i == 2) L.cky[2 * bk + 1][s] = yy;   // after step 10 bk + 5
+                    yy += ae[i] * ae[i] - ce[i] * ce[i];
+                }
+                L.cky[2 * bk + 2][s] = yy;                   // after step 10 bk + 10
+            }
         }
         __syncthreads();   // the coarse arrays are dead: their space takes the partial sums from here on
         if (dec_lane) {

@@ -58,7 +58,6 @@ template <class T> __device__ __forceinline__ void st_global(void *p, T v)
 // from the value loop-variant for the compiler: otherwise every address of every phase is hoisted out of the frame loop as
 // loop invariant, hundreds of registers wide, and spilled (measured: 300 spills in k_rnn without it, none with it).
 __device__ __forceinline__ void wf_setprio_high() { __builtin_amdgcn_s_setprio(3); }
-__device__ __forceinline__ void wf_setprio_normal() { __builtin_amdgcn_s_setprio(0); }
 __device__ __forceinline__ int launder_v(int x)
 {
     asm volatile("" : "+v"(x));
@@ -110,12 +109,6 @@ __device__ __forceinline__ v2f pk_add(v2f a, v2f b)
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ v2f pk_sub(v2f a, v2f b)       // (a.x - b.x, a.y - b.y)
-{
-    v2f r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 
 // Frame-to-frame hand-off between workgroups of one launch (k_pitch): the producer makes its results visible device-wide
 // and then stores the flag; the consumer polls the flag and only then reads the results.
@@ -132,8 +125,6 @@ __device__ __forceinline__ unsigned ticket_take(unsigned *ctr)
 {
     return __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// 1 / x to about an ulp (v_rcp_f32), for estimates that decide no result
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // true when the predicate holds on any active lane of the wave (wave-uniform)
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 // bit l: the predicate on lane l (wave-uniform)

@@ -26,7 +26,6 @@ for S, T in ((4096, 4), (65536, 4)):
     d = [(st[idx[i + 1]] - st[idx[i]]) / 2100.0 for i in range(len(names))]   # shader-clock cycles at ~2.1 GHz -> us (approximate)
     print(f"S={S} k_pitch last frame of block 0 [us, approximate]: total {sum(d):.1f}")
     print("   " + "  ".join(f"{n} {v:.2f}" for n, v in zip(names, d)))
-    print(f"   (find_best coarse: wave 0's own scan {(st[61] - st[5]) / 2100.0:.2f}, then the barrier {(st[6] - st[61]) / 2100.0:.2f})")
-    print("   coarse phase, from its start: " + "  ".join(f"{n} {(st[i] - st[4]) / 2100.0:.2f}" for n, i in (("xcorr wave 0 done", 2), ("wave 1", 40), ("wave 2", 41), ("coarse-lag energies", 3), ("fine-lag energies", 62), ("yy_lookup", 63))))
+    print(f"   (find_best coarse: wave 0's own scan {(st[61] - st[5]) / 2100.0:.2f}, then waiting for the energy scans {(st[6] - st[61]) / 2100.0:.2f})")
     bd.close()
 PY

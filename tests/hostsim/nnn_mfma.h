@@ -59,7 +59,6 @@ static inline uint4 ld_global_u4(const void *p) { return ld_global<uint4>(p); }
 template <class T> static inline void st_global(void *p, T v) { memcpy(p, &v, sizeof(T)); }
 
 static inline void wf_setprio_high() {}
-static inline void wf_setprio_normal() {}
 static inline int launder_v(int x) { return x; }
 static inline int launder_s(int x) { return x; }
 static inline void keep_v(float) {}
@@ -72,7 +71,6 @@ static inline v2f pk_mul(v2f a, v2f b) { return mk2(a.x * b.x, a.y * b.y); }
 static inline v2f pk_mul_bx(v2f a, v2f b) { return mk2(a.x * b.x, a.x * b.y); }
 static inline v2f pk_mul_by(v2f a, v2f b) { return mk2(a.y * b.x, a.y * b.y); }
 static inline v2f pk_add(v2f a, v2f b) { return mk2(a.x + b.x, a.y + b.y); }
-static inline v2f pk_sub(v2f a, v2f b) { return mk2(a.x - b.x, a.y - b.y); }
 static inline float sadd(float a, float b) { return a + b; }
 
 // (the interpreter runs the workgroups of a launch one after the other in index order: a flag is always set when it is read)
@@ -93,7 +91,6 @@ static inline unsigned long long wave_ballot(bool p)
     hostsim::wave_collective(&p, &m, detail::ballot_fn);
     return m;
 }
-static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline bool wave_any(bool) { return true; }   // (a skipped no-op update and an executed one leave the same state)
 static inline void chain_pause() {}
 static inline void __threadfence() {}
