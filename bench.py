@@ -236,7 +236,7 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
         bd.set_inputs_ready(True)
     stream = torch.cuda.current_stream().cuda_stream if dev.type == "cuda" else 0
 
-    def run(f0, n):   # n frames of every stream starting at frame f0 of the pool: never past its end
+    def run(f0, n, bd=bd):   # n frames of every stream starting at frame f0 of the pool: never past its end
         assert 0 <= f0 and n > 0 and f0 + n <= pool, (f0, n, pool)
         off = f0 * 480 * Cc * esz
         if fmt or Cc > 1:
@@ -248,11 +248,11 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
         else:
             bd.process_device(x.data_ptr() + off, y.data_ptr() + off, vad.data_ptr() + f0 * S * 4, n, pool * 480, 480, stream)
 
-    def run_span(pos, n):   # n frames starting at absolute frame `pos`, wrapping around the pool as often as needed
+    def run_span(pos, n, bd=bd):   # n frames starting at absolute frame `pos`, wrapping around the pool as often as needed
         while n > 0:
             f0 = pos % pool
             m = min(n, pool - f0)
-            run(f0, m)
+            run(f0, m, bd)
             pos += m
             n -= m
 
@@ -306,7 +306,24 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
         barrier()
         tt = time.perf_counter() - t1
         tf, tmax = aggregate(d, S * kt, tt, dev)
-        res["tick"] = {"frames_per_step": 1, "value": tf / tmax, "unit": "frames/s", "ms_per_step": tmax * 1e3 / kt, "steps": kt}
+        res["tick"] = {"frames_per_step": 1, "value": tf / tmax, "unit": "frames/s", "ms_per_step": tmax * 1e3 / kt, "steps": kt,
+                       "kb_per_stream": round(bd.device_bytes() / S / 1024, 1)}
+        # ... and on a batch created for it (nnn_batch_opts.max_group_frames = 1: scratch and history rings for one-frame groups)
+        bd1 = nn.BatchDenoiser(S, model=model, device=0 if args.dry_run else local_rank, max_group_frames=1)
+        if not args.no_overlap:
+            bd1.set_inputs_ready(True)
+        for j in range(10):
+            run_span(pos + j, 1, bd1)
+        barrier()
+        t1 = time.perf_counter()
+        for j in range(10, 10 + kt):
+            run_span(pos + j, 1, bd1)
+        barrier()
+        tt = time.perf_counter() - t1
+        tf, tmax = aggregate(d, S * kt, tt, dev)
+        res["tick"]["batch_sized_for_ticks"] = {"value": tf / tmax, "ms_per_step": tmax * 1e3 / kt,
+                                                "kb_per_stream": round(bd1.device_bytes() / S / 1024, 1)}
+        bd1.close()
 
     def close():
         nonlocal x, y, vad

@@ -49,6 +49,14 @@ extern "C" {
         n_groups: c_int,
         device: c_int,
     ) -> *mut RawBatch;
+    fn nnn_batch_create_opts(
+        models: *const *const RawModel,
+        group_streams: *const c_int,
+        n_groups: c_int,
+        device: c_int,
+        opts: *const BatchOpts,
+    ) -> *mut RawBatch;
+    fn nnn_batch_device_bytes(b: *const RawBatch) -> usize;
     fn nnn_batch_process_pcm_host(
         b: *mut RawBatch,
         input: *const c_void,
@@ -116,7 +124,31 @@ pub struct BatchDenoiser {
 }
 unsafe impl Send for BatchDenoiser {}
 
+/// `struct nnn_batch_opts` (include/nnn_batch.h)
+#[repr(C)]
+#[derive(Default)]
+pub struct BatchOpts {
+    pub max_group_frames: c_int,
+    pub reserved: [c_int; 7],
+}
+
 impl BatchDenoiser {
+    /// A batch sized for calls of at most `max_group_frames` frames: a real-time host that ticks one frame per call (what
+    /// `DenoiseSignal` does, src/signal.rs:102-104) passes 1 and holds 44 KB per stream instead of 650.
+    pub fn sized(n_streams: usize, max_group_frames: usize, model: Option<&RnnModel>, device: i32) -> Option<BatchDenoiser> {
+        let m = model.map_or(std::ptr::null(), |m| m.0 as *const RawModel);
+        let n = n_streams as c_int;
+        let opts = BatchOpts { max_group_frames: max_group_frames as c_int, ..Default::default() };
+        let raw = unsafe { nnn_batch_create_opts(&m, &n, 1, device, &opts) };
+        if raw.is_null() {
+            None
+        } else {
+            Some(BatchDenoiser { raw, n: n_streams })
+        }
+    }
+    pub fn device_bytes(&self) -> usize {
+        unsafe { nnn_batch_device_bytes(self.raw) }
+    }
     pub fn new(n_streams: usize, model: Option<&RnnModel>, device: i32) -> Option<BatchDenoiser> {
         let m = model.map_or(std::ptr::null(), |m| m.0 as *const RawModel);
         let raw = unsafe { nnn_batch_create(m, n_streams as c_int, device) };

@@ -51,6 +51,21 @@ nnn_batch *nnn_batch_create(const RNNModel *model, int n_streams, int device);
  * a multiple of 64 streams (the kernels' tile).  models == NULL or models[i] == NULL selects the built-in model.
  * Everything except the RNN kernel is model-independent; the RNN runs as one launch per group. */
 nnn_batch *nnn_batch_create_grouped(const RNNModel *const *models, const int *group_streams, int n_groups, int device);
+/* The same with options (NULL = defaults; zero-initialise the struct).
+ * max_group_frames: the kernels work on groups of consecutive frames -- up to 24 by default, which sizes the per-stream scratch
+ * and history rings for it (650 KB per stream).  A host whose calls are short says so here and gets a batch sized for groups of
+ * that many frames: a real-time host that ticks ONE 10 ms frame per call passes 1 and pays 44 KB per stream (the reference's
+ * DenoiseState is 10.3 KB, src/features.rs:18-46), i.e. 6.5 million live streams' worth of HBM instead of 440 thousand.  Longer
+ * calls still work on such a batch, cut into groups of at most this many frames (slower, same results).  0 = default. */
+typedef struct nnn_batch_opts {
+    int max_group_frames;
+    int reserved[7];                     /* must be zero */
+} nnn_batch_opts;
+nnn_batch *nnn_batch_create_opts(const RNNModel *const *models, const int *group_streams, int n_groups, int device,
+                                 const nnn_batch_opts *opts);
+int nnn_batch_max_group_frames(const nnn_batch *b);
+/* Device memory the batch holds (state, scratch, tables, weights), bytes. */
+size_t nnn_batch_device_bytes(const nnn_batch *b);
 void nnn_batch_destroy(nnn_batch *b);
 int nnn_batch_num_streams(const nnn_batch *b);
 /* Back to freshly-created state (all zeros, src/features.rs:58-74). */

@@ -92,7 +92,20 @@ class BatchDenoiser {
         b_.reset(nnn_batch_create_grouped(ms.data(), ns.data(), (int)ns.size(), device), nnn_batch_destroy);
         if (!b_) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
     }
+    // a batch sized for calls of at most `max_group_frames` frames (1 = a real-time host ticking one frame per call: 44 KB per
+    // stream instead of 650; longer calls still work, cut into groups of that many frames)
+    static BatchDenoiser sized(int n_streams, int max_group_frames, const RnnModel *model = nullptr, int device = 0)
+    {
+        const RNNModel *m = model ? model->raw() : nullptr;
+        nnn_batch_opts o = {};
+        o.max_group_frames = max_group_frames;
+        BatchDenoiser d(nnn_batch_create_opts(&m, &n_streams, 1, device, &o));
+        if (!d.b_) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+        return d;
+    }
     int num_streams() const { return nnn_batch_num_streams(b_.get()); }
+    size_t device_bytes() const { return nnn_batch_device_bytes(b_.get()); }
+    int max_group_frames() const { return nnn_batch_max_group_frames(b_.get()); }
     // packed PCM in the reference callers' formats (int16 / unit floats, interleaved channels, first frame dropped)
     void process_pcm(const void *in, void *out, float *vad, int n_frames, const nnn_pcm_layout &layout)
     {

@@ -106,8 +106,11 @@ class RnnModel:
 class BatchDenoiser:
     """n_streams DenoiseStates in lock-step on one GPU."""
 
-    def __init__(self, n_streams, model=None, device=0, lib=None, groups=None, taps=False, _handle=None):
-        """groups: [(model_or_None, n_streams), ...] keeps several models resident, one per run of streams (every run
+    def __init__(self, n_streams, model=None, device=0, lib=None, groups=None, taps=False, max_group_frames=None, _handle=None):
+        """max_group_frames: the longest run of frames the kernels take at once (default 24).  A real-time host that ticks one frame
+        per call passes 1: the batch then holds 44 KB per stream instead of 650 (`device_bytes()`); longer calls still work on it,
+        cut into groups of that many frames.
+        groups: [(model_or_None, n_streams), ...] keeps several models resident, one per run of streams (every run
         but the last a multiple of 64); it replaces `model` and must add up to n_streams.  taps=True also stores the
         intermediate quantities the kernels otherwise keep on chip (parity tests: everything inside the pitch kernel -- tap("xlp"),
         "xcorr1", "best1", "xcorr2c", "pitch_search" --, "P" beyond bin 399, "features")."""
@@ -118,19 +121,34 @@ class BatchDenoiser:
         if _handle is not None:   # clone()
             self._h = _handle
             return
-        if groups:
-            if sum(n for _, n in groups) != self.n_streams:
+        if max_group_frames is not None and int(max_group_frames) < 1:
+            raise ValueError("max_group_frames must be at least 1")
+        if groups or max_group_frames is not None:
+            groups_ = groups or [(model, self.n_streams)]
+            if sum(n for _, n in groups_) != self.n_streams:
                 raise ValueError("group sizes must add up to n_streams")
-            self._model = [m for m, _ in groups]
-            hs = (C.c_void_p * len(groups))(*[m._h if m is not None else None for m, _ in groups])
-            ns = (C.c_int * len(groups))(*[int(n) for _, n in groups])
-            self._h = self._lib.L.nnn_batch_create_grouped(hs, ns, len(groups), device)
+            if groups:
+                self._model = [m for m, _ in groups_]
+            hs = (C.c_void_p * len(groups_))(*[m._h if m is not None else None for m, _ in groups_])
+            ns = (C.c_int * len(groups_))(*[int(n) for _, n in groups_])
+            if max_group_frames is not None:
+                opts = _ffi.BatchOpts(max_group_frames=int(max_group_frames))
+                self._h = self._lib.L.nnn_batch_create_opts(hs, ns, len(groups_), device, C.byref(opts))
+            else:
+                self._h = self._lib.L.nnn_batch_create_grouped(hs, ns, len(groups_), device)
         else:
             self._h = self._lib.L.nnn_batch_create(model._h if model is not None else None, self.n_streams, device)
         if not self._h:
             raise RuntimeError("nnnoiseless_amd: " + self._lib.error())
         if taps:
             self.set_taps(True)
+
+    def device_bytes(self):
+        """Device memory the batch holds (state, scratch, tables, weights)."""
+        return int(self._lib.L.nnn_batch_device_bytes(self._h))
+
+    def max_group_frames(self):
+        return int(self._lib.L.nnn_batch_max_group_frames(self._h))
 
     def clone(self):
         """A second batch with the same models and a copy of every stream's state (DenoiseState: Clone, src/denoise.rs:36)."""

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -27,12 +28,15 @@ static thread_local std::string g_err;
 // on another: the HIP runtime rejects those ("would make the legacy stream depend on a capturing blocking stream").
 // Those short sections -- never the per-frame launches -- take this lock.
 static std::recursive_mutex g_rt_mu;
-// Batches alive in this process.  With more than one -- the real-time serving pattern: independent batches ticking one frame per
-// call, each on its own HIP stream -- one-frame groups take k_rnn, which does not hold every compute unit for the pipelined
-// kernel's five ticks.  (Also tried for that pattern: running short calls on the batch's own stream so that two batches would not
+// The real-time serving pattern: independent batches ticking one frame per call, each on its own HIP stream.  A batch that sees
+// others doing so runs its one-frame groups on k_rnn, which does not hold every compute unit for the pipelined kernel's five
+// ticks.  (Also tried for that pattern: running short calls on the batch's own stream so that two batches would not
 // depend on the hardware queue their callers' streams share -- 2 x 4096 streams 23.5 -> 19.0 M frames/s, 8 x 4096 43.2 -> 36.4:
 // the extra event hops cost more than they free; with GPU_MAX_HW_QUEUES=8 in the environment two batches do overlap, 33.5 M.)
-static std::atomic<int> g_live_batches{0};
+// "Other batches are ticking beside this one": another batch made a call within the last few milliseconds (remembered for 20 ms).
+// Alive is not enough -- a host may hold idle batches -- and the answer only picks between two kernels that give the same bits.
+static std::atomic<uint64_t> g_call_mark{0};   // (batch id << 44) | microseconds of the most recent call of any batch
+static std::atomic<uint64_t> g_next_batch_id{1};
 #define NNN_RT_LOCK std::lock_guard<std::recursive_mutex> rt_lock_(g_rt_mu)
 extern "C" const char *nnn_last_error(void) { return g_err.c_str(); }
 static int fail(const char *fmt, ...)
@@ -85,7 +89,10 @@ struct nnn_batch {
     int device = 0;
     int S = 0, S_pad = 0, NT = 0;
     uint64_t frame_count = 0;
-    uint64_t group_count = 0;      // groups launched so far: group_count % DEPTH picks the block of GROUP scratch sets
+    int gmax = GROUP;              // frames per group at most (nnn_batch_opts.max_group_frames): sizes the scratch sets and the history rings
+    int nset = NSET, nslot = slots_for(GROUP);
+    size_t device_bytes = 0;       // everything dalloc / upload allocated
+    uint64_t group_count = 0;      // groups launched so far: group_count % DEPTH picks the block of gmax scratch sets
     int last_set = 0;              // scratch set of the most recent frame (parity taps)
     std::vector<void *> allocs;     // everything hipMalloc'ed
     std::vector<std::pair<void *, size_t>> state_bufs;  // zeroed by reset, copied by clone / save / load
@@ -119,7 +126,8 @@ struct nnn_batch {
     unsigned *frame_log = nullptr;  // nnn_batch_set_frame_log: the next frame's record (device), and the frames that still have room
     size_t frame_log_left = 0;
     int lpc_wide = -1;              // k_lpc_wide (one lag per wave): -1 = for launches below 512 waves, 0 / 1 = never / always (env NNN_LPC_WIDE; tests)
-    bool counted = false;           // in g_live_batches
+    uint64_t id = 0, other_seen_us = 0;   // see g_call_mark
+    bool beside_others = false;     // as of the current call
     bool host_call = false;         // inside a host-buffer entry point: the input is an upload enqueued by this library, final only in stream order
     hipEvent_t ev_in = nullptr;     // the caller's stream at the start of a pipelined call
     hipEvent_t ev_last = nullptr;   // end of the most recent call, on the stream it was made on
@@ -148,6 +156,7 @@ template <class T> static hipError_t dalloc(nnn_batch *h, T **p, size_t count, b
     hipError_t e = hipMalloc((void **)p, bytes ? bytes : 4);
     if (e != hipSuccess) return e;
     h->allocs.push_back(*p);
+    h->device_bytes += bytes ? bytes : 4;
     e = hipMemset(*p, 0, bytes);
     if (is_state) h->state_bufs.push_back({(void *)*p, bytes});
     return e;
@@ -220,7 +229,6 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
         if (h->ev_done[p]) hipEventDestroy(h->ev_done[p]);
     }
     if (h->ev_in) hipEventDestroy(h->ev_in);
-    if (h->counted) g_live_batches.fetch_sub(1);
     if (h->ev_last) hipEventDestroy(h->ev_last);
     for (hipEvent_t e : h->evp) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
@@ -281,8 +289,11 @@ static int rnn_small_batch_blocks()
     return v;
 }
 
-static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *group_streams, int n_groups, int device)
+static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *group_streams, int n_groups, int device, int gmax)
 {
+    h->gmax = gmax < 1 ? 1 : (gmax > GROUP ? GROUP : gmax);
+    h->nset = DEPTH * h->gmax;
+    h->nslot = slots_for(h->gmax);
     int n_streams = 0;
     for (int g = 0; g < n_groups; g++) {
         if (group_streams[g] <= 0) return fail("group %d: stream count must be positive", g);
@@ -377,14 +388,15 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     Buffers &b = h->b[0];
     memset(&b, 0, sizeof(b));
     b.S = h->S; b.S_pad = h->S_pad; b.NT = h->NT;
+    b.nslot = h->nslot;
     b.gru_v_w = md.nv; b.gru_n_w = md.nn; b.gru_dn_w = md.ndn;
     // persistent state
-    HIPCHK(dalloc(h, &b.hist, Sp * HSTR, true));
+    HIPCHK(dalloc(h, &b.hist, Sp * hist_stride(h->nslot), true));
     HIPCHK(dalloc(h, &b.hp_mem, Sp * 2, true));
     HIPCHK(dalloc(h, &b.hp_last, Sp, true));
-    HIPCHK(dalloc(h, &b.dec, Sp * DEC_LEN, true));
-    HIPCHK(dalloc(h, &b.xlp0, Sp * NSLOT, true));
-    HIPCHK(dalloc(h, &b.lpc, Sp * NSLOT * 10, false));   // (remade for every frame before it is read: not part of a snapshot)
+    HIPCHK(dalloc(h, &b.dec, Sp * dec_len(h->nslot), true));
+    HIPCHK(dalloc(h, &b.xlp0, Sp * h->nslot, true));
+    HIPCHK(dalloc(h, &b.lpc, Sp * h->nslot * 10, false));   // (remade for every frame before it is read: not part of a snapshot)
     HIPCHK(dalloc(h, &b.ceps_mem, Sp * CEPS_MEM * NB, true));
     HIPCHK(dalloc(h, &b.mem_id, Sp, true));
     HIPCHK(dalloc(h, &b.synth_mem, Sp * FRAME, true));
@@ -454,33 +466,47 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
         h->groups[g].wq = (const uint4 *)dq;
         HIPCHK(upload(h, &h->groups[g].fpar, fpars[g]));
     }
-    {   // per-frame scratch (doubles as parity taps): every array holds NSET sets back to back
+    {   // per-frame scratch (doubles as parity taps): every array holds nset sets back to back
         Buffers &q = h->b[0];
         // (the arrays only the parity taps fill, 4.1 KB per stream and set, wait for nnn_batch_set_taps(1))
-#define NNN_F(name, len) HIPCHK(dalloc(h, &q.name, Sp * (size_t)(len) * NSET, false));
+#define NNN_F(name, len) HIPCHK(dalloc(h, &q.name, Sp * (size_t)(len) * h->nset, false));
         NNN_WORK_FIELDS(NNN_F)
 #undef NNN_F
-        for (int set = 1; set < NSET; set++) h->b[set] = frame_view(h->b[0], set);
-        h->state_bufs.push_back({(void *)q.pflag, Sp * NSET * sizeof(int)});   // frame numbers restart with reset / load_state
+        for (int set = 1; set < h->nset; set++) h->b[set] = frame_view(h->b[0], set);
+        h->state_bufs.push_back({(void *)q.pflag, Sp * h->nset * sizeof(int)});   // frame numbers restart with reset / load_state
     }
     // the RNN kernel's dynamic LDS limit is a per-device function attribute: raise it to the hardware's 160 KB once
     HIPCHK(hipFuncSetAttribute((const void *)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     HIPCHK(hipFuncSetAttribute((const void *)k_rnn_wf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     HIPCHK(hipDeviceSynchronize());
-    g_live_batches.fetch_add(1);
-    h->counted = true;
+    h->id = g_next_batch_id.fetch_add(1) & 0xFFFFFu;
+    if (!h->id) h->id = g_next_batch_id.fetch_add(1) & 0xFFFFFu;
     return 0;
 }
 
-extern "C" nnn_batch *nnn_batch_create_grouped(const RNNModel *const *models, const int *group_streams, int n_groups, int device)
+extern "C" nnn_batch *nnn_batch_create_opts(const RNNModel *const *models, const int *group_streams, int n_groups, int device,
+                                             const nnn_batch_opts *opts)
 {
     if (n_groups <= 0 || !group_streams) {
         fail("need at least one group of streams");
         return nullptr;
     }
+    int gmax = GROUP;
+    if (opts) {
+        for (int r : opts->reserved)
+            if (r != 0) {
+                fail("nnn_batch_opts.reserved must be zero");
+                return nullptr;
+            }
+        if (opts->max_group_frames < 0) {
+            fail("nnn_batch_opts.max_group_frames must not be negative");
+            return nullptr;
+        }
+        if (opts->max_group_frames > 0) gmax = opts->max_group_frames;
+    }
     NNN_RT_LOCK;
     nnn_batch *h = new nnn_batch();
-    if (create_impl(h, models, group_streams, n_groups, device) != 0) {
+    if (create_impl(h, models, group_streams, n_groups, device, gmax) != 0) {
         std::string keep = g_err;
         nnn_batch_destroy(h);
         g_err = keep;
@@ -488,6 +514,14 @@ extern "C" nnn_batch *nnn_batch_create_grouped(const RNNModel *const *models, co
     }
     return h;
 }
+
+extern "C" nnn_batch *nnn_batch_create_grouped(const RNNModel *const *models, const int *group_streams, int n_groups, int device)
+{
+    return nnn_batch_create_opts(models, group_streams, n_groups, device, nullptr);
+}
+
+extern "C" int nnn_batch_max_group_frames(const nnn_batch *h) { return h ? h->gmax : 0; }
+extern "C" size_t nnn_batch_device_bytes(const nnn_batch *h) { return h ? h->device_bytes : 0; }
 
 extern "C" nnn_batch *nnn_batch_create(const RNNModel *model, int n_streams, int device)
 {
@@ -585,7 +619,7 @@ extern "C" int nnn_batch_load_state(nnn_batch *h, const void *host_src, size_t s
     if (src_bytes < sizeof(hd)) return fail("not a state snapshot");
     memcpy(&hd, host_src, sizeof(hd));
     if (hd.magic != kSnapMagic || hd.n_bufs != h->state_bufs.size() || hd.total != need || hd.streams != (uint64_t)h->S || src_bytes < need)
-        return fail("state snapshot does not match this batch (streams / models / library build)");
+        return fail("state snapshot does not match this batch (streams / models / max_group_frames / library build)");
     if (int rc = quiesce(h)) return rc;
     const char *p = (const char *)host_src + sizeof(hd);
     for (auto &sb : h->state_bufs) {
@@ -607,7 +641,9 @@ extern "C" nnn_batch *nnn_batch_clone(nnn_batch *h)
     if (quiesce(h)) return nullptr;
     std::vector<const RNNModel *> mp;
     for (const RNNModel &m : h->models) mp.push_back(&m);
-    nnn_batch *c = nnn_batch_create_grouped(mp.data(), h->group_streams.data(), (int)h->group_streams.size(), h->device);
+    nnn_batch_opts o = {};
+    o.max_group_frames = h->gmax;
+    nnn_batch *c = nnn_batch_create_opts(mp.data(), h->group_streams.data(), (int)h->group_streams.size(), h->device, &o);
     if (!c) return nullptr;
     bool ok = c->state_bufs.size() == h->state_bufs.size();
     for (size_t i = 0; ok && i < h->state_bufs.size(); i++)
@@ -688,9 +724,9 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
             // the layer-pipelined kernel spends g + 4 ticks on g frames: for a lone frame on a batch of many block rounds the
             // plain kernel's eleven phases are shorter (one frame per call at 16 384 / 32 768 / 65 536 streams: +6 / +7 / +7 %;
             // at 4096 streams, one round of blocks, the pipelined kernel stays 8 % ahead).  Same bits either way.
-            // ... and with other batches alive the lone frame's kernel is chosen for their sake too (k_rnn_wf holds every compute unit
+            // ... and with other batches ticking beside this one (g_call_mark) the lone frame's kernel is chosen for their sake too (k_rnn_wf holds every compute unit
             // for its five ticks: eight 4096-stream batches ticking side by side 40.2 -> 43.4 M frames/s with k_rnn, a lone batch -8 %)
-            const int min_g = h->wf_min_g > 0 ? h->wf_min_g : ((G.ntiles * (TILE / WF_ROWS) >= 1024 || g_live_batches.load() > 1) ? 2 : 1);
+            const int min_g = h->wf_min_g > 0 ? h->wf_min_g : ((G.ntiles * (TILE / WF_ROWS) >= 1024 || h->beside_others) ? 2 : 1);
             if (G.wf && g >= min_g)
                 L.go(K_RNN, k_rnn_wf, dim3((unsigned)(G.ntiles * (TILE / WF_ROWS))), dim3(64 * WF_WAVES), G.wf_lds, b, G.plan, G.wp, G.wq,
                      G.fpar, G.tile0, g);
@@ -737,6 +773,13 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
 {
     HIPCHK(hipSetDevice(h->device));
     if (int rc = report_fault(h)) return rc;   // an earlier call's hand-off failure (seen as soon as the device has written it)
+    {
+        const uint64_t mask = (1ull << 44) - 1;
+        const uint64_t now = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() & mask;
+        const uint64_t prev = g_call_mark.exchange((h->id << 44) | now, std::memory_order_relaxed);
+        if ((prev >> 44) != h->id && (prev >> 44) != 0 && now - (prev & mask) < 5000) h->other_seen_us = now | (1ull << 63);
+        h->beside_others = (h->other_seen_us >> 63) && now - (h->other_seen_us & mask) < 20000;
+    }
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
     // calls are ordered even when consecutive ones arrive on different streams
     if (h->have_last && h->last_stream != st) HIPCHK(hipStreamWaitEvent(st, h->ev_last, 0));
@@ -749,7 +792,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     v0.fmt = fmt;
     v0.channels = channels;
     v0.discard = drop;
-    v0.slot = (int)(h->frame_count % NSLOT);
+    v0.slot = (int)(h->frame_count % h->nslot);
     v0.n_streams = h->S;
     v0.log = h->frame_log_left ? h->frame_log : nullptr;
     v0.log_frames = (int)(h->frame_log_left < (size_t)n_frames ? h->frame_log_left : (size_t)n_frames);
@@ -777,17 +820,17 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     std::vector<int> sizes;
     if (pipe && h->ramp == 0) {
         int k = 2;
-        while ((n_frames + k - 1) / k > GROUP) k += 2;
+        while ((n_frames + k - 1) / k > h->gmax) k += 2;
         for (int i = 0; i < k; i++) sizes.push_back(n_frames / k + (i < n_frames % k ? 1 : 0));
     }
     for (int rem = sizes.empty() ? n_frames : 0, k = 0; rem > 0; k++) {
-        int g = GROUP;
+        int g = h->gmax;
         if (pipe && h->ramp == 1) {
-            g = GROUP < k + 1 ? GROUP : k + 1;
+            g = h->gmax < k + 1 ? h->gmax : k + 1;
             const int half = (rem + 1) / 2 > 1 ? (rem + 1) / 2 : 1;
             if (g > half) g = half;
         } else if (pipe && h->ramp >= 2 && k == 0) {
-            g = GROUP / h->ramp;   // a short first group: the stages behind the high-pass start sooner
+            g = h->gmax / h->ramp > 0 ? h->gmax / h->ramp : 1;   // a short first group: the stages behind the high-pass start sooner
         }
         if (g > rem) g = rem;
         sizes.push_back(g);
@@ -808,14 +851,14 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     const bool early_hp = pipe && h->inputs_ready && !h->host_call && h->prev_pipe && h->prev_st == st && h->sched == SCHED_LANES && h->pool[0];
     if (early_hp) {
         if (h->have_done[par]) chk(hipStreamWaitEvent(h->pool[0], h->ev_done[par], 0));   // the table's previous user (two calls back)
-        hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, h->pool[0], tab, v0, n_frames);
+        hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, h->pool[0], tab, v0, n_frames, h->nslot);
         h->pool_call[0] = h->call_count;   // (no wait for the caller's stream on this one)
     } else {
-        hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, st, tab, v0, n_frames);
+        hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, st, tab, v0, n_frames, h->nslot);
     }
     if (!pipe) {
         for (int k = 0, t = 0; k < n_groups; k++) {
-            const int g = sizes[k], set0 = (int)(h->group_count % DEPTH) * GROUP;
+            const int g = sizes[k], set0 = (int)(h->group_count % DEPTH) * h->gmax;
             for (int s = 0; s < ST_COUNT; s++) launch_stage(h, s, set0, g, tab + t, st, h->profiling);
             h->group_count += 1;
             h->frame_count += g;
@@ -841,7 +884,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
             return false;
         };
         for (int k = 0; k < n_groups; k++) {
-            const int g = sizes[k], set0 = (int)(h->group_count % DEPTH) * GROUP;
+            const int g = sizes[k], set0 = (int)(h->group_count % DEPTH) * h->gmax;
             for (int s = 0; s < ST_COUNT; s++) {
                 const int si = stream_of(s, k);
                 if (si >= 0 && !h->pool[si]) chk(hipStreamCreateWithFlags(&h->pool[si], hipStreamNonBlocking));
@@ -858,9 +901,9 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
                 if (s == ST_HP || s == ST_PITCH || s == ST_RNN || s == ST_SYN) wait_for(s, k - 1);
                 if (s == ST_PITCH) wait_for(ST_SYN, k - DEPTH);
                 if (s == ST_HP) {
-                    // slots written now held frames (newest of this group) - NSLOT and older; their last readers are the
+                    // slots written now held frames (newest of this group) - nslot and older; their last readers are the
                     // frames up to 3 later
-                    const int need = first[k] + g - 1 + 3 - NSLOT;
+                    const int need = first[k] + g - 1 + 3 - h->nslot;
                     int dk = -1;   // the group of this call that holds frame `need` (none: it precedes the call)
                     for (int j = 0; j < k; j++)
                         if (first[j] <= need) dk = j;
@@ -1096,7 +1139,7 @@ extern "C" int nnn_batch_process_pcm_host(nnn_batch *h, const void *in, void *ou
 
 // ---- taps ---------------------------------------------------------------------------------------
 struct TapDesc { int len; int is_int; int layout; /* 0 TI, 2 SM float2 rows of FSTR, 3 hist ring */ int sub_ofs; int sub_len; int needs_taps; };
-static int last_slot(const nnn_batch *h) { return h ? (int)((h->frame_count + NSLOT - 1) % NSLOT) : 0; }   // ring slot of the most recent frame
+static int last_slot(const nnn_batch *h) { return h ? (int)((h->frame_count + h->nslot - 1) % h->nslot) : 0; }   // ring slot of the most recent frame
 static bool tap_desc(const nnn_batch *h, int tap, TapDesc &d, const void **ptr)
 {
     const Buffers *b = h ? &h->b[h->last_set] : nullptr;   // scratch set of the most recent frame
@@ -1104,8 +1147,8 @@ static bool tap_desc(const nnn_batch *h, int tap, TapDesc &d, const void **ptr)
     switch (tap) {
     case NNN_TAP_FILTERED: d = {FRAME, 0, 3, 0, FRAME, 0}; *ptr = TP(hist); return true;
     case NNN_TAP_XLP: d = {XLP, 0, 0, 0, XLP, 1}; *ptr = TP(xlp_ti); return true;
-    case NNN_TAP_AC: d = {5, 0, 0, last_slot(h) * 10, NSLOT * 10, 0}; *ptr = TP(lpc); return true;
-    case NNN_TAP_LPC2: d = {5, 0, 0, last_slot(h) * 10 + 5, NSLOT * 10, 0}; *ptr = TP(lpc); return true;
+    case NNN_TAP_AC: d = {5, 0, 0, last_slot(h) * 10, (h ? h->nslot : 0) * 10, 0}; *ptr = TP(lpc); return true;
+    case NNN_TAP_LPC2: d = {5, 0, 0, last_slot(h) * 10 + 5, (h ? h->nslot : 0) * 10, 0}; *ptr = TP(lpc); return true;
     case NNN_TAP_XCORR1: d = {NLAG1, 0, 0, 0, NLAG1, 1}; *ptr = TP(xc1); return true;
     case NNN_TAP_BEST1: d = {2, 1, 0, 0, 2, 1}; *ptr = TP(best1); return true;
     case NNN_TAP_XCORR2C: d = {10, 0, 0, 0, 10, 1}; *ptr = TP(xc2); return true;
@@ -1141,18 +1184,18 @@ extern "C" int nnn_tap_info(int tap, int *len, int *is_int)
 extern "C" int nnn_batch_set_taps(nnn_batch *h, int on)
 {
     if (!h) return fail("null batch");
-    if (on && !h->taps_alloc) {   // first use: the tap-only arrays, NSET sets like every scratch array
+    if (on && !h->taps_alloc) {   // first use: the tap-only arrays, nset sets like every scratch array
         NNN_RT_LOCK;
         if (int rc = quiesce(h)) return rc;
         const size_t Sp = (size_t)h->S_pad;
         Buffers &q = h->b[0];
-#define NNN_F(name, len) HIPCHK(dalloc(h, &q.name, Sp * (size_t)(len) * NSET, false));
+#define NNN_F(name, len) HIPCHK(dalloc(h, &q.name, Sp * (size_t)(len) * h->nset, false));
         NNN_TAP_FIELDS(NNN_F)
 #undef NNN_F
-        for (int set = 1; set < NSET; set++) h->b[set] = frame_view(h->b[0], set);
+        for (int set = 1; set < h->nset; set++) h->b[set] = frame_view(h->b[0], set);
         h->taps_alloc = true;
     }
-    for (int set = 0; set < NSET; set++) h->b[set].taps = on != 0;
+    for (int set = 0; set < h->nset; set++) h->b[set].taps = on != 0;
     return 0;
 }
 
@@ -1180,10 +1223,11 @@ extern "C" int nnn_batch_read_tap(nnn_batch *h, int tap, void *host_dst, size_t 
         HIPCHK(hipMemcpy(tmp.data(), p, tmp.size() * 4, hipMemcpyDeviceToHost));
         for (int s = 0; s < h->S; s++) memcpy(dst + (size_t)s * d.len, tmp.data() + (size_t)s * 2 * FSTR, (size_t)d.len * 4);
     } else {  // newest frame in the history ring
-        std::vector<uint32_t> tmp(Sp * HSTR);
+        const size_t hstr = (size_t)hist_stride(h->nslot);
+        std::vector<uint32_t> tmp(Sp * hstr);
         HIPCHK(hipMemcpy(tmp.data(), p, tmp.size() * 4, hipMemcpyDeviceToHost));
-        int slot = (int)((h->frame_count + NSLOT - 1) % NSLOT);  // slot of the most recent frame
-        for (int s = 0; s < h->S; s++) memcpy(dst + (size_t)s * FRAME, tmp.data() + (size_t)s * HSTR + slot * FRAME, FRAME * 4);
+        int slot = last_slot(h);  // slot of the most recent frame
+        for (int s = 0; s < h->S; s++) memcpy(dst + (size_t)s * FRAME, tmp.data() + (size_t)s * hstr + slot * FRAME, FRAME * 4);
     }
     return 0;
 }
@@ -1271,7 +1315,7 @@ extern "C" int nnn_batch_debug_withhold_flag(nnn_batch *h, int frames_ahead)
 {
     if (!h) return fail("null batch");
     const int seq = frames_ahead < 0 ? 0 : (int)((h->frame_count + (uint64_t)frames_ahead) & 0x3fffffffu) + 1;
-    for (int set = 0; set < NSET; set++) h->b[set].dbg_withhold = seq;
+    for (int set = 0; set < h->nset; set++) h->b[set].dbg_withhold = seq;
     return 0;
 }
 extern "C" int nnn_batch_set_pipeline(nnn_batch *h, int on)
@@ -1350,11 +1394,11 @@ static void enqueue_feature_group(nnn_batch *h, hipStream_t st, const float *in,
     v.fmt = PCM_F32;
     v.channels = 1;
     v.discard = 0;
-    v.slot = (int)(h->frame_count % NSLOT);
+    v.slot = (int)(h->frame_count % h->nslot);
     v.n_streams = h->S;
     v.log = nullptr;
     v.log_frames = 0;
-    hipLaunchKernelGGL(k_fill_params, dim3(1), dim3(64), 0, st, sp, v, g);
+    hipLaunchKernelGGL(k_fill_params, dim3(1), dim3(64), 0, st, sp, v, g, h->nslot);
     hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, (const StepParams *)sp, g);
     if (full) {
         if (h->lpc_wide >= 0 ? h->lpc_wide != 0 : NT * ug < 512u) hipLaunchKernelGGL(k_lpc_wide, dim3(NT * ug), dim3(320), 0, st, b, (const StepParams *)sp, g);
@@ -1382,8 +1426,9 @@ extern "C" int nnn_train_process_device(nnn_train *t, const float *d_signal, con
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
     const size_t S = (size_t)h->S;
-    for (int f0 = 0; f0 < n_frames; f0 += GROUP) {
-        const int g = n_frames - f0 < GROUP ? n_frames - f0 : GROUP;
+    const int gmax = t->comb->gmax;
+    for (int f0 = 0; f0 < n_frames; f0 += gmax) {
+        const int g = n_frames - f0 < gmax ? n_frames - f0 : gmax;
         const size_t off = (size_t)f0 * frame_stride;
         enqueue_feature_group(t->comb, st, d_combined + off, stream_stride, frame_stride, g, true);
         enqueue_feature_group(t->clean, st, d_signal + off, stream_stride, frame_stride, g, false);

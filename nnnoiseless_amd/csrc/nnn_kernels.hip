@@ -156,17 +156,18 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp,
     nxt.load(in, sstride);
     float m0 = st.m0, m1 = st.m1, prev = st.prev;
     NNN_STAMP(b, 24);
-    float *ring = NNN_TI(b.dec, DEC_LEN, tile, lane);
-    float *h = b.hist + (size_t)s * HSTR;
+    const int nslot = b.nslot, hstr = hist_stride(nslot);
+    float *ring = NNN_TI(b.dec, dec_len(nslot), tile, lane);
+    float *h = b.hist + (size_t)s * hstr;
     {   // x_lp[0] = (x[1] / 2 + x[0]) / 2 on the oldest two samples of this frame's 1728-sample history: kept beside
         // the ring, per slot (the ring position it replaces is still a regular value for the previous frame)
-        const int rb = ring_base(slot);
-        const float x0 = h[rb], x1 = h[(rb + 1) % RING];
-        NNN_TI(b.xlp0, NSLOT, tile, lane)[(size_t)slot * TILE] = (x1 / 2.0f + x0) / 2.0f;
+        const int rb = ring_base(slot, nslot);
+        const float x0 = h[rb], x1 = h[rb + 1];   // (rb + 1 = the ring's length reads the copy of sample 0 kept there)
+        NNN_TI(b.xlp0, nslot, tile, lane)[(size_t)slot * TILE] = (x1 / 2.0f + x0) / 2.0f;
     }
     float *dec = ring + (size_t)(240 * slot) * TILE;
     const bool mirror = slot < DEC_MIRROR;
-    float4 *hw = (float4 *)(h + slot * FRAME);   // RING * 4 and FRAME * 4 are multiples of 16
+    float4 *hw = (float4 *)(h + slot * FRAME);   // the stride * 4 and FRAME * 4 are multiples of 16
     const double a0 = (double)-1.99599f, a1 = (double)0.99600f, b0 = (double)-2.0f, b1 = (double)1.0f;
     // Software pipeline over HP_CH-sample chunks.  Loads and stores share one in-order counter (vmcnt), so waiting for
     // chunk c's samples also waits for every store issued before: the stores of chunk c - 1 are therefore issued right
@@ -180,7 +181,7 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp,
             for (int t = 0; t < HP_CH / 2; t++) dec[(size_t)(HP_CH / 2 * (c - 1) + t) * TILE] = dvs[t];
             if (mirror) {
 #pragma unroll
-                for (int t = 0; t < HP_CH / 2; t++) dec[(size_t)(DEC_RING + HP_CH / 2 * (c - 1) + t) * TILE] = dvs[t];
+                for (int t = 0; t < HP_CH / 2; t++) dec[(size_t)(dec_ring_len(nslot) + HP_CH / 2 * (c - 1) + t) * TILE] = dvs[t];
             }
             if (HP_CH == 32) {
                 wave_lds_sync();   // (the previous chunk's rows have been read)
@@ -191,14 +192,14 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp,
                 for (int it = 0; it < 8; it++) {
                     const int r = 8 * it + (lane >> 3);
                     const float *y = Ly + r * HP_LD + 4 * (lane & 7);
-                    float4 *hr = (float4 *)(b.hist + (size_t)(tile * TILE + r) * HSTR + slot * FRAME + (c - 1) * HP_CH) + (lane & 7);
+                    float4 *hr = (float4 *)(b.hist + (size_t)(tile * TILE + r) * hstr + slot * FRAME + (c - 1) * HP_CH) + (lane & 7);
                     *hr = make_float4(y[0], y[1], y[2], y[3]);
                 }
             } else {
 #pragma unroll
                 for (int q = 0; q < HP_CH / 4; q++) hw[HP_CH / 4 * (c - 1) + q] = make_float4(ys[4 * q], ys[4 * q + 1], ys[4 * q + 2], ys[4 * q + 3]);
             }
-            if (slot == 0 && c == 1) h[RING] = ys[0];   // the ring's first sample again behind its end (8-byte reads across the wrap)
+            if (slot == 0 && c == 1) h[ring_len(nslot)] = ys[0];   // the ring's first sample again behind its end (8-byte reads across the wrap)
         }
         if (c == FRAME / HP_CH) break;
         if (c + 1 < FRAME / HP_CH) nxt.load(in + (long long)(c + 1) * HP_CH * sstride, sstride);
@@ -322,8 +323,8 @@ __device__ __forceinline__ void lpc_body(const Buffers &b, const StepParams *sp0
         }
     }
     const int slot = sp0[f].slot;
-    const float *base = b.dec + ((size_t)tile * DEC_LEN + (size_t)dec_base(slot)) * TILE + lane;
-    const float x0 = NNN_TI(b.xlp0, NSLOT, tile, lane)[(size_t)slot * TILE];   // x_lp[0] is special (ref: src/pitch.rs:458)
+    const float *base = b.dec + ((size_t)tile * dec_len(b.nslot) + (size_t)dec_base(slot, b.nslot)) * TILE + lane;
+    const float x0 = NNN_TI(b.xlp0, b.nslot, tile, lane)[(size_t)slot * TILE];   // x_lp[0] is special (ref: src/pitch.rs:458)
     float ac[5];
     if (WIDE) {
         float a1[1];
@@ -377,7 +378,7 @@ __device__ __forceinline__ void lpc_body(const Buffers &b, const StepParams *sp0
     l2[2] = lpc[2] + 0.8f * lpc[1];
     l2[3] = lpc[3] + 0.8f * lpc[2];
     l2[4] = 0.8f * lpc[3];
-    float *o = NNN_TI(b.lpc, NSLOT * 10, tile, lane) + (size_t)(slot * 10) * TILE;
+    float *o = NNN_TI(b.lpc, b.nslot * 10, tile, lane) + (size_t)(slot * 10) * TILE;
 #pragma unroll
     for (int i = 0; i < 5; i++) { o[(size_t)i * TILE] = ac[i]; o[(size_t)(5 + i) * TILE] = l2[i]; }
 }
@@ -540,15 +541,15 @@ __device__ __forceinline__ void pk_window_load(const Buffers &b, const StepParam
     if (ch >= PK_NCH) return;
     const int slot = sp->slot;
     {
-        const float *lp = NNN_TI(b.lpc, NSLOT * 10, tile, q0 + col) + (size_t)(slot * 10) * TILE;
+        const float *lp = NNN_TI(b.lpc, b.nslot * 10, tile, q0 + col) + (size_t)(slot * 10) * TILE;
 #pragma unroll
         for (int i = 0; i < 5; i++) fir[i] = lp[(size_t)(5 + i) * TILE];
     }
-    const float *base = b.dec + ((size_t)tile * DEC_LEN + (size_t)dec_base(slot)) * TILE + q0;   // uniform
+    const float *base = b.dec + ((size_t)tile * dec_len(b.nslot) + (size_t)dec_base(slot, b.nslot)) * TILE + q0;   // uniform
     const unsigned off = (unsigned)(ch * PK_CH) * TILE + (unsigned)col;
 #pragma unroll
     for (int i = 0; i < PK_CH; i++) v[i] = base[off + (unsigned)i * TILE];
-    if (ch == 0) v[0] = NNN_TI(b.xlp0, NSLOT, tile, q0 + col)[(size_t)slot * TILE];   // x_lp[0] is special (ref: src/pitch.rs:458)
+    if (ch == 0) v[0] = NNN_TI(b.xlp0, b.nslot, tile, q0 + col)[(size_t)slot * TILE];   // x_lp[0] is special (ref: src/pitch.rs:458)
 }
 
 // 4-way interleaved inner-product partials (ref: src/pitch.rs:225-244) of NCAND candidates against the fixed operand
@@ -1451,16 +1452,16 @@ struct __attribute__((packed, aligned(4))) SamplePair { float x, y; };   // two 
 // windowed 960 samples ending `lag` samples before the newest one -> Z (packed as 480 complex), transform in place,
 // spectrum bins into Y (lane owns bins lane + 64 u), scaled by wnorm
 // the 960 samples ending `lag` samples before the newest one, as the sample pairs n = j + 60 r of the transform's first pass
-__device__ __forceinline__ void window_load(const float *h, int rb, int lag, int lane, SamplePair (&sm)[8])
+__device__ __forceinline__ void window_load(const float *h, int ring, int rb, int lag, int lane, SamplePair (&sm)[8])
 {
-    int start = rb + (HIST - WINDOW) - lag;   // in (0, 2 RING)
-    if (start >= RING) start -= RING;
+    int start = rb + (HIST - WINDOW) - lag;   // in (0, 2 ring)
+    if (start >= ring) start -= ring;
     const int j = lane < FFT_P1 ? lane : FFT_P1 - 1;   // (lanes 60..63 shadow lane 59 and store nothing)
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         int i0 = start + 2 * (j + FFT_P1 * r);
-        if (i0 >= RING) i0 -= RING;
-        sm[r] = *(const SamplePair *)(h + i0);   // (i0 + 1 = RING reads the copy of sample 0 kept there)
+        if (i0 >= ring) i0 -= ring;
+        sm[r] = *(const SamplePair *)(h + i0);   // (i0 + 1 = ring reads the copy of sample 0 kept there)
     }
 }
 __device__ __forceinline__ void window_rfft(const Buffers &b, const SamplePair (&sm)[8], const float2 (&w)[8], const FftLds &t,
@@ -1506,19 +1507,19 @@ template <bool WITH_P>
 __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepParams *sp, int bx, FftLds &t, float2 *Z, float *part)
 {
     const int lane = threadIdx.x & 63, s = bx * FFT_SPB + (int)(threadIdx.x >> 6), tile = s >> 6, sl = s & 63;
-    const int rb = ring_base(sp->slot);
+    const int ring = ring_len(b.nslot), rb = ring_base(sp->slot, b.nslot);
     float2 w[8];   // the window at sample pairs j + 60 r: the order of the transforms' first pass (window_rfft)
 #pragma unroll
     for (int r = 0; r < 8; r++) w[r] = ((const float2 *)b.window_a)[(lane < FFT_P1 ? lane : FFT_P1 - 1) + FFT_P1 * r];
     const int lag = WITH_P ? NNN_TI(b.pitch, 1, tile, sl)[0] : 0;
     fft_tables_load(t, b);
-    const float *h = b.hist + (size_t)s * HSTR;
+    const float *h = b.hist + (size_t)s * hist_stride(b.nslot);
     // both windows' samples are requested now: the second transform's used to be requested when it started, a trip to memory on
     // the wave's critical path per stream-frame (these kernels move enough bytes for that to show)
     SamplePair sx[8], spw[8];
-    window_load(h, rb, 0, lane, sx);
+    window_load(h, ring, rb, 0, lane, sx);
 #ifndef NNN_FFT_LATE_P   // (A/B knob: the second window requested where its transform starts, as before)
-    if (WITH_P) window_load(h, rb, lag, lane, spw);
+    if (WITH_P) window_load(h, ring, rb, lag, lane, spw);
 #endif
     float2 X[8];
     window_rfft(b, sx, w, t, Z, X, lane, true);
@@ -1552,7 +1553,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     wave_lds_sync();
     float2 Y[8];
 #ifdef NNN_FFT_LATE_P
-    window_load(h, rb, lag, lane, spw);
+    window_load(h, ring, rb, lag, lane, spw);
 #endif
     window_rfft(b, spw, w, t, Z, Y, lane, false);
     float2 *dp = b.P + (size_t)s * FSTR;
@@ -3009,7 +3010,7 @@ __global__ void k_activation_kat(const float *tansig, const float *x, float *y, 
 }
 
 // Per-frame launch parameters of a call (one thread per frame): entry t describes frame t of the call (v = frame 0).
-__global__ void k_fill_params(StepParams *tab, StepParams v, int n)
+__global__ void k_fill_params(StepParams *tab, StepParams v, int n, int nslot)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -3018,7 +3019,7 @@ __global__ void k_fill_params(StepParams *tab, StepParams v, int n)
     p.out = v.out + (long long)(t - v.discard) * v.frame_stride;   // dropped frames take no room in the output
     p.discard = t < v.discard;
     p.vad = v.vad ? v.vad + (size_t)t * v.n_streams : nullptr;
-    p.slot = (v.slot + t) % NSLOT;
+    p.slot = (v.slot + t) % nslot;
     p.log = (v.log && t < v.log_frames) ? v.log + (size_t)t * v.n_streams * FRAME_LOG_WORDS : nullptr;
     tab[t] = p;
 }

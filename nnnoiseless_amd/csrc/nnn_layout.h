@@ -35,12 +35,16 @@ constexpr int GROUP = NNN_GROUP;  // frames per launch: every kernel is launched
                                   // prologues per frame: 55.5 -> 57.2 M frames/s at 4096 streams, same at 65536; 64-frame calls stay
                                   // 4 x 16.  The price is memory: 48 scratch sets and 76 ring slots per stream instead of 32 / 52.
 constexpr int DEPTH = NNN_DEPTH;  // groups in flight (blocks of GROUP scratch sets in rotation)
-constexpr int NSET = DEPTH * GROUP;   // per-frame scratch sets
-constexpr int NSLOT = (DEPTH + 1) * GROUP + 4;   // history ring slots: the high-pass may run a group ahead of the DEPTH groups in flight,
-                                  // whose oldest frame still reads a 1728-sample history (3 slots behind it)
-constexpr int RING = NSLOT * 480; // history ring instead of the reference's memmove
-constexpr int HSTR = RING + 32;   // a stream's stride in the history array (whole 128-byte lines): hist[RING] repeats hist[0], so a sample pair that starts on the
-                                  // ring's last sample is still one 8-byte read
+// A batch is sized for groups of up to `gmax` <= GROUP frames (GROUP unless the host says its calls are shorter: a real-time host
+// that ticks one frame per call asks for gmax = 1 and pays a seventeenth of the memory, nnn_batch_create_opts):
+//   scratch sets   DEPTH * gmax
+//   ring slots     (DEPTH + 1) * gmax + 4: the high-pass may run a group ahead of the DEPTH groups in flight, whose oldest frame
+//                  still reads a 1728-sample history (3 slots behind it).  History ring instead of the reference's memmove.
+constexpr int NSET = DEPTH * GROUP;              // the most scratch sets a batch can have
+__host__ __device__ inline int slots_for(int gmax) { return (DEPTH + 1) * gmax + 4; }
+__host__ __device__ inline int ring_len(int nslot) { return nslot * 480; }
+__host__ __device__ inline int hist_stride(int nslot) { return nslot * 480 + 32; }   // a stream's stride in the history array (whole 128-byte lines):
+                                  // hist[ring_len] repeats hist[0], so a sample pair that starts on the ring's last sample is still one 8-byte read
 constexpr int XLP = 864;          // HIST / 2
 constexpr int PITCH_MIN = 60, PITCH_MAX = 768;
 constexpr int NLAG1 = 147;        // coarse lags  (PITCH_MAX - 3*PITCH_MIN) / 4
@@ -80,13 +84,14 @@ struct RnnPlan {
 
 struct Buffers {
     // ---- persistent per-stream state (src/denoise.rs:37-42, features.rs:18-46, pitch.rs:4-17, rnn.rs:65-70)
-    float *hist;         // SM [HSTR]   high-passed input history, ring of NSLOT frame slots (+ the wrap-around sample)
+    int nslot;           // history ring slots of this batch (slots_for(gmax))
+    float *hist;         // SM [hist_stride(nslot)]   high-passed input history, ring of nslot frame slots (+ the wrap-around sample)
     float *hp_mem;       // TI [2]      biquad state
     float *hp_last;      // TI [1]      last filtered sample of the previous frame
-    float *dec;          // TI [DEC_LEN]  2:1 decimated history: ring of NSLOT x 240 values whose first 960 are mirrored behind its end,
+    float *dec;          // TI [dec_len(nslot)]  2:1 decimated history: ring of nslot x 240 values whose first 960 are mirrored behind its end,
                          //             so that the 864-value window of any frame is one contiguous run (240 values are new per frame)
-    float *xlp0;         // TI [NSLOT]  per ring slot: pitch_downsample's special first element (x[1]/2 + x[0])/2 of that frame
-    float *lpc;          // TI [NSLOT * 10]  per ring slot: that frame's windowed autocorrelation ac[5] and FIR taps lpc2[5], k_lpc -> k_pitch.
+    float *xlp0;         // TI [nslot]  per ring slot: pitch_downsample's special first element (x[1]/2 + x[0])/2 of that frame
+    float *lpc;          // TI [nslot * 10]  per ring slot: that frame's windowed autocorrelation ac[5] and FIR taps lpc2[5], k_lpc -> k_pitch.
                          //             Kept by ring slot, not by scratch set: k_lpc rides on the high-pass stream, which runs ahead of the
                          //             groups in flight, and the ring's slots are what that stream already waits for
     float *ceps_mem;     // TI [8*22]
@@ -170,7 +175,7 @@ struct StepParams {
     long long group_stride, frame_stride;   // bytes
     int fmt, channels;
     int discard;       // frame tables: != 0 = this frame's audio is not written; call parameters: frames to drop
-    int slot;          // history ring slot that receives this frame (frame index mod NSLOT)
+    int slot;          // history ring slot that receives this frame (frame index mod nslot)
     int n_streams;
     // optional per-frame record for parity tests (nnn_batch_set_frame_log): [n_streams][FRAME_LOG_WORDS] words, or null.
     // Frame tables: this frame's record; call parameters: the first frame's record and the frames that still have room.
@@ -180,11 +185,19 @@ struct StepParams {
 constexpr int FRAME_LOG_WORDS = 2 + NB;   // pitch index, branch mask, the 22 smoothed band gains (f32 bits)
 
 // ring position of logical input_mem[0] when the newest frame sits in slot `slot`
-__host__ __device__ inline int ring_base(int slot) { return (FRAME * slot + RING - (HIST - FRAME)) % RING; }
+__host__ __device__ inline int ring_base(int slot, int nslot)
+{
+    const int x = FRAME * slot - (HIST - FRAME);
+    return x < 0 ? x + ring_len(nslot) : x;
+}
 // ring position of logical decimated index 0 (864 logical values, the newest 240 in slot `slot`)
-constexpr int DEC_RING = NSLOT * 240;
 constexpr int DEC_MIRROR = 4;               // frames whose 240 values are stored twice (slots 0..3 cover the 864-value overhang)
-constexpr int DEC_LEN = DEC_RING + DEC_MIRROR * 240;
-__host__ __device__ inline int dec_base(int slot) { return (240 * slot + DEC_RING - (XLP - 240)) % DEC_RING; }
+__host__ __device__ inline int dec_ring_len(int nslot) { return nslot * 240; }
+__host__ __device__ inline int dec_len(int nslot) { return (nslot + DEC_MIRROR) * 240; }
+__host__ __device__ inline int dec_base(int slot, int nslot)
+{
+    const int x = 240 * slot - (XLP - 240);
+    return x < 0 ? x + dec_ring_len(nslot) : x;
+}
 
 }  // namespace nnn

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """One 10 ms frame per call, the way a real-time server is driven: H independent batches (handles) of S streams each, every batch
 on its own HIP stream, called round-robin.  Calls of different batches overlap on the GPU; a single batch called back to back
-(bench.py's `tick`) cannot overlap with itself.  usage: tick_capacity.py [streams_per_batch] [batches] [rounds] [host_threads]"""
-import sys, time
+(bench.py's `tick`) cannot overlap with itself.  usage: tick_capacity.py [streams_per_batch] [batches] [rounds] [host_threads] [max_group_frames: 0 = default batch, 1 = sized for ticks]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import nnnoiseless_amd as nn
 from nnnoiseless_amd.synthetic import make_streams_device
@@ -15,7 +16,8 @@ pool = 16
 xs = [make_streams_device(torch, dev, S, pool, seed=h) for h in range(H)]
 ys = [torch.empty_like(x) for x in xs]
 vs = [torch.empty((pool, S), dtype=torch.float32, device=dev) for _ in range(H)]
-bds = [nn.BatchDenoiser(S) for _ in range(H)]
+GM = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+bds = [nn.BatchDenoiser(S, max_group_frames=GM or None) for _ in range(H)]
 streams = [torch.cuda.Stream() for _ in range(H)]
 for b in bds:
     b.set_inputs_ready(True)
@@ -53,4 +55,5 @@ run(R, 10)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"{NT} host thread(s), {H} batches x {S} streams, one frame per call: {H * S * R / dt / 1e6:.2f} M frames/s "
-      f"({dt / R * 1e6:.0f} us per round of {H} calls = {H * S} streams served; {dt / R / H * 1e6:.0f} us per call)", flush=True)
+      f"({dt / R * 1e6:.0f} us per round of {H} calls = {H * S} streams served; {dt / R / H * 1e6:.0f} us per call); "
+      f"max_group_frames {bds[0].max_group_frames()}, {bds[0].device_bytes() / S / 1024:.1f} KB per stream", flush=True)

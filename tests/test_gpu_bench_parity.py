@@ -242,6 +242,40 @@ def test_host_calls_with_inputs_ready_do_not_race_their_upload(nn):
         bd.close()
 
 
+@pytest.mark.parametrize("gmax", [1, 4])
+def test_batch_sized_for_real_time_ticks(nn, oracle_mod, weights_bytes, gmax):
+    """a batch created with max_group_frames = 1 (4) holds a small fraction of the default batch's memory and
+    gives the same bits, tick after tick (rings wrapping a dozen times) and on a longer call cut into short groups; 64 of its
+    streams against the oracle."""
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T = 4096, 60
+    x = np.tile(make_streams(5, 128, T), (S // 128, 1, 1))
+    ref_bd = nn.BatchDenoiser(S)
+    want, want_vad = ref_bd.process(x)
+    bd = nn.BatchDenoiser(S, max_group_frames=gmax)
+    got, vad = np.zeros_like(want), np.zeros_like(want_vad)
+    for t in range(40):
+        got[:, t:t + 1], vad[t:t + 1] = bd.process(x[:, t:t + 1])
+    got[:, 40:], vad[40:] = bd.process(x[:, 40:])          # 20 frames on a batch sized for groups of gmax
+    assert np.array_equal(got, want) and np.array_equal(vad, want_vad)
+    per_stream, per_stream_default = bd.device_bytes() / S, ref_bd.device_bytes() / S
+    print(f"max_group_frames={gmax}: {per_stream / 1024:.1f} KB per stream (default {per_stream_default / 1024:.1f} KB)")
+    assert per_stream < (64 if gmax == 1 else 160) * 1024 and per_stream_default > 500 * 1024
+    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x[:64], n_threads=os.cpu_count() or 1, want=("out", "pitch", "vad"))
+    bd.reset()
+    import torch
+    dlog = torch.zeros((T, S, 24), dtype=torch.int32, device="cuda")
+    bd.set_frame_log(dlog.data_ptr(), T)
+    for t in range(T):
+        bd.process(x[:, t:t + 1])
+    bd.synchronize()
+    log = dlog.cpu().numpy().view(np.uint32)
+    assert np.array_equal(log[:, :64, 0].T.astype(np.int32), ref["pitch"])
+    assert rel_rms(got[:64, 1:], ref["out"][:, 1:]) < 1e-4
+    bd.close()
+    ref_bd.close()
+
+
 def test_withheld_handoff_flag_raises_a_sticky_fault(nn, gpu_lib):
     """a hand-off flag that never arrives (test hook) times out instead of hanging, and the failure reaches a
     caller that never calls nnn_batch_synchronize: nnn_batch_fault() reads it, the next process call refuses, reset clears."""

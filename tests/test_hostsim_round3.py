@@ -120,3 +120,34 @@ def test_lpc_kernel_variants_agree_bit_for_bit(hostsim_lib, oracle_mod, weights_
         ot = st.taps()
         for k, i in (("ac", 2), ("lpc2", 3), ("xlp", 4)):
             assert np.array_equal(res["0"][i][s].view(np.uint32), np.atleast_1d(ot[k]).astype(np.float32).view(np.uint32)), (k, s)
+
+
+@pytest.mark.parametrize("gmax", [1, 2, 5])
+def test_batches_sized_for_short_groups(hostsim_lib, gmax):
+    """nnn_batch_create_opts(max_group_frames): scratch sets and history rings sized for groups of that many frames.  One-frame ticks
+    and longer calls (cut into groups of <= gmax frames, ring wrapping many times) give the default batch's bits; the batch holds a
+    fraction of the memory; clone keeps the size; a snapshot of a differently sized batch is refused."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T = 6, 23
+    x = make_streams(11, S, T)
+    ref = nn.BatchDenoiser(S, lib=hostsim_lib)
+    want, want_vad = ref.process(x)
+    bd = nn.BatchDenoiser(S, lib=hostsim_lib, max_group_frames=gmax)
+    assert bd.max_group_frames() == gmax and ref.max_group_frames() == 24
+    got = np.zeros_like(want)
+    vad = np.zeros_like(want_vad)
+    t = 0
+    for n in (1, 1, 3, 1, 7, 1, 1, 8):            # 23 frames in calls of mixed length
+        o, v = bd.process(x[:, t:t + n])
+        got[:, t:t + n], vad[t:t + n] = o, v
+        t += n
+        if t == 5:
+            bd = bd.clone()
+            assert bd.max_group_frames() == gmax
+    assert np.array_equal(got, want) and np.array_equal(vad, want_vad)
+    assert bd.device_bytes() < ref.device_bytes() * (0.3 if gmax <= 2 else 0.5)
+    with pytest.raises(RuntimeError, match="does not match"):
+        bd.load_state(ref.save_state())
+    with pytest.raises(ValueError):
+        nn.BatchDenoiser(S, lib=hostsim_lib, max_group_frames=0)
