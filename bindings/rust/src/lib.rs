@@ -222,14 +222,14 @@ pub struct DenoiseState(BatchDenoiser);
 impl DenoiseState {
     pub const FRAME_SIZE: usize = 480;
     pub fn new() -> Box<DenoiseState> {
-        Box::new(DenoiseState(BatchDenoiser::new(1, None, 0).expect("no MI355X backend")))
+        Box::new(DenoiseState(BatchDenoiser::sized(1, 1, None, 0).expect("no MI355X backend")))
     }
     pub fn from_model(model: RnnModel) -> Box<DenoiseState> {
         Self::with_model(&model)
     }
     pub fn with_model(model: &RnnModel) -> Box<DenoiseState> {
         // the backend copies the model to the device, so no borrow needs to outlive this call
-        Box::new(DenoiseState(BatchDenoiser::new(1, Some(model), 0).expect("no MI355X backend")))
+        Box::new(DenoiseState(BatchDenoiser::sized(1, 1, Some(model), 0).expect("no MI355X backend")))
     }
     pub fn process_frame(&mut self, output: &mut [f32], input: &[f32]) -> f32 {
         assert!(input.len() == Self::FRAME_SIZE); // src/features.rs:98

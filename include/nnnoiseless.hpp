@@ -199,7 +199,7 @@ class DenoiseState {
     DenoiseState clone() const { return DenoiseState(b_.clone()); }   // #[derive(Clone)], src/denoise.rs:36
 
   private:
-    DenoiseState(const RnnModel *m, int device) : b_(1, m, device) {}
+    DenoiseState(const RnnModel *m, int device) : b_(BatchDenoiser::sized(1, 1, m, device)) {}   // one frame per call: sized for it
     explicit DenoiseState(BatchDenoiser b) : b_(std::move(b)) {}
     BatchDenoiser b_;
 };

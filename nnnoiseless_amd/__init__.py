@@ -289,7 +289,8 @@ class DenoiseState:
     FRAME_SIZE = FRAME_SIZE
 
     def __init__(self, model=None, device=0, lib=None, _batch=None):
-        self._b = _batch if _batch is not None else BatchDenoiser(1, model, device, lib)
+        # process_frame takes one frame per call: a batch sized for one-frame groups
+        self._b = _batch if _batch is not None else BatchDenoiser(1, model, device, lib, max_group_frames=1)
 
     def clone(self):
         """`impl Clone for DenoiseState` (src/denoise.rs:36)."""

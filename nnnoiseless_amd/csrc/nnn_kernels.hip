@@ -255,43 +255,46 @@ __global__ void __launch_bounds__(64, HP_CH <= 16 ? 3 : 1) k_hp(Buffers b, const
 //     frames of a group run side by side (nothing here carries over from frame to frame), every load is a whole 256-byte row,
 //     and the launch rides on the high-pass stream, ahead of the pitch stage.  Output: ac[5], FIR taps[5] per stream-frame.
 // ---------------------------------------------------------------------------------------------
-constexpr int LPC_CH = 20;   // rows per unrolled chunk: 860 = 43 x 20
-static_assert((XLP - 4) % LPC_CH == 0, "");
+constexpr int LPC_CH = 20;    // rows per unrolled chunk: 860 = 43 x 20
+constexpr int LPC_CHW = 43;   // k_lpc_wide: 20 chunks.  A lone one-frame launch has the GPU to itself and is paced by the trips to memory it
+                              // makes one after the other, not by the rows in flight: 23.5 -> 17 us for a frame of 4096 streams (of which some
+                              // 8 us are the launch; 86 rows on four waves per block, with the overflow in AGPRs, measured no better)
+static_assert((XLP - 4) % LPC_CH == 0 && (XLP - 4) % LPC_CHW == 0, "");
 // lags K0 .. K0 + NK - 1 of the autocorrelation of the 864 rows at base[i * TILE] (row 0 replaced by x0): the reference's
 // sequential sum per lag, then its tail (ref: src/pitch.rs:433-446)
-template <int K0, int NK>
+template <int K0, int NK, int CH>
 __device__ __forceinline__ void lpc_chains(const float *base, float x0, float (&ac)[NK])
 {
-    float cur[LPC_CH + 4], nxt[LPC_CH];
+    float cur[CH + 4], nxt[CH];
 #pragma unroll
-    for (int i = 0; i < LPC_CH + 4; i++) cur[i] = base[(size_t)i * TILE];
+    for (int i = 0; i < CH + 4; i++) cur[i] = base[(size_t)i * TILE];
     cur[0] = x0;
     float c[NK];
 #pragma unroll
     for (int k = 0; k < NK; k++) c[k] = 0.0f;
-    constexpr int NCH = (XLP - 4) / LPC_CH;
+    constexpr int NCH = (XLP - 4) / CH;
 #pragma nounroll
     for (int ch = 0; ch < NCH; ch++) {
-        // rows 20 (ch + 1) + 4 .. + 23 travel while this chunk is summed (the last chunk re-reads its own rows: in range, unused)
-        const float *nb = base + (size_t)((ch + 1 < NCH ? ch + 1 : ch) * LPC_CH + 4) * TILE;
+        // rows CH (ch + 1) + 4 .. + CH + 3 travel while this chunk is summed (the last chunk re-reads its own rows: in range, unused)
+        const float *nb = base + (size_t)((ch + 1 < NCH ? ch + 1 : ch) * CH + 4) * TILE;
 #pragma unroll
-        for (int i = 0; i < LPC_CH; i++) nxt[i] = nb[(size_t)i * TILE];
+        for (int i = 0; i < CH; i++) nxt[i] = nb[(size_t)i * TILE];
         // ac[k] += x[i] * x[i + k], i ascending: the reference's sequential sum per lag (pitch_xcorr's unrolling keeps that order)
 #pragma unroll
-        for (int j = 0; j < LPC_CH; j++)
+        for (int j = 0; j < CH; j++)
 #pragma unroll
             for (int k = 0; k < NK; k++) c[k] += cur[j] * cur[j + K0 + k];
         if (ch + 1 < NCH) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) cur[i] = cur[LPC_CH + i];
+            for (int i = 0; i < 4; i++) cur[i] = cur[CH + i];
 #pragma unroll
-            for (int i = 0; i < LPC_CH; i++) cur[4 + i] = nxt[i];
+            for (int i = 0; i < CH; i++) cur[4 + i] = nxt[i];
         }
     }
-    // tail d_k = sum_{i = k + 860}^{863} x[i] x[i - k], added after the main sum; cur[] holds rows 840 .. 863
+    // tail d_k = sum_{i = k + 860}^{863} x[i] x[i - k], added after the main sum; cur[] holds the last CH + 4 rows
 #pragma unroll
     for (int kk = 0; kk < NK; kk++) {
-        constexpr int O = XLP - LPC_CH - 4;
+        constexpr int O = XLP - CH - 4;
         const int k = K0 + kk;
         float d = 0.0f;
 #pragma unroll
@@ -328,18 +331,18 @@ __device__ __forceinline__ void lpc_body(const Buffers &b, const StepParams *sp0
     float ac[5];
     if (WIDE) {
         float a1[1];
-        if (wave == 0) lpc_chains<0, 1>(base, x0, a1);
-        else if (wave == 1) lpc_chains<1, 1>(base, x0, a1);
-        else if (wave == 2) lpc_chains<2, 1>(base, x0, a1);
-        else if (wave == 3) lpc_chains<3, 1>(base, x0, a1);
-        else lpc_chains<4, 1>(base, x0, a1);
+        if (wave == 0) lpc_chains<0, 1, LPC_CHW>(base, x0, a1);
+        else if (wave == 1) lpc_chains<1, 1, LPC_CHW>(base, x0, a1);
+        else if (wave == 2) lpc_chains<2, 1, LPC_CHW>(base, x0, a1);
+        else if (wave == 3) lpc_chains<3, 1, LPC_CHW>(base, x0, a1);
+        else lpc_chains<4, 1, LPC_CHW>(base, x0, a1);
         acs[wave][lane] = a1[0];
         __syncthreads();
         if (wave != 0) return;
 #pragma unroll
         for (int k = 0; k < 5; k++) ac[k] = acs[k][lane];
     } else {
-        lpc_chains<0, 5>(base, x0, ac);
+        lpc_chains<0, 5, LPC_CH>(base, x0, ac);
     }
     // lag window, Levinson, bandwidth expansion, extra zero (ref: src/pitch.rs:460-480, 257-292)
     ac[0] *= 1.0001f;

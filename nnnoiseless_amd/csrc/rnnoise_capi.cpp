@@ -25,7 +25,12 @@ extern "C" int rnnoise_get_size(void) { return (int)sizeof(DenoiseState); }     
 
 extern "C" int rnnoise_init(DenoiseState *st, RNNModel *model)                        // src/capi.rs:32-43
 {
-    st->batch = nnn_batch_create(model, 1, pick_device());
+    // process_frame takes one frame per call: a batch sized for one-frame groups (3 MB for the 64-stream tile instead of 41)
+    nnn_batch_opts opts = {};
+    opts.max_group_frames = 1;
+    const RNNModel *m = model;
+    const int one = 1;
+    st->batch = nnn_batch_create_opts(&m, &one, 1, pick_device(), &opts);
     if (!st->batch) {
         fprintf(stderr, "rnnoise_init: %s\n", nnn_last_error());
         return -1;  // the reference cannot fail here; a missing GPU can
