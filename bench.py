@@ -51,7 +51,7 @@ BYTES_PER_FRAME_FUSED = 16948  # I/O + resident-state to
 FLOPS_PER_FRAME = 0.42e6
 
 # Algorithmic HBM bytes per stream-frame of each kernel (its own inputs + outputs, each counted once; per-group state traffic
-# divided by the 16 frames of a full group; derivation in DESIGN.md "Kernels")
+# divided by the G frames of a full group; derivation in DESIGN.md "Kernels")
 G = 24   # frames of a full group (a 48-frame call is two of them)
 KERNEL_BYTES = {
     "k_hp": 1920 + 1920 + 960 + 960 // 5 + 4 + (16 + 8) // G,     # input, history slot, 240 decimated values (+ mirrored share), x_lp[0]; biquad state per group
