@@ -29,6 +29,24 @@ namespace nnn {
     const int bx = (int)blockIdx.x - frame * (int)(PER); \
     b = frame_view(b, frame);
 
+// Block index -> (tile, block of the tile) for kernels that give a tile's 64 streams to `bpt` consecutive blocks.  Workgroup i runs on
+// XCD i mod 8 (observed dispatch order; a speed matter only), so consecutive blocks would spread a tile over several XCDs -- and the
+// tile-interleaved per-stream scalars (band energies, gains, cepstrum, pitch: 64 streams to a 256-byte row) would be fetched into,
+// and written back from, as many L2s.  Tile t goes to XCD t mod 8 instead: where k_hp's block t and k_pitch's blocks of tile t ran.
+__device__ __forceinline__ void xcd_tile_block(int blk, int ntiles, int bpt, int &tile, int &sub)
+{
+#ifndef NNN_NO_XCD_MAP
+    if ((ntiles & 7) == 0) {
+        const int xcd = blk & 7, j = blk >> 3;
+        tile = xcd + 8 * (j / bpt);
+        sub = j % bpt;
+        return;
+    }
+#endif
+    tile = blk / bpt;
+    sub = blk % bpt;
+}
+
 // Optional phase stamps (developer instrumentation, off in the shipped build): block 0 / thread 0 records the
 // shader clock at labelled points so a phase breakdown can be read back through nnn_batch_read_stamps.
 #ifdef NNN_STAMPS
@@ -1509,7 +1527,9 @@ __device__ __forceinline__ int rfft_slot_bin(int lane, int u)
 template <bool WITH_P>
 __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepParams *sp, int bx, FftLds &t, float2 *Z, float *part)
 {
-    const int lane = threadIdx.x & 63, s = bx * FFT_SPB + (int)(threadIdx.x >> 6), tile = s >> 6, sl = s & 63;
+    int tile, sub;
+    xcd_tile_block(bx, b.NT, TILE / FFT_SPB, tile, sub);
+    const int lane = threadIdx.x & 63, sl = sub * FFT_SPB + (int)(threadIdx.x >> 6), s = tile * TILE + sl;
     const int ring = ring_len(b.nslot), rb = ring_base(sp->slot, b.nslot);
     float2 w[8];   // the window at sample pairs j + 60 r: the order of the transforms' first pass (window_rfft)
 #pragma unroll
@@ -2195,8 +2215,10 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     const int lane0 = threadIdx.x & 63;
     int wave = wave0, lane = lane0, tid = threadIdx.x;
     const int per = TILE / rm, mbt = rm >> 4;
-    const int tile = tile0 + (int)blockIdx.x / per;        // tile0: first tile of this model's run
-    const int r0 = ((int)blockIdx.x % per) * rm;           // first row of the tile handled here
+    int tile, sub;
+    xcd_tile_block((int)blockIdx.x, (tile0 & 7) ? 1 : (int)gridDim.x / per, per, tile, sub);
+    tile += tile0;                                         // tile0: first tile of this model's run
+    const int r0 = sub * rm;                               // first row of the tile handled here
     const bool rowl = lane < rm;                           // lane = stream phases: this lane has a row
     const int trow = r0 + (rowl ? lane : 0);               // its row in the tile
     // ---- LDS carve-up (rnn_lds_bytes on the host mirrors it)
@@ -2589,8 +2611,10 @@ __global__ void __launch_bounds__(64 * WF_WAVES, NNN_WF_MINWAVES) k_rnn_wf(Buffe
     const int wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane0 = threadIdx.x & 63;
     int wave = wave0, lane = lane0;
-    const int tile = tile0 + (int)blockIdx.x / (TILE / rm);
-    const int r0 = ((int)blockIdx.x % (TILE / rm)) * rm;     // first row of the tile handled here
+    int tile, sub;
+    xcd_tile_block((int)blockIdx.x, (tile0 & 7) ? 1 : (int)gridDim.x / (TILE / rm), TILE / rm, tile, sub);
+    tile += tile0;
+    const int r0 = sub * rm;                                 // first row of the tile handled here
     const bool rowl = lane0 < rm;
     const int trow = r0 + (rowl ? lane0 : 0);
     NNN_STAMP(b, 50);
@@ -2827,7 +2851,9 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
     const int wave = threadIdx.x >> 6;
     float2 *A = A_[wave];
     float *ebuf = (float *)A, *r = r_[wave], *r2 = r + NB, *gg = r + 2 * NB;
-    const int lane0 = threadIdx.x & 63, s = blockIdx.x * FFT_SPB + wave, tile = s >> 6, sl = s & 63;
+    int tile, sub;
+    xcd_tile_block((int)blockIdx.x, b.NT, TILE / FFT_SPB, tile, sub);
+    const int lane0 = threadIdx.x & 63, sl = sub * FFT_SPB + wave, s = tile * TILE + sl;
     int lane = lane0;
     fft_tables_load(t, b);
     float *sm = b.synth_mem + (size_t)s * FRAME;

@@ -151,3 +151,16 @@ def test_batches_sized_for_short_groups(hostsim_lib, gmax):
         bd.load_state(ref.save_state())
     with pytest.raises(ValueError):
         nn.BatchDenoiser(S, lib=hostsim_lib, max_group_frames=0)
+
+
+def test_xcd_tile_mapping_changes_no_bits(hostsim_lib):
+    """Batches of a multiple of 8 tiles send the blocks of tile t to XCD t mod 8 (k_fft_xp, k_rnn / k_rnn_wf, k_synth: another
+    block -> stream mapping); other batches keep blocks in stream order.  The same streams give the same bits either way."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    T = 3
+    x = make_streams(9, 512, T)
+    a, va = nn.BatchDenoiser(512, lib=hostsim_lib).process(x)            # 8 tiles: mapped
+    b, vb = nn.BatchDenoiser(448, lib=hostsim_lib).process(x[:448])      # 7 tiles: stream order
+    assert np.array_equal(a[:448], b) and np.array_equal(va[:, :448], vb)
+    assert np.abs(a[448:]).max() > 0
