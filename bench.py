@@ -55,7 +55,8 @@ FLOPS_PER_FRAME = 0.42e6
 G = 24   # frames of a full group (a 48-frame call is two of them)
 KERNEL_BYTES = {
     "k_hp": 1920 + 1920 + 960 + 960 // 5 + 4 + (16 + 8) // G,     # input, history slot, 240 decimated values (+ mirrored share), x_lp[0]; biquad state per group
-    "k_lpc": 3456 + 4 + 40,                                         # decimated window + x_lp[0] in; autocorrelation and FIR taps out
+    "k_lpc": (864 + 3 * 240) * 4 // 4 + 4 + 40,                     # decimated windows of four consecutive frames read once by their wave (1584 B per frame; small launches
+                                                                   # take fewer frames per wave, up to 3456 B) + x_lp[0] in; autocorrelation and FIR taps out
     "k_pitch": 3456 + 4 + 20 + 8 + 16 // G,                         # decimated window + x_lp[0] + FIR taps in; pitch index + gain out; last pitch per group
                                                                    # (pitch_buf, coarse xcorr, the running energies and their check points never leave LDS)
     "k_fft_xp": 3840 + 1200 + 4 + 3848 + 3200 + 264 + 112 + 4,     # 960 + (mean lag 300) history samples; X (481 bins), P (400 bins), band energies, cepstrum head out

@@ -125,6 +125,7 @@ struct nnn_batch {
     unsigned tickets = 0;           // work items handed out so far by chained k_pitch launches (Buffers::ticket never restarts)
     unsigned *frame_log = nullptr;  // nnn_batch_set_frame_log: the next frame's record (device), and the frames that still have room
     size_t frame_log_left = 0;
+    int lpc_fc = 0;                 // k_lpc: frames per wave, 0 = by launch size (env NNN_LPC_FC; tests)
     int lpc_wide = -1;              // k_lpc_wide (one lag per wave): -1 = for launches below 512 waves, 0 / 1 = never / always (env NNN_LPC_WIDE; tests)
     uint64_t id = 0, other_seen_us = 0;   // see g_call_mark
     bool beside_others = false;     // as of the current call
@@ -322,6 +323,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     if (const char *e = getenv("NNN_RNN_WF_MIN_G")) h->wf_min_g = atoi(e);
     if (const char *e = getenv("NNN_PITCH_CHAIN")) h->pitch_chain = atoi(e);
     if (const char *e = getenv("NNN_LPC_WIDE")) h->lpc_wide = atoi(e);
+    if (const char *e = getenv("NNN_LPC_FC")) h->lpc_fc = atoi(e);
     if (const char *e = getenv("NNN_SCHED")) {
         if (!strcmp(e, "seq")) h->sched = SCHED_SEQ;
         else if (!strcmp(e, "lanes")) h->sched = SCHED_LANES;
@@ -661,6 +663,7 @@ extern "C" nnn_batch *nnn_batch_clone(nnn_batch *h)
     c->use_pipeline = h->use_pipeline;
     c->pitch_chain = h->pitch_chain;
     c->lpc_wide = h->lpc_wide;
+    c->lpc_fc = h->lpc_fc;
     c->inputs_ready = h->inputs_ready;
     if (h->b[0].taps && nnn_batch_set_taps(c, 1) != 0) {
         nnn_batch_destroy(c);
@@ -706,7 +709,13 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
         // the LPC analysis of the group's frames (lane = stream, frames side by side) rides on the same stream, ahead of the pitch stage
         // (launches too small to fill the GPU spread the five lags of a stream over five waves)
         if (h->lpc_wide >= 0 ? h->lpc_wide != 0 : NT * ug < 512u) L.go(K_LPC, k_lpc_wide, dim3(NT * ug), dim3(320), 0, b, sp0, g);
-        else L.go(K_LPC, k_lpc, dim3(NT * ug), dim3(64), 0, b, sp0, g);
+        else {
+            // frames per wave (k_lpc): as many as still leave two waves per SIMD
+            int fc = LPC_FC;
+            while (fc > 1 && NT * ((ug + fc - 1) / fc) < 2048u) fc /= 2;
+            if (h->lpc_fc > 0) fc = h->lpc_fc < LPC_FC ? h->lpc_fc : LPC_FC;
+            L.go(K_LPC, k_lpc, dim3(NT * ((ug + fc - 1) / fc)), dim3(64), 0, b, sp0, g, fc);
+        }
         break;
     case ST_PITCH: {
         // frames side by side, chained through flags (k_pitch), while one frame's workgroups cannot fill the GPU (below 16384
@@ -718,7 +727,7 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
         if (chain) h->tickets += grid;   // (launches of one batch's pitch stage are ordered among themselves: a stateful stage)
         break;
     }
-    case ST_FFT: L.go(K_FFT_XP, k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0); break;
+    case ST_FFT: L.go(K_FFT_XP, k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0, g); break;
     case ST_RNN:
         for (const nnn_batch::ModelGroup &G : h->groups) {   // one launch per resident model (a run of whole tiles)
             // the layer-pipelined kernel spends g + 4 ticks on g frames: for a lone frame on a batch of many block rounds the
@@ -1402,15 +1411,20 @@ static void enqueue_feature_group(nnn_batch *h, hipStream_t st, const float *in,
     hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, (const StepParams *)sp, g);
     if (full) {
         if (h->lpc_wide >= 0 ? h->lpc_wide != 0 : NT * ug < 512u) hipLaunchKernelGGL(k_lpc_wide, dim3(NT * ug), dim3(320), 0, st, b, (const StepParams *)sp, g);
-        else hipLaunchKernelGGL(k_lpc, dim3(NT * ug), dim3(64), 0, st, b, (const StepParams *)sp, g);
+        else {
+            int fc = LPC_FC;
+            while (fc > 1 && NT * ((ug + fc - 1) / fc) < 2048u) fc /= 2;
+            if (h->lpc_fc > 0) fc = h->lpc_fc < LPC_FC ? h->lpc_fc : LPC_FC;
+            hipLaunchKernelGGL(k_lpc, dim3(NT * ((ug + fc - 1) / fc)), dim3(64), 0, st, b, (const StepParams *)sp, g, fc);
+        }
         const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
         const unsigned grid = Sp / PK_SPB * (chain ? ug : 1u);
         hipLaunchKernelGGL(k_pitch, dim3(grid), dim3(PK_T), 0, st, b, (const StepParams *)sp, g, chain, seq0, h->tickets);
         if (chain) h->tickets += grid;
-        hipLaunchKernelGGL(k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp);
+        hipLaunchKernelGGL(k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp, g);
         hipLaunchKernelGGL(k_features, dim3(NT), dim3(64 * FEAT_WAVES), 0, st, b, g);
     } else {
-        hipLaunchKernelGGL(k_fft_x, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp);
+        hipLaunchKernelGGL(k_fft_x, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp, g);
     }
     h->frame_count += g;
 }

@@ -321,48 +321,10 @@ __device__ __forceinline__ void lpc_chains(const float *base, float x0, float (&
     }
 }
 
-// WIDE = false: one wave per (tile, frame), every lane carries its stream's five chains.  WIDE = true, for launches too small to
-// fill the GPU (a one-frame call on a few thousand streams is 64 waves walking five 860-step chains each): five waves per (tile,
-// frame), one lag each, the five sums meeting in LDS.
-template <bool WIDE>
-__device__ __forceinline__ void lpc_body(const Buffers &b, const StepParams *sp0, int g, float (*acs)[TILE])
+// lag window, Levinson recursion, bandwidth expansion, extra zero (ref: src/pitch.rs:460-480, 257-292) on a frame's five sums; the
+// windowed autocorrelation and the FIR taps go to the frame's ring slot
+__device__ __forceinline__ void lpc_finish(const Buffers &b, int tile, int lane, int slot, float (&ac)[5])
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // block -> (tile, frame).  Workgroup i runs on XCD i mod 8 (observed; a speed matter only): the g frames of a tile read
-    // overlapping windows (624 of 864 rows shared by neighbours), so they go to one XCD -- tile t's to XCD t mod 8, where k_hp's
-    // block t wrote the ring.
-    int tile, f;
-    {
-        const int blk = (int)blockIdx.x;
-        if ((b.NT & 7) == 0) {
-            const int xcd = blk & 7, i = blk >> 3;
-            tile = xcd + 8 * (i / g);
-            f = i % g;
-        } else {
-            tile = blk / g;
-            f = blk % g;
-        }
-    }
-    const int slot = sp0[f].slot;
-    const float *base = b.dec + ((size_t)tile * dec_len(b.nslot) + (size_t)dec_base(slot, b.nslot)) * TILE + lane;
-    const float x0 = NNN_TI(b.xlp0, b.nslot, tile, lane)[(size_t)slot * TILE];   // x_lp[0] is special (ref: src/pitch.rs:458)
-    float ac[5];
-    if (WIDE) {
-        float a1[1];
-        if (wave == 0) lpc_chains<0, 1, LPC_CHW>(base, x0, a1);
-        else if (wave == 1) lpc_chains<1, 1, LPC_CHW>(base, x0, a1);
-        else if (wave == 2) lpc_chains<2, 1, LPC_CHW>(base, x0, a1);
-        else if (wave == 3) lpc_chains<3, 1, LPC_CHW>(base, x0, a1);
-        else lpc_chains<4, 1, LPC_CHW>(base, x0, a1);
-        acs[wave][lane] = a1[0];
-        __syncthreads();
-        if (wave != 0) return;
-#pragma unroll
-        for (int k = 0; k < 5; k++) ac[k] = acs[k][lane];
-    } else {
-        lpc_chains<0, 5, LPC_CH>(base, x0, ac);
-    }
-    // lag window, Levinson, bandwidth expansion, extra zero (ref: src/pitch.rs:460-480, 257-292)
     ac[0] *= 1.0001f;
 #pragma unroll
     for (int i = 1; i < 5; i++) ac[i] -= ac[i] * (0.008f * (float)i) * (0.008f * (float)i);
@@ -403,11 +365,136 @@ __device__ __forceinline__ void lpc_body(const Buffers &b, const StepParams *sp0
 #pragma unroll
     for (int i = 0; i < 5; i++) { o[(size_t)i * TILE] = ac[i]; o[(size_t)(5 + i) * TILE] = l2[i]; }
 }
-__global__ void __launch_bounds__(64) k_lpc(Buffers b, const StepParams *sp0, int g) { lpc_body<false>(b, sp0, g, nullptr); }
+
+// k_lpc: one wave per (tile, LPC_FC consecutive frames).  Consecutive frames' windows overlap by 624 of 864 rows, and frames of a
+// tile running as separate waves do not find each other's rows in L2 (the few hundred waves an XCD has in flight read 16 MB of
+// rows between two uses of a line: 3.4 KB per stream-frame from HBM).  Here a wave walks the union of its frames' windows once
+// -- 864 + 240 per further frame rows -- and every row serves each frame whose window holds it: the same sums in the same order
+// per frame (up to 4 x 5 independent chains in flight), 2.2x fewer rows.
+constexpr int LPC_FC = 4;
+static_assert(240 % LPC_CH == 0, "");
+// `fc` <= LPC_FC frames per wave: the host gives small launches fewer (more, shorter waves)
+__global__ void __launch_bounds__(64) k_lpc(Buffers b, const StepParams *sp0, int g, int fc)
+{
+    const int lane = threadIdx.x;
+    const int nch = (g + fc - 1) / fc;
+    // block -> (tile, chunk of frames).  Workgroup i runs on XCD i mod 8 (observed; a speed matter only): tile t's chunks go to XCD
+    // t mod 8, where k_hp's block t wrote the ring.
+    int tile, chunk;
+    {
+        const int blk = (int)blockIdx.x;
+        if ((b.NT & 7) == 0) {
+            const int xcd = blk & 7, i = blk >> 3;
+            tile = xcd + 8 * (i / nch);
+            chunk = i % nch;
+        } else {
+            tile = blk / nch;
+            chunk = blk % nch;
+        }
+    }
+    const int f0 = chunk * fc, nf = g - f0 < fc ? g - f0 : fc;
+    const int nslot = b.nslot, ring = dec_ring_len(nslot);
+    int slot[LPC_FC];
+    float x0[LPC_FC];   // x_lp[0] of each frame is special (ref: src/pitch.rs:458)
+#pragma unroll
+    for (int c = 0; c < LPC_FC; c++) {
+        slot[c] = sp0[f0 + (c < nf ? c : 0)].slot;
+        x0[c] = NNN_TI(b.xlp0, nslot, tile, lane)[(size_t)slot[c] * TILE];
+    }
+    // union row r of the chunk sits at ring position (base0 + r) mod ring (consecutive frames' windows start 240 apart)
+    const float *rows = b.dec + (size_t)tile * dec_len(nslot) * TILE + lane;
+    const int base0 = dec_base(slot[0], nslot);
+    auto row = [&](int r) {
+        int p = base0 + r;
+        p = p >= ring ? p - ring : p;
+        return rows[(size_t)p * TILE];
+    };
+    constexpr int NCH = (XLP - 4) / LPC_CH, STEP = 240 / LPC_CH;   // chunks of a window (43), chunks between two windows (12)
+    const int J = NCH + STEP * (nf - 1);
+    float cur[LPC_CH + 4], nxt[LPC_CH];
+#pragma unroll
+    for (int i = 0; i < LPC_CH + 4; i++) cur[i] = row(i);
+    float acc[LPC_FC][5];
+#pragma unroll
+    for (int c = 0; c < LPC_FC; c++)
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc[c][k] = 0.0f;
+#pragma nounroll
+    for (int j = 0; j < J; j++) {
+        // rows 20 (j + 1) + 4 .. + 23 travel while this chunk is summed (the last chunk re-reads its own rows: in range, unused)
+        const int jn = j + 1 < J ? j + 1 : j;
+#pragma unroll
+        for (int i = 0; i < LPC_CH; i++) nxt[i] = row(jn * LPC_CH + 4 + i);
+#pragma unroll
+        for (int c = 0; c < LPC_FC; c++) {
+            const int jj = j - STEP * c;   // this chunk's place in frame c's window
+            if (c < nf && jj >= 0 && jj < NCH) {
+                // ac[k] += x[i] * x[i + k], i ascending: the reference's sequential sum per lag (ref: src/pitch.rs:433-446)
+                const float first = jj == 0 ? x0[c] : cur[0];
+#pragma unroll
+                for (int i = 0; i < LPC_CH; i++) {
+                    const float xi = i == 0 ? first : cur[i];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) acc[c][k] += xi * (i + k == 0 ? first : cur[i + k]);
+                }
+                if (jj == NCH - 1) {
+                    // tail d_k = sum_{i = k + 860}^{863} x[i] x[i - k], added after the main sum; cur[] holds rows 840 .. 863 of the window
+                    float ac[5];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        constexpr int O = XLP - LPC_CH - 4;
+                        float d = 0.0f;
+#pragma unroll
+                        for (int i = k + XLP - 4; i < XLP; i++) d += cur[i - O] * cur[i - k - O];
+                        ac[k] = acc[c][k] + d;
+                    }
+                    lpc_finish(b, tile, lane, slot[c], ac);
+                }
+            }
+        }
+        if (j + 1 < J) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) cur[i] = cur[LPC_CH + i];
+#pragma unroll
+            for (int i = 0; i < LPC_CH; i++) cur[4 + i] = nxt[i];
+        }
+    }
+}
+
+// k_lpc_wide, for launches too small to fill the GPU (a one-frame call on a few thousand streams is 64 waves walking five 860-step
+// chains each): five waves per (tile, frame), one lag each, the five sums meeting in LDS.
 __global__ void __launch_bounds__(320) k_lpc_wide(Buffers b, const StepParams *sp0, int g)
 {
     __shared__ float acs[5][TILE];
-    lpc_body<true>(b, sp0, g, acs);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int tile, f;
+    {
+        const int blk = (int)blockIdx.x;
+        if ((b.NT & 7) == 0) {
+            const int xcd = blk & 7, i = blk >> 3;
+            tile = xcd + 8 * (i / g);
+            f = i % g;
+        } else {
+            tile = blk / g;
+            f = blk % g;
+        }
+    }
+    const int slot = sp0[f].slot;
+    const float *base = b.dec + ((size_t)tile * dec_len(b.nslot) + (size_t)dec_base(slot, b.nslot)) * TILE + lane;
+    const float x0 = NNN_TI(b.xlp0, b.nslot, tile, lane)[(size_t)slot * TILE];   // x_lp[0] is special (ref: src/pitch.rs:458)
+    float a1[1];
+    if (wave == 0) lpc_chains<0, 1, LPC_CHW>(base, x0, a1);
+    else if (wave == 1) lpc_chains<1, 1, LPC_CHW>(base, x0, a1);
+    else if (wave == 2) lpc_chains<2, 1, LPC_CHW>(base, x0, a1);
+    else if (wave == 3) lpc_chains<3, 1, LPC_CHW>(base, x0, a1);
+    else lpc_chains<4, 1, LPC_CHW>(base, x0, a1);
+    acs[wave][lane] = a1[0];
+    __syncthreads();
+    if (wave != 0) return;
+    float ac[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) ac[k] = acs[k][lane];
+    lpc_finish(b, tile, lane, slot, ac);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1525,10 +1612,8 @@ __device__ __forceinline__ int rfft_slot_bin(int lane, int u)
 }
 
 template <bool WITH_P>
-__device__ __forceinline__ void transform_inputs(const Buffers &b, const StepParams *sp, int bx, FftLds &t, float2 *Z, float *part)
+__device__ __forceinline__ void transform_inputs(const Buffers &b, const StepParams *sp, int tile, int sub, FftLds &t, float2 *Z, float *part)
 {
-    int tile, sub;
-    xcd_tile_block(bx, b.NT, TILE / FFT_SPB, tile, sub);
     const int lane = threadIdx.x & 63, sl = sub * FFT_SPB + (int)(threadIdx.x >> 6), s = tile * TILE + sl;
     const int ring = ring_len(b.nslot), rb = ring_base(sp->slot, b.nslot);
     float2 w[8];   // the window at sample pairs j + 60 r: the order of the transforms' first pass (window_rfft)
@@ -1663,25 +1748,51 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
 #ifndef NNN_FFT_MINWAVES
 #define NNN_FFT_MINWAVES 4
 #endif
-__global__ void __launch_bounds__(64 * FFT_SPB, NNN_FFT_MINWAVES) k_fft_xp(Buffers b, const StepParams *sp)
+// Block index -> (frame, tile, four streams of the tile) for the g frames of a group.  Batches of a multiple of 8 tiles: the blocks an
+// XCD receives (i mod 8, in index order) are the g frames of one quartet of streams, then the next quartet's, tile t on XCD t mod 8:
+// consecutive frames of a stream share three quarters of the history samples their two windows read, and blocks that run
+// side by side on one XCD fetch them into its L2 once (frame-major order -- all streams of frame 0, then frame 1 ... -- puts
+// 250 MB of other streams' samples between two uses of a line).
+__device__ __forceinline__ void fft_block(const Buffers &b, int g, int &frame, int &tile, int &sub)
+{
+    constexpr int BPT = TILE / FFT_SPB;
+    const int i = (int)blockIdx.x;
+#ifndef NNN_NO_XCD_MAP
+    if ((b.NT & 7) == 0) {
+        const int xcd = i & 7, j = i >> 3, tb = j / g;
+        frame = j - tb * g;
+        tile = xcd + 8 * (tb / BPT);
+        sub = tb % BPT;
+        return;
+    }
+#endif
+    const int per = b.NT * BPT;
+    frame = i / per;
+    xcd_tile_block(i - frame * per, b.NT, BPT, tile, sub);
+}
+__global__ void __launch_bounds__(64 * FFT_SPB, NNN_FFT_MINWAVES) k_fft_xp(Buffers b, const StepParams *sp, int g)
 {
     __shared__ FftLds t;
     __shared__ float2 Z[FFT_SPB][NFFT_BUF];
     __shared__ float part[FFT_SPB][3 * 64];   // the feature head's staging: correlation, log energies, band energies
-    NNN_FRAME_SPLIT(b.S_pad / FFT_SPB)
+    int frame, tile, sub;
+    fft_block(b, g, frame, tile, sub);
+    b = frame_view(b, frame);
     const int wave = threadIdx.x >> 6;
-    transform_inputs<true>(b, sp + frame, bx, t, Z[wave], part[wave]);
+    transform_inputs<true>(b, sp + frame, tile, sub, t, Z[wave], part[wave]);
 }
 
 // lag-0 transform and band energies only (training rows: clean and noise states)
-__global__ void __launch_bounds__(64 * FFT_SPB) k_fft_x(Buffers b, const StepParams *sp)
+__global__ void __launch_bounds__(64 * FFT_SPB) k_fft_x(Buffers b, const StepParams *sp, int g)
 {
     __shared__ FftLds t;
     __shared__ float2 Z[FFT_SPB][NFFT_BUF];
     __shared__ float part[FFT_SPB][4];   // (the feature head's staging: unused without the second transform)
-    NNN_FRAME_SPLIT(b.S_pad / FFT_SPB)
+    int frame, tile, sub;
+    fft_block(b, g, frame, tile, sub);
+    b = frame_view(b, frame);
     const int wave = threadIdx.x >> 6;
-    transform_inputs<false>(b, sp + frame, bx, t, Z[wave], part[wave]);
+    transform_inputs<false>(b, sp + frame, tile, sub, t, Z[wave], part[wave]);
 }
 
 #pragma clang fp contract(off)

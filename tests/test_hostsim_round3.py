@@ -98,20 +98,23 @@ def test_caller_supplied_buffers_are_validated(hostsim_lib):
 
 
 def test_lpc_kernel_variants_agree_bit_for_bit(hostsim_lib, oracle_mod, weights_bytes, monkeypatch):
-    """k_lpc (every lane carries its stream's five autocorrelation chains) and k_lpc_wide (one lag per wave, what launches too small
-    to fill the GPU use) give the same bits, and both the oracle's: autocorrelation, FIR taps and everything downstream."""
+    """k_lpc (every lane carries its stream's five autocorrelation chains, a wave walking the windows of 1, 2 or 4 consecutive
+    frames at once) and k_lpc_wide (one lag per wave, what launches too small to fill the GPU use) give the same bits, and both the
+    oracle's: autocorrelation, FIR taps and everything downstream."""
     import nnnoiseless_amd as nn
     from nnnoiseless_amd.synthetic import make_streams
-    S, T = 7, 4
+    S, T = 7, 7
     x = make_streams(40, S, T)
     res = {}
-    for wide in ("0", "1"):
+    for wide, fc in (("0", "1"), ("0", "2"), ("0", "4"), ("1", "0")):
         monkeypatch.setenv("NNN_LPC_WIDE", wide)
+        monkeypatch.setenv("NNN_LPC_FC", fc)
         bd = nn.BatchDenoiser(S, lib=hostsim_lib, taps=True)
-        out, vad = bd.process(x)
-        res[wide] = (out, vad, bd.tap("ac").copy(), bd.tap("lpc2").copy(), bd.tap("xlp").copy(), bd.tap("pitch").copy())
-    for a, b in zip(res["0"], res["1"]):
-        assert np.array_equal(a, b)
+        out, vad = bd.process(x)                     # one group of 7 frames: with four frames per wave, a wave of 4 and a wave of 3
+        res[wide + fc] = (out, vad, bd.tap("ac").copy(), bd.tap("lpc2").copy(), bd.tap("xlp").copy(), bd.tap("pitch").copy())
+    for key in ("02", "04", "10"):
+        for a, b in zip(res["01"], res[key]):
+            assert np.array_equal(a, b), key
     om = oracle_mod.Model(weights_bytes)
     for s in range(S):
         st = oracle_mod.State(om)
@@ -119,7 +122,7 @@ def test_lpc_kernel_variants_agree_bit_for_bit(hostsim_lib, oracle_mod, weights_
             st.process_frame(x[s, t])
         ot = st.taps()
         for k, i in (("ac", 2), ("lpc2", 3), ("xlp", 4)):
-            assert np.array_equal(res["0"][i][s].view(np.uint32), np.atleast_1d(ot[k]).astype(np.float32).view(np.uint32)), (k, s)
+            assert np.array_equal(res["04"][i][s].view(np.uint32), np.atleast_1d(ot[k]).astype(np.float32).view(np.uint32)), (k, s)
 
 
 @pytest.mark.parametrize("gmax", [1, 2, 5])
