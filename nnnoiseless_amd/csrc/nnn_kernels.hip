@@ -35,16 +35,41 @@ namespace nnn {
 // and written back from, as many L2s.  Tile t goes to XCD t mod 8 instead: where k_hp's block t and k_pitch's blocks of tile t ran.
 __device__ __forceinline__ void xcd_tile_block(int blk, int ntiles, int bpt, int &tile, int &sub)
 {
-#ifndef NNN_NO_XCD_MAP
-    if ((ntiles & 7) == 0) {
+    int m8 = ntiles & ~7;   // the tiles that come in eights are dealt to the XCDs; the last few keep block order
+#ifdef NNN_NO_XCD_MAP
+    m8 = 0;
+#endif
+    if (blk < m8 * bpt) {
         const int xcd = blk & 7, j = blk >> 3;
         tile = xcd + 8 * (j / bpt);
         sub = j % bpt;
-        return;
+    } else {
+        const int r = blk - m8 * bpt;
+        tile = m8 + r / bpt;
+        sub = r % bpt;
     }
+}
+// the same for launches that cover `n` units (frames, chunks of frames) per tile-block, the units of a tile-block on consecutive
+// blocks of its XCD: blk -> (unit, tile, sub)
+__device__ __forceinline__ void xcd_tile_block_units(int blk, int ntiles, int bpt, int n, int &unit, int &tile, int &sub)
+{
+    int m8 = ntiles & ~7;
+#ifdef NNN_NO_XCD_MAP
+    m8 = 0;
 #endif
-    tile = blk / bpt;
-    sub = blk % bpt;
+    if (blk < m8 * bpt * n) {
+        const int xcd = blk & 7, j = blk >> 3, tb = j / n;
+        unit = j - tb * n;
+        tile = xcd + 8 * (tb / bpt);
+        sub = tb % bpt;
+    } else {
+        // (what is left keeps the order the kernels had before: unit-major)
+        const int r = blk - m8 * bpt * n, per = (ntiles - m8) * bpt;
+        unit = r / per;
+        const int q = r - unit * per;
+        tile = m8 + q / bpt;
+        sub = q % bpt;
+    }
 }
 
 // Optional phase stamps (developer instrumentation, off in the shipped build): block 0 / thread 0 records the
@@ -380,18 +405,8 @@ __global__ void __launch_bounds__(64) k_lpc(Buffers b, const StepParams *sp0, in
     const int nch = (g + fc - 1) / fc;
     // block -> (tile, chunk of frames).  Workgroup i runs on XCD i mod 8 (observed; a speed matter only): tile t's chunks go to XCD
     // t mod 8, where k_hp's block t wrote the ring.
-    int tile, chunk;
-    {
-        const int blk = (int)blockIdx.x;
-        if ((b.NT & 7) == 0) {
-            const int xcd = blk & 7, i = blk >> 3;
-            tile = xcd + 8 * (i / nch);
-            chunk = i % nch;
-        } else {
-            tile = blk / nch;
-            chunk = blk % nch;
-        }
-    }
+    int tile, chunk, sub_;
+    xcd_tile_block_units((int)blockIdx.x, b.NT, 1, nch, chunk, tile, sub_);
     const int f0 = chunk * fc, nf = g - f0 < fc ? g - f0 : fc;
     const int nslot = b.nslot, ring = dec_ring_len(nslot);
     int slot[LPC_FC];
@@ -467,18 +482,8 @@ __global__ void __launch_bounds__(320) k_lpc_wide(Buffers b, const StepParams *s
 {
     __shared__ float acs[5][TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int tile, f;
-    {
-        const int blk = (int)blockIdx.x;
-        if ((b.NT & 7) == 0) {
-            const int xcd = blk & 7, i = blk >> 3;
-            tile = xcd + 8 * (i / g);
-            f = i % g;
-        } else {
-            tile = blk / g;
-            f = blk % g;
-        }
-    }
+    int tile, f, sub_;
+    xcd_tile_block_units((int)blockIdx.x, b.NT, 1, g, f, tile, sub_);
     const int slot = sp0[f].slot;
     const float *base = b.dec + ((size_t)tile * dec_len(b.nslot) + (size_t)dec_base(slot, b.nslot)) * TILE + lane;
     const float x0 = NNN_TI(b.xlp0, b.nslot, tile, lane)[(size_t)slot * TILE];   // x_lp[0] is special (ref: src/pitch.rs:458)
@@ -723,12 +728,9 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
     // block indices would spread them over four XCDs, each fetching the same lines.
     const int per = b.S_pad / PK_SPB;   // blocks per frame
     const int f_begin = chain ? item / per : 0, f_end = chain ? f_begin + 1 : g;
-    int blk = item - f_begin * per;
-    if ((per & 31) == 0) {
-        const int xcd = blk & 7, i = blk >> 3;
-        blk = 4 * (8 * (i >> 2) + xcd) + (i & 3);
-    }
-    const int tile = (blk * PK_SPB) >> 6, q0 = (blk * PK_SPB) & 63;   // first stream of this block within its tile
+    int tile, sub_;
+    xcd_tile_block(item - f_begin * per, b.NT, TILE / PK_SPB, tile, sub_);
+    const int q0 = sub_ * PK_SPB;   // first stream of this block within its tile
     const int min_period = PITCH_MIN / 2, max_period = PITCH_MAX / 2;
     const bool dec_lane = wave == 0 && lane0 < PK_SPB;                // lane = stream decisions
     int last_period = 0;
@@ -1755,20 +1757,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
 // 250 MB of other streams' samples between two uses of a line).
 __device__ __forceinline__ void fft_block(const Buffers &b, int g, int &frame, int &tile, int &sub)
 {
-    constexpr int BPT = TILE / FFT_SPB;
-    const int i = (int)blockIdx.x;
-#ifndef NNN_NO_XCD_MAP
-    if ((b.NT & 7) == 0) {
-        const int xcd = i & 7, j = i >> 3, tb = j / g;
-        frame = j - tb * g;
-        tile = xcd + 8 * (tb / BPT);
-        sub = tb % BPT;
-        return;
-    }
-#endif
-    const int per = b.NT * BPT;
-    frame = i / per;
-    xcd_tile_block(i - frame * per, b.NT, BPT, tile, sub);
+    xcd_tile_block_units((int)blockIdx.x, b.NT, TILE / FFT_SPB, g, frame, tile, sub);
 }
 __global__ void __launch_bounds__(64 * FFT_SPB, NNN_FFT_MINWAVES) k_fft_xp(Buffers b, const StepParams *sp, int g)
 {

@@ -157,13 +157,20 @@ def test_batches_sized_for_short_groups(hostsim_lib, gmax):
 
 
 def test_xcd_tile_mapping_changes_no_bits(hostsim_lib):
-    """Batches of a multiple of 8 tiles send the blocks of tile t to XCD t mod 8 (k_fft_xp, k_rnn / k_rnn_wf, k_synth: another
-    block -> stream mapping); other batches keep blocks in stream order.  The same streams give the same bits either way."""
+    """The tiles of a batch that come in eights are dealt to the XCDs -- tile t's blocks to XCD t mod 8 in k_lpc, k_pitch, k_fft_xp,
+    k_rnn / k_rnn_wf and k_synth, i.e. another block -> stream mapping --, the last few keep block order.  The same streams give the
+    same bits whichever way their batch is cut: 10 tiles (8 dealt + 2), 8 tiles (all dealt), 7 tiles (none)."""
     import nnnoiseless_amd as nn
     from nnnoiseless_amd.synthetic import make_streams
     T = 3
-    x = make_streams(9, 512, T)
-    a, va = nn.BatchDenoiser(512, lib=hostsim_lib).process(x)            # 8 tiles: mapped
-    b, vb = nn.BatchDenoiser(448, lib=hostsim_lib).process(x[:448])      # 7 tiles: stream order
-    assert np.array_equal(a[:448], b) and np.array_equal(va[:, :448], vb)
-    assert np.abs(a[448:]).max() > 0
+    x = make_streams(9, 600, T)
+    a, va = nn.BatchDenoiser(600, lib=hostsim_lib).process(x)
+    b, vb = nn.BatchDenoiser(512, lib=hostsim_lib).process(x[:512])
+    c, vc = nn.BatchDenoiser(448, lib=hostsim_lib).process(x[:448])
+    assert np.array_equal(a[:512], b) and np.array_equal(va[:, :512], vb)
+    assert np.array_equal(a[:448], c) and np.array_equal(va[:, :448], vc)
+    assert np.abs(a[512:]).max() > 0
+    one = nn.BatchDenoiser(600, lib=hostsim_lib)                          # ... and frame by frame (one-frame launches)
+    for t in range(T):
+        o, v = one.process(x[:, t:t + 1])
+        assert np.array_equal(o[:, 0], a[:, t]) and np.array_equal(v[0], va[t])
