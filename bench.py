@@ -576,10 +576,13 @@ def main():
                                        "unit": "unit-range f32"}[args.pcm] + (f", {args.channels} interleaved channels" if args.channels > 1 else ""),
                    "streams_per_gpu": S, "streams_total": S * world, "frames_per_step": fps,
                    "inputs_ready": not args.no_overlap,
-                   "schedule": os.environ.get("NNN_SCHED", "lanes"), "lanes": int(os.environ.get("NNN_LANES", "2")),
+                   # the library's own choice unless the environment asks: one stream in order from 16 384 streams up (every kernel fills the
+                   # GPU alone), below that the high-pass chain on a stream of its own ahead of one lane
+                   "schedule": os.environ.get("NNN_SCHED", "seq" if ((S + 63) // 64 * 64 >= 16384 and "NNN_LANES" not in os.environ) else "lanes"),
+                   "lanes": int(os.environ.get("NNN_LANES", "1")),
                    "pipeline": os.environ.get("NNN_PIPELINE", "1") != "0",
                    "inputs": "resident in HBM and final before the timed region" + ("" if args.no_overlap else "; declared to the library "
-                             "(nnn_batch_set_inputs_ready): consecutive calls overlap at their boundary, outputs stay stream-ordered"),
+                             "(nnn_batch_set_inputs_ready): with the lanes schedule consecutive calls overlap at their boundary, outputs stay stream-ordered"),
                    "parallelism": f"streams sharded x{world}, one process per GPU, no data-path collective"},
         "ranks_seen": ranks_seen, "timed_s": res["timed_s"], "pool_frames": res["pool_frames"],
         "tick": res.get("tick"),

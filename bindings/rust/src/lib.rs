@@ -134,7 +134,7 @@ pub struct BatchOpts {
 
 impl BatchDenoiser {
     /// A batch sized for calls of at most `max_group_frames` frames: a real-time host that ticks one frame per call (what
-    /// `DenoiseSignal` does, src/signal.rs:102-104) passes 1 and holds 44 KB per stream instead of 650.
+    /// `DenoiseSignal` does, src/signal.rs:102-104) passes 1 and holds 33 KB per stream instead of 360.
     pub fn sized(n_streams: usize, max_group_frames: usize, model: Option<&RnnModel>, device: i32) -> Option<BatchDenoiser> {
         let m = model.map_or(std::ptr::null(), |m| m.0 as *const RawModel);
         let n = n_streams as c_int;

@@ -53,9 +53,9 @@ nnn_batch *nnn_batch_create(const RNNModel *model, int n_streams, int device);
 nnn_batch *nnn_batch_create_grouped(const RNNModel *const *models, const int *group_streams, int n_groups, int device);
 /* The same with options (NULL = defaults; zero-initialise the struct).
  * max_group_frames: the kernels work on groups of consecutive frames -- up to 24 by default, which sizes the per-stream scratch
- * and history rings for it (650 KB per stream).  A host whose calls are short says so here and gets a batch sized for groups of
- * that many frames: a real-time host that ticks ONE 10 ms frame per call passes 1 and pays 44 KB per stream (the reference's
- * DenoiseState is 10.3 KB, src/features.rs:18-46), i.e. 6.5 million live streams' worth of HBM instead of 440 thousand.  Longer
+ * and history rings for it (360 KB per stream).  A host whose calls are short says so here and gets a batch sized for groups of
+ * that many frames: a real-time host that ticks ONE 10 ms frame per call passes 1 and pays 33 KB per stream (the reference's
+ * DenoiseState is 10.3 KB, src/features.rs:18-46), i.e. 8.7 million live streams' worth of HBM instead of 800 thousand.  Longer
  * calls still work on such a batch, cut into groups of at most this many frames (slower, same results).  0 = default. */
 typedef struct nnn_batch_opts {
     int max_group_frames;

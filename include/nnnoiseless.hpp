@@ -92,8 +92,8 @@ class BatchDenoiser {
         b_.reset(nnn_batch_create_grouped(ms.data(), ns.data(), (int)ns.size(), device), nnn_batch_destroy);
         if (!b_) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
     }
-    // a batch sized for calls of at most `max_group_frames` frames (1 = a real-time host ticking one frame per call: 44 KB per
-    // stream instead of 650; longer calls still work, cut into groups of that many frames)
+    // a batch sized for calls of at most `max_group_frames` frames (1 = a real-time host ticking one frame per call: 33 KB per
+    // stream instead of 360; longer calls still work, cut into groups of that many frames)
     static BatchDenoiser sized(int n_streams, int max_group_frames, const RnnModel *model = nullptr, int device = 0)
     {
         const RNNModel *m = model ? model->raw() : nullptr;

@@ -32,6 +32,17 @@ def library():
     global _lib
     if _lib is None:
         import os
+        import sys
+        # A process that also uses PyTorch holds two HIP runtimes (torch ships its own): torch's does not come up once the
+        # system one is running ("No HIP GPUs are available"), the other order works.  If torch is already imported, bring its
+        # device up first; a host that imports torch later has to do the same itself (torch.cuda.init()) before its first batch.
+        t = sys.modules.get("torch")
+        if t is not None:
+            try:
+                if t.cuda.is_available():
+                    t.cuda.init()
+            except Exception:
+                pass
         _lib = _ffi.Library(os.environ.get("NNN_LIBRARY", LIB_PATH))   # developer override: an experimental build
     return _lib
 
@@ -108,7 +119,7 @@ class BatchDenoiser:
 
     def __init__(self, n_streams, model=None, device=0, lib=None, groups=None, taps=False, max_group_frames=None, _handle=None):
         """max_group_frames: the longest run of frames the kernels take at once (default 24).  A real-time host that ticks one frame
-        per call passes 1: the batch then holds 44 KB per stream instead of 650 (`device_bytes()`); longer calls still work on it,
+        per call passes 1: the batch then holds 33 KB per stream instead of 360 (`device_bytes()`); longer calls still work on it,
         cut into groups of that many frames.
         groups: [(model_or_None, n_streams), ...] keeps several models resident, one per run of streams (every run
         but the last a multiple of 64); it replaces `model` and must add up to n_streams.  taps=True also stores the

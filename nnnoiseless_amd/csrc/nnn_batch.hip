@@ -89,10 +89,11 @@ struct nnn_batch {
     int device = 0;
     int S = 0, S_pad = 0, NT = 0;
     uint64_t frame_count = 0;
+    int depth = 1;                 // scratch-set blocks in rotation = groups in flight behind the high-pass (1 or DEPTH)
     int gmax = GROUP;              // frames per group at most (nnn_batch_opts.max_group_frames): sizes the scratch sets and the history rings
-    int nset = NSET, nslot = slots_for(GROUP);
+    int nset = GROUP, nslot = slots_for(GROUP, 1);
     size_t device_bytes = 0;       // everything dalloc / upload allocated
-    uint64_t group_count = 0;      // groups launched so far: group_count % DEPTH picks the block of gmax scratch sets
+    uint64_t group_count = 0;      // groups launched so far: group_count % depth picks the block of gmax scratch sets
     int last_set = 0;              // scratch set of the most recent frame (parity taps)
     std::vector<void *> allocs;     // everything hipMalloc'ed
     std::vector<std::pair<void *, size_t>> state_bufs;  // zeroed by reset, copied by clone / save / load
@@ -136,7 +137,10 @@ struct nnn_batch {
     bool have_last = false;
     uint64_t call_count = 0;
     int sched = SCHED_LANES;        // how a multi-frame call spreads over streams (env NNN_SCHED: seq | lanes | stages)
-    int n_lanes = 2;                // SCHED_LANES: lanes (the caller's stream + internal ones) besides the high-pass stream; env NNN_LANES, 1..4
+    bool sched_auto = true;         // nobody chose a schedule (NNN_SCHED / NNN_LANES / nnn_batch_set_schedule): lanes below 16384 streams, one stream from there
+    int n_lanes = 1;                // SCHED_LANES: lanes (the caller's stream + internal ones) besides the high-pass stream; env NNN_LANES, 1..4.
+                                    // One since the end of round 3: with the frames of a group side by side in every kernel a second group in flight
+                                    // only gets in the first one's way (4096 streams: 55.5 against 54.8 M frames/s, 16 384: 63.8 / 62.3; profiles AN)
                                     // (measured at 4096 streams x 48 frames: 1: 28.5, 2: 37.1, 3: 32.9, 4: 32.2 M frames/s -- the default 4 hardware
                                     // queues are shared with the host's own streams)
     int pitch_chain = 1;            // k_pitch: one workgroup per (frame, quarter tile) instead of a frame loop: 1 = below 16384 streams, 0 = never, 2 = always (env NNN_PITCH_CHAIN)
@@ -293,8 +297,6 @@ static int rnn_small_batch_blocks()
 static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *group_streams, int n_groups, int device, int gmax)
 {
     h->gmax = gmax < 1 ? 1 : (gmax > GROUP ? GROUP : gmax);
-    h->nset = DEPTH * h->gmax;
-    h->nslot = slots_for(h->gmax);
     int n_streams = 0;
     for (int g = 0; g < n_groups; g++) {
         if (group_streams[g] <= 0) return fail("group %d: stream count must be positive", g);
@@ -328,15 +330,21 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
         if (!strcmp(e, "seq")) h->sched = SCHED_SEQ;
         else if (!strcmp(e, "lanes")) h->sched = SCHED_LANES;
         else if (!strcmp(e, "stages")) h->sched = SCHED_STAGES;
+        h->sched_auto = false;
     }
     if (const char *e = getenv("NNN_LANES")) {
         const int v = atoi(e);
         if (v >= 1 && v <= NSTREAMS - 1) h->n_lanes = v;
+        h->sched_auto = false;
     }
     if (const char *e = getenv("NNN_RNN_ROWS")) {
         const int v = atoi(e);
         if (v == 16 || v == 32) h->rnn_rows = v;
     }
+    // groups in flight behind the high-pass: what the schedule chosen at creation can use (a schedule set later works on what is there)
+    h->depth = (h->n_lanes >= 2 || h->sched == SCHED_STAGES) ? DEPTH : 1;
+    h->nset = h->depth * h->gmax;
+    h->nslot = slots_for(h->gmax, h->depth);
     h->S = n_streams;
     h->S_pad = (n_streams + TILE - 1) / TILE * TILE;
     h->NT = h->S_pad / TILE;
@@ -659,6 +667,7 @@ extern "C" nnn_batch *nnn_batch_clone(nnn_batch *h)
     c->frame_count = h->frame_count;
     c->group_count = h->group_count;
     c->sched = h->sched;
+    c->sched_auto = h->sched_auto;
     c->n_lanes = h->n_lanes;
     c->use_pipeline = h->use_pipeline;
     c->pitch_chain = h->pitch_chain;
@@ -766,7 +775,7 @@ static int drain_profile(nnn_batch *h)
 
 // Common body of the process entry points: strides in BYTES, `drop` leading frames of the call produce no audio.
 //
-// A call is cut into groups of up to GROUP frames; group k uses scratch-set block (group_count mod DEPTH).  Short calls
+// A call is cut into groups of up to GROUP frames; group k uses scratch-set block (group_count mod depth).  Short calls
 // (and profiling) run the groups' stages back to back on the caller's stream.  Longer calls spread over the batch's
 // internal streams so that independent stages overlap (at 4096 streams a lone stage cannot fill the GPU):
 //   lanes   the high-pass chain on its own stream, running ahead as far as the history rings allow; stages pitch .. synth of
@@ -774,7 +783,7 @@ static int drain_profile(nnn_batch *h)
 //   stages  one stream per stage: hp | pitch | fft_xp | rnn | synth; every stream is a chain of groups
 // An edge of the DAG whose ends share a stream needs nothing (streams are in-order); the others are an event record + wait.
 // Edges: previous stage of the same group; the same stage of the previous group for the four stateful stages; the scratch-set
-// block's previous user (synth of group k - DEPTH, before pitch of group k); the history rings (synth of the group holding the
+// block's previous user (synth of group k - depth, before pitch of group k); the history rings (synth of the group holding the
 // newest frame whose history slots group k's high-pass overwrites).  Everything before this call is ordered by the caller's
 // stream, which every internal stream waits for at its first use and which waits for the last synth at the end.
 static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_vad, int n_frames, int fmt, int channels,
@@ -825,7 +834,9 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     // 48-frame call: 55.5 M frames/s at 4096 streams; two of 24: 57.2 M) -- everything else into full groups of GROUP frames, the
     // remainder last (NNN_RAMP keeps round 2a's smaller groups at the ends of a pipelined call for comparison).
     constexpr int PIPE_MIN = 32;
-    const bool pipe = h->use_pipeline && h->sched != SCHED_SEQ && !h->profiling && n_frames >= PIPE_MIN;
+    // (from 16 384 streams up every kernel fills the GPU on its own and a launch beside it only costs it cache: one stream, in order,
+    // unless a schedule was asked for -- 32 768 streams: 65.9 M frames/s against 64.8 with the high-pass on a stream of its own)
+    const bool pipe = h->use_pipeline && h->sched != SCHED_SEQ && !h->profiling && n_frames >= PIPE_MIN && !(h->sched_auto && h->S_pad >= 16384);
     std::vector<int> sizes;
     if (pipe && h->ramp == 0) {
         int k = 2;
@@ -867,7 +878,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     }
     if (!pipe) {
         for (int k = 0, t = 0; k < n_groups; k++) {
-            const int g = sizes[k], set0 = (int)(h->group_count % DEPTH) * h->gmax;
+            const int g = sizes[k], set0 = (int)(h->group_count % h->depth) * h->gmax;
             for (int s = 0; s < ST_COUNT; s++) launch_stage(h, s, set0, g, tab + t, st, h->profiling);
             h->group_count += 1;
             h->frame_count += g;
@@ -893,7 +904,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
             return false;
         };
         for (int k = 0; k < n_groups; k++) {
-            const int g = sizes[k], set0 = (int)(h->group_count % DEPTH) * h->gmax;
+            const int g = sizes[k], set0 = (int)(h->group_count % h->depth) * h->gmax;
             for (int s = 0; s < ST_COUNT; s++) {
                 const int si = stream_of(s, k);
                 if (si >= 0 && !h->pool[si]) chk(hipStreamCreateWithFlags(&h->pool[si], hipStreamNonBlocking));
@@ -908,7 +919,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
                 };
                 if (s > 0) wait_for(s - 1, k);
                 if (s == ST_HP || s == ST_PITCH || s == ST_RNN || s == ST_SYN) wait_for(s, k - 1);
-                if (s == ST_PITCH) wait_for(ST_SYN, k - DEPTH);
+                if (s == ST_PITCH) wait_for(ST_SYN, k - h->depth);
                 if (s == ST_HP) {
                     // slots written now held frames (newest of this group) - nslot and older; their last readers are the
                     // frames up to 3 later
@@ -1339,6 +1350,7 @@ extern "C" int nnn_batch_set_schedule(nnn_batch *h, int mode, int lanes)
     if (mode < SCHED_SEQ || mode > SCHED_STAGES) return fail("unknown schedule %d", mode);
     h->sched = mode;
     if (lanes >= 1 && lanes <= NSTREAMS - 1) h->n_lanes = lanes;
+    h->sched_auto = false;
     return 0;
 }
 

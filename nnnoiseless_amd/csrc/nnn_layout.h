@@ -37,11 +37,12 @@ constexpr int GROUP = NNN_GROUP;  // frames per launch: every kernel is launched
 constexpr int DEPTH = NNN_DEPTH;  // groups in flight (blocks of GROUP scratch sets in rotation)
 // A batch is sized for groups of up to `gmax` <= GROUP frames (GROUP unless the host says its calls are shorter: a real-time host
 // that ticks one frame per call asks for gmax = 1 and pays a seventeenth of the memory, nnn_batch_create_opts):
-//   scratch sets   DEPTH * gmax
-//   ring slots     (DEPTH + 1) * gmax + 4: the high-pass may run a group ahead of the DEPTH groups in flight, whose oldest frame
+//   scratch sets   depth * gmax, depth = the groups a batch keeps in flight behind the high-pass: 1 (one lane, the default since the
+//                  end of round 3) or DEPTH = 2 (NNN_LANES >= 2 / NNN_SCHED=stages at creation)
+//   ring slots     (depth + 1) * gmax + 4: the high-pass may run a group ahead of the depth groups in flight, whose oldest frame
 //                  still reads a 1728-sample history (3 slots behind it).  History ring instead of the reference's memmove.
 constexpr int NSET = DEPTH * GROUP;              // the most scratch sets a batch can have
-__host__ __device__ inline int slots_for(int gmax) { return (DEPTH + 1) * gmax + 4; }
+__host__ __device__ inline int slots_for(int gmax, int depth = DEPTH) { return (depth + 1) * gmax + 4; }
 __host__ __device__ inline int ring_len(int nslot) { return nslot * 480; }
 __host__ __device__ inline int hist_stride(int nslot) { return nslot * 480 + 32; }   // a stream's stride in the history array (whole 128-byte lines):
                                   // hist[ring_len] repeats hist[0], so a sample pair that starts on the ring's last sample is still one 8-byte read
