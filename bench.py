@@ -79,7 +79,9 @@ CONFIGS = {
     2: {"streams": 65536, "model": None, "name": "configs[2]: 65536 concurrent streams on one GPU, built-in weights.rnn, GRU as batched MFMA GEMM"},
     3: {"streams": 32768, "model": None, "name": "configs[3]: 262144 streams sharded over 8 GPUs = 32768 per GPU, built-in weights.rnn"},
     4: {"streams": 65536, "model": os.path.join(ROOT, "tests", "golden", "sh.rnn"),
-        "name": "configs[4]: custom model (GregorR rnnoise-models 'sh' converted to .rnn), 65536 streams"},
+        "name": "configs[4]: custom model (GregorR rnnoise-models 'sh' converted to .rnn), 65536 streams",
+        "parity": "oracle-only: the reference holds no output for sh.rnn (SURVEY 8(c)), so this configuration is checked device-against-oracle, "
+                  "never against a reference-issued vector"},
 }
 
 
@@ -364,10 +366,15 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
         avg_s = kern[dom]["avg_us"] * 1e-6
         bytes_per_launch = KERNEL_BYTES.get(dom, 0) * S * frames_per_launch
         achieved = bytes_per_launch / avg_s / 1e9
-        traffic = None
-        pm = pmc_profile("traffic", S)   # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (same workload only)
+        # HBM-side bytes from the committed rocprofv3 --pmc passes at this stream count, per stream-frame there and scaled to THIS run's
+        # launch (streams x frames per launch) so that `traffic` and `bytes_per_launch` describe the same launch; the per-stream-frame
+        # pair is printed beside them (the PMC passes' own group length: `traffic_source`)
+        traffic = traffic_psf = traffic_src = None
+        pm = pmc_profile("traffic", S)
         if pm and dom in pm["kernels"]:
-            traffic = pm["kernels"][dom]["hbm_bytes_per_launch"]
+            traffic_psf = pm["kernels"][dom]["hbm_bytes_per_stream_frame"]
+            traffic = traffic_psf * S * frames_per_launch
+            traffic_src = f"profiles/pmc_traffic_{S}streams.json (2*FETCH_SIZE+WRITE_SIZE, separate passes, {pm.get('frames_per_launch')}-frame launches there)"
         # what binds the dominant kernel: the busiest on-chip resource of the committed SQ counter pass at this stream count
         binding = None
         sq = pmc_profile("sq", S)
@@ -382,6 +389,7 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
         return {"kernels": kern, "roofline": {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "alg_bytes_per_stream_frame": KERNEL_BYTES.get(dom, 0), "traffic_per_stream_frame": traffic_psf, "traffic_source": traffic_src,
             "avg_kernel_us": avg_s * 1e6, "frames_per_launch": frames_per_launch, "bytes_per_launch": bytes_per_launch,
             "binding": binding,
             "useful_tflops": kern[dom]["useful_tflops"], "roof_tflops": kern[dom]["roof_tflops"], "roof": kern[dom]["roof"],
@@ -536,7 +544,8 @@ def main():
             if rf:
                 r.update(rf())
             also[f"configs[{c}]"] = {
-                "workload": CONFIGS[c]["name"], "value": r["value"], "unit": "frames/s", "steps": r["steps"], "warmup": a.warmup,
+                "workload": CONFIGS[c]["name"], "parity": CONFIGS[c].get("parity", "oracle pinned by the reference's golden pair (built-in model)"),
+                "value": r["value"], "unit": "frames/s", "steps": r["steps"], "warmup": a.warmup,
                 "ms_per_step": r["ms_per_step"], "timed_s": r["timed_s"], "frames_per_step": args.frames_per_step,
                 "outputs_finite": r["outputs_finite"], "pool_frames": r["pool_frames"], "tick": r.get("tick"),
                 "pipeline_hbm_frac": r["value"] * BYTES_PER_FRAME_FUSED / 1e9 / HBM_PEAK_GBS,
@@ -571,6 +580,7 @@ def main():
                                f"{'' if model_path == cfg['model'] else ', model ' + os.path.basename(model_path or 'built-in')}, "
                                f"synthetic 48 kHz sine+noise, {fps} frame(s) per stream per step",
                    "baseline_config_index": args.config,
+                   "parity": cfg.get("parity", "oracle pinned by the reference's golden pair (built-in model)"),
                    "model": os.path.basename(model_path) if model_path else "built-in weights.rnn",
                    "boundary_format": {"f32": "f32 planar (process_frame's own)", "i16": "packed int16",
                                        "unit": "unit-range f32"}[args.pcm] + (f", {args.channels} interleaved channels" if args.channels > 1 else ""),
@@ -590,6 +600,8 @@ def main():
         "outputs_finite": res["outputs_finite"],
         "roofline": res.get("roofline"), "cpu_baseline": cpu, "kernels": res.get("kernels", {}), "also": also,
         "default_semantics": default_semantics, "host_boundary": host,
+        # like-for-like across rounds whatever the default --config is: configs[1] (4096 streams x 48 frames) under a key that never moves
+        "configs1_value": (res["value"] if args.config == 1 and S == CONFIGS[1]["streams"] else (also or {}).get("configs[1]", {}).get("value")),
     }
     if args.dry_run:
         line["dry_run"] = "gloo + CPU tensors + NNN_LIBRARY build: plumbing only, numbers meaningless"

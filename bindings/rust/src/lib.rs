@@ -16,6 +16,7 @@ extern "C" {
     fn nnn_model_from_bytes(bytes: *const u8, len: usize) -> *mut RawModel;
     fn nnn_model_default() -> *mut RawModel;
     fn nnn_model_free(m: *mut RawModel);
+    fn nnn_model_clone(m: *const RawModel) -> *mut RawModel;
     fn nnn_batch_create(model: *const RawModel, n_streams: c_int, device: c_int) -> *mut RawBatch;
     fn nnn_batch_destroy(b: *mut RawBatch);
     fn nnn_batch_reset(b: *mut RawBatch) -> c_int;
@@ -111,6 +112,14 @@ impl Default for RnnModel {
         RnnModel(unsafe { nnn_model_default() })
     }
 }
+/// `#[derive(Clone)]` in the reference (src/rnn.rs:54): an independent copy of the parameters (`nnn_model_clone`).
+impl Clone for RnnModel {
+    fn clone(&self) -> RnnModel {
+        let p = unsafe { nnn_model_clone(self.0 as *const RawModel) };
+        assert!(!p.is_null(), "nnnoiseless-mi355x: model clone failed");
+        RnnModel(p)
+    }
+}
 impl Drop for RnnModel {
     fn drop(&mut self) {
         unsafe { nnn_model_free(self.0) }
@@ -123,6 +132,10 @@ pub struct BatchDenoiser {
     n: usize,
 }
 unsafe impl Send for BatchDenoiser {}
+// The reference asserts `DenoiseState: Send + Sync` (src/denoise.rs:125).  Every call that touches the batch's state takes
+// `&mut self`; what `&self` reaches (`fault`, `device_bytes`) only reads fields the backend never changes after creation or
+// a word of page-locked memory the device writes: sharing a `&BatchDenoiser` between threads is sound.
+unsafe impl Sync for BatchDenoiser {}
 
 /// `struct nnn_batch_opts` (include/nnn_batch.h)
 #[repr(C)]

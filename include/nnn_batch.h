@@ -40,6 +40,9 @@ RNNModel *nnn_model_default(void);
 long nnn_convert_rnnoise_text(const char *text, size_t len, uint8_t *out, size_t cap);
 RNNModel *nnn_model_from_rnnoise_text(const char *text, size_t len);
 void nnn_model_free(RNNModel *m);
+/* RnnModel is Clone (#[derive(Clone)], src/rnn.rs:54): an independent copy of the parameters, freed with nnn_model_free.
+ * NULL on a NULL model. */
+RNNModel *nnn_model_clone(const RNNModel *m);
 /* shape[0..5] = input_dense in/out, vad/noise/denoise GRU neurons, gains out; shape[6..11] = activations */
 void nnn_model_shape(const RNNModel *m, int32_t shape[12]);
 
@@ -56,7 +59,10 @@ nnn_batch *nnn_batch_create_grouped(const RNNModel *const *models, const int *gr
  * and history rings for it (360 KB per stream).  A host whose calls are short says so here and gets a batch sized for groups of
  * that many frames: a real-time host that ticks ONE 10 ms frame per call passes 1 and pays 33 KB per stream (the reference's
  * DenoiseState is 10.3 KB, src/features.rs:18-46), i.e. 8.7 million live streams' worth of HBM instead of 800 thousand.  Longer
- * calls still work on such a batch, cut into groups of at most this many frames (slower, same results).  0 = default. */
+ * calls still work on such a batch, cut into groups of at most this many frames (slower, same results).  0 = default;
+ * values above 24 (the kernels' longest group) are rejected.  How many groups a batch keeps in flight (1, or 2 under
+ * NNN_LANES >= 2 / NNN_SCHED=stages) is fixed when it is created -- nnn_batch_set_schedule on an existing batch works with
+ * the scratch sets and ring slots that are there -- and is part of what a state snapshot must match. */
 typedef struct nnn_batch_opts {
     int max_group_frames;
     int reserved[7];                     /* must be zero */
@@ -134,7 +140,8 @@ int nnn_batch_synchronize(nnn_batch *b);
 /* 1 if a pitch workgroup of an earlier call ran out of patience waiting for the previous frame's result (the frames of a group
  * run side by side below 16 384 streams and hand the last pitch from workgroup to workgroup): the state of the affected streams
  * is invalid from that frame on.  Work items are handed out in the order workgroups start, so the wait cannot deadlock whatever
- * order the hardware dispatches them in; the condition exists as a safety net.  It is sticky: every later process call and
+ * order the hardware dispatches them in; the condition exists as a safety net, and what trips it is wall time (10 s without the
+ * predecessor's flag, NNN_HANDOFF_TIMEOUT_MS), not a spin count: a predecessor slowed by a shared GPU is waited for.  It is sticky: every later process call and
  * nnn_batch_synchronize fail with it until nnn_batch_reset or nnn_batch_load_state.  Cheap (a read of page-locked host memory the
  * device writes into): callers that synchronise their own stream instead of calling nnn_batch_synchronize can poll it. */
 int nnn_batch_fault(const nnn_batch *b);

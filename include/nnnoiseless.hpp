@@ -46,6 +46,13 @@ class RnnModel {
     }
     static RnnModel default_model() { return RnnModel(nnn_model_default()); }
     const RNNModel *raw() const { return m_.get(); }
+    // a copy with its own storage (nnn_model_clone); plain copies of this class share one immutable model
+    RnnModel deep_clone() const
+    {
+        RNNModel *m = nnn_model_clone(m_.get());
+        if (!m) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+        return RnnModel(m);
+    }
 
   private:
     explicit RnnModel(RNNModel *m) : m_(m, nnn_model_free) {}

@@ -103,6 +103,15 @@ class RnnModel:
         lib = lib or library()
         return cls(lib.L.nnn_model_default(), lib)
 
+    def clone(self):
+        """`RnnModel: Clone` (src/rnn.rs:54): an independent copy."""
+        h = self._lib.L.nnn_model_clone(self._h)
+        if not h:
+            raise RuntimeError(self._lib.error())
+        return RnnModel(h, self._lib)
+
+    __copy__ = clone
+
     def shape(self):
         s = (C.c_int32 * 12)()
         self._lib.L.nnn_model_shape(self._h, s)

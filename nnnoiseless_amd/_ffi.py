@@ -11,7 +11,7 @@ TAPS = ["filtered", "xlp", "ac", "lpc2", "xcorr1", "best1", "xcorr2c", "pitch_se
 
 # every symbol the two headers declare (tests check that the built library exports all of them)
 BATCH_SYMBOLS = [
-    "nnn_model_from_bytes", "nnn_model_default", "nnn_model_free", "nnn_model_shape",
+    "nnn_model_from_bytes", "nnn_model_default", "nnn_model_free", "nnn_model_clone", "nnn_model_shape",
     "nnn_convert_rnnoise_text", "nnn_model_from_rnnoise_text",
     "nnn_batch_create", "nnn_batch_create_grouped", "nnn_batch_destroy", "nnn_batch_num_streams", "nnn_batch_reset",
     "nnn_batch_process_device", "nnn_batch_process_host", "nnn_batch_process_pcm_device", "nnn_batch_process_pcm_host",
@@ -65,6 +65,8 @@ class Library:
         L.nnn_model_from_bytes.argtypes = [C.c_char_p, sz]
         L.nnn_model_default.restype = vp
         L.nnn_model_free.argtypes = [vp]
+        L.nnn_model_clone.restype = vp
+        L.nnn_model_clone.argtypes = [vp]
         L.nnn_model_shape.argtypes = [vp, C.POINTER(C.c_int32)]
         L.nnn_convert_rnnoise_text.restype = C.c_long
         L.nnn_convert_rnnoise_text.argtypes = [C.c_char_p, sz, vp, sz]

@@ -123,6 +123,7 @@ struct nnn_batch {
     std::vector<int> prev_first;
     bool inputs_ready = false;      // the caller's promise that a call's input is final when the call is made
     volatile int *fault_host = nullptr;   // host view of Buffers::fault (page-locked, mapped): a hand-off that never arrived
+    long long handoff_ticks = 0;    // Buffers::handoff_ticks outside the test hook
     unsigned tickets = 0;           // work items handed out so far by chained k_pitch launches (Buffers::ticket never restarts)
     unsigned *frame_log = nullptr;  // nnn_batch_set_frame_log: the next frame's record (device), and the frames that still have room
     size_t frame_log_left = 0;
@@ -426,6 +427,12 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
         b.fault = (int *)dp;
     }
     HIPCHK(dalloc(h, &b.ticket, 1, false));
+    {
+        const char *e = getenv("NNN_HANDOFF_TIMEOUT_MS");
+        const long long ms = e && atoll(e) > 0 ? atoll(e) : 10000;
+        h->handoff_ticks = ms * 100000ll;   // 100 MHz
+        b.handoff_ticks = h->handoff_ticks;
+    }
     HIPCHK(hipMalloc((void **)&h->sp_tab, 2 * 64 * sizeof(StepParams)));   // two tables: consecutive calls alternate
     h->sp_tab_cap = 64;
     // tables
@@ -510,6 +517,10 @@ extern "C" nnn_batch *nnn_batch_create_opts(const RNNModel *const *models, const
             }
         if (opts->max_group_frames < 0) {
             fail("nnn_batch_opts.max_group_frames must not be negative");
+            return nullptr;
+        }
+        if (opts->max_group_frames > GROUP) {
+            fail("nnn_batch_opts.max_group_frames must not exceed %d (the kernels' longest frame group)", GROUP);
             return nullptr;
         }
         if (opts->max_group_frames > 0) gmax = opts->max_group_frames;
@@ -709,6 +720,7 @@ struct Launcher {
 // stage `s` of the group of `g` frames in scratch sets set0 .. set0 + g - 1, parameters at sp0[0..g), on stream `st`
 static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams *sp0, hipStream_t st, bool prof)
 {
+    if (g <= 0) return;   // (never a launch with an empty grid)
     const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad, ug = (unsigned)g;
     const Buffers &b = h->b[set0];
     Launcher L{h, st, prof};
@@ -841,6 +853,8 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     if (pipe && h->ramp == 0) {
         int k = 2;
         while ((n_frames + k - 1) / k > h->gmax) k += 2;
+        // (a batch sized for one-frame groups and an odd frame count: the even count overshoots the frames -- never an empty group)
+        if (k > n_frames) k = n_frames;
         for (int i = 0; i < k; i++) sizes.push_back(n_frames / k + (i < n_frames % k ? 1 : 0));
     }
     for (int rem = sizes.empty() ? n_frames : 0, k = 0; rem > 0; k++) {
@@ -1335,7 +1349,10 @@ extern "C" int nnn_batch_debug_withhold_flag(nnn_batch *h, int frames_ahead)
 {
     if (!h) return fail("null batch");
     const int seq = frames_ahead < 0 ? 0 : (int)((h->frame_count + (uint64_t)frames_ahead) & 0x3fffffffu) + 1;
-    for (int set = 0; set < h->nset; set++) h->b[set].dbg_withhold = seq;
+    for (int set = 0; set < h->nset; set++) {
+        h->b[set].dbg_withhold = seq;
+        h->b[set].handoff_ticks = seq ? 20000000ll : h->handoff_ticks;   // the withheld flag is given up on after 0.2 s
+    }
     return 0;
 }
 extern "C" int nnn_batch_set_pipeline(nnn_batch *h, int on)
@@ -1582,6 +1599,15 @@ extern "C" RNNModel *nnn_model_from_rnnoise_text(const char *text, size_t len)
     return nnn_model_from_bytes(bytes.data(), bytes.size());
 }
 extern "C" void nnn_model_free(RNNModel *m) { delete m; }
+// RnnModel is Clone in the reference (#[derive(Clone)], src/rnn.rs:54): an independent copy of the parameters
+extern "C" RNNModel *nnn_model_clone(const RNNModel *m)
+{
+    if (!m) {
+        fail("null model");
+        return nullptr;
+    }
+    return new RNNModel(*m);
+}
 extern "C" void nnn_model_shape(const RNNModel *m, int32_t s[12])
 {
     s[0] = m->input_dense.nb_inputs; s[1] = m->input_dense.nb_neurons; s[2] = m->vad_gru.nb_neurons;

@@ -1144,9 +1144,16 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             if (chain && f > 0) {
                 // the previous frame of these streams is another workgroup's: wait for its flag, then take its pitch and gain
                 const int *flag = (const int *)NNN_TIF(b, pflag, 1, f - 1, tile, q0);
-                int spins = 0;
-                while (flag_read(flag) != seq0 + f - 1 && spins < (1 << 22)) { spins++; chain_pause(); }
-                if (spins >= (1 << 22)) *b.fault = 1;   // never seen (cannot happen, see the ticket order above): reported to the host, not hung on
+                // (the ticket order guarantees the wait ends; the limit is wall time on the constant clock, not a spin count, so that a
+                // predecessor slowed by a shared GPU or a stalled queue is waited for: giving up invalidates the streams' state for good)
+                const long long t_wait = realtime_ticks();
+                unsigned spins = 0;
+                bool lost = false;
+                while (flag_read(flag) != seq0 + f - 1 && !lost) {
+                    chain_pause();
+                    if ((++spins & 255u) == 0 && realtime_ticks() - t_wait > b.handoff_ticks) lost = true;
+                }
+                if (lost) *b.fault = 1;   // never seen (cannot happen, see the ticket order above): reported to the host, not hung on
                 last_period = NNN_TIF(b, pitch, 1, f - 1, tile, sl)[0];
                 last_gain = NNN_TIF(b, pgain, 1, f - 1, tile, sl)[0];
             }

@@ -136,6 +136,9 @@ struct Buffers {
                              //      mapped into the device, so the host sees it without a copy (checked at every call, sticky until reset)
     unsigned *ticket;        // [1]  chained k_pitch launches: workgroups take their work item in the order they START (see k_pitch)
     int dbg_withhold;        // test hook: the frame number whose hand-off flag is never published (0 = none)
+    long long handoff_ticks; // how long a pitch workgroup waits for its predecessor's flag before it raises the fault: ticks of the 100 MHz
+                             // constant clock (s_memrealtime), i.e. wall time -- a slow but live predecessor (a shared GPU, a debugger
+                             // stall) is not a lost hand-off; 10 s unless NNN_HANDOFF_TIMEOUT_MS says otherwise, 0.2 s under the test hook
     const int *seg;          // [192] band-sum segments: k0[64], count[64], first segment[32], segments[32] per interval
     const void *fft_img;     // the transform kernels' LDS tables (twiddles, band weights, bands, segments) in their LDS layout (FftLds)
     float wnorm;

@@ -130,5 +130,7 @@ __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballo
 // bit l: the predicate on lane l (wave-uniform)
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ void chain_pause() { __builtin_amdgcn_s_sleep(4); }
+// the constant 100 MHz clock (s_memrealtime): wall time, whatever the shader clock does
+__device__ __forceinline__ long long realtime_ticks() { return (long long)__builtin_amdgcn_s_memrealtime(); }
 
 }  // namespace nnn

@@ -3,6 +3,7 @@
 // with the fragment layout documented for v_mfma_f32_16x16x32_bf16.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <time.h>
 
 namespace nnn {
 
@@ -93,6 +94,12 @@ static inline unsigned long long wave_ballot(bool p)
 }
 static inline bool wave_any(bool) { return true; }   // (a skipped no-op update and an executed one leave the same state)
 static inline void chain_pause() {}
+static inline long long realtime_ticks()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 100000000ll + ts.tv_nsec / 10;
+}
 static inline void __threadfence() {}
 
 }  // namespace nnn

@@ -58,6 +58,30 @@ def test_model_container_rules(lib, weights_bytes):
         assert nn.RnnModel.from_bytes(bad) is None
 
 
+def test_model_clone_is_an_independent_copy(lib, weights_bytes):
+    """`RnnModel: Clone` (src/rnn.rs:54) through nnn_model_clone: same parameters, its own storage -- the copy outlives the
+    original; a NULL model gives NULL and an error text, not a crash."""
+    import copy
+    import nnnoiseless_amd as nn
+    sh = nn.RnnModel.from_bytes(open(os.path.join(GOLDEN, "sh.rnn"), "rb").read())
+    c = sh.clone()
+    assert c._h != sh._h and c.shape() == sh.shape()
+    want = sh.shape()
+    del sh
+    assert c.shape() == want and copy.copy(c).shape() == want
+    assert not lib.L.nnn_model_clone(None)
+    assert b"null model" in lib.L.nnn_last_error()
+
+
+def test_rust_facade_keeps_clone_and_sync():
+    """The Rust façade (never compiled here: no toolchain) must keep what the reference promises: `RnnModel: Clone`
+    (src/rnn.rs:54) and `DenoiseState: Clone + Send + Sync` (src/denoise.rs:36,125).  A text check is all this image allows."""
+    src = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
+    for needle in ("impl Clone for RnnModel", "fn nnn_model_clone(", "unsafe impl Sync for BatchDenoiser", "unsafe impl Send for BatchDenoiser",
+                   "#[derive(Clone)]\npub struct DenoiseState(BatchDenoiser);"):
+        assert needle in src, needle
+
+
 def test_model_from_file_closes_and_parses(lib, tmp_path, weights_bytes):
     """rnnoise_model_from_file takes ownership of the FILE* (src/capi.rs:93-94)."""
     libc = C.CDLL(None)

@@ -156,6 +156,30 @@ def test_batches_sized_for_short_groups(hostsim_lib, gmax):
         nn.BatchDenoiser(S, lib=hostsim_lib, max_group_frames=0)
 
 
+@pytest.mark.parametrize("n_frames", [33, 35, 47])
+def test_long_odd_calls_on_a_batch_sized_for_ticks(hostsim_lib, n_frames):
+    """a pipelined call (32 frames or more) with an ODD frame count on a max_group_frames = 1 batch used to be
+    cut into an even number of groups, one more than there are frames -- an empty group, launches with an empty grid and scratch
+    set -1.  `Longer calls still work on such a batch` (include/nnn_batch.h): same bits as the default batch, taps readable."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    S = 6
+    x = make_streams(5, S, n_frames)
+    want, want_vad = nn.BatchDenoiser(S, lib=hostsim_lib).process(x)
+    bd = nn.BatchDenoiser(S, lib=hostsim_lib, max_group_frames=1)
+    got, vad = bd.process(x)
+    assert np.array_equal(got, want) and np.array_equal(vad, want_vad)
+    assert bd.tap("pitch").shape == (S, 1) and not bd.fault()
+
+
+def test_oversize_group_request_is_refused(hostsim_lib):
+    """max_group_frames above the kernels' longest group (24) used to be clamped silently."""
+    import nnnoiseless_amd as nn
+    with pytest.raises(RuntimeError, match="must not exceed 24"):
+        nn.BatchDenoiser(6, lib=hostsim_lib, max_group_frames=25)
+    assert nn.BatchDenoiser(6, lib=hostsim_lib, max_group_frames=24).max_group_frames() == 24
+
+
 def test_xcd_tile_mapping_changes_no_bits(hostsim_lib):
     """The tiles of a batch that come in eights are dealt to the XCDs -- tile t's blocks to XCD t mod 8 in k_lpc, k_pitch, k_fft_xp,
     k_rnn / k_rnn_wf and k_synth, i.e. another block -> stream mapping --, the last few keep block order.  The same streams give the
