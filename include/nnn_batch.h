@@ -150,7 +150,7 @@ int nnn_batch_debug_withhold_flag(nnn_batch *b, int frames_ahead);
 
 /* Parity taps: intermediate quantities of the most recent frame, copied to the host as
  * [n_streams][len] (float32 or int32, see nnn_tap_info).  Test/diagnostic interface.  Everything inside the pitch kernel
- * (XLP, XCORR1, BEST1, XCORR2C, PITCH_SEARCH), P beyond bin 399 and FEATURES are quantities the kernels keep on
+ * (XLP, XCORR1, BEST1, XCORR2C, PITCH_SEARCH), X, P and FEATURES are quantities the kernels keep on
  * chip: they are stored to device memory only after nnn_batch_set_taps(batch, 1) (which also allocates their arrays), and
  * reading them without it is an error. */
 enum nnn_tap {
@@ -209,6 +209,13 @@ int nnn_batch_set_pipeline(nnn_batch *b, int on);
  * Outputs stay ordered on the caller's stream exactly as without it; results are bit-identical.  0 (default): a call's
  * input is read only after everything enqueued on its stream before the call. */
 int nnn_batch_set_inputs_ready(nnn_batch *b, int on);
+/* Which kernels run the part of a frame behind the pitch analysis.  0: transforms (k_fft_xp) -> RNN (k_rnn / k_rnn_wf) -> synthesis
+ * (k_synth), the spectra crossing device memory in between.  1 (default): groups of ONE frame -- the real-time host ticking 10 ms per
+ * call, the reference's primary use (src/capi.rs:75-85, src/signal.rs:102-104) -- take the fused back end instead (k_back: one launch,
+ * both spectra in registers from their transforms to the inverse transform); 2: every group does.  3 / 4: the fused kernel's RNN
+ * stretch alone replaces the RNN kernels for one-frame / all groups (measurement).  Environment: NNN_BACK.  The RNN's bits are the
+ * same whichever kernel runs it; what comes out of the transforms agrees to rounding (multiply-adds may fuse differently). */
+int nnn_batch_set_back_end(nnn_batch *b, int mode);
 /* How a pipelined call uses the internal streams: mode 0 = not at all (as set_pipeline(0)); 1 = "lanes": the high-pass
  * chain on its own stream, the other four stages of group k on lane k mod `lanes` (1..4; default 2; lane 0 is the caller's stream);
  * 2 = "stages": one stream per stage, every stream a chain of groups.  Environment: NNN_SCHED=seq|lanes|stages,

@@ -268,6 +268,11 @@ class BatchDenoiser:
     def set_graph(self, on):
         self._lib.check(self._lib.L.nnn_batch_set_graph(self._h, int(on)))
 
+    def set_back_end(self, mode):
+        """0: transforms -> RNN -> synthesis as three launches; 1 (default): one-frame groups take the fused back end (k_back);
+        2: every group; 3 / 4: the fused kernel's RNN stretch alone as the RNN kernel (include/nnn_batch.h nnn_batch_set_back_end)."""
+        self._lib.check(self._lib.L.nnn_batch_set_back_end(self._h, int(mode)))
+
     def set_pipeline(self, on):
         self._lib.check(self._lib.L.nnn_batch_set_pipeline(self._h, int(on)))
 

@@ -20,7 +20,7 @@ BATCH_SYMBOLS = [
     "nnn_tap_info", "nnn_batch_read_tap", "nnn_batch_set_profiling", "nnn_batch_num_kernels",
     "nnn_batch_kernel_name", "nnn_batch_read_kernel_times", "nnn_batch_set_graph", "nnn_batch_set_pipeline", "nnn_batch_read_stamps",
     "nnn_host_alloc", "nnn_host_free", "nnn_last_error", "nnn_batch_fault", "nnn_batch_debug_withhold_flag", "nnn_batch_set_frame_log",
-    "nnn_batch_create_opts", "nnn_batch_max_group_frames", "nnn_batch_device_bytes",
+    "nnn_batch_create_opts", "nnn_batch_max_group_frames", "nnn_batch_device_bytes", "nnn_batch_set_back_end",
 ]
 TRAIN_SYMBOLS = [
     "nnn_train_create", "nnn_train_destroy", "nnn_train_reset", "nnn_train_process_device", "nnn_train_process_host",
@@ -108,7 +108,7 @@ class Library:
         L.nnn_batch_set_inputs_ready.argtypes = [vp, i32]
         for name, at in (("nnn_batch_set_frame_log", [vp, vp, sz]), ("nnn_batch_fault", [vp]), ("nnn_batch_debug_withhold_flag", [vp, i32]),
                          ("nnn_batch_create_opts", [C.POINTER(vp), C.POINTER(i32), i32, i32, C.POINTER(BatchOpts)]),
-                         ("nnn_batch_max_group_frames", [vp]), ("nnn_batch_device_bytes", [vp])):
+                         ("nnn_batch_max_group_frames", [vp]), ("nnn_batch_device_bytes", [vp]), ("nnn_batch_set_back_end", [vp, i32])):
             if hasattr(L, name):   # (experimental builds of older sources, loaded through NNN_LIBRARY, lack the newest entry points)
                 getattr(L, name).argtypes = at
         if hasattr(L, "nnn_batch_create_opts"):

@@ -8,7 +8,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libnnnoiseless_mi355x.so")
 WEIGHTS = os.path.join(HERE, "data", "weights.rnn")
 SOURCES = ["nnn_batch.hip", "nnn_resample.hip", "nnn_model.cpp", "rnnoise_capi.cpp"]
-DEPS = SOURCES + ["nnn_kernels.hip", "nnn_layout.h", "nnn_model.h", "nnn_mfma.h"]
+DEPS = SOURCES + ["nnn_kernels.hip", "nnn_back.hip", "nnn_layout.h", "nnn_model.h", "nnn_mfma.h"]
 
 
 def _stale():

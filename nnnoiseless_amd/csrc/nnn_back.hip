@@ -1,0 +1,664 @@
+// nnn_back.hip -- the fused back end of the batched process_frame path: everything of a frame behind the pitch analysis in ONE
+// launch per 16-stream block -- transform_input x 2, band energies and correlation, the 42 features, the RNN, pitch filter, gains,
+// inverse transform and overlap-add (ref: src/denoise.rs:100-114, src/features.rs:119-275, src/rnn.rs:343-379) -- with the two spectra
+// X and P held in the registers of the stream's wave from their transforms to the synthesis.  In the unfused pipeline (k_fft_xp ->
+// k_rnn_wf -> k_synth) they cross HBM once each way around the RNN: 14 of the path's 28 KB per stream-frame, and two launch
+// boundaries on the critical path of a one-frame (real-time) call.
+//
+// Block = 16 consecutive streams of a tile = 16 waves.  A frame is three stretches:
+//   wave = stream   the two windowed transforms, band sums, feature head (the code of k_fft_xp, FUSED variant of transform_inputs),
+//                   then the stream's own feature stage on all 64 lanes of its wave (cepstral ring and pair distances in LDS)
+//   16 waves, one layer at a time
+//                   the RNN on the 16 rows (one MFMA M-tile): every GRU is split into (neuron block, gate) units dealt over the
+//                   16 waves -- z and r gates with their recurrent and input products, the candidate's input part -- then, behind
+//                   a barrier, the candidate's recurrent part on r * state and the update.  Per gate the MFMAs run in the order
+//                   k_rnn and k_rnn_wf use (bias, recurrent k-steps, input k-steps; planes hi, mid, lo inside a k-step), so the
+//                   three kernels give the same bits.  k_rnn runs a (neuron block, all three gates) unit per wave: at 16 rows six
+//                   of its eight waves carry 63 dependent MFMAs and 32 activations each per phase; here a wave carries at most 33
+//                   and 8.
+//   wave = stream   pitch filter, band renormalisation, gains, inverse transform, overlap-add (the code of k_synth on the
+//                   transforms' own bin order), output conversion.
+// The launch loops over the g frames of its group: GRU states (LDS planes), cepstral ring and pair distances (LDS), overlap memory
+// (registers) stay on chip from frame to frame.  FUSED = false is the RNN stretch alone between k_fft_xp and k_synth (features from
+// and gains to the scratch arrays): the stand-alone measurement of the 16-wave RNN step, and a one-frame RNN kernel in its own right.
+#pragma once
+#include "nnn_kernels.hip"
+
+namespace nnn {
+
+constexpr int BK_ROWS = 16, BK_WAVES = 16, BK_T = 64 * BK_WAVES;
+constexpr int BK_ZW = 136;       // row stride (floats) of the z-gate buffer: up to 128 neuron columns + 8
+constexpr int BK_CW = 32;        // row stride of the per-stream cepstrum staging and pair distances (28 used)
+constexpr int BK_GW = 48;        // per-stream gains handed to the synthesis: raw [0, 22), smoothed [24, 46)
+
+// The kernel is compiled for a SHAPE CLASS -- the layer sizes (input dense, vad / noise / denoise GRU neurons) as compile-time constants,
+// so that every LDS offset, row stride, k-step count and unit count is an immediate and every k-step loop unrolls; with the plan as
+// run-time values (k_rnn's way) a 16-wave kernel that also holds two spectra per wave runs out of scalar registers (500 scalar spills
+// into vector registers in the first build).  bk_make_plan restates nnn_model_pack's column plan and packing offsets (nnn_model.cpp)
+// for given sizes; the host compares it with the model's own plan field by field and takes the unfused kernels for any model outside
+// the compiled classes.  Activation kinds stay run-time values (the models of a class differ in them).
+constexpr int bk_pad(int v, int m) { return (v + m - 1) / m * m; }
+constexpr int bk_ks(int cols) { return (cols + 31) / 32; }
+constexpr GemmDesc bk_gd(int &at, int n, int ngates, int ksteps, int kbase)
+{
+    GemmDesc g{at, ksteps, kbase, ngates};
+    at += bk_pad(n, 16) / 16 * ngates * ksteps * 64;
+    return g;
+}
+constexpr LayerDesc bk_ld(GemmDesc in, GemmDesc rec, int n, int &bias_at, int nbias, int out_col)
+{
+    LayerDesc L{in, rec, n, bk_pad(n, 16) / 16, 0, bias_at, out_col};
+    bias_at += nbias;
+    return L;
+}
+constexpr RnnPlan bk_make_plan(int nd, int nv, int nn, int ndn)
+{
+    const int cN = 0, cV = bk_pad(nn, 8), cF = cV + bk_pad(nv, 8), cD = cF + 48, NF = 42;
+    int at = 0, bias = 0;
+    RnnPlan p{};
+    const GemmDesc none{0, 0, 0, 0};
+    const GemmDesc d_in = bk_gd(at, nd, 1, 2, cF);
+    p.dense = bk_ld(d_in, none, nd, bias, nd, cD);
+    const GemmDesc v_in = bk_gd(at, nv, 3, bk_ks(nd), cD), v_rec = bk_gd(at, nv, 3, bk_ks(nv), 0);
+    p.vad = bk_ld(v_in, v_rec, nv, bias, 3 * nv, cV);
+    const GemmDesc n_in = bk_gd(at, nn, 3, bk_ks(cD + nd - cV), cV), n_rec = bk_gd(at, nn, 3, bk_ks(nn), 0);
+    p.noise = bk_ld(n_in, n_rec, nn, bias, 3 * nn, cN);
+    const GemmDesc dn_in = bk_gd(at, ndn, 3, bk_ks(cF + NF), 0), dn_rec = bk_gd(at, ndn, 3, bk_ks(ndn), 0);
+    p.dn = bk_ld(dn_in, dn_rec, ndn, bias, 3 * ndn, 0);
+    const GemmDesc o_in = bk_gd(at, 22, 1, bk_ks(ndn), 0);
+    p.out = bk_ld(o_in, none, 22, bias, 22, 0);
+    p.vo_w = bias;
+    p.vo_b = bias + nv;
+    p.act_vo = 0;
+    p.cF = cF;
+    p.cV = cV;
+    int width = bk_pad(ndn, 8);
+    const GemmDesc all[5] = {d_in, v_in, n_in, dn_in, o_in};
+    for (int i = 0; i < 5; i++) width = width > all[i].kbase + 32 * all[i].ksteps ? width : all[i].kbase + 32 * all[i].ksteps;
+    p.in_w = bk_pad(width, 16) + 8;
+    const int widest = nv > nn ? (nv > ndn ? nv : ndn) : (nn > ndn ? nn : ndn);
+    p.rec_w = bk_pad(32 * bk_ks(widest), 16) + 8;
+    return p;
+}
+// everything of two plans but the activation kinds
+inline bool bk_same_shape(const RnnPlan &a, const RnnPlan &b)
+{
+    auto gd = [](const GemmDesc &x, const GemmDesc &y) { return x.wofs == y.wofs && x.ksteps == y.ksteps && x.kbase == y.kbase && x.ngates == y.ngates; };
+    auto ld = [&](const LayerDesc &x, const LayerDesc &y) {
+        return gd(x.in, y.in) && gd(x.rec, y.rec) && x.n == y.n && x.nb == y.nb && x.bias == y.bias && x.out_col == y.out_col;
+    };
+    return a.in_w == b.in_w && a.rec_w == b.rec_w && a.cF == b.cF && a.cV == b.cV && ld(a.dense, b.dense) && ld(a.vad, b.vad) && ld(a.noise, b.noise) &&
+           ld(a.dn, b.dn) && ld(a.out, b.out) && a.vo_w == b.vo_w && a.vo_b == b.vo_b;
+}
+// the built-in model's class (src/weights.rnn; GregorR's rnnoise-models share it): 24 / 24 / 48 / 96
+struct BkShapeBuiltin { static constexpr RnnPlan plan() { return bk_make_plan(24, 24, 48, 96); } };
+
+// byte offsets into the kernel's dynamic LDS
+struct BackLds {
+    int tab, live, flag, vadl, gout, crs, dcw, cnw, FS, SPv, SPn, SPdn, tbl, U, IN, RS, ZB, Z, part, total;
+    int sw_v, sw_n, sw_dn;
+};
+constexpr int bk_take(int &at, int bytes) { const int r = at; at += (bytes + 15) & ~15; return r; }
+constexpr BackLds back_lds(const RnnPlan &pl, bool fused)
+{
+    BackLds o{};
+    o.sw_v = 32 * pl.vad.rec.ksteps + 8; o.sw_n = 32 * pl.noise.rec.ksteps + 8; o.sw_dn = 32 * pl.dn.rec.ksteps + 8;
+    int at = 0;
+    o.tab = bk_take(at, 256 * 4);
+    o.live = bk_take(at, BK_ROWS * 4);
+    o.flag = bk_take(at, BK_ROWS * 4);
+    o.vadl = bk_take(at, BK_ROWS * 4);
+    o.gout = bk_take(at, BK_ROWS * BK_GW * 4);
+    o.crs = bk_take(at, BK_ROWS * CEPS_MEM * NB * 4);
+    o.dcw = bk_take(at, BK_ROWS * BK_CW * 4);
+    o.cnw = bk_take(at, BK_ROWS * BK_CW * 4);
+    o.FS = bk_take(at, 3 * BK_ROWS * FS_W * 2);
+    o.SPv = bk_take(at, 3 * BK_ROWS * o.sw_v * 2);
+    o.SPn = bk_take(at, 3 * BK_ROWS * o.sw_n * 2);
+    o.SPdn = bk_take(at, 3 * BK_ROWS * o.sw_dn * 2);
+    o.tbl = fused ? bk_take(at, (int)sizeof(FftLds)) : at;
+    o.U = at;
+    // the RNN's per-frame operands ...
+    o.IN = bk_take(at, 3 * BK_ROWS * pl.in_w * 2);
+    o.RS = bk_take(at, 3 * BK_ROWS * pl.rec_w * 2);
+    o.ZB = bk_take(at, BK_ROWS * BK_ZW * 4);
+    const int end_rnn = at;
+    // ... share their space with the transforms' buffers: neither outlives its stretch of the frame
+    at = o.U;
+    o.Z = bk_take(at, fused ? BK_ROWS * NFFT_BUF * 8 : 0);
+    o.part = bk_take(at, fused ? BK_ROWS * 3 * 64 * 4 : 0);
+    o.total = at > end_rnn ? at : end_rnn;
+    return o;
+}
+
+// ---- the feature stage of one frame for one stream on its own wave (ref: src/features.rs:170-219): ring update, the 7 pair distances
+//      the new cepstrum takes part in (lane = partner row), the 42 outputs (lane = output).  Same operations in the same order as
+//      features_row / wf_features; `cnw` holds the frame's cepstrum (22) and pitch-correlation DCT (6).
+__device__ __forceinline__ void bk_features(const Buffers &b, int f, int tile, int trow, int row, int lane, int pitch, bool silent,
+                                            float *crs, float *dcw, const float *cnw, unsigned short *FS, int *live, int &mem_id)
+{
+    float fr = 0.0f;
+    if (!silent) {   // (wave-uniform) "if there's no audio, avoid messing up the state" (ref: src/features.rs:160-166)
+        const int c0 = mem_id, c1 = mem_id < 1 ? CEPS_MEM + mem_id - 1 : mem_id - 1;
+        const int c2 = mem_id < 2 ? CEPS_MEM + mem_id - 2 : mem_id - 2;
+        if (lane < NB) {
+            const float v = cnw[lane];
+            crs[c0 * NB + lane] = v;
+            NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, trow)[(size_t)(c0 * NB + lane) * TILE] = v;
+        }
+        mem_id = mem_id + 1 == CEPS_MEM ? 0 : mem_id + 1;
+        if (lane < CEPS_MEM && lane != c0) {
+            // squared distance of the new row to ring row `lane`, summed over the 22 bands in order (ref: src/features.rs:203-208)
+            const float *rj = crs + lane * NB;
+            float dist = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const float d = cnw[k] - rj[k];
+                dist += d * d;
+            }
+            dcw[pair_index(lane < c0 ? lane : c0, lane < c0 ? c0 : lane)] = dist;
+        }
+        wave_lds_sync();
+        if (lane < NFEAT) {
+            const int k = lane;
+            const int i = k < 6 ? k : (k >= 28 ? k - 28 : (k >= NB ? k - NB : 0));   // band of the delta features
+            const int ic = i < 6 ? i : 0;
+            const float v0 = cnw[k < NB ? k : (k < 34 ? ic : (k < 40 ? NB + (k - 34) : 0))];
+            const float v1 = crs[c1 * NB + ic], v2 = crs[c2 * NB + ic];
+            if (k < 6) fr = v0 + v1 + v2;
+            else if (k < NB) fr = v0;
+            else if (k < NB + 6) fr = v0 - v2;
+            else if (k < NB + 12) fr = v0 - 2.0f * v1 + v2;
+            else if (k < 40) fr = v0;
+            else if (k == 40) fr = 0.01f * ((float)pitch - 300.0f);
+            else fr = spectral_variability(dcw, 0, 1);
+        }
+    }
+    if (lane == 0) live[row] = silent ? 0 : 1;
+    if (lane < NFEAT) {
+        if (b.taps) NNN_TIF(b, feat, NFEAT, f, tile, trow)[(size_t)lane * TILE] = fr;
+        store_split(FS, BK_ROWS * FS_W, row * FS_W + lane, fr);
+    }
+}
+
+// ---- the RNN on 16 rows, 16 waves ---------------------------------------------------------------------------------------------
+struct BkRnn {
+    const float *tab;
+    const int *live;
+    unsigned short *IN, *RS;
+    float *ZB;
+    int in_ps, in_w, rs_ps, rec_w;
+};
+
+// acc += A[16 rows][kbase ..] * B(one gate of one neuron block) over all k-steps and the three activation planes, in gemm_acc's order
+// (k-step major; planes hi, mid, lo inside a k-step): the same chain of MFMAs per output element as k_rnn / k_rnn_wf issue.  `Bg` points
+// at the gate's fragments [k-step][lane].  Written for small code (the kernel holds eight of these per GRU layer): the first KSMAX
+// k-steps' fragments are requested together, each k-step is a uniform branch; the next k-step's operand planes are read before the
+// current one's MFMAs issue.
+struct BkFrags { uint4 f[KSMAX]; };
+__device__ __forceinline__ void bk_frags_load(BkFrags &fr, const GemmDesc &g, const uint4 *__restrict__ Bg, int lane)
+{
+#pragma unroll
+    for (int ks = 0; ks < KSMAX; ks++) fr.f[ks] = ks < g.ksteps ? Bg[ks * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+}
+__device__ __forceinline__ f32x4 bk_gemm(f32x4 acc, const unsigned short *A, int plane_stride, int row_w, const GemmDesc &g,
+                                         const uint4 *__restrict__ Bg, int lane, const BkFrags &fr)
+{
+    const unsigned short *a0 = A + (size_t)(lane & 15) * row_w + g.kbase + 8 * (lane >> 4);
+    uint4 cur[3], nxt[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) cur[pl] = *(const uint4 *)(a0 + (size_t)pl * plane_stride);
+#pragma unroll
+    for (int ks = 0; ks < KSMAX; ks++) {
+        if (ks < g.ksteps) {
+            if (ks + 1 < g.ksteps) {
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) nxt[pl] = *(const uint4 *)(a0 + (size_t)pl * plane_stride + (ks + 1) * 32);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) acc = mfma_16x16x32_bf16(cur[pl], fr.f[ks], acc);
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) cur[pl] = nxt[pl];
+        }
+    }
+#pragma nounroll
+    for (int ks = KSMAX; ks < g.ksteps; ks++) {   // (layers wider than 4 k-steps: fetch as we go)
+        const uint4 bf = Bg[ks * 64 + lane];
+        if (ks + 1 < g.ksteps) {
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) nxt[pl] = *(const uint4 *)(a0 + (size_t)pl * plane_stride + (ks + 1) * 32);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) acc = mfma_16x16x32_bf16(cur[pl], bf, acc);
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) cur[pl] = nxt[pl];
+    }
+    return acc;
+}
+
+// what a candidate unit keeps from the first phase of its layer to the second
+struct BkH {
+    f32x4 acc;
+    int nbi;
+    bool on;
+};
+
+// One GRU layer on the block's 16 waves (ref: src/rnn.rs:292-327).  Units 0 .. 2 nb - 1 are the (neuron block, z | r) pairs: bias,
+// recurrent product on the state planes, input product; z -> ZB, r * state -> RS.  Units 2 nb .. 3 nb - 1 are the candidates: bias +
+// input product in the first phase; behind the barrier the recurrent product on r * state, the activation and the state update, the
+// new state going to the layer's state planes and to its columns of the input matrix.  Wave w takes units w and w + 16 (layers of
+// up to 8 neuron blocks; at most one of a wave's two units is a candidate).  `between` runs on every wave after its first-phase
+// units (work that fits beside them: the vad output on a wave the layer leaves idle).
+template <class Between>
+__device__ __forceinline__ void bk_gru(const LayerDesc &L, const BkRnn &R, unsigned short *SP, int sw, const uint4 *__restrict__ Wq,
+                                       const float *__restrict__ fpar, int wave, int lane, Between &&between)
+{
+    const float scale = 1.0f / 256.0f;
+    const int nzr = 2 * L.nb, units = 3 * L.nb, ps = BK_ROWS * sw, kcols = 32 * L.rec.ksteps;
+    BkH h;
+    h.on = false;
+    h.nbi = 0;
+    h.acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma nounroll
+    for (int rd = 0; rd < 2; rd++) {
+        const int u = wave + BK_WAVES * rd;
+        if (u >= units) break;
+        const bool cand = u >= nzr;
+        const int nbi = cand ? u - nzr : u >> 1, gate = cand ? 2 : (u & 1);
+        const int neuron = nbi * 16 + (lane & 15);
+        const bool nvalid = neuron < L.n;
+        const uint4 *Bin = Wq + L.in.wofs + ((size_t)nbi * 3 + gate) * L.in.ksteps * 64;
+        const uint4 *Brec = Wq + L.rec.wofs + ((size_t)nbi * 3 + gate) * L.rec.ksteps * 64;
+        BkFrags f_rec, f_in;
+        if (!cand) bk_frags_load(f_rec, L.rec, Brec, lane);
+        bk_frags_load(f_in, L.in, Bin, lane);
+        const float bias = nvalid ? fpar[L.bias + gate * L.n + neuron] : 0.0f;
+        f32x4 acc = f32x4{bias, bias, bias, bias};
+        if (!cand) acc = bk_gemm(acc, SP, ps, sw, L.rec, Brec, lane, f_rec);
+        acc = bk_gemm(acc, R.IN, R.in_ps, R.in_w, L.in, Bin, lane, f_in);
+        if (cand) {
+            h.acc = acc;
+            h.nbi = nbi;
+            h.on = true;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int row = 4 * (lane >> 4) + q;
+                const float sg = sigmoid_approx(scale * acc[q], R.tab);
+                if (gate == 0) {
+                    R.ZB[row * BK_ZW + neuron] = sg;
+                } else {
+                    const float so = nvalid ? load_split(SP, ps, row * sw + neuron) : 0.0f;   // the three planes hold the state exactly
+                    const float rs = so * sg;
+                    if (neuron < kcols) store_split(R.RS, R.rs_ps, row * R.rec_w + neuron, rs);
+                    if (nbi == L.nb - 1 && neuron + 16 < kcols) store_split(R.RS, R.rs_ps, row * R.rec_w + neuron + 16, 0.0f);
+                }
+            }
+        }
+    }
+    between();
+    lds_barrier();   // z and r * state complete; every wave is done reading the old state planes and the layer's inputs
+    if (h.on) {
+        const int nbi = h.nbi, neuron = nbi * 16 + (lane & 15);
+        const uint4 *Brec = Wq + L.rec.wofs + ((size_t)nbi * 3 + 2) * L.rec.ksteps * 64;
+        BkFrags f_rec;
+        bk_frags_load(f_rec, L.rec, Brec, lane);
+        const f32x4 acc = bk_gemm(h.acc, R.RS, R.rs_ps, R.rec_w, L.rec, Brec, lane, f_rec);
+        if (neuron < L.n) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int row = 4 * (lane >> 4) + q;
+                const float hh = activate(L.act, scale * acc[q], R.tab);
+                const float z = R.ZB[row * BK_ZW + neuron], so = load_split(SP, ps, row * sw + neuron);
+                float snew = z * so + (1.0f - z) * hh;
+                snew = R.live[row] ? snew : so;   // silent frames leave the state alone (ref: src/denoise.rs:100)
+                store_split(R.IN, R.in_ps, row * R.in_w + L.out_col + neuron, snew);
+                store_split(SP, ps, row * sw + neuron, snew);
+            }
+        }
+    }
+    lds_barrier();
+}
+
+// dense layer: neuron block w on wave w; sink(row, neuron, value, q) with row = 4 (lane >> 4) + q
+template <class Sink>
+__device__ __forceinline__ void bk_dense(const LayerDesc &L, const BkRnn &R, const uint4 *__restrict__ Wq, const float *__restrict__ fpar, int wave,
+                                         int lane, Sink &&sink)
+{
+#pragma nounroll
+    for (int nbi = wave; nbi < L.nb; nbi += BK_WAVES) {
+        const int neuron = nbi * 16 + (lane & 15);
+        const uint4 *Bnb = Wq + L.in.wofs + (size_t)nbi * L.in.ksteps * 64;
+        BkFrags fr;
+        bk_frags_load(fr, L.in, Bnb, lane);
+        const float bv = neuron < L.n ? fpar[L.bias + neuron] : 0.0f;
+        const f32x4 acc = bk_gemm(f32x4{bv, bv, bv, bv}, R.IN, R.in_ps, R.in_w, L.in, Bnb, lane, fr);
+        if (neuron < L.n) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) sink(4 * (lane >> 4) + q, neuron, activate(L.act, acc[q] * (1.0f / 256.0f), R.tab), q);
+        }
+    }
+}
+
+#if NNN_FFT_CONTRACT
+#pragma clang fp contract(fast)   // (the synthesis: downstream of the transforms, as k_synth)
+#endif
+// ---- pitch filter, band renormalisation, gains, inverse transform, overlap-add for the stream of this wave (ref: src/features.rs:223-275,
+//      src/denoise.rs:103-114): k_synth's frame body on spectra that are already in the wave's registers, in the transforms' own
+//      bin order (rfft_slot_bin).  b_* are the lane's band (lane < NB) quantities.
+__device__ __forceinline__ void bk_synth(const Buffers &b, const StepParams *sp, int f, int tile, int sl, int s, int lane, const FftLds &t, float2 *A,
+                                         float *r, float2 (&Xr)[8], const float2 (&Pk)[8], float b_ex, float b_ep, float b_xp, float b_graw,
+                                         float b_g, float vadv, bool live, float *sm)
+{
+    // the overlap memory of the stream as sample pairs (ref: src/features.rs:271-274): read and written once per frame here -- held in
+    // registers across a group's frames (k_synth's way) it costs eight of the 128 registers a wave of a 16-wave block has, on top
+    // of the two spectra, and the block's streams re-read it from the L2 of their own compute unit's XCD
+    float2 smv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int n = lane + 64 * u;
+        smv[u] = n < FRAME / 2 ? ((const float2 *)sm)[n] : make_float2(0.0f, 0.0f);
+    }
+    float *ebuf = (float *)A, *r2 = r + NB, *gg = r + 2 * NB;
+    float *vad_out = sp->vad;
+    const int fmt = sp->fmt;
+    const int ch = sp->channels, grp = s / ch, elem = pcm_elem_bytes(fmt), sstride = ch * elem;
+    char *o = sp->out + (long long)grp * sp->group_stride + (long long)(s - grp * ch) * elem;
+    const bool store = s < b.S && !sp->discard;
+    const bool pair_ok = ch == 1 && (((size_t)o) & (size_t)(2 * elem - 1)) == 0;
+    int bmask = 1 << NB;             // lane 0: this frame's branch mask (bit 22: silent)
+    if (live) {
+        const bool up = b_xp > b_graw;   // the branch the parity tests compare (ref: src/features.rs:227)
+        const int mask = (int)(wave_ballot(up && lane < NB) & ((1ull << NB) - 1));   // bit i: band i took `exp > g`
+        if (lane < NB) {
+            float v;
+            if (up) v = 1.0f;
+            else {
+                float exp_sq = b_xp * b_xp, g_sq = b_graw * b_graw;
+                v = exp_sq * (1.0f - g_sq) / (0.001f + g_sq * (1.0f - exp_sq));
+            }
+            v = sqrtf(fminf(fmaxf(v, 0.0f), 1.0f));
+            v *= sqrtf(b_ex / (1e-8f + b_ep));
+            r[lane] = v;
+            gg[lane] = b_g;
+        }
+        wave_lds_sync();
+        if (lane == 0) {
+            NNN_TIF(b, branch, 1, f, tile, sl)[0] = mask;
+            bmask = mask;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = rfft_slot_bin(lane, u);
+            if (k >= 0) {
+                float2 X = Xr[u];
+                const float2 P = k < 400 ? Pk[u] : make_float2(0.0f, 0.0f);   // from bin 400 up the filter gain is zero
+                const float rf = interp_gain(r, k, t.frac, t.band);
+                X.x = X.x + P.x * rf;
+                X.y = X.y + P.y * rf;
+                Xr[u] = X;
+                if (k < 400) ebuf[bsk(k)] = X.x * X.x + X.y * X.y;
+            }
+        }
+        wave_lds_sync();
+        {
+            const float *const v[1] = {ebuf};
+            float ne[1];
+            band_sums_par<1>(t, v, ne, lane);
+            if (lane < NB) r2[lane] = sqrtf(b_ex / (1e-8f + ne[0]));
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = rfft_slot_bin(lane, u);
+            if (k >= 0) {
+                float rf, gf;
+                interp_gain2(r2, gg, k, t.frac, t.band, rf, gf);
+                Xr[u].x *= rf; Xr[u].y *= rf;
+                Xr[u].x *= gf; Xr[u].y *= gf;
+            }
+        }
+    } else if (lane == 0) {
+        NNN_TIF(b, branch, 1, f, tile, sl)[0] = 1 << NB;
+    }
+    if (sp->log && s < b.S) {   // parity-test record of this frame: pitch index, branch mask, smoothed gains
+        unsigned *lg = sp->log + (size_t)s * FRAME_LOG_WORDS;
+        if (lane < NB) lg[2 + lane] = __float_as_uint(live ? b_g : 0.0f);
+        if (lane == 0) {
+            lg[0] = (unsigned)NNN_TIF(b, pitch, 1, f, tile, sl)[0];
+            lg[1] = (unsigned)bmask;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = rfft_slot_bin(lane, u);
+        if (k >= 0) A[k] = Xr[u];
+    }
+    wave_lds_sync();
+    // complex-to-real 960-point inverse as a 480-point complex inverse (see k_synth)
+    float2 zin[8];
+    {
+        const int j = lane < FFT_P1 ? lane : FFT_P1 - 1;
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++) {
+            const int k = j + FFT_P1 * rr;
+            float2 a = A[k], c = A[NFFT - k];
+            float2 e2 = make_float2(a.x + c.x, a.y - c.y);
+            float2 d = make_float2(a.x - c.x, a.y + c.y);
+            float2 w = t.tw[k];
+            w.y = -w.y;
+            float2 o2 = cmulf(d, w);
+            zin[rr] = make_float2(e2.y + o2.x, e2.x - o2.y);
+        }
+    }
+    wave_lds_sync();   // the spectrum has been read: the transform takes its buffer
+    float2 wlo[4], whi[4];   // the two window halves, as sample pairs
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int n = lane + 64 * u;
+        const bool on = n < FRAME / 2;
+        wlo[u] = on ? ((const float2 *)b.window_s)[n] : make_float2(0.0f, 0.0f);
+        whi[u] = on ? ((const float2 *)b.window_s)[FRAME / 2 + n] : make_float2(0.0f, 0.0f);
+    }
+    fft480_regs(zin, A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
+    if (lane == 0 && vad_out && s < b.S) vad_out[s] = vadv;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int n = lane + 64 * u;
+        if (n < FRAME / 2) {
+            float2 lo = A[n], hi = A[n + FRAME / 2];
+            float v0 = lo.y * wlo[u].x, v1 = lo.x * wlo[u].y;
+            float u0 = hi.y * whi[u].x, u1 = hi.x * whi[u].y;
+            if (store) {
+                const float y0 = v0 + smv[u].x, y1 = v1 + smv[u].y;
+                if (pair_ok && fmt == PCM_F32) ((float2 *)o)[n] = make_float2(y0, y1);
+                else if (pair_ok && fmt == PCM_I16)
+                    ((unsigned *)o)[n] = (unsigned)(unsigned short)pcm_to_i16(y0) | ((unsigned)(unsigned short)pcm_to_i16(y1) << 16);
+                else if (pair_ok) ((float2 *)o)[n] = make_float2(pcm_to_unit(y0), pcm_to_unit(y1));
+                else {
+                    pcm_store(o + (long long)(2 * n) * sstride, fmt, y0);
+                    pcm_store(o + (long long)(2 * n + 1) * sstride, fmt, y1);
+                }
+            }
+            ((float2 *)sm)[n] = make_float2(u0, u1);
+        }
+    }
+    wave_lds_sync();   // A is refilled by the next frame
+}
+#pragma clang fp contract(off)
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_back<true>: the fused back end.  k_back<false>: its RNN stretch alone (features in from k_fft_xp's scratch, gains out to k_synth's).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct BkActs { int dense, vad, noise, dn, out, vo; };   // activation kinds of the model at hand (ref: src/rnn.rs:242-250)
+template <bool FUSED, class SH>
+__global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0, BkActs acts, const uint4 *__restrict__ Wq,
+                                              const float *__restrict__ fpar, int tile0, int g)
+{
+    HIP_DYNAMIC_SHARED(float, lds_raw)
+    char *lds = (char *)lds_raw;
+    constexpr RnnPlan plan0 = SH::plan();
+    constexpr BackLds o = back_lds(plan0, FUSED);
+    RnnPlan pl = plan0;   // (compile-time values; the activation kinds come with the launch)
+    pl.dense.act = acts.dense; pl.vad.act = acts.vad; pl.noise.act = acts.noise; pl.dn.act = acts.dn; pl.out.act = acts.out; pl.act_vo = acts.vo;
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane0 = threadIdx.x & 63;
+    int wave = wave0, lane = lane0;
+    constexpr int per = TILE / BK_ROWS;
+    int tile, sub;
+    xcd_tile_block((int)blockIdx.x, (tile0 & 7) ? 1 : (int)gridDim.x / per, per, tile, sub);
+    tile += tile0;                                 // tile0: first tile of this model's run
+    const int r0 = sub * BK_ROWS;                  // first row of the tile handled here
+    const int sl = r0 + wave0, s = tile * TILE + sl;   // this wave's stream: its row in the tile, its index in the batch
+    // ---- LDS
+    float *tab = (float *)(lds + o.tab);
+    int *live = (int *)(lds + o.live), *flagw = (int *)(lds + o.flag) + wave0;
+    float *vadl = (float *)(lds + o.vadl), *gout = (float *)(lds + o.gout);
+    float *crs = (float *)(lds + o.crs) + wave0 * (CEPS_MEM * NB), *dcw = (float *)(lds + o.dcw) + wave0 * BK_CW,
+          *cnw = (float *)(lds + o.cnw) + wave0 * BK_CW;
+    unsigned short *FS = (unsigned short *)(lds + o.FS);
+    unsigned short *SPv = (unsigned short *)(lds + o.SPv), *SPn = (unsigned short *)(lds + o.SPn), *SPdn = (unsigned short *)(lds + o.SPdn);
+    unsigned short *IN = (unsigned short *)(lds + o.IN), *RS = (unsigned short *)(lds + o.RS);
+    float *ZB = (float *)(lds + o.ZB);
+    FftLds &t = *(FftLds *)(lds + o.tbl);
+    float2 *Z = (float2 *)(lds + o.Z) + wave0 * NFFT_BUF;
+    float *part = (float *)(lds + o.part) + wave0 * (3 * 64);
+    const int in_ps = BK_ROWS * pl.in_w, rs_ps = BK_ROWS * pl.rec_w;
+    const BkRnn R{tab, live, IN, RS, ZB, in_ps, pl.in_w, rs_ps, pl.rec_w};
+    float *sv = b.gru_v + ((size_t)tile * TILE * b.gru_v_w + (size_t)r0 * pl.vad.n),
+          *sn = b.gru_n + ((size_t)tile * TILE * b.gru_n_w + (size_t)r0 * pl.noise.n),
+          *sdn = b.gru_dn + ((size_t)tile * TILE * b.gru_dn_w + (size_t)r0 * pl.dn.n);
+    // ---- once per launch: zero the persistent operand planes (padding columns must read as 0), tables, ring, states, overlap memory
+    {
+        uint4 *z = (uint4 *)FS;
+        const int n16 = (o.SPdn + 3 * BK_ROWS * o.sw_dn * 2 - o.FS) / 16;
+        for (int i = (int)threadIdx.x; i < n16; i += BK_T) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = (int)threadIdx.x; i < 201; i += BK_T) tab[i] = b.tansig[i];
+        if (FUSED) fft_tables_load(t, b);
+        const float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, sl);
+        float stg[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) stg[i] = lane + 64 * i < CEPS_MEM * NB ? cm[(size_t)(lane + 64 * i) * TILE] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (lane + 64 * i < CEPS_MEM * NB) crs[lane + 64 * i] = stg[i];
+    }
+    float *sm = b.synth_mem + (size_t)s * FRAME;
+    lds_barrier();
+    {
+        auto load_state = [&](const LayerDesc &L, const float *state, unsigned short *SP, int sw) {
+            for (int e = (int)threadIdx.x; e < BK_ROWS * L.n; e += BK_T) {
+                const int row = e / L.n, col = e - row * L.n;
+                store_split(SP, BK_ROWS * sw, row * sw + col, state[e]);
+            }
+        };
+        load_state(pl.vad, sv, SPv, o.sw_v);
+        load_state(pl.noise, sn, SPn, o.sw_n);
+        load_state(pl.dn, sdn, SPdn, o.sw_dn);
+        if (lane < 28) dcw[lane] = pair_dist(crs, lane, 0, 1);
+    }
+    int mem_id = NNN_TI(b.mem_id, 1, tile, sl)[0];   // (wave-uniform)
+    if (FUSED) __syncthreads();   // (the tables came from global memory)
+    else lds_barrier();
+    for (int f = 0; f < g; f++) {
+        lane = launder_v(lane0);   // keep the frame loop's addresses inside the loop (see launder_v)
+        wave = launder_s(wave0);
+        const StepParams *sp = sp0 + f;
+        const Buffers bf = frame_view(b, f);
+        // ---------------- wave = stream: transforms, band quantities, feature head; then the stream's feature stage
+        XpKeep K;
+        int pitch;
+        bool silent;
+        if (FUSED) {
+            K.sl = sl;
+            K.cnw = cnw;
+            K.flag = flagw;
+            transform_inputs<true, true>(bf, sp, tile, 0, t, Z, part, &K);
+            pitch = NNN_TI(bf.pitch, 1, tile, sl)[0];
+            silent = __builtin_amdgcn_readfirstlane(K.silent) != 0;
+        } else {
+            const float cv = lane < 28 ? NNN_TI(bf.cn, 28, tile, sl)[(size_t)lane * TILE] : 0.0f;
+            pitch = NNN_TI(bf.pitch, 1, tile, sl)[0];
+            silent = __builtin_amdgcn_readfirstlane(NNN_TI(bf.silence, 1, tile, sl)[0]) != 0;
+            if (lane < 28) cnw[lane] = cv;
+        }
+        wave_lds_sync();
+        bk_features(b, f, tile, sl, wave, lane, pitch, silent, crs, dcw, cnw, FS, live, mem_id);
+        // the last gains of the rows and bands this lane smooths (the output layer's units), needed at the end of the RNN stretch
+        float lastg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (wave < pl.out.nb) {
+            const int band = wave * 16 + (lane & 15);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (band < NB) lastg[q] = NNN_TI(b.lastg, NB, tile, r0 + 4 * (lane >> 4) + q)[(size_t)band * TILE];
+        }
+        lds_barrier();   // every stream's features staged; the transforms' buffers are free: the RNN's operands take their space
+        // ---------------- 16 waves, one layer at a time
+        {   // the input matrix of this frame: zeros (padding columns must read as 0) with the staged features in their columns
+            const int w8 = pl.in_w / 8, n16 = 3 * BK_ROWS * w8, c0 = pl.cF / 8;
+            for (int i = (int)threadIdx.x; i < n16; i += BK_T) {
+                const int plx = i / (BK_ROWS * w8), rem = i - plx * (BK_ROWS * w8), row = rem / w8, c8 = rem - row * w8;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (c8 >= c0 && c8 < c0 + 6) v = *(const uint4 *)(FS + (size_t)plx * BK_ROWS * FS_W + row * FS_W + 8 * (c8 - c0));
+                *(uint4 *)(IN + (size_t)plx * in_ps + row * pl.in_w + 8 * c8) = v;
+            }
+        }
+        lds_barrier();
+        // input dense (ref: src/rnn.rs:353-355)
+        bk_dense(pl.dense, R, Wq, fpar, wave, lane, [&](int row, int neuron, float v, int) {
+            store_split(IN, in_ps, row * pl.in_w + pl.dense.out_col + neuron, v);
+        });
+        lds_barrier();
+        bk_gru(pl.vad, R, SPv, o.sw_v, Wq, fpar, wave, lane, []() {});                         // ref: src/rnn.rs:356-358
+        bk_gru(pl.noise, R, SPn, o.sw_n, Wq, fpar, wave, lane, [&]() {                          // ref: src/rnn.rs:361-366
+            if (wave == BK_WAVES - 1 && lane < BK_ROWS) {   // vad output, 1 x nv, lane = stream (ref: src/rnn.rs:359)
+                float acc = fpar[pl.vo_b];
+                for (int k = 0; k < pl.vad.n; k++) acc = fmaf(fpar[pl.vo_w + k], load_split(IN, in_ps, lane * pl.in_w + pl.cV + k), acc);
+                const float v = live[lane] ? activate(pl.act_vo, acc * (1.0f / 256.0f), tab) : 0.0f;
+                vadl[lane] = v;
+                NNN_TIF(b, vad, 1, f, tile, r0 + lane)[0] = v;
+            }
+        });
+        bk_gru(pl.dn, R, SPdn, o.sw_dn, Wq, fpar, wave, lane, []() {});                        // ref: src/rnn.rs:368-377
+        // gains (ref: src/rnn.rs:378) and smoothing g = max(g, 0.6 lastg) (ref: src/denoise.rs:106-109)
+        bk_dense(pl.out, R, Wq, fpar, wave, lane, [&](int lrow, int band, float v, int q) {
+            const int row = r0 + lrow;
+            const bool lv = live[lrow] != 0;
+            const float gr = lv ? v : 0.0f;
+            NNN_TIF(b, g_raw, NB, f, tile, row)[(size_t)band * TILE] = gr;
+            float gs = 0.0f;
+            if (lv) {
+                const float lg = q == 0 ? lastg[0] : (q == 1 ? lastg[1] : (q == 2 ? lastg[2] : lastg[3]));
+                gs = fmaxf(gr, 0.6f * lg);
+                NNN_TI(b.lastg, NB, tile, row)[(size_t)band * TILE] = gs;
+            }
+            NNN_TIF(b, g, NB, f, tile, row)[(size_t)band * TILE] = gs;
+            gout[lrow * BK_GW + band] = gr;
+            gout[lrow * BK_GW + 24 + band] = gs;
+        });
+        if (!FUSED) {
+            lds_barrier();   // (the next frame's features may be staged)
+            continue;
+        }
+        lds_barrier();   // gains and vad of every row in place; the RNN's operands are dead: the synthesis takes their space
+        // ---------------- wave = stream: pitch filter, gains, inverse transform, overlap-add
+        {
+            const float b_graw = lane < NB ? gout[wave * BK_GW + lane] : 0.0f, b_g = lane < NB ? gout[wave * BK_GW + 24 + lane] : 0.0f;
+            bk_synth(b, sp, f, tile, sl, s, lane, t, Z, part, K.X, K.P, K.ex, K.ep, K.xn, b_graw, b_g, vadl[wave], !silent, sm);
+        }
+    }
+    // ---- states back to HBM
+    {
+        auto save_state = [&](const LayerDesc &L, float *state, const unsigned short *SP, int sw) {
+            for (int e = (int)threadIdx.x; e < BK_ROWS * L.n; e += BK_T) {
+                const int row = e / L.n, col = e - row * L.n;
+                state[e] = load_split(SP, BK_ROWS * sw, row * sw + col);
+            }
+        };
+        save_state(pl.vad, sv, SPv, o.sw_v);
+        save_state(pl.noise, sn, SPn, o.sw_n);
+        save_state(pl.dn, sdn, SPdn, o.sw_dn);
+    }
+    if (lane0 == 0) NNN_TI(b.mem_id, 1, tile, sl)[0] = mem_id;
+}
+
+}  // namespace nnn

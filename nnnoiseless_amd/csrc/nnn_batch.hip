@@ -17,7 +17,7 @@
 
 #include "../../include/nnn_batch.h"
 #include "../../include/nnn_train.h"
-#include "nnn_kernels.hip"
+#include "nnn_back.hip"
 #include "nnn_model.h"
 
 using namespace nnn;
@@ -56,8 +56,8 @@ int nnn_set_error(const char *msg) { return fail("%s", msg); }   // for the libr
         if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));  \
     } while (0)
 
-enum KernelId { K_HP, K_LPC, K_PITCH, K_FFT_XP, K_RNN, K_SYNTH, K_COUNT };
-static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_pitch", "k_fft_xp", "k_rnn", "k_synth"};
+enum KernelId { K_HP, K_LPC, K_PITCH, K_FFT_XP, K_RNN, K_SYNTH, K_BACK, K_COUNT };
+static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_pitch", "k_fft_xp", "k_rnn", "k_synth", "k_back"};
 
 // The five stages of a frame group, one kernel launch each (hp: k_hp + k_lpc; k_rnn: one per resident model).  hp, pitch, rnn and synth carry
 // state from frame to frame and loop over the group's frames inside the launch; fft_xp covers all frames of the group
@@ -81,7 +81,11 @@ struct nnn_batch {
         size_t wf_lds = 0;
         int rows = 32;                 // stream rows per RNN block: 32 or 16
         int tile0 = 0, ntiles = 0;
+        size_t back_lds = 0, rnn16_lds = 0;   // dynamic LDS of k_back<true> / k_back<false>; 0 = the model is outside the kernel's shape class
+        BkActs acts = {};
     };
+    int back_mode = 1;             // the fused back end (k_back, nnn_back.hip): 0 = never, 1 = one-frame groups (the real-time tick), 2 = every group;
+                                   // 3 / 4 = its RNN stretch alone (k_back<false>) in place of k_rnn / k_rnn_wf for one-frame / all groups (env NNN_BACK)
     int rnn_rows = 0;              // forced rows per RNN block (env NNN_RNN_ROWS), 0 = by model size and batch size
     std::vector<ModelGroup> groups;
     std::vector<RNNModel> models;  // host copies of the resident models (clone)
@@ -324,6 +328,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     if (const char *e = getenv("NNN_RAMP")) h->ramp = atoi(e);
     if (const char *e = getenv("NNN_HOST_CHUNK")) h->host_chunk = atoi(e);
     if (const char *e = getenv("NNN_RNN_WF_MIN_G")) h->wf_min_g = atoi(e);
+    if (const char *e = getenv("NNN_BACK")) h->back_mode = atoi(e);
     if (const char *e = getenv("NNN_PITCH_CHAIN")) h->pitch_chain = atoi(e);
     if (const char *e = getenv("NNN_LPC_WIDE")) h->lpc_wide = atoi(e);
     if (const char *e = getenv("NNN_LPC_FC")) h->lpc_fc = atoi(e);
@@ -386,6 +391,15 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
         // blocks in the input dense / vad / noise / denoise layers)
         G.wp = rnn_wf_plan(G.plan);
         G.wf_lds = rnn_wf_lds_bytes(G.wp);
+        // the fused back end / its RNN stretch alone: layers of up to 8 neuron blocks (two units per wave) whose operands fit the LDS
+        // (compiled for the built-in model's shape class, nnn_back.hip; any other model takes the unfused kernels)
+        {
+            const bool shape_ok = bk_same_shape(G.plan, BkShapeBuiltin::plan());
+            const size_t fb = (size_t)back_lds(G.plan, true).total, rb = (size_t)back_lds(G.plan, false).total;
+            G.back_lds = shape_ok && fb <= kLdsMax ? fb : 0;
+            G.rnn16_lds = shape_ok && rb <= kLdsMax ? rb : 0;
+            G.acts = BkActs{G.plan.dense.act, G.plan.vad.act, G.plan.noise.act, G.plan.dn.act, G.plan.out.act, G.plan.act_vo};
+        }
         G.wf = rnn_wf_enabled() && !h->rnn_rows && G.plan.dense.nb <= 2 && G.plan.vad.nb <= 2 && G.plan.noise.nb <= 3 && G.plan.dn.nb <= 6 && G.plan.vad.rec.ksteps <= WF_KS_REC &&
                G.plan.noise.rec.ksteps <= WF_KS_REC && G.plan.dn.rec.ksteps <= WF_KS_REC && G.wf_lds <= kLdsMax;   // (k_rnn_wf's wave roles)
         tile0 += G.ntiles;
@@ -495,6 +509,8 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     // the RNN kernel's dynamic LDS limit is a per-device function attribute: raise it to the hardware's 160 KB once
     HIPCHK(hipFuncSetAttribute((const void *)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     HIPCHK(hipFuncSetAttribute((const void *)k_rnn_wf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+    HIPCHK(hipFuncSetAttribute((const void *)k_back<true, BkShapeBuiltin>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+    HIPCHK(hipFuncSetAttribute((const void *)k_back<false, BkShapeBuiltin>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     HIPCHK(hipDeviceSynchronize());
     h->id = g_next_batch_id.fetch_add(1) & 0xFFFFFu;
     if (!h->id) h->id = g_next_batch_id.fetch_add(1) & 0xFFFFFu;
@@ -682,6 +698,7 @@ extern "C" nnn_batch *nnn_batch_clone(nnn_batch *h)
     c->n_lanes = h->n_lanes;
     c->use_pipeline = h->use_pipeline;
     c->pitch_chain = h->pitch_chain;
+    c->back_mode = h->back_mode;
     c->lpc_wide = h->lpc_wide;
     c->lpc_fc = h->lpc_fc;
     c->inputs_ready = h->inputs_ready;
@@ -718,12 +735,26 @@ struct Launcher {
 // Per-group DAG: hp -> pitch -> fft_xp -> rnn -> synth.  Four stages carry state from group to group -- the
 // biquad (hp), the last pitch (pitch), GRU / cepstral / last-gain state (rnn), the overlap memory (synth).
 // stage `s` of the group of `g` frames in scratch sets set0 .. set0 + g - 1, parameters at sp0[0..g), on stream `st`
+// which back end a group of g frames takes: 0 = k_fft_xp -> k_rnn / k_rnn_wf -> k_synth, 1 = the same with k_back<false> as the RNN, 2 = k_back<true>
+// (the fused back end).  One-frame groups by default: there the unfused chain's three launches and the round trip of the spectra through
+// HBM buy nothing -- the layer-pipelined RNN has no second frame to pipeline.
+static int back_choice(const nnn_batch *h, int g)
+{
+    const int m = h->back_mode;
+    if (m <= 0) return 0;
+    const bool fused = m == 1 || m == 2, all_g = m == 2 || m == 4;
+    if (g > 1 && !all_g) return 0;
+    for (const nnn_batch::ModelGroup &G : h->groups)
+        if ((fused ? G.back_lds : G.rnn16_lds) == 0) return 0;
+    return fused ? 2 : 1;
+}
 static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams *sp0, hipStream_t st, bool prof)
 {
     if (g <= 0) return;   // (never a launch with an empty grid)
     const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad, ug = (unsigned)g;
     const Buffers &b = h->b[set0];
     Launcher L{h, st, prof};
+    const int back = back_choice(h, g);
     switch (s) {
     case ST_HP:
         L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g);
@@ -748,9 +779,21 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
         if (chain) h->tickets += grid;   // (launches of one batch's pitch stage are ordered among themselves: a stateful stage)
         break;
     }
-    case ST_FFT: L.go(K_FFT_XP, k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0, g); break;
+    case ST_FFT:
+        if (back == 2) {   // the fused back end takes the place of this stage and the two behind it: one launch per resident model
+            for (const nnn_batch::ModelGroup &G : h->groups)
+                L.go(K_BACK, k_back<true, BkShapeBuiltin>, dim3((unsigned)(G.ntiles * (TILE / BK_ROWS))), dim3(BK_T), G.back_lds, b, sp0, G.acts, G.wq, G.fpar, G.tile0, g);
+            break;
+        }
+        L.go(K_FFT_XP, k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0, g);
+        break;
     case ST_RNN:
+        if (back == 2) break;
         for (const nnn_batch::ModelGroup &G : h->groups) {   // one launch per resident model (a run of whole tiles)
+            if (back == 1) {
+                L.go(K_RNN, k_back<false, BkShapeBuiltin>, dim3((unsigned)(G.ntiles * (TILE / BK_ROWS))), dim3(BK_T), G.rnn16_lds, b, sp0, G.acts, G.wq, G.fpar, G.tile0, g);
+                continue;
+            }
             // the layer-pipelined kernel spends g + 4 ticks on g frames: for a lone frame on a batch of many block rounds the
             // plain kernel's eleven phases are shorter (one frame per call at 16 384 / 32 768 / 65 536 streams: +6 / +7 / +7 %;
             // at 4096 streams, one round of blocks, the pipelined kernel stays 8 % ahead).  Same bits either way.
@@ -765,7 +808,10 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
                      G.tile0, G.rows, g);
         }
         break;
-    case ST_SYN: L.go(K_SYNTH, k_synth, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0, g); break;
+    case ST_SYN:
+        if (back == 2) break;
+        L.go(K_SYNTH, k_synth, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0, g);
+        break;
     }
 }
 
@@ -1189,7 +1235,7 @@ static bool tap_desc(const nnn_batch *h, int tap, TapDesc &d, const void **ptr)
     case NNN_TAP_PITCH_SEARCH: d = {1, 1, 0, 0, 1, 1}; *ptr = TP(psearch); return true;
     case NNN_TAP_PITCH: d = {1, 1, 0, 0, 1, 0}; *ptr = TP(pitch); return true;
     case NNN_TAP_PITCH_GAIN: d = {1, 0, 0, 0, 1, 0}; *ptr = TP(pgain); return true;
-    case NNN_TAP_X: d = {2 * FREQ, 0, 2, 0, 2 * FREQ, 0}; *ptr = TP(X); return true;
+    case NNN_TAP_X: d = {2 * FREQ, 0, 2, 0, 2 * FREQ, 1}; *ptr = TP(X); return true;   // (the fused back end keeps both spectra in registers)
     case NNN_TAP_P: d = {2 * FREQ, 0, 2, 0, 2 * FREQ, 1}; *ptr = TP(P); return true;
     case NNN_TAP_EX: d = {NB, 0, 0, 0, NB, 0}; *ptr = TP(ex); return true;
     case NNN_TAP_EP: d = {NB, 0, 0, 0, NB, 0}; *ptr = TP(ep); return true;
@@ -1353,6 +1399,13 @@ extern "C" int nnn_batch_debug_withhold_flag(nnn_batch *h, int frames_ahead)
         h->b[set].dbg_withhold = seq;
         h->b[set].handoff_ticks = seq ? 20000000ll : h->handoff_ticks;   // the withheld flag is given up on after 0.2 s
     }
+    return 0;
+}
+extern "C" int nnn_batch_set_back_end(nnn_batch *h, int mode)
+{
+    if (!h) return fail("null batch");
+    if (mode < 0 || mode > 4) return fail("unknown back-end mode %d", mode);
+    h->back_mode = mode;
     return 0;
 }
 extern "C" int nnn_batch_set_pipeline(nnn_batch *h, int on)

@@ -1620,16 +1620,28 @@ __device__ __forceinline__ int rfft_slot_bin(int lane, int u)
     return k < NFFT / 2 ? NFFT - k : -1;
 }
 
-template <bool WITH_P>
-__device__ __forceinline__ void transform_inputs(const Buffers &b, const StepParams *sp, int tile, int sub, FftLds &t, float2 *Z, float *part)
+// What the fused back end (k_back, nnn_back.hip) keeps of a frame's transforms instead of sending it through HBM: both spectra in the
+// registers of the stream's wave (slot order of window_rfft), the three per-band quantities the pitch filter needs on lanes 0..21, the
+// silence flag; the feature head's 28 outputs go to `cnw` (LDS) for the feature stage that follows on the same wave.
+struct XpKeep {
+    float2 X[8], P[8];
+    float ex, ep, xn;     // lane < NB: band energies of X and P, normalised correlation
+    int silent;           // wave-uniform
+    int sl;               // in: the stream's row in its tile
+    float *cnw;           // in: LDS staging of the frame's cepstrum (22) + pitch-correlation DCT (6)
+    int *flag;            // in: one LDS word of the wave (the silence flag travels through it)
+};
+template <bool WITH_P, bool FUSED = false>
+__device__ __forceinline__ void transform_inputs(const Buffers &b, const StepParams *sp, int tile, int sub, FftLds &t, float2 *Z, float *part,
+                                                 XpKeep *keep = nullptr)
 {
-    const int lane = threadIdx.x & 63, sl = sub * FFT_SPB + (int)(threadIdx.x >> 6), s = tile * TILE + sl;
+    const int lane = threadIdx.x & 63, sl = FUSED ? keep->sl : sub * FFT_SPB + (int)(threadIdx.x >> 6), s = tile * TILE + sl;
     const int ring = ring_len(b.nslot), rb = ring_base(sp->slot, b.nslot);
     float2 w[8];   // the window at sample pairs j + 60 r: the order of the transforms' first pass (window_rfft)
 #pragma unroll
     for (int r = 0; r < 8; r++) w[r] = ((const float2 *)b.window_a)[(lane < FFT_P1 ? lane : FFT_P1 - 1) + FFT_P1 * r];
     const int lag = WITH_P ? NNN_TI(b.pitch, 1, tile, sl)[0] : 0;
-    fft_tables_load(t, b);
+    if (!FUSED) fft_tables_load(t, b);   // (the fused kernel loads them once per launch)
     const float *h = b.hist + (size_t)s * hist_stride(b.nslot);
     // both windows' samples are requested now: the second transform's used to be requested when it started, a trip to memory on
     // the wave's critical path per stream-frame (these kernels move enough bytes for that to show)
@@ -1639,16 +1651,18 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     if (WITH_P) window_load(h, ring, rb, lag, lane, spw);
 #endif
     float2 X[8];
-    window_rfft(b, sx, w, t, Z, X, lane, true);
+    window_rfft(b, sx, w, t, Z, X, lane, !FUSED);
     float2 *dx = b.X + (size_t)s * FSTR;
     // NNN_PROBE_XP (developer probe, wrong audio, timing only): the spectra are not stored here and k_synth reads them from a
     // region small enough to stay in the XCD's L2 -- an upper bound on what keeping X and P on chip between the transforms
     // and the synthesis (a fused back end) could gain from the removed HBM round trip.
 #ifndef NNN_PROBE_XP
+    if (!FUSED || b.taps) {   // (fused: the spectra stay in registers; memory sees them for the parity taps only)
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const int k = rfft_slot_bin(lane, u);
-        if (k >= 0) dx[k] = X[u];
+        for (int u = 0; u < 8; u++) {
+            const int k = rfft_slot_bin(lane, u);
+            if (k >= 0) dx[k] = X[u];
+        }
     }
 #endif
     float *vv = (float *)Z, *vc = vv + BSK_LEN;   // per-bin quantities of the band sums, skewed (bsk)
@@ -1676,10 +1690,12 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     float2 *dp = b.P + (size_t)s * FSTR;
     const int np = b.taps ? FREQ : 400;   // the pitch filter reads bins 0..399 only
 #ifndef NNN_PROBE_XP
+    if (!FUSED || b.taps) {
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const int k = rfft_slot_bin(lane, u);
-        if (k >= 0 && k < np) dp[k] = Y[u];
+        for (int u = 0; u < 8; u++) {
+            const int k = rfft_slot_bin(lane, u);
+            if (k >= 0 && k < np) dp[k] = Y[u];
+        }
     }
 #endif
 #pragma unroll
@@ -1699,9 +1715,10 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     // the silence test, and the two DCTs -- lane = band.  Same operations in the same order as when one lane did it all.
     wave_lds_sync();
     float *xc = part, *ly = part + 64, *exl = part + 128;
-    float lyv = -2.0f;
+    float lyv = -2.0f, xnv = 0.0f;
     if (lane < NB) {
         const float xn = o[1] / sqrtf(0.001f + exv * o[0]);
+        xnv = xn;
         NNN_TI(b.ep, NB, tile, sl)[(size_t)lane * TILE] = o[0];
         NNN_TI(b.exp_, NB, tile, sl)[(size_t)lane * TILE] = xn;
         xc[lane] = xn;
@@ -1738,6 +1755,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
 #pragma unroll
         for (int i = 0; i < NB; i++) e += exl[i];
         NNN_TI(b.silence, 1, tile, sl)[0] = e < 0.04f ? 1 : 0;
+        if (FUSED) keep->flag[0] = e < 0.04f ? 1 : 0;
     }
     // the two DCTs side by side: lanes 0..21 the cepstrum of the floored log energies, lanes 32..37 the first six coefficients
     // of the pitch correlation (ref: src/features.rs:141-147, 167-169; src/lib.rs:139-148)
@@ -1749,8 +1767,18 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
             float c = dct_out(second ? xc : ly, t.dct, i);
             if (second) c -= i == 0 ? 1.3f : (i == 1 ? 0.9f : 0.0f);
             else c -= i == 0 ? 12.0f : (i == 1 ? 4.0f : 0.0f);
-            cn[(size_t)((second ? NB : 0) + i) * TILE] = c;
+            if (FUSED) keep->cnw[(second ? NB : 0) + i] = c;   // (the feature stage follows on this wave)
+            else cn[(size_t)((second ? NB : 0) + i) * TILE] = c;
         }
+    }
+    if (FUSED) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) { keep->X[u] = X[u]; keep->P[u] = Y[u]; }
+        keep->ex = exv;
+        keep->ep = o[0];
+        keep->xn = xnv;
+        wave_lds_sync();
+        keep->silent = keep->flag[0];
     }
 }
 
