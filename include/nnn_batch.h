@@ -210,11 +210,13 @@ int nnn_batch_set_pipeline(nnn_batch *b, int on);
  * input is read only after everything enqueued on its stream before the call. */
 int nnn_batch_set_inputs_ready(nnn_batch *b, int on);
 /* Which kernels run the part of a frame behind the pitch analysis.  0: transforms (k_fft_xp) -> RNN (k_rnn / k_rnn_wf) -> synthesis
- * (k_synth), the spectra crossing device memory in between.  1 (default): groups of ONE frame -- the real-time host ticking 10 ms per
- * call, the reference's primary use (src/capi.rs:75-85, src/signal.rs:102-104) -- take the fused back end instead (k_back: one launch,
- * both spectra in registers from their transforms to the inverse transform); 2: every group does.  3 / 4: the fused kernel's RNN
- * stretch alone replaces the RNN kernels for one-frame / all groups (measurement).  Environment: NNN_BACK.  The RNN's bits are the
- * same whichever kernel runs it; what comes out of the transforms agrees to rounding (multiply-adds may fuse differently). */
+ * (k_synth), the spectra crossing device memory in between.  1: groups of ONE frame -- the real-time host ticking 10 ms per call, the
+ * reference's primary use (src/capi.rs:75-85, src/signal.rs:102-104) -- take the fused back end instead (k_back: one launch, both
+ * spectra in registers from their transforms to the inverse transform); 2: every group does.  3 / 4: the fused kernel's RNN stretch
+ * alone (16 waves, one layer at a time) replaces the RNN kernels for one-frame / all groups.  -1 (default): by batch size, as
+ * measured -- one-frame groups take the fused kernel up to 8192 streams and the RNN stretch alone above that or while other batches
+ * tick beside this one; longer groups stay with the layer-pipelined RNN between k_fft_xp and k_synth.  Environment: NNN_BACK.
+ * Every choice gives the same bits: a stream may change back end from call to call. */
 int nnn_batch_set_back_end(nnn_batch *b, int mode);
 /* How a pipelined call uses the internal streams: mode 0 = not at all (as set_pipeline(0)); 1 = "lanes": the high-pass
  * chain on its own stream, the other four stages of group k on lane k mod `lanes` (1..4; default 2; lane 0 is the caller's stream);

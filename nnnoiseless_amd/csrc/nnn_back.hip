@@ -247,15 +247,39 @@ struct BkH {
 // recurrent product on the state planes, input product; z -> ZB, r * state -> RS.  Units 2 nb .. 3 nb - 1 are the candidates: bias +
 // input product in the first phase; behind the barrier the recurrent product on r * state, the activation and the state update, the
 // new state going to the layer's state planes and to its columns of the input matrix.  Wave w takes units w and w + 16 (layers of
-// up to 8 neuron blocks; at most one of a wave's two units is a candidate).  `between` runs on every wave after its first-phase
-// units (work that fits beside them: the vad output on a wave the layer leaves idle).
-template <class Between>
-__device__ __forceinline__ void bk_gru(const LayerDesc &L, const BkRnn &R, unsigned short *SP, int sw, const uint4 *__restrict__ Wq,
-                                       const float *__restrict__ fpar, int wave, int lane, Between &&between)
+// up to 8 neuron blocks; at most one of a wave's two units is a candidate).
+// The weight fragments of a wave's first unit of a phase (bias included) are requested BEFORE the barrier that opens the phase
+// (bk_gru_load_a / bk_gru_load_b, called at the end of the phase before): a phase then starts with its operands in registers
+// instead of with a trip to the L2 -- the trip is 1 of the 2 us a phase took without it.
+struct BkW {
+    BkFrags rec, in;
+    float bias;
+};
+__device__ __forceinline__ void bk_unit_of(const LayerDesc &L, int u, bool &cand, int &nbi, int &gate)
+{
+    const int nzr = 2 * L.nb;
+    cand = u >= nzr;
+    nbi = cand ? u - nzr : u >> 1;
+    gate = cand ? 2 : (u & 1);
+}
+__device__ __forceinline__ void bk_gru_load_a(const LayerDesc &L, const uint4 *__restrict__ Wq, const float *__restrict__ fpar, int u, int lane, BkW &w)
+{
+    if (u >= 3 * L.nb) return;
+    bool cand;
+    int nbi, gate;
+    bk_unit_of(L, u, cand, nbi, gate);
+    const int neuron = nbi * 16 + (lane & 15);
+    const uint4 *Bin = Wq + L.in.wofs + ((size_t)nbi * 3 + gate) * L.in.ksteps * 64;
+    const uint4 *Brec = Wq + L.rec.wofs + ((size_t)nbi * 3 + gate) * L.rec.ksteps * 64;
+    if (!cand) bk_frags_load(w.rec, L.rec, Brec, lane);
+    bk_frags_load(w.in, L.in, Bin, lane);
+    w.bias = neuron < L.n ? fpar[L.bias + gate * L.n + neuron] : 0.0f;
+}
+__device__ __forceinline__ void bk_gru_phase_a(const LayerDesc &L, const BkRnn &R, const unsigned short *SP, int sw, const uint4 *__restrict__ Wq,
+                                               const float *__restrict__ fpar, int wave, int lane, BkW &w, BkH &h)
 {
     const float scale = 1.0f / 256.0f;
-    const int nzr = 2 * L.nb, units = 3 * L.nb, ps = BK_ROWS * sw, kcols = 32 * L.rec.ksteps;
-    BkH h;
+    const int units = 3 * L.nb, ps = BK_ROWS * sw, kcols = 32 * L.rec.ksteps;
     h.on = false;
     h.nbi = 0;
     h.acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -263,19 +287,17 @@ __device__ __forceinline__ void bk_gru(const LayerDesc &L, const BkRnn &R, unsig
     for (int rd = 0; rd < 2; rd++) {
         const int u = wave + BK_WAVES * rd;
         if (u >= units) break;
-        const bool cand = u >= nzr;
-        const int nbi = cand ? u - nzr : u >> 1, gate = cand ? 2 : (u & 1);
+        if (rd) bk_gru_load_a(L, Wq, fpar, u, lane, w);   // (the second unit of a wave: fetched on the spot)
+        bool cand;
+        int nbi, gate;
+        bk_unit_of(L, u, cand, nbi, gate);
         const int neuron = nbi * 16 + (lane & 15);
         const bool nvalid = neuron < L.n;
         const uint4 *Bin = Wq + L.in.wofs + ((size_t)nbi * 3 + gate) * L.in.ksteps * 64;
         const uint4 *Brec = Wq + L.rec.wofs + ((size_t)nbi * 3 + gate) * L.rec.ksteps * 64;
-        BkFrags f_rec, f_in;
-        if (!cand) bk_frags_load(f_rec, L.rec, Brec, lane);
-        bk_frags_load(f_in, L.in, Bin, lane);
-        const float bias = nvalid ? fpar[L.bias + gate * L.n + neuron] : 0.0f;
-        f32x4 acc = f32x4{bias, bias, bias, bias};
-        if (!cand) acc = bk_gemm(acc, SP, ps, sw, L.rec, Brec, lane, f_rec);
-        acc = bk_gemm(acc, R.IN, R.in_ps, R.in_w, L.in, Bin, lane, f_in);
+        f32x4 acc = f32x4{w.bias, w.bias, w.bias, w.bias};
+        if (!cand) acc = bk_gemm(acc, SP, ps, sw, L.rec, Brec, lane, w.rec);
+        acc = bk_gemm(acc, R.IN, R.in_ps, R.in_w, L.in, Bin, lane, w.in);
         if (cand) {
             h.acc = acc;
             h.nbi = nbi;
@@ -296,43 +318,56 @@ __device__ __forceinline__ void bk_gru(const LayerDesc &L, const BkRnn &R, unsig
             }
         }
     }
-    between();
-    lds_barrier();   // z and r * state complete; every wave is done reading the old state planes and the layer's inputs
-    if (h.on) {
-        const int nbi = h.nbi, neuron = nbi * 16 + (lane & 15);
-        const uint4 *Brec = Wq + L.rec.wofs + ((size_t)nbi * 3 + 2) * L.rec.ksteps * 64;
-        BkFrags f_rec;
-        bk_frags_load(f_rec, L.rec, Brec, lane);
-        const f32x4 acc = bk_gemm(h.acc, R.RS, R.rs_ps, R.rec_w, L.rec, Brec, lane, f_rec);
-        if (neuron < L.n) {
+}
+// the candidate unit's recurrent fragments, requested ahead of the barrier between the two phases
+__device__ __forceinline__ void bk_gru_load_b(const LayerDesc &L, const uint4 *__restrict__ Wq, int lane, const BkH &h, BkW &w)
+{
+    if (!h.on) return;
+    const uint4 *Brec = Wq + L.rec.wofs + ((size_t)h.nbi * 3 + 2) * L.rec.ksteps * 64;
+    bk_frags_load(w.rec, L.rec, Brec, lane);
+}
+__device__ __forceinline__ void bk_gru_phase_b(const LayerDesc &L, const BkRnn &R, unsigned short *SP, int sw, const uint4 *__restrict__ Wq, int lane,
+                                               const BkW &w, const BkH &h)
+{
+    if (!h.on) return;
+    const float scale = 1.0f / 256.0f;
+    const int ps = BK_ROWS * sw;
+    const int nbi = h.nbi, neuron = nbi * 16 + (lane & 15);
+    const uint4 *Brec = Wq + L.rec.wofs + ((size_t)nbi * 3 + 2) * L.rec.ksteps * 64;
+    const f32x4 acc = bk_gemm(h.acc, R.RS, R.rs_ps, R.rec_w, L.rec, Brec, lane, w.rec);
+    if (neuron < L.n) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int row = 4 * (lane >> 4) + q;
-                const float hh = activate(L.act, scale * acc[q], R.tab);
-                const float z = R.ZB[row * BK_ZW + neuron], so = load_split(SP, ps, row * sw + neuron);
-                float snew = z * so + (1.0f - z) * hh;
-                snew = R.live[row] ? snew : so;   // silent frames leave the state alone (ref: src/denoise.rs:100)
-                store_split(R.IN, R.in_ps, row * R.in_w + L.out_col + neuron, snew);
-                store_split(SP, ps, row * sw + neuron, snew);
-            }
+        for (int q = 0; q < 4; q++) {
+            const int row = 4 * (lane >> 4) + q;
+            const float hh = activate(L.act, scale * acc[q], R.tab);
+            const float z = R.ZB[row * BK_ZW + neuron], so = load_split(SP, ps, row * sw + neuron);
+            float snew = z * so + (1.0f - z) * hh;
+            snew = R.live[row] ? snew : so;   // silent frames leave the state alone (ref: src/denoise.rs:100)
+            store_split(R.IN, R.in_ps, row * R.in_w + L.out_col + neuron, snew);
+            store_split(SP, ps, row * sw + neuron, snew);
         }
     }
-    lds_barrier();
 }
 
-// dense layer: neuron block w on wave w; sink(row, neuron, value, q) with row = 4 (lane >> 4) + q
+// dense layer: neuron block w on wave w (its fragments and bias requested ahead by bk_dense_load); sink(row, neuron, value, q) with
+// row = 4 (lane >> 4) + q
+__device__ __forceinline__ void bk_dense_load(const LayerDesc &L, const uint4 *__restrict__ Wq, const float *__restrict__ fpar, int nbi, int lane, BkW &w)
+{
+    if (nbi >= L.nb) return;
+    const int neuron = nbi * 16 + (lane & 15);
+    bk_frags_load(w.in, L.in, Wq + L.in.wofs + (size_t)nbi * L.in.ksteps * 64, lane);
+    w.bias = neuron < L.n ? fpar[L.bias + neuron] : 0.0f;
+}
 template <class Sink>
 __device__ __forceinline__ void bk_dense(const LayerDesc &L, const BkRnn &R, const uint4 *__restrict__ Wq, const float *__restrict__ fpar, int wave,
-                                         int lane, Sink &&sink)
+                                         int lane, BkW &w, Sink &&sink)
 {
 #pragma nounroll
     for (int nbi = wave; nbi < L.nb; nbi += BK_WAVES) {
+        if (nbi != wave) bk_dense_load(L, Wq, fpar, nbi, lane, w);
         const int neuron = nbi * 16 + (lane & 15);
         const uint4 *Bnb = Wq + L.in.wofs + (size_t)nbi * L.in.ksteps * 64;
-        BkFrags fr;
-        bk_frags_load(fr, L.in, Bnb, lane);
-        const float bv = neuron < L.n ? fpar[L.bias + neuron] : 0.0f;
-        const f32x4 acc = bk_gemm(f32x4{bv, bv, bv, bv}, R.IN, R.in_ps, R.in_w, L.in, Bnb, lane, fr);
+        const f32x4 acc = bk_gemm(f32x4{w.bias, w.bias, w.bias, w.bias}, R.IN, R.in_ps, R.in_w, L.in, Bnb, lane, w.in);
         if (neuron < L.n) {
 #pragma unroll
             for (int q = 0; q < 4; q++) sink(4 * (lane >> 4) + q, neuron, activate(L.act, acc[q] * (1.0f / 256.0f), R.tab), q);
@@ -460,7 +495,7 @@ __device__ __forceinline__ void bk_synth(const Buffers &b, const StepParams *sp,
         wlo[u] = on ? ((const float2 *)b.window_s)[n] : make_float2(0.0f, 0.0f);
         whi[u] = on ? ((const float2 *)b.window_s)[FRAME / 2 + n] : make_float2(0.0f, 0.0f);
     }
-    fft480_regs(zin, A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
+    fft480_regs<true>(zin, A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
     if (lane == 0 && vad_out && s < b.S) vad_out[s] = vadv;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -527,43 +562,58 @@ __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0,
     float *sv = b.gru_v + ((size_t)tile * TILE * b.gru_v_w + (size_t)r0 * pl.vad.n),
           *sn = b.gru_n + ((size_t)tile * TILE * b.gru_n_w + (size_t)r0 * pl.noise.n),
           *sdn = b.gru_dn + ((size_t)tile * TILE * b.gru_dn_w + (size_t)r0 * pl.dn.n);
-    // ---- once per launch: zero the persistent operand planes (padding columns must read as 0), tables, ring, states, overlap memory
+    // ---- once per launch: zero the persistent operand planes (padding columns must read as 0), tables, ring, states.  Everything that
+    //      comes from global memory is requested first and lands while the planes are zeroed; only the transforms' tables have to be
+    //      in place before the first frame's wave = stream stretch, which needs none of the rest.
+    NNN_STAMP(b, 0);
+    float *sm = b.synth_mem + (size_t)s * FRAME;
+    int mem_id;
     {
-        uint4 *z = (uint4 *)FS;
-        const int n16 = (o.SPdn + 3 * BK_ROWS * o.sw_dn * 2 - o.FS) / 16;
-        for (int i = (int)threadIdx.x; i < n16; i += BK_T) z[i] = make_uint4(0u, 0u, 0u, 0u);
-        for (int i = (int)threadIdx.x; i < 201; i += BK_T) tab[i] = b.tansig[i];
-        if (FUSED) fft_tables_load(t, b);
+        constexpr int NV = BK_ROWS * plan0.vad.n, NN_ = BK_ROWS * plan0.noise.n, ND = BK_ROWS * plan0.dn.n;
+        constexpr int PV = (NV + BK_T - 1) / BK_T, PN = (NN_ + BK_T - 1) / BK_T, PD = (ND + BK_T - 1) / BK_T;
+        float stg[3], gv[PV], gn[PN], gd[PD];
         const float *cm = NNN_TI(b.ceps_mem, CEPS_MEM * NB, tile, sl);
-        float stg[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) stg[i] = lane + 64 * i < CEPS_MEM * NB ? cm[(size_t)(lane + 64 * i) * TILE] : 0.0f;
 #pragma unroll
+        for (int i = 0; i < PV; i++) gv[i] = (int)threadIdx.x + BK_T * i < NV ? sv[threadIdx.x + BK_T * i] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < PN; i++) gn[i] = (int)threadIdx.x + BK_T * i < NN_ ? sn[threadIdx.x + BK_T * i] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < PD; i++) gd[i] = (int)threadIdx.x + BK_T * i < ND ? sdn[threadIdx.x + BK_T * i] : 0.0f;
+        mem_id = NNN_TI(b.mem_id, 1, tile, sl)[0];   // (wave-uniform)
+        if (FUSED) fft_tables_load(t, b);
+        for (int i = (int)threadIdx.x; i < 201; i += BK_T) tab[i] = b.tansig[i];
+        uint4 *z = (uint4 *)FS;
+        constexpr int n16 = (o.SPdn + 3 * BK_ROWS * o.sw_dn * 2 - o.FS) / 16;
+        for (int i = (int)threadIdx.x; i < n16; i += BK_T) z[i] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
         for (int i = 0; i < 3; i++)
             if (lane + 64 * i < CEPS_MEM * NB) crs[lane + 64 * i] = stg[i];
-    }
-    float *sm = b.synth_mem + (size_t)s * FRAME;
-    lds_barrier();
-    {
-        auto load_state = [&](const LayerDesc &L, const float *state, unsigned short *SP, int sw) {
-            for (int e = (int)threadIdx.x; e < BK_ROWS * L.n; e += BK_T) {
-                const int row = e / L.n, col = e - row * L.n;
-                store_split(SP, BK_ROWS * sw, row * sw + col, state[e]);
-            }
+        lds_barrier();   // planes zeroed, tables and ring in place
+        auto put = [&](unsigned short *SP, int sw, int n, int e, float v) {
+            const int row = e / n, col = e - row * n;
+            store_split(SP, BK_ROWS * sw, row * sw + col, v);
         };
-        load_state(pl.vad, sv, SPv, o.sw_v);
-        load_state(pl.noise, sn, SPn, o.sw_n);
-        load_state(pl.dn, sdn, SPdn, o.sw_dn);
+#pragma unroll
+        for (int i = 0; i < PV; i++)
+            if ((int)threadIdx.x + BK_T * i < NV) put(SPv, o.sw_v, plan0.vad.n, threadIdx.x + BK_T * i, gv[i]);
+#pragma unroll
+        for (int i = 0; i < PN; i++)
+            if ((int)threadIdx.x + BK_T * i < NN_) put(SPn, o.sw_n, plan0.noise.n, threadIdx.x + BK_T * i, gn[i]);
+#pragma unroll
+        for (int i = 0; i < PD; i++)
+            if ((int)threadIdx.x + BK_T * i < ND) put(SPdn, o.sw_dn, plan0.dn.n, threadIdx.x + BK_T * i, gd[i]);
         if (lane < 28) dcw[lane] = pair_dist(crs, lane, 0, 1);
+        // (the state planes are first read behind the barrier that closes the first frame's feature stage)
     }
-    int mem_id = NNN_TI(b.mem_id, 1, tile, sl)[0];   // (wave-uniform)
-    if (FUSED) __syncthreads();   // (the tables came from global memory)
-    else lds_barrier();
+    NNN_STAMP(b, 1);
     for (int f = 0; f < g; f++) {
         lane = launder_v(lane0);   // keep the frame loop's addresses inside the loop (see launder_v)
         wave = launder_s(wave0);
         const StepParams *sp = sp0 + f;
         const Buffers bf = frame_view(b, f);
+        NNN_STAMP(b, 2);
         // ---------------- wave = stream: transforms, band quantities, feature head; then the stream's feature stage
         XpKeep K;
         int pitch;
@@ -575,6 +625,10 @@ __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0,
             transform_inputs<true, true>(bf, sp, tile, 0, t, Z, part, &K);
             pitch = NNN_TI(bf.pitch, 1, tile, sl)[0];
             silent = __builtin_amdgcn_readfirstlane(K.silent) != 0;
+#ifdef NNN_PROBE_BACK_NOHOLD   // (developer probe, wrong audio, timing only: what the stretch costs when the spectra need not be kept)
+#pragma unroll
+            for (int u = 0; u < 8; u++) { K.X[u] = make_float2((float)u, 1.0f); K.P[u] = make_float2(1.0f, (float)u); }
+#endif
         } else {
             const float cv = lane < 28 ? NNN_TI(bf.cn, 28, tile, sl)[(size_t)lane * TILE] : 0.0f;
             pitch = NNN_TI(bf.pitch, 1, tile, sl)[0];
@@ -582,7 +636,9 @@ __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0,
             if (lane < 28) cnw[lane] = cv;
         }
         wave_lds_sync();
+        NNN_STAMP(b, 3);
         bk_features(b, f, tile, sl, wave, lane, pitch, silent, crs, dcw, cnw, FS, live, mem_id);
+        NNN_STAMP(b, 4);
         // the last gains of the rows and bands this lane smooths (the output layer's units), needed at the end of the RNN stretch
         float lastg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (wave < pl.out.nb) {
@@ -592,6 +648,7 @@ __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0,
                 if (band < NB) lastg[q] = NNN_TI(b.lastg, NB, tile, r0 + 4 * (lane >> 4) + q)[(size_t)band * TILE];
         }
         lds_barrier();   // every stream's features staged; the transforms' buffers are free: the RNN's operands take their space
+        NNN_STAMP(b, 5);
         // ---------------- 16 waves, one layer at a time
         {   // the input matrix of this frame: zeros (padding columns must read as 0) with the staged features in their columns
             const int w8 = pl.in_w / 8, n16 = 3 * BK_ROWS * w8, c0 = pl.cF / 8;
@@ -602,25 +659,51 @@ __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0,
                 *(uint4 *)(IN + (size_t)plx * in_ps + row * pl.in_w + 8 * c8) = v;
             }
         }
+        BkW W;
+        BkH H;
+        bk_dense_load(pl.dense, Wq, fpar, wave, lane, W);
         lds_barrier();
+        NNN_STAMP(b, 6);
         // input dense (ref: src/rnn.rs:353-355)
-        bk_dense(pl.dense, R, Wq, fpar, wave, lane, [&](int row, int neuron, float v, int) {
+        bk_dense(pl.dense, R, Wq, fpar, wave, lane, W, [&](int row, int neuron, float v, int) {
             store_split(IN, in_ps, row * pl.in_w + pl.dense.out_col + neuron, v);
         });
+        bk_gru_load_a(pl.vad, Wq, fpar, wave, lane, W);
         lds_barrier();
-        bk_gru(pl.vad, R, SPv, o.sw_v, Wq, fpar, wave, lane, []() {});                         // ref: src/rnn.rs:356-358
-        bk_gru(pl.noise, R, SPn, o.sw_n, Wq, fpar, wave, lane, [&]() {                          // ref: src/rnn.rs:361-366
-            if (wave == BK_WAVES - 1 && lane < BK_ROWS) {   // vad output, 1 x nv, lane = stream (ref: src/rnn.rs:359)
-                float acc = fpar[pl.vo_b];
-                for (int k = 0; k < pl.vad.n; k++) acc = fmaf(fpar[pl.vo_w + k], load_split(IN, in_ps, lane * pl.in_w + pl.cV + k), acc);
-                const float v = live[lane] ? activate(pl.act_vo, acc * (1.0f / 256.0f), tab) : 0.0f;
-                vadl[lane] = v;
-                NNN_TIF(b, vad, 1, f, tile, r0 + lane)[0] = v;
-            }
-        });
-        bk_gru(pl.dn, R, SPdn, o.sw_dn, Wq, fpar, wave, lane, []() {});                        // ref: src/rnn.rs:368-377
+        NNN_STAMP(b, 7);
+        // vad GRU (ref: src/rnn.rs:356-358)
+        bk_gru_phase_a(pl.vad, R, SPv, o.sw_v, Wq, fpar, wave, lane, W, H);
+        bk_gru_load_b(pl.vad, Wq, lane, H, W);
+        lds_barrier();   // z and r * state complete; every wave is done reading the old state planes and the layer's inputs
+        bk_gru_phase_b(pl.vad, R, SPv, o.sw_v, Wq, lane, W, H);
+        bk_gru_load_a(pl.noise, Wq, fpar, wave, lane, W);
+        lds_barrier();
+        NNN_STAMP(b, 8);
+        // noise GRU (ref: src/rnn.rs:361-366); beside its first phase, on a wave it leaves idle, the vad output
+        bk_gru_phase_a(pl.noise, R, SPn, o.sw_n, Wq, fpar, wave, lane, W, H);
+        if (wave == BK_WAVES - 1 && lane < BK_ROWS) {   // 1 x nv, lane = stream (ref: src/rnn.rs:359)
+            float acc = fpar[pl.vo_b];
+            for (int k = 0; k < pl.vad.n; k++) acc = fmaf(fpar[pl.vo_w + k], load_split(IN, in_ps, lane * pl.in_w + pl.cV + k), acc);
+            const float v = live[lane] ? activate(pl.act_vo, acc * (1.0f / 256.0f), tab) : 0.0f;
+            vadl[lane] = v;
+            NNN_TIF(b, vad, 1, f, tile, r0 + lane)[0] = v;
+        }
+        bk_gru_load_b(pl.noise, Wq, lane, H, W);
+        lds_barrier();
+        bk_gru_phase_b(pl.noise, R, SPn, o.sw_n, Wq, lane, W, H);
+        bk_gru_load_a(pl.dn, Wq, fpar, wave, lane, W);
+        lds_barrier();
+        NNN_STAMP(b, 9);
+        // denoise GRU (ref: src/rnn.rs:368-377)
+        bk_gru_phase_a(pl.dn, R, SPdn, o.sw_dn, Wq, fpar, wave, lane, W, H);
+        bk_gru_load_b(pl.dn, Wq, lane, H, W);
+        lds_barrier();
+        bk_gru_phase_b(pl.dn, R, SPdn, o.sw_dn, Wq, lane, W, H);
+        bk_dense_load(pl.out, Wq, fpar, wave, lane, W);
+        lds_barrier();
+        NNN_STAMP(b, 10);
         // gains (ref: src/rnn.rs:378) and smoothing g = max(g, 0.6 lastg) (ref: src/denoise.rs:106-109)
-        bk_dense(pl.out, R, Wq, fpar, wave, lane, [&](int lrow, int band, float v, int q) {
+        bk_dense(pl.out, R, Wq, fpar, wave, lane, W, [&](int lrow, int band, float v, int q) {
             const int row = r0 + lrow;
             const bool lv = live[lrow] != 0;
             const float gr = lv ? v : 0.0f;
@@ -637,14 +720,17 @@ __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0,
         });
         if (!FUSED) {
             lds_barrier();   // (the next frame's features may be staged)
+            NNN_STAMP(b, 11);
             continue;
         }
         lds_barrier();   // gains and vad of every row in place; the RNN's operands are dead: the synthesis takes their space
+        NNN_STAMP(b, 11);
         // ---------------- wave = stream: pitch filter, gains, inverse transform, overlap-add
         {
             const float b_graw = lane < NB ? gout[wave * BK_GW + lane] : 0.0f, b_g = lane < NB ? gout[wave * BK_GW + 24 + lane] : 0.0f;
             bk_synth(b, sp, f, tile, sl, s, lane, t, Z, part, K.X, K.P, K.ex, K.ep, K.xn, b_graw, b_g, vadl[wave], !silent, sm);
         }
+        NNN_STAMP(b, 12);
     }
     // ---- states back to HBM
     {
@@ -659,6 +745,7 @@ __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0,
         save_state(pl.dn, sdn, SPdn, o.sw_dn);
     }
     if (lane0 == 0) NNN_TI(b.mem_id, 1, tile, sl)[0] = mem_id;
+    NNN_STAMP(b, 13);
 }
 
 }  // namespace nnn

@@ -84,8 +84,10 @@ struct nnn_batch {
         size_t back_lds = 0, rnn16_lds = 0;   // dynamic LDS of k_back<true> / k_back<false>; 0 = the model is outside the kernel's shape class
         BkActs acts = {};
     };
-    int back_mode = 1;             // the fused back end (k_back, nnn_back.hip): 0 = never, 1 = one-frame groups (the real-time tick), 2 = every group;
-                                   // 3 / 4 = its RNN stretch alone (k_back<false>) in place of k_rnn / k_rnn_wf for one-frame / all groups (env NNN_BACK)
+    int back_mode = -1;            // the fused back end (k_back, nnn_back.hip): 0 = never, 1 = one-frame groups (the real-time tick), 2 = every group;
+                                   // 3 / 4 = its RNN stretch alone (k_back<false>) in place of k_rnn / k_rnn_wf for one-frame / all groups;
+                                   // -1 = by measurement (back_choice): one-frame groups only, fused up to 8192 streams, the RNN stretch
+                                   // alone above that or with other batches ticking beside this one (env NNN_BACK)
     int rnn_rows = 0;              // forced rows per RNN block (env NNN_RNN_ROWS), 0 = by model size and batch size
     std::vector<ModelGroup> groups;
     std::vector<RNNModel> models;  // host copies of the resident models (clone)
@@ -740,8 +742,17 @@ struct Launcher {
 // HBM buy nothing -- the layer-pipelined RNN has no second frame to pipeline.
 static int back_choice(const nnn_batch *h, int g)
 {
-    const int m = h->back_mode;
-    if (m <= 0) return 0;
+    int m = h->back_mode;
+    if (m < 0) {
+        // Measured on one MI355X (scripts/back_ab.py, profiles/r4_back_ab.txt), one frame per call: fused 143 us against 162 (unfused) and
+        // 148 (RNN stretch alone) at 4096 streams, level with the RNN stretch alone at 8192, behind it from 16 384 streams up (a block of
+        // sixteen waves that holds a compute unit through three stretches fills the GPU worse than three launches of small blocks once
+        // there are several rounds of them); 24-frame groups: the layer-pipelined RNN between k_fft_xp and k_synth stays ahead of
+        // both (65.5 against 59.7 M frames/s at 65 536 streams).
+        if (g > 1) return 0;
+        m = (h->S_pad <= 8192 && !h->beside_others) ? 1 : 3;
+    }
+    if (m == 0) return 0;
     const bool fused = m == 1 || m == 2, all_g = m == 2 || m == 4;
     if (g > 1 && !all_g) return 0;
     for (const nnn_batch::ModelGroup &G : h->groups)
@@ -1404,7 +1415,7 @@ extern "C" int nnn_batch_debug_withhold_flag(nnn_batch *h, int frames_ahead)
 extern "C" int nnn_batch_set_back_end(nnn_batch *h, int mode)
 {
     if (!h) return fail("null batch");
-    if (mode < 0 || mode > 4) return fail("unknown back-end mode %d", mode);
+    if (mode < -1 || mode > 4) return fail("unknown back-end mode %d", mode);
     h->back_mode = mode;
     return 0;
 }

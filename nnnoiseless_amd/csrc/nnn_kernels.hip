@@ -1266,12 +1266,15 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
 // un-normalised in both directions.
 // ---------------------------------------------------------------------------------------------
 // Everything from here to the end of k_fft_x, and k_synth further down, is downstream of an FFT: the reference itself is only
-// defined to f32 rounding there (its FFT picks AVX / SSE / scalar code at run time), parity is a tolerance, and these kernels
-// are bound by vector-instruction issue -- so a multiply may fuse with the add that follows it (v_fma_f32 / v_pk_fma_f32),
-// which the translation unit's -ffp-contract=off forbids everywhere else (the pitch path rounds like the scalar reference, the
-// activation functions are compared bit for bit).  NNN_FFT_CONTRACT=0 builds the unfused variant for A/B runs.
+// defined to f32 rounding there (its FFT picks AVX / SSE / scalar code at run time) and parity is a tolerance.  A multiply fuses
+// with an add exactly where the source says fmaf (complex products, band sums); nowhere else.  Round 3 let the compiler fuse at
+// will in these regions (#pragma clang fp contract(fast): -5 % / -1 % static vector instructions in k_fft_xp / k_synth, no measured
+// time, profiles/r3_experiments_ab.txt block A).  Round 4 took that back: the same source then rounds the same way in every kernel
+// it is inlined into, and the fused back end (k_back) -- the same transforms and synthesis inside another kernel, where the
+// compiler's choices came out differently in a third of the spectrum's bins -- gives the bits of k_fft_xp / k_synth, so a stream
+// may change back end from call to call.  NNN_FFT_CONTRACT=1 builds the freely fusing variant for A/B runs.
 #ifndef NNN_FFT_CONTRACT
-#define NNN_FFT_CONTRACT 1
+#define NNN_FFT_CONTRACT 0
 #endif
 #if NNN_FFT_CONTRACT
 #pragma clang fp contract(fast)
@@ -1471,6 +1474,9 @@ __device__ __forceinline__ void fft480(float2 *buf, const float2 *tw, int lane)
 // The same with the input handed over in registers in the first pass's own order -- lane j < 60 holds elements j + 60 r, r < 8
 // (lanes 60..63 hold anything) -- instead of staged in buf: both callers can produce their input in that order, which saves the
 // staging store, the first pass's reads and a synchronisation per transform.  Every earlier reader of buf must be done.
+// RL (the fused back end, a wave of 128 registers that also holds two spectra): the lane index is laundered between the passes, so that
+// each pass forms its LDS addresses and twiddle indices where it starts instead of all of them up front (see launder_v)
+template <bool RL = false>
 __device__ __forceinline__ void fft480_regs(float2 (&v)[8], float2 *buf, const float2 *tw, int lane)
 {
     dft8(v);
@@ -1479,7 +1485,9 @@ __device__ __forceinline__ void fft480_regs(float2 (&v)[8], float2 *buf, const f
         for (int r = 0; r < 8; r++) buf[9 * lane + r] = v[r];   // skewed, as fft_pass<8, 1, false, true> leaves it
     }
     wave_lds_sync();
+    if (RL) lane = launder_v(lane);
     fft_pass<6, 8, true, false>(buf, tw, lane);
+    if (RL) lane = launder_v(lane);
     fft_pass<10, 48, false, false>(buf, tw, lane);
 }
 constexpr int FFT_P1 = NFFT / 8;   // butterflies (= lanes at work) of the first pass
@@ -1581,6 +1589,7 @@ __device__ __forceinline__ void window_load(const float *h, int ring, int rb, in
         sm[r] = *(const SamplePair *)(h + i0);   // (i0 + 1 = ring reads the copy of sample 0 kept there)
     }
 }
+template <bool RL = false>
 __device__ __forceinline__ void window_rfft(const Buffers &b, const SamplePair (&sm)[8], const float2 (&w)[8], const FftLds &t,
                                             float2 *Z, float2 (&Y)[8], int lane, bool first)
 {
@@ -1589,7 +1598,8 @@ __device__ __forceinline__ void window_rfft(const Buffers &b, const SamplePair (
 #pragma unroll
     for (int r = 0; r < 8; r++) v[r] = make_float2(sm[r].x * w[r].x, sm[r].y * w[r].y);
     if (first) __syncthreads();   // tables in place; from here on every wave is on its own
-    fft480_regs(v, Z, t.tw, lane);
+    fft480_regs<RL>(v, Z, t.tw, lane);
+    if (RL) lane = launder_v(lane);
     // Bins k and 480 - k come from the same two transform outputs (E[480 - k] = conj E[k], O[480 - k] = conj O[k], the twiddle
     // of 480 - k is -conj of k's): a lane takes them as a pair -- one read of each output, one twiddle, one complex product for
     // both -- and owns bins rfft_slot_bin(lane, u): k = lane + 64 u in slots u < 4 (k <= 240), 480 - k in slot 4 + u (k < 240).
@@ -1632,10 +1642,15 @@ struct XpKeep {
     int *flag;            // in: one LDS word of the wave (the silence flag travels through it)
 };
 template <bool WITH_P, bool FUSED = false>
-__device__ __forceinline__ void transform_inputs(const Buffers &b, const StepParams *sp, int tile, int sub, FftLds &t, float2 *Z, float *part,
+__device__ __forceinline__ void transform_inputs(const Buffers &b, const StepParams *sp, int tile_in, int sub, FftLds &t, float2 *Z, float *part,
                                                  XpKeep *keep = nullptr)
 {
-    const int lane = threadIdx.x & 63, sl = FUSED ? keep->sl : sub * FFT_SPB + (int)(threadIdx.x >> 6), s = tile * TILE + sl;
+    int tile = tile_in;
+    // (fused: the lane index is laundered again between the stages -- see launder_v -- so that the addresses of a later stage are formed
+    // where it starts instead of at the top of the function, where the first build kept dozens of them alive in spilled registers)
+    int lane = threadIdx.x & 63;
+    int sl = FUSED ? keep->sl : sub * FFT_SPB + (int)(threadIdx.x >> 6), s = tile * TILE + sl;
+#define NNN_FUSED_RELAUNDER() do { if (FUSED) { lane = launder_v(lane); tile = launder_s(tile); sl = launder_s(sl); s = tile * TILE + sl; } } while (0)
     const int ring = ring_len(b.nslot), rb = ring_base(sp->slot, b.nslot);
     float2 w[8];   // the window at sample pairs j + 60 r: the order of the transforms' first pass (window_rfft)
 #pragma unroll
@@ -1648,10 +1663,10 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     SamplePair sx[8], spw[8];
     window_load(h, ring, rb, 0, lane, sx);
 #ifndef NNN_FFT_LATE_P   // (A/B knob: the second window requested where its transform starts, as before)
-    if (WITH_P) window_load(h, ring, rb, lag, lane, spw);
+    if (WITH_P && !FUSED) window_load(h, ring, rb, lag, lane, spw);   // (fused: sixteen registers it has not got; requested after the first transform)
 #endif
     float2 X[8];
-    window_rfft(b, sx, w, t, Z, X, lane, !FUSED);
+    window_rfft<FUSED>(b, sx, w, t, Z, X, lane, !FUSED);
     float2 *dx = b.X + (size_t)s * FSTR;
     // NNN_PROBE_XP (developer probe, wrong audio, timing only): the spectra are not stored here and k_synth reads them from a
     // region small enough to stay in the XCD's L2 -- an upper bound on what keeping X and P on chip between the transforms
@@ -1665,6 +1680,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
         }
     }
 #endif
+    NNN_FUSED_RELAUNDER();
     float *vv = (float *)Z, *vc = vv + BSK_LEN;   // per-bin quantities of the band sums, skewed (bsk)
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -1682,11 +1698,18 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     }
     if (!WITH_P) return;
     wave_lds_sync();
+    NNN_FUSED_RELAUNDER();
     float2 Y[8];
 #ifdef NNN_FFT_LATE_P
     window_load(h, ring, rb, lag, lane, spw);
+#else
+    if (FUSED) window_load(b.hist + (size_t)s * hist_stride(b.nslot), ring, rb, lag, lane, spw);
 #endif
-    window_rfft(b, spw, w, t, Z, Y, lane, false);
+    if (FUSED) {   // (the window again, from the L2: sixteen registers less across the first transform and the band sums of a wave that has 128)
+#pragma unroll
+        for (int r = 0; r < 8; r++) w[r] = ((const float2 *)b.window_a)[(lane < FFT_P1 ? lane : FFT_P1 - 1) + FFT_P1 * r];
+    }
+    window_rfft<FUSED>(b, spw, w, t, Z, Y, lane, false);
     float2 *dp = b.P + (size_t)s * FSTR;
     const int np = b.taps ? FREQ : 400;   // the pitch filter reads bins 0..399 only
 #ifndef NNN_PROBE_XP
@@ -1707,6 +1730,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
         }
     }
     wave_lds_sync();
+    NNN_FUSED_RELAUNDER();
     const float *const v[2] = {vv, vc};
     float o[2];
     band_sums_par<2>(t, v, o, lane);
@@ -1714,6 +1738,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     // launch covers a whole frame group: the correlation normalised by the band energies, the floored log energies,
     // the silence test, and the two DCTs -- lane = band.  Same operations in the same order as when one lane did it all.
     wave_lds_sync();
+    NNN_FUSED_RELAUNDER();
     float *xc = part, *ly = part + 64, *exl = part + 128;
     float lyv = -2.0f, xnv = 0.0f;
     if (lane < NB) {
@@ -1780,6 +1805,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
         wave_lds_sync();
         keep->silent = keep->flag[0];
     }
+#undef NNN_FUSED_RELAUNDER
 }
 
 #ifndef NNN_FFT_MINWAVES
