@@ -759,7 +759,7 @@ static int back_choice(const nnn_batch *h, int g)
         if ((fused ? G.back_lds : G.rnn16_lds) == 0) return 0;
     return fused ? 2 : 1;
 }
-static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams *sp0, hipStream_t st, bool prof)
+static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams *sp0, hipStream_t st, bool prof, const StepParams *call = nullptr, int fill = 0)
 {
     if (g <= 0) return;   // (never a launch with an empty grid)
     const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad, ug = (unsigned)g;
@@ -768,7 +768,8 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
     const int back = back_choice(h, g);
     switch (s) {
     case ST_HP:
-        L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g);
+        // (`fill`: this is the first launch of a call whose parameter table is k_hp's to fill, see k_hp)
+        L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g, call ? *call : StepParams{}, call ? fill : 0);
         // the LPC analysis of the group's frames (lane = stream, frames side by side) rides on the same stream, ahead of the pitch stage
         // (launches too small to fill the GPU spread the five lags of a stream over five waves)
         if (h->lpc_wide >= 0 ? h->lpc_wide != 0 : NT * ug < 512u) L.go(K_LPC, k_lpc_wide, dim3(NT * ug), dim3(320), 0, b, sp0, g);
@@ -940,17 +941,20 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     // (never for the library's own host-buffer calls: their input is an upload enqueued just before on the caller's stream or on
     // a copy stream, final only in that stream's order -- the promise is about buffers the CALLER filled)
     const bool early_hp = pipe && h->inputs_ready && !h->host_call && h->prev_pipe && h->prev_st == st && h->sched == SCHED_LANES && h->pool[0];
+    // the per-frame parameter table: a launch of its own ahead of a pipelined call's streams; otherwise the call's first kernel (k_hp of
+    // the first group) fills it on its way (a one-frame call is a handful of launches of 15-35 us: one fewer is 4 % of it)
+    const bool fold_fill = !pipe && !h->profiling;
     if (early_hp) {
         if (h->have_done[par]) chk(hipStreamWaitEvent(h->pool[0], h->ev_done[par], 0));   // the table's previous user (two calls back)
         hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, h->pool[0], tab, v0, n_frames, h->nslot);
         h->pool_call[0] = h->call_count;   // (no wait for the caller's stream on this one)
-    } else {
+    } else if (!fold_fill) {
         hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, st, tab, v0, n_frames, h->nslot);
     }
     if (!pipe) {
         for (int k = 0, t = 0; k < n_groups; k++) {
             const int g = sizes[k], set0 = (int)(h->group_count % h->depth) * h->gmax;
-            for (int s = 0; s < ST_COUNT; s++) launch_stage(h, s, set0, g, tab + t, st, h->profiling);
+            for (int s = 0; s < ST_COUNT; s++) launch_stage(h, s, set0, g, tab + t, st, h->profiling, (fold_fill && k == 0) ? &v0 : nullptr, n_frames);
             h->group_count += 1;
             h->frame_count += g;
             h->last_set = set0 + g - 1;
@@ -1501,7 +1505,7 @@ static void enqueue_feature_group(nnn_batch *h, hipStream_t st, const float *in,
     v.log = nullptr;
     v.log_frames = 0;
     hipLaunchKernelGGL(k_fill_params, dim3(1), dim3(64), 0, st, sp, v, g, h->nslot);
-    hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, (const StepParams *)sp, g);
+    hipLaunchKernelGGL(k_hp, dim3(NT), dim3(64), 0, st, b, (const StepParams *)sp, g, StepParams{}, 0);
     if (full) {
         if (h->lpc_wide >= 0 ? h->lpc_wide != 0 : NT * ug < 512u) hipLaunchKernelGGL(k_lpc_wide, dim3(NT * ug), dim3(320), 0, st, b, (const StepParams *)sp, g);
         else {

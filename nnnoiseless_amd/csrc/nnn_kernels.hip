@@ -187,14 +187,15 @@ struct HpState { float m0, m1, prev; };
 // (row stride 33 floats: conflict-free both ways) and leave as 8 stores of 8 streams x 128 contiguous bytes.
 constexpr int HP_LD = HP_CH + 1;
 template <int FMT, bool VEC>
-__device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp, int tile, int lane, HpState &st, float *Ly)
+__device__ __forceinline__ void hp_frame(const Buffers &b, const char *sp_in, long long sp_group_stride, int slot, int ch, int tile, int lane, HpState &st, float *Ly)
 {
-    const int slot = sp->slot;
-    const int elem = pcm_elem_bytes(FMT), ch = sp->channels, sstride = ch * elem;
+    const int elem = pcm_elem_bytes(FMT), sstride = ch * elem;
     const int s = tile * TILE + lane;
     // padding lanes of the last tile re-read the last real stream: their state is never looked at
     const int sc = s < b.S ? s : b.S - 1, grp = sc / ch;
-    const char *in = sp->in + (long long)grp * sp->group_stride + (long long)(sc - grp * ch) * elem;
+    const char *in = sp_in + (long long)grp * sp_group_stride + (long long)(sc - grp * ch) * elem;
+    // (two chunks in flight -- chunk c + 2 requested when chunk c leaves its registers -- was measured in round 4 for the lone waves of a
+    // one-frame call: 378 registers, the launch 27 -> 34 us.  One chunk ahead it stays.)
     HpChunk<FMT, VEC> nxt;
     nxt.load(in, sstride);
     float m0 = st.m0, m1 = st.m1, prev = st.prev;
@@ -265,27 +266,53 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const StepParams *sp,
     NNN_STAMP(b, 25);
 }
 
+// Entry t of a call's per-frame parameter table from the call's own parameters `v` (frame 0): what k_fill_params writes, and what
+// k_hp -- the first kernel of a call -- works out for itself when the table is its to fill.
+__device__ __forceinline__ StepParams step_params_at(const StepParams &v, int t, int nslot)
+{
+    StepParams p = v;
+    p.in = v.in + (long long)t * v.frame_stride;
+    p.out = v.out + (long long)(t - v.discard) * v.frame_stride;   // dropped frames take no room in the output
+    p.discard = t < v.discard;
+    p.vad = v.vad ? v.vad + (size_t)t * v.n_streams : nullptr;
+    p.slot = (v.slot + t) % nslot;
+    p.log = (v.log && t < v.log_frames) ? v.log + (size_t)t * v.n_streams * FRAME_LOG_WORDS : nullptr;
+    return p;
+}
+
+// `fill` > 0: this launch is the first of a call of `fill` frames whose table nobody has filled -- a launch of its own for that costs
+// a one-frame call 6 of its 150 us -- so block 0 writes it (for the kernels behind this one, which start when this one is done) and
+// every block takes its own frames' entries from the call's parameters `v0`; the group's first frame is entry `t0` of the call.
 template <int FMT, bool VEC>
-__device__ __forceinline__ void hp_group(const Buffers &b, const StepParams *sp, int g, int tile, int lane, float *Ly)
+__device__ __forceinline__ void hp_group(const Buffers &b, const StepParams *sp, int g, int tile, int lane, float *Ly, const StepParams &v0, int fill)
 {
     float *hp = NNN_TI(b.hp_mem, 2, tile, lane);
     float *hl = NNN_TI(b.hp_last, 1, tile, lane);
     HpState st{hp[0], hp[TILE], hl[0]};
-    for (int f = 0; f < g; f++) hp_frame<FMT, VEC>(b, sp + f, tile, lane, st, Ly);
+    for (int f = 0; f < g; f++) {
+        // (what a frame needs of its table entry: where its input starts and which ring slot takes it)
+        const char *in = fill > 0 ? v0.in + (long long)f * v0.frame_stride : sp[f].in;
+        const int slot = fill > 0 ? (v0.slot + f) % b.nslot : sp[f].slot;
+        hp_frame<FMT, VEC>(b, in, fill > 0 ? v0.group_stride : sp[f].group_stride, slot, fill > 0 ? v0.channels : sp[f].channels, tile, lane, st, Ly);
+    }
     hp[0] = st.m0;
     hp[TILE] = st.m1;
     hl[0] = st.prev;
 }
 
-__global__ void __launch_bounds__(64, HP_CH <= 16 ? 3 : 1) k_hp(Buffers b, const StepParams *sp, int g)
+__global__ void __launch_bounds__(64, HP_CH <= 16 ? 3 : 1) k_hp(Buffers b, const StepParams *sp, int g, StepParams v0, int fill)
 {
-    const int lane = threadIdx.x, tile = blockIdx.x, fmt = sp->fmt;
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    if (fill > 0 && tile == 0)
+        for (int t = lane; t < fill; t += 64) ((StepParams *)sp)[t] = step_params_at(v0, t, b.nslot);
+    const int fmt = fill > 0 ? v0.fmt : sp->fmt;
     wf_setprio_high();   // a lone wave on a serial chain that shares its SIMD with another kernel's wave (+1 % at 4096 streams)
-    const bool vec = sp->channels == 1 && ((((size_t)sp->in) | (size_t)sp->group_stride | (size_t)sp->frame_stride) & 15) == 0;
+    const StepParams &lay = fill > 0 ? v0 : *sp;
+    const bool vec = lay.channels == 1 && ((((size_t)lay.in) | (size_t)lay.group_stride | (size_t)lay.frame_stride) & 15) == 0;
     __shared__ float Ly[TILE * HP_LD];
-    if (fmt == PCM_F32) { if (vec) hp_group<PCM_F32, true>(b, sp, g, tile, lane, Ly); else hp_group<PCM_F32, false>(b, sp, g, tile, lane, Ly); }
-    else if (fmt == PCM_I16) { if (vec) hp_group<PCM_I16, true>(b, sp, g, tile, lane, Ly); else hp_group<PCM_I16, false>(b, sp, g, tile, lane, Ly); }
-    else { if (vec) hp_group<PCM_F32_UNIT, true>(b, sp, g, tile, lane, Ly); else hp_group<PCM_F32_UNIT, false>(b, sp, g, tile, lane, Ly); }
+    if (fmt == PCM_F32) { if (vec) hp_group<PCM_F32, true>(b, sp, g, tile, lane, Ly, v0, fill); else hp_group<PCM_F32, false>(b, sp, g, tile, lane, Ly, v0, fill); }
+    else if (fmt == PCM_I16) { if (vec) hp_group<PCM_I16, true>(b, sp, g, tile, lane, Ly, v0, fill); else hp_group<PCM_I16, false>(b, sp, g, tile, lane, Ly, v0, fill); }
+    else { if (vec) hp_group<PCM_F32_UNIT, true>(b, sp, g, tile, lane, Ly, v0, fill); else hp_group<PCM_F32_UNIT, false>(b, sp, g, tile, lane, Ly, v0, fill); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3204,14 +3231,7 @@ __global__ void k_fill_params(StepParams *tab, StepParams v, int n, int nslot)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    StepParams p = v;
-    p.in = v.in + (long long)t * v.frame_stride;
-    p.out = v.out + (long long)(t - v.discard) * v.frame_stride;   // dropped frames take no room in the output
-    p.discard = t < v.discard;
-    p.vad = v.vad ? v.vad + (size_t)t * v.n_streams : nullptr;
-    p.slot = (v.slot + t) % nslot;
-    p.log = (v.log && t < v.log_frames) ? v.log + (size_t)t * v.n_streams * FRAME_LOG_WORDS : nullptr;
-    tab[t] = p;
+    tab[t] = step_params_at(v, t, nslot);
 }
 
 }  // namespace nnn
