@@ -62,17 +62,21 @@ KERNEL_BYTES = {
     "k_fft_xp": 3840 + 1200 + 4 + 3848 + 3200 + 264 + 112 + 4,     # 960 + (mean lag 300) history samples; X (481 bins), P (400 bins), band energies, cepstrum head out
     "k_rnn": 120 + 88 + 4 + 2 * 88 + 2 * 88 + (704 + 2 * 672 + 8) // G,   # features head in; ring row, vad, gains, last gains; ring + GRU states per group
     "k_synth": 3848 + 3200 + 440 + 8 + 1920 + 8 + 3840 // G,       # X, P, band quantities in; audio, vad, branch out; overlap memory per group
+    # the fused back end (transforms + features + RNN + synthesis in one launch, the spectra in registers): history samples and pitch in; band
+    # quantities (parity taps), ring row, vad, gains, last gains, branch, audio out; overlap memory in and out per frame; ring + GRU states per launch
+    "k_back": 3840 + 1200 + 4 + 268 + 88 + 4 + 2 * 88 + 2 * 88 + 4 + 1920 + 3840 + (704 + 2 * 672 + 8) // 1,
 }
 
 # Useful arithmetic per stream-frame of each kernel (SURVEY.md 8(d)'s break-down of the 0.42 MFLOP) and the roof that applies to
 # it (TFLOP/s): the pitch analysis may not fuse a multiply with an add (bit-exact sums in the reference's order), so its roof
 # is half the FP32 vector peak; the transforms run at the full FP32 vector peak; the RNN's products run as three bf16 planes
 # per f32 activation on the matrix cores (dense bf16 peak / 3); the biquad is an f64 chain.
-KERNEL_FLOPS = {"k_hp": 480 * 13, "k_lpc": 8.7e3, "k_pitch": 126e3, "k_fft_xp": 66e3, "k_rnn": 174e3, "k_synth": 42e3}
+KERNEL_FLOPS = {"k_hp": 480 * 13, "k_lpc": 8.7e3, "k_pitch": 126e3, "k_fft_xp": 66e3, "k_rnn": 174e3, "k_synth": 42e3, "k_back": 66e3 + 174e3 + 42e3}
 KERNEL_ROOF_TFLOPS = {"k_hp": FP32_PEAK_TFLOPS / 2, "k_lpc": FP32_PEAK_TFLOPS / 2, "k_pitch": FP32_PEAK_TFLOPS / 2, "k_fft_xp": FP32_PEAK_TFLOPS, "k_synth": FP32_PEAK_TFLOPS,
-                      "k_rnn": 2500.0 / 3}
+                      "k_rnn": 2500.0 / 3, "k_back": FP32_PEAK_TFLOPS}
 KERNEL_ROOF_NAME = {"k_hp": "f64 vector, serial chain", "k_lpc": "FP32 vector without FMA (exact sums)", "k_pitch": "FP32 vector without FMA (exact sums)", "k_fft_xp": "FP32 vector",
-                    "k_synth": "FP32 vector", "k_rnn": "bf16 MFMA / 3 planes"}
+                    "k_synth": "FP32 vector", "k_rnn": "bf16 MFMA / 3 planes",
+                    "k_back": "FP32 vector (transforms and synthesis; its RNN stretch runs on bf16 MFMA / 3 planes)"}
 
 CONFIGS = {
     1: {"streams": 4096, "model": None, "name": "configs[1]: 4096 concurrent mono streams per GPU, built-in weights.rnn"},
@@ -185,6 +189,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] / configs[4] measurements of the default run")
     ap.add_argument("--min-timed-s", type=float, default=0.5, help="the `also` entries run enough steps to be timed for at least this long")
     ap.add_argument("--pool-bytes", type=float, default=6.5e9, help="HBM budget for the resident input pool (and as much again for the output)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="all --gpus devices from ONE process through the library's node object (include/nnn_node.h: one batch and one host "
+                         "thread per device, the stream split inside the library) instead of one rank per GPU under torch.distributed")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a GPU: gloo backend, CPU tensors, the library named by NNN_LIBRARY (the tests "
                          "point it at the SIMT-interpreter build), a few streams; the numbers mean nothing")
@@ -460,10 +467,66 @@ def host_boundary(S, fps, calls=4):
     return out
 
 
+def single_process(args):
+    """--single-process: the node object (nnn_node_*) drives every GPU of the node from this one process; buffers resident on each
+    shard's own device, calls asynchronous, one synchronize per step batch.  Same metric, same per-GPU share as the launcher path."""
+    import torch
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams_device
+    cfg = CONFIGS[args.config]
+    N, S1, fps, K, W = args.gpus, args.streams or cfg["streams"], args.frames_per_step, args.steps, args.warmup
+    if torch.cuda.device_count() < N:
+        raise SystemExit(f"bench: --gpus {N} --single-process but only {torch.cuda.device_count()} devices visible")
+    model = nn.RnnModel.from_bytes(open(args.model or cfg["model"], "rb").read()) if (args.model or cfg["model"]) else None
+    node = nn.NodeDenoiser(S1 * N, list(range(N)), model=model)
+    pool = 2 * fps
+    parts = []
+    for i, (d, lo, hi) in enumerate(node.shards()):
+        dev = torch.device("cuda", d)
+        x = make_streams_device(torch, dev, hi - lo, pool, seed=i)
+        parts.append((x, torch.empty_like(x), torch.empty((pool, hi - lo), dtype=torch.float32, device=dev)))
+    for i in range(N):
+        nn.library().check(nn.library().L.nnn_batch_set_inputs_ready(node.batch_handle(i), 1))
+
+    def step(j):
+        f0 = (j % 2) * fps
+        node.process_device([p[0].data_ptr() + f0 * 480 * 4 for p in parts], [p[1].data_ptr() + f0 * 480 * 4 for p in parts],
+                            [p[2].data_ptr() + f0 * (p[2].shape[1]) * 4 for p in parts], fps, pool * 480, 480)
+
+    def sync():
+        node.synchronize()
+        for d in range(N):
+            torch.cuda.synchronize(d)
+
+    sync()
+    for j in range(W):
+        step(j)
+    sync()
+    t0 = time.perf_counter()
+    for j in range(W, W + K):
+        step(j)
+    sync()
+    dt = time.perf_counter() - t0
+    if node.fault():
+        raise SystemExit("bench: the library reports a frame hand-off fault: results invalid")
+    line = {"metric": "480-sample frames/sec (whole node) at N concurrent streams", "value": S1 * N * fps * K / dt, "unit": "frames/s", "n_gpus": N,
+            "steps": K, "warmup": W, "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{cfg['name']}, synthetic 48 kHz sine+noise, {fps} frame(s) per stream per step", "baseline_config_index": args.config,
+                       "streams_per_gpu": S1, "streams_total": S1 * N, "frames_per_step": fps,
+                       "parallelism": f"streams sharded x{N} inside the library (nnn_node_*: one batch and one host thread per device), ONE process, "
+                                      "no data-path collective", "shards": node.shards()},
+            "outputs_finite": all(bool(torch.isfinite(p[1]).all().item()) for p in parts), "timed_s": dt}
+    print(json.dumps(line), flush=True)
+    node.close()
+
+
 def main():
     args = parse_args()
     if args.config == 0:
         return config0()
+    if args.single_process:
+        return single_process(args)
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
         # not under a launcher: start one rank per GPU ourselves

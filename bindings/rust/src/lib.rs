@@ -11,12 +11,28 @@ pub struct RawModel {
 pub struct RawBatch {
     _p: [u8; 0],
 }
+#[repr(C)]
+pub struct RawNode {
+    _p: [u8; 0],
+}
 
 extern "C" {
     fn nnn_model_from_bytes(bytes: *const u8, len: usize) -> *mut RawModel;
     fn nnn_model_default() -> *mut RawModel;
     fn nnn_model_free(m: *mut RawModel);
     fn nnn_model_clone(m: *const RawModel) -> *mut RawModel;
+    fn nnn_node_create(model: *const RawModel, n_streams: c_int, devices: *const c_int, n_devices: c_int, opts: *const BatchOpts) -> *mut RawNode;
+    fn nnn_node_destroy(n: *mut RawNode);
+    fn nnn_node_reset(n: *mut RawNode) -> c_int;
+    fn nnn_node_process_host(
+        n: *mut RawNode,
+        input: *const c_float,
+        output: *mut c_float,
+        vad: *mut c_float,
+        n_frames: c_int,
+        stream_stride: usize,
+        frame_stride: usize,
+    ) -> c_int;
     fn nnn_batch_create(model: *const RawModel, n_streams: c_int, device: c_int) -> *mut RawBatch;
     fn nnn_batch_destroy(b: *mut RawBatch);
     fn nnn_batch_reset(b: *mut RawBatch) -> c_int;
@@ -291,3 +307,50 @@ impl Drop for PinnedBuf {
 }
 
 unsafe impl Send for PinnedBuf {}
+
+/// All the GPUs of a node behind one object (include/nnn_node.h): the `states` vector of the reference's hosts
+/// (src/nnnoiseless.rs:305-320) cut into contiguous shards, one batch and one host thread per device, no data between devices.
+pub struct NodeDenoiser {
+    raw: *mut RawNode,
+    n: usize,
+}
+unsafe impl Send for NodeDenoiser {}
+unsafe impl Sync for NodeDenoiser {}
+
+impl NodeDenoiser {
+    pub fn new(n_streams: usize, devices: &[i32], model: Option<&RnnModel>) -> Option<NodeDenoiser> {
+        let m = model.map_or(std::ptr::null(), |m| m.0 as *const RawModel);
+        let raw = unsafe { nnn_node_create(m, n_streams as c_int, devices.as_ptr(), devices.len() as c_int, std::ptr::null()) };
+        if raw.is_null() {
+            None
+        } else {
+            Some(NodeDenoiser { raw, n: n_streams })
+        }
+    }
+    /// `input`/`output`: `[n_streams][n_frames][480]`; `vad`: `[n_frames][n_streams]`; every device works on its share at once.
+    pub fn process(&mut self, output: &mut [f32], input: &[f32], vad: &mut [f32], n_frames: usize) {
+        assert_eq!(input.len(), self.n * n_frames * DenoiseState::FRAME_SIZE);
+        assert_eq!(output.len(), input.len());
+        assert_eq!(vad.len(), self.n * n_frames);
+        let rc = unsafe {
+            nnn_node_process_host(
+                self.raw,
+                input.as_ptr(),
+                output.as_mut_ptr(),
+                vad.as_mut_ptr(),
+                n_frames as c_int,
+                n_frames * DenoiseState::FRAME_SIZE,
+                DenoiseState::FRAME_SIZE,
+            )
+        };
+        assert_eq!(rc, 0, "nnnoiseless-mi355x: backend error");
+    }
+    pub fn reset(&mut self) {
+        unsafe { nnn_node_reset(self.raw) };
+    }
+}
+impl Drop for NodeDenoiser {
+    fn drop(&mut self) {
+        unsafe { nnn_node_destroy(self.raw) }
+    }
+}

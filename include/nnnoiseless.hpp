@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "nnn_batch.h"
+#include "nnn_node.h"
 #include "nnn_resample.h"
 #include "nnn_train.h"
 
@@ -231,6 +232,36 @@ class Resampler {
 
   private:
     std::shared_ptr<nnn_resampler> r_;
+};
+
+
+// All the GPUs of a node behind one object (include/nnn_node.h): contiguous stream shards, one batch and one host thread per device.
+class NodeDenoiser {
+  public:
+    NodeDenoiser(int n_streams, const std::vector<int> &devices, const RnnModel *model = nullptr, int max_group_frames = 0)
+    {
+        nnn_batch_opts o = {};
+        o.max_group_frames = max_group_frames;
+        n_ = nnn_node_create(model ? model->raw() : nullptr, n_streams, devices.data(), (int)devices.size(), max_group_frames ? &o : nullptr);
+        if (!n_) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+    }
+    ~NodeDenoiser() { nnn_node_destroy(n_); }
+    NodeDenoiser(const NodeDenoiser &) = delete;
+    NodeDenoiser &operator=(const NodeDenoiser &) = delete;
+    int num_streams() const { return nnn_node_num_streams(n_); }
+    int num_shards() const { return nnn_node_num_shards(n_); }
+    // in / out: [n_streams][n_frames][480], vad: [n_frames][n_streams] (may be null); every device works on its share at once
+    void process(const float *in, float *out, float *vad, int n_frames)
+    {
+        if (nnn_node_process_host(n_, in, out, vad, n_frames, (size_t)n_frames * NNN_FRAME_SIZE, NNN_FRAME_SIZE))
+            throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+    }
+    void reset() { nnn_node_reset(n_); }
+    bool fault() const { return nnn_node_fault(n_) != 0; }
+    nnn_node *raw() { return n_; }
+
+  private:
+    nnn_node *n_ = nullptr;
 };
 
 }  // namespace nnnoiseless

@@ -339,3 +339,6 @@ class DenoiseState:
         out, vad = self._b.process(input.reshape(1, 1, FRAME_SIZE))
         output[:] = out[0, 0]
         return float(vad[0, 0])
+
+
+from .node import NodeDenoiser  # noqa: E402  (all the GPUs of a node behind one object, include/nnn_node.h)

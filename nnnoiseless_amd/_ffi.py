@@ -29,6 +29,10 @@ RESAMPLE_SYMBOLS = [
     "nnn_resampler_create", "nnn_resampler_destroy", "nnn_resampler_reset", "nnn_resampler_max_output",
     "nnn_resampler_process_device", "nnn_resampler_process_host",
 ]
+NODE_SYMBOLS = [
+    "nnn_node_create", "nnn_node_destroy", "nnn_node_num_streams", "nnn_node_num_shards", "nnn_node_shard", "nnn_node_batch", "nnn_node_reset",
+    "nnn_node_process_host", "nnn_node_process_pcm_host", "nnn_node_process_device", "nnn_node_synchronize", "nnn_node_fault",
+]
 RNNOISE_SYMBOLS = [
     "rnnoise_get_frame_size", "rnnoise_get_size", "rnnoise_init", "rnnoise_create", "rnnoise_destroy",
     "rnnoise_process_frame", "rnnoise_model_from_file", "rnnoise_model_free",
@@ -114,6 +118,21 @@ class Library:
         if hasattr(L, "nnn_batch_create_opts"):
             L.nnn_batch_create_opts.restype = vp
             L.nnn_batch_device_bytes.restype = sz
+        if hasattr(L, "nnn_node_create"):
+            L.nnn_node_create.restype = vp
+            L.nnn_node_create.argtypes = [vp, i32, C.POINTER(i32), i32, C.POINTER(BatchOpts)]
+            L.nnn_node_destroy.argtypes = [vp]
+            L.nnn_node_num_streams.argtypes = [vp]
+            L.nnn_node_num_shards.argtypes = [vp]
+            L.nnn_node_shard.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+            L.nnn_node_batch.restype = vp
+            L.nnn_node_batch.argtypes = [vp, i32]
+            L.nnn_node_reset.argtypes = [vp]
+            L.nnn_node_process_host.argtypes = [vp, vp, vp, vp, i32, sz, sz]
+            L.nnn_node_process_pcm_host.argtypes = [vp, vp, vp, vp, i32, C.POINTER(PcmLayout)]
+            L.nnn_node_process_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, sz, sz]
+            L.nnn_node_synchronize.argtypes = [vp]
+            L.nnn_node_fault.argtypes = [vp]
         L.nnn_train_create.restype = vp
         L.nnn_train_create.argtypes = [i32, i32]
         L.nnn_train_destroy.argtypes = [vp]

@@ -7,7 +7,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libnnnoiseless_mi355x.so")
 WEIGHTS = os.path.join(HERE, "data", "weights.rnn")
-SOURCES = ["nnn_batch.hip", "nnn_resample.hip", "nnn_model.cpp", "rnnoise_capi.cpp"]
+SOURCES = ["nnn_batch.hip", "nnn_resample.hip", "nnn_model.cpp", "rnnoise_capi.cpp", "nnn_node.cpp"]
 DEPS = SOURCES + ["nnn_kernels.hip", "nnn_back.hip", "nnn_layout.h", "nnn_model.h", "nnn_mfma.h"]
 
 

@@ -943,7 +943,8 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     const bool early_hp = pipe && h->inputs_ready && !h->host_call && h->prev_pipe && h->prev_st == st && h->sched == SCHED_LANES && h->pool[0];
     // the per-frame parameter table: a launch of its own ahead of a pipelined call's streams; otherwise the call's first kernel (k_hp of
     // the first group) fills it on its way (a one-frame call is a handful of launches of 15-35 us: one fewer is 4 % of it)
-    const bool fold_fill = !pipe && !h->profiling;
+    static const bool fold_ok = !(getenv("NNN_FOLD_FILL") && atoi(getenv("NNN_FOLD_FILL")) == 0);   // (A/B knob)
+    const bool fold_fill = !pipe && !h->profiling && fold_ok;
     if (early_hp) {
         if (h->have_done[par]) chk(hipStreamWaitEvent(h->pool[0], h->ev_done[par], 0));   // the table's previous user (two calls back)
         hipLaunchKernelGGL(k_fill_params, dim3((n_frames + 63) / 64), dim3(64), 0, h->pool[0], tab, v0, n_frames, h->nslot);

@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, "_build", "libnnn_hostsim.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(CSRC, s) for s in ("nnn_batch.hip", "nnn_resample.hip", "nnn_model.cpp", "rnnoise_capi.cpp")]
+    srcs = [os.path.join(CSRC, s) for s in ("nnn_batch.hip", "nnn_resample.hip", "nnn_model.cpp", "rnnoise_capi.cpp", "nnn_node.cpp")]
     srcs.append(os.path.join(HERE, "hostsim.cpp"))
     deps = srcs + [os.path.join(CSRC, d) for d in ("nnn_kernels.hip", "nnn_back.hip", "nnn_layout.h", "nnn_model.h")]
     deps += [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "nnn_mfma.h"), os.path.join(HERE, "hostsim.cpp")]

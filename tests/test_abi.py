@@ -27,8 +27,8 @@ def _declared(header):
 
 def test_exports_every_declared_symbol(lib):
     from nnnoiseless_amd import _ffi
-    declared = _declared("nnn_batch.h") | _declared("rnnoise.h") | _declared("nnn_train.h") | _declared("nnn_resample.h")
-    assert declared == set(_ffi.BATCH_SYMBOLS) | set(_ffi.RNNOISE_SYMBOLS) | set(_ffi.TRAIN_SYMBOLS) | set(_ffi.RESAMPLE_SYMBOLS)
+    declared = _declared("nnn_batch.h") | _declared("rnnoise.h") | _declared("nnn_train.h") | _declared("nnn_resample.h") | _declared("nnn_node.h")
+    assert declared == set(_ffi.BATCH_SYMBOLS) | set(_ffi.RNNOISE_SYMBOLS) | set(_ffi.TRAIN_SYMBOLS) | set(_ffi.RESAMPLE_SYMBOLS) | set(_ffi.NODE_SYMBOLS)
     for sym in declared:
         assert hasattr(lib.L, sym), sym
     out = subprocess.check_output(["nm", "-D", "--defined-only", lib.path]).decode()

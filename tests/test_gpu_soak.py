@@ -58,6 +58,9 @@ def test_soak_4096_streams_3000_frames_mixed_calls(oracle_mod, weights_bytes):
         x = base_d[:, t:t + n][idx_d].contiguous()              # [S, n, 480]
         y = torch.empty_like(x)
         v = torch.empty((n, S), dtype=torch.float32, device=dev)
+        # the input is final before the call -- the promise made above, and torch's null stream (`stream` = 0 selects the batch's own
+        # non-blocking stream) is not ordered with the library's otherwise
+        torch.cuda.synchronize()
         bd.process_device(x.data_ptr(), y.data_ptr(), v.data_ptr(), n, n * 480, 480, stream)
         torch.cuda.synchronize()
         ys, vs = y[first_d], v[:, first_d]
