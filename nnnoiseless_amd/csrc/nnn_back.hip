@@ -429,10 +429,10 @@ __device__ __forceinline__ void bk_synth(const Buffers &b, const StepParams *sp,
                 float2 X = Xr[u];
                 const float2 P = k < 400 ? Pk[u] : make_float2(0.0f, 0.0f);   // from bin 400 up the filter gain is zero
                 const float rf = interp_gain(r, k, t.frac, t.band);
-                X.x = X.x + P.x * rf;
-                X.y = X.y + P.y * rf;
+                X.x = fmaf(P.x, rf, X.x);
+                X.y = fmaf(P.y, rf, X.y);
                 Xr[u] = X;
-                if (k < 400) ebuf[bsk(k)] = X.x * X.x + X.y * X.y;
+                if (k < 400) ebuf[bsk(k)] = fmaf(X.y, X.y, X.x * X.x);
             }
         }
         wave_lds_sync();
@@ -502,10 +502,9 @@ __device__ __forceinline__ void bk_synth(const Buffers &b, const StepParams *sp,
         const int n = lane + 64 * u;
         if (n < FRAME / 2) {
             float2 lo = A[n], hi = A[n + FRAME / 2];
-            float v0 = lo.y * wlo[u].x, v1 = lo.x * wlo[u].y;
             float u0 = hi.y * whi[u].x, u1 = hi.x * whi[u].y;
             if (store) {
-                const float y0 = v0 + smv[u].x, y1 = v1 + smv[u].y;
+                const float y0 = fmaf(lo.y, wlo[u].x, smv[u].x), y1 = fmaf(lo.x, wlo[u].y, smv[u].y);
                 if (pair_ok && fmt == PCM_F32) ((float2 *)o)[n] = make_float2(y0, y1);
                 else if (pair_ok && fmt == PCM_I16)
                     ((unsigned *)o)[n] = (unsigned)(unsigned short)pcm_to_i16(y0) | ((unsigned)(unsigned short)pcm_to_i16(y1) << 16);

@@ -1337,11 +1337,11 @@ __device__ __forceinline__ void dft3(float2 &v0, float2 &v1, float2 &v2)
     const float s = 0.86602540378443864676f;  // sin(2 pi / 3)
     float2 t1 = cadd(v1, v2);
     float2 t2 = csub(v1, v2);
-    float2 m = make_float2(v0.x - 0.5f * t1.x, v0.y - 0.5f * t1.y);
-    float2 js = make_float2(s * t2.y, -s * t2.x);  // -i * s * t2
+    float2 m = make_float2(fmaf(-0.5f, t1.x, v0.x), fmaf(-0.5f, t1.y, v0.y));
     v0 = cadd(v0, t1);
-    v1 = cadd(m, js);
-    v2 = csub(m, js);
+    // v1 = m + (-i s t2), v2 = m - (-i s t2): the products fused into the sums (written out: the compiler's own contraction is off)
+    v1 = make_float2(fmaf(s, t2.y, m.x), fmaf(-s, t2.x, m.y));
+    v2 = make_float2(fmaf(-s, t2.y, m.x), fmaf(s, t2.x, m.y));
 }
 
 __device__ __forceinline__ void dft5(float2 &v0, float2 &v1, float2 &v2, float2 &v3, float2 &v4)
@@ -1351,10 +1351,10 @@ __device__ __forceinline__ void dft5(float2 &v0, float2 &v1, float2 &v2, float2 
     float2 a1 = cadd(v1, v4), b1 = csub(v1, v4);
     float2 a2 = cadd(v2, v3), b2 = csub(v2, v3);
     float2 x0 = v0;
-    float2 m1 = make_float2(x0.x + c1 * a1.x + c2 * a2.x, x0.y + c1 * a1.y + c2 * a2.y);
-    float2 m2 = make_float2(x0.x + c2 * a1.x + c1 * a2.x, x0.y + c2 * a1.y + c1 * a2.y);
-    float2 n1 = make_float2(s1 * b1.y + s2 * b2.y, -(s1 * b1.x + s2 * b2.x));  // -i (s1 b1 + s2 b2)
-    float2 n2 = make_float2(s2 * b1.y - s1 * b2.y, -(s2 * b1.x - s1 * b2.x));  // -i (s2 b1 - s1 b2)
+    float2 m1 = make_float2(fmaf(c2, a2.x, fmaf(c1, a1.x, x0.x)), fmaf(c2, a2.y, fmaf(c1, a1.y, x0.y)));
+    float2 m2 = make_float2(fmaf(c1, a2.x, fmaf(c2, a1.x, x0.x)), fmaf(c1, a2.y, fmaf(c2, a1.y, x0.y)));
+    float2 n1 = make_float2(fmaf(s2, b2.y, s1 * b1.y), -fmaf(s2, b2.x, s1 * b1.x));   // -i (s1 b1 + s2 b2)
+    float2 n2 = make_float2(fmaf(-s1, b2.y, s2 * b1.y), -fmaf(-s1, b2.x, s2 * b1.x));  // -i (s2 b1 - s1 b2)
     v0 = make_float2(x0.x + a1.x + a2.x, x0.y + a1.y + a2.y);
     v1 = cadd(m1, n1);
     v4 = csub(m1, n1);
@@ -1712,7 +1712,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         const int k = rfft_slot_bin(lane, u);
-        if (k >= 0 && k < 400) vv[bsk(k)] = X[u].x * X[u].x + X[u].y * X[u].y;
+        if (k >= 0 && k < 400) vv[bsk(k)] = fmaf(X[u].y, X[u].y, X[u].x * X[u].x);
     }
     wave_lds_sync();
     float exv;
@@ -1752,8 +1752,8 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     for (int u = 0; u < 8; u++) {
         const int k = rfft_slot_bin(lane, u);
         if (k >= 0 && k < 400) {
-            vv[bsk(k)] = Y[u].x * Y[u].x + Y[u].y * Y[u].y;
-            vc[bsk(k)] = X[u].x * Y[u].x + X[u].y * Y[u].y;
+            vv[bsk(k)] = fmaf(Y[u].y, Y[u].y, Y[u].x * Y[u].x);
+            vc[bsk(k)] = fmaf(X[u].y, Y[u].y, X[u].x * Y[u].x);
         }
     }
     wave_lds_sync();
@@ -3008,7 +3008,7 @@ __device__ __forceinline__ float interp_gain(const float *g, int k, const float 
     if (k >= 400) return 0.0f;
     int i = bin_band[k];
     float frac = bin_frac[bsk(k)];   // (the LDS table is skewed)
-    return (1.0f - frac) * g[i] + frac * g[i + 1];
+    return fmaf(frac, g[i + 1], (1.0f - frac) * g[i]);
 }
 // the same for two gain vectors at once (one look-up of the bin's band and weight serves both)
 __device__ __forceinline__ void interp_gain2(const float *ga, const float *gb, int k, const float *bin_frac, const unsigned char *bin_band,
@@ -3019,8 +3019,8 @@ __device__ __forceinline__ void interp_gain2(const float *ga, const float *gb, i
     if (k >= 400) return;
     const int i = bin_band[k];
     const float frac = bin_frac[bsk(k)], om = 1.0f - frac;
-    ra = om * ga[i] + frac * ga[i + 1];
-    rb = om * gb[i] + frac * gb[i + 1];
+    ra = fmaf(frac, ga[i + 1], om * ga[i]);
+    rb = fmaf(frac, gb[i + 1], om * gb[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3113,10 +3113,10 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
                 if (k < FREQ) {
                     float2 X = Xr[u];
                     const float rf = interp_gain(r, k, t.frac, t.band);
-                    X.x = X.x + Pr[u].x * rf;
-                    X.y = X.y + Pr[u].y * rf;
+                    X.x = fmaf(Pr[u].x, rf, X.x);
+                    X.y = fmaf(Pr[u].y, rf, X.y);
                     Xr[u] = X;
-                    if (k < 400) ebuf[bsk(k)] = X.x * X.x + X.y * X.y;
+                    if (k < 400) ebuf[bsk(k)] = fmaf(X.y, X.y, X.x * X.x);
                 }
             }
             wave_lds_sync();
@@ -3190,10 +3190,9 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
             const int n = lane + 64 * u;
             if (n < FRAME / 2) {
                 float2 lo = A[n], hi = A[n + FRAME / 2];
-                float v0 = lo.y * wlo[u].x, v1 = lo.x * wlo[u].y;   // (x / 2) * w and x * (w / 2) are the same float
-                float u0 = hi.y * whi[u].x, u1 = hi.x * whi[u].y;
+                float u0 = hi.y * whi[u].x, u1 = hi.x * whi[u].y;   // (x / 2) * w and x * (w / 2) are the same float
                 if (store) {
-                    const float y0 = v0 + smv[u].x, y1 = v1 + smv[u].y;
+                    const float y0 = fmaf(lo.y, wlo[u].x, smv[u].x), y1 = fmaf(lo.x, wlo[u].y, smv[u].y);
                     if (pair_ok && fmt == PCM_F32) ((float2 *)o)[n] = make_float2(y0, y1);
                     else if (pair_ok && fmt == PCM_I16)
                         ((unsigned *)o)[n] = (unsigned)(unsigned short)pcm_to_i16(y0) | ((unsigned)(unsigned short)pcm_to_i16(y1) << 16);

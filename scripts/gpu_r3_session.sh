@@ -87,7 +87,7 @@ pmc)
     for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS"; do
       tag=$(echo $C | cut -d' ' -f1)
       rm -rf $O/pmcs_$tag
-      timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/pmcs_$tag -o pmc -- python $R/bench.py --streams $S --frames-per-step 16 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-also --no-tick --no-host > $O/pmcs_$tag.json 2> $O/pmcs_$tag.err
+      timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/pmcs_$tag -o pmc -- python $R/bench.py --streams $S --frames-per-step 24 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-also --no-tick --no-host > $O/pmcs_$tag.json 2> $O/pmcs_$tag.err
       tail -1 $O/pmcs_$tag.err | cut -c1-150
     done
     cd $R

@@ -20,7 +20,7 @@ for db in sys.argv[2:]:
                        "on k.dispatch_id = e.dispatch_id group by k.name, e.counter_name").fetchall()
     for n, c, avg in rows:
         t[n.split("(")[0].replace("nnn::", "").replace("void ", "")][c] = avg
-out = {"streams": S, "frames_per_launch": 16, "kernels": {}, "note": __doc__.split("\n\n", 1)[1]}
+out = {"streams": S, "frames_per_launch": 24, "kernels": {}, "note": __doc__.split("\n\n", 1)[1]}
 for k, v in sorted(t.items()):
     if not k.startswith("k_") or k == "k_fill_params":
         continue

@@ -21,7 +21,7 @@ fetch, write, streams = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.ar
 fpl = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 out = {"streams": streams, "frames_per_launch": fpl, "kernels": {}, "calibration": {},
        "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (scripts/gpu_pmc_traffic.sh, bench.py "
-               "--frames-per-step 16: every launch covers a full group of 16 frames of every stream); KB per launch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE reports half "
+               "--frames-per-step 24: every launch covers a full group of 24 frames of every stream, the production group length); KB per launch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE reports half "
                "of coalesced streaming reads, MI355X_MICROARCH.md HBM section; see `calibration`: torch's abs kernel over the "
                "bench input reads and writes the same number of bytes).  At 4096 streams the working set sits in the 256 MiB "
                "Infinity Cache, whose hits these fabric-side counters include."}

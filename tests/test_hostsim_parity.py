@@ -153,7 +153,8 @@ def test_nonfinite_inputs_stay_contained(hostsim_lib, oracle_mod, weights_bytes)
     assert np.array_equal(bd.tap("pitch")[:, 0], ref["pitch"][:, -1])
     assert np.array_equal(np.isnan(out), np.isnan(ref["out"]))
     ok = np.isfinite(out) & np.isfinite(ref["out"])
-    assert np.allclose(out[ok], ref["out"][ok], rtol=1e-4, atol=1e-2)
+    # (f32 rounding of the transforms is ~1e-6 of a stream's peak: the absolute slack follows the peak, 1e4 here, not a fixed 0.01)
+    assert np.allclose(out[ok], ref["out"][ok], rtol=1e-4, atol=5e-6 * float(np.abs(clean).max()))
 
 
 def test_call_length_patterns(hostsim_lib):

@@ -37,17 +37,21 @@ def check_rows(rows, ref, ref32=None):
     if ref32 is not None:
         # rows are [frame][stream][87].  The yardstick is what f32 rounding in the FFT alone does to these quotients of two
         # noise-floor energies: the oracle's own f32-FFT build against its f64-FFT build.  As a whole the device's error must
-        # not exceed that build's (worst case and rms, 25 % margin); stream by stream it stays within 2e-4 or ten times the
-        # stream's own spread (one pair of builds is a small sample of a chaotic quantity: at three times, 1 % of the streams
-        # fail -- for round 2's kernels and these alike -- while the device's error distribution sits inside the f32 oracle's).
+        # not exceed that build's (worst case and rms, 25 % margin).  Stream by stream (10 x the stream's own spread was
+        # the loosest bar of the suite): within 2e-4 or FIVE times the stream's spread for all but 1 % of the streams -- one pair of
+        # builds is a small sample of a chaotic quantity, and at three times 1 % of the streams fail for every build measured
+        # (round 2's kernels, round 3's, the oracle's f32 build judged against a second f32 build: scripts/train_corr_probe.py) --
+        # and those few within twenty times, under the global worst-case bound above.
         e_dev, e_o32 = np.abs(rows[..., 34:40] - ref[..., 34:40]), np.abs(ref32[..., 34:40] - ref[..., 34:40])
         assert e_dev.max() <= 1.25 * e_o32.max(), (e_dev.max(), e_o32.max())
         assert np.sqrt((e_dev ** 2).mean()) <= 1.25 * np.sqrt((e_o32 ** 2).mean())
-        err, tol = e_dev.max(axis=(0, -1)), np.maximum(2e-4, 10.0 * e_o32.max(axis=(0, -1)))
-        bad = np.argwhere(err > tol)
-        assert not len(bad), (len(bad), bad[:8].ravel(), err[bad[0]], tol[bad[0]])
+        err, spread = e_dev.max(axis=(0, -1)), e_o32.max(axis=(0, -1))
+        over5 = np.argwhere(err > np.maximum(2e-4, 5.0 * spread))
+        assert len(over5) <= max(1, err.size // 100), (len(over5), err.size, over5[:8].ravel())
+        bad = np.argwhere(err > np.maximum(2e-4, 20.0 * spread))
+        assert not len(bad), (len(bad), bad[:8].ravel(), err[bad[0]], spread[bad[0]])
         print(f"pitch-correlation features: worst error {e_dev.max():.2e} (oracle f32 build {e_o32.max():.2e}), rms {np.sqrt((e_dev ** 2).mean()):.2e} "
-              f"({np.sqrt((e_o32 ** 2).mean()):.2e}); worst stream at {(err / np.maximum(e_o32.max(axis=(0, -1)), 2e-5)).max():.1f} x its own spread")
+              f"({np.sqrt((e_o32 ** 2).mean()):.2e}); {len(over5)} of {err.size} streams beyond 5 x their own spread, worst at {(err / np.maximum(spread, 4e-5)).max():.1f} x")
     else:
         assert d[34:40].max() < 4e-2, d
     assert np.sqrt(((rows[..., 34:40] - ref[..., 34:40]) ** 2).mean()) < 5e-4
