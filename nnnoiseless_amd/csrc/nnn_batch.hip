@@ -759,6 +759,14 @@ static int back_choice(const nnn_batch *h, int g)
         if ((fused ? G.back_lds : G.rnn16_lds) == 0) return 0;
     return fused ? 2 : 1;
 }
+// one-frame groups of batches whose pitch launch is a single round of workgroups (two 8-wave blocks per compute unit)
+// run the LPC analysis inside k_pitch: one launch fewer on the critical path of a real-time tick (env NNN_LPC_IN_PITCH=0 / 1 forces)
+static bool lpc_in_pitch(const nnn_batch *h, int g)
+{
+    static const int force = getenv("NNN_LPC_IN_PITCH") ? atoi(getenv("NNN_LPC_IN_PITCH")) : -1;
+    if (force >= 0) return force != 0 && g == 1;
+    return g == 1 && h->S_pad <= 6144 && h->lpc_wide < 0 && h->lpc_fc == 0;   // (measured: -6 us at 4096 streams, level at 8192, +9 us at 16 384)
+}
 static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams *sp0, hipStream_t st, bool prof, const StepParams *call = nullptr, int fill = 0)
 {
     if (g <= 0) return;   // (never a launch with an empty grid)
@@ -772,6 +780,7 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
         L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g, call ? *call : StepParams{}, call ? fill : 0);
         // the LPC analysis of the group's frames (lane = stream, frames side by side) rides on the same stream, ahead of the pitch stage
         // (launches too small to fill the GPU spread the five lags of a stream over five waves)
+        if (lpc_in_pitch(h, g)) break;   // (a lone frame of a small batch: k_pitch does it on its way, see there)
         if (h->lpc_wide >= 0 ? h->lpc_wide != 0 : NT * ug < 512u) L.go(K_LPC, k_lpc_wide, dim3(NT * ug), dim3(320), 0, b, sp0, g);
         else {
             // frames per wave (k_lpc): as many as still leave two waves per SIMD
@@ -787,7 +796,7 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
         // matters instead: 468 -> 515); flag values are frame numbers (> 0)
         const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
         const unsigned grid = Sp / PK_SPB * (chain ? ug : 1u);
-        L.go(K_PITCH, k_pitch, dim3(grid), dim3(PK_T), 0, b, sp0, g, chain, seq0, h->tickets);
+        L.go(K_PITCH, k_pitch, dim3(grid), dim3(PK_T), 0, b, sp0, g, chain, seq0, h->tickets, lpc_in_pitch(h, g) ? 1 : 0);
         if (chain) h->tickets += grid;   // (launches of one batch's pitch stage are ordered among themselves: a stateful stage)
         break;
     }
@@ -1517,7 +1526,7 @@ static void enqueue_feature_group(nnn_batch *h, hipStream_t st, const float *in,
         }
         const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
         const unsigned grid = Sp / PK_SPB * (chain ? ug : 1u);
-        hipLaunchKernelGGL(k_pitch, dim3(grid), dim3(PK_T), 0, st, b, (const StepParams *)sp, g, chain, seq0, h->tickets);
+        hipLaunchKernelGGL(k_pitch, dim3(grid), dim3(PK_T), 0, st, b, (const StepParams *)sp, g, chain, seq0, h->tickets, 0);
         if (chain) h->tickets += grid;
         hipLaunchKernelGGL(k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp, g);
         hipLaunchKernelGGL(k_features, dim3(NT), dim3(64 * FEAT_WAVES), 0, st, b, g);

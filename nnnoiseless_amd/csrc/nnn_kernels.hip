@@ -375,7 +375,7 @@ __device__ __forceinline__ void lpc_chains(const float *base, float x0, float (&
 
 // lag window, Levinson recursion, bandwidth expansion, extra zero (ref: src/pitch.rs:460-480, 257-292) on a frame's five sums; the
 // windowed autocorrelation and the FIR taps go to the frame's ring slot
-__device__ __forceinline__ void lpc_finish(const Buffers &b, int tile, int lane, int slot, float (&ac)[5])
+__device__ __forceinline__ void lpc_finish(const Buffers &b, int tile, int lane, int slot, float (&ac)[5], float *taps = nullptr)
 {
     ac[0] *= 1.0001f;
 #pragma unroll
@@ -416,6 +416,10 @@ __device__ __forceinline__ void lpc_finish(const Buffers &b, int tile, int lane,
     float *o = NNN_TI(b.lpc, b.nslot * 10, tile, lane) + (size_t)(slot * 10) * TILE;
 #pragma unroll
     for (int i = 0; i < 5; i++) { o[(size_t)i * TILE] = ac[i]; o[(size_t)(5 + i) * TILE] = l2[i]; }
+    if (taps) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) taps[i] = l2[i];
+    }
 }
 
 // k_lpc: one wave per (tile, LPC_FC consecutive frames).  Consecutive frames' windows overlap by 624 of 864 rows, and frames of a
@@ -726,6 +730,44 @@ __device__ __forceinline__ void pk_inner(const float *pb, int s, int q, const in
     }
 }
 
+// Lag K of the autocorrelation of a stream's 864-value window in LDS (`pbs` = L.pb + stream: row r at pk_at(r, 0)): the reference's
+// sequential sum over i = 0 .. 859 and its tail (ref: src/pitch.rs:433-446), one lag per wave so that the lag is a compile-time
+// offset into a sliding run of rows held in registers: a row is read once per lag, a step is one multiply and one dependent add.
+template <int K>
+__device__ __forceinline__ float pk_autocorr(const float *pbs)
+{
+    const float *E = pbs, *O = pbs + PK_ODD;
+    auto row = [&](const float *e, const float *o, int j) { return (j & 1) ? o[(j >> 1) * PK_SPB] : e[(j >> 1) * PK_SPB]; };
+    float run[20];   // run[j] = x[16 blk + j]
+#pragma unroll
+    for (int j = 0; j < 20; j++) run[j] = row(E, O, j);
+    float c = 0.0f;
+    constexpr int NBLK = 52;   // 52 blocks of 16 steps, then 28 steps on rows 832 .. 863
+#pragma nounroll
+    for (int blk = 0; blk < NBLK; blk++) {
+        float nxt[16];   // rows 16 (blk + 1) + 4 .. + 19 travel while this block's steps are summed
+        const float *En = E + (8 * (blk + 1) + 2) * PK_SPB, *On = O + (8 * (blk + 1) + 2) * PK_SPB;
+#pragma unroll
+        for (int j = 0; j < 16; j++) nxt[j] = row(En, On, j);
+#pragma unroll
+        for (int j = 0; j < 16; j++) c += run[j] * run[j + K];
+#pragma unroll
+        for (int j = 0; j < 4; j++) run[j] = run[16 + j];
+#pragma unroll
+        for (int j = 0; j < 16; j++) run[4 + j] = nxt[j];
+    }
+    float last[12];   // rows 852 .. 863
+#pragma unroll
+    for (int j = 0; j < 12; j++) last[j] = row(E + (8 * NBLK + 10) * PK_SPB, O + (8 * NBLK + 10) * PK_SPB, j);
+    auto x = [&](int i) { return i < 16 * NBLK + 20 ? run[i - 16 * NBLK] : last[i - 16 * NBLK - 20]; };   // rows 832 .. 863 (static index)
+#pragma unroll
+    for (int i = 16 * NBLK; i < XLP - 4; i++) c += x(i) * x(i + K);
+    float d = 0.0f;   // tail d_K = sum_{i = K + 860}^{863} x[i] x[i - K], added after the main sum
+#pragma unroll
+    for (int i = K + XLP - 4; i < XLP; i++) d += x(i) * x(i - K);
+    return c + d;
+}
+
 #ifndef NNN_PK_MINWAVES
 #define NNN_PK_MINWAVES 4   // waves per SIMD: two blocks of 8 waves per CU, <= 128 registers
 #endif
@@ -738,7 +780,11 @@ __device__ __forceinline__ void pk_inner(const float *pb, int s, int q, const in
 // (HIP promises none; in the observed in-order dispatch ticket and block index coincide).  `seq0` numbers the group's first frame;
 // flag values are frame numbers, so a flag left by an earlier use of the scratch set never matches.  `chain` == 0: one workgroup
 // per quarter tile loops over the frames.
-__global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, const StepParams *sp0, int g, int chain, int seq0, unsigned tbase)
+// `lpc_here` != 0 (one-frame launches of a few thousand streams, the real-time tick): the LPC analysis runs here, on five of the block's
+// waves ahead of the FIR, instead of as a launch of its own (k_lpc_wide) ahead of this one -- round 2's arrangement, which costs the
+// block 9 us with six waves waiting; for a group of frames that was the kernel's worst phase, for a lone frame it is cheaper than the
+// 14.5 us launch plus its gap on the call's critical path.  Same sums in the same order: bit-identical to k_lpc / k_lpc_wide.
+__global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, const StepParams *sp0, int g, int chain, int seq0, unsigned tbase, int lpc_here)
 {
     __shared__ PkLds L;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane0 = threadIdx.x & 63;
@@ -787,6 +833,33 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         NNN_STAMP(b, 1);
         // (the autocorrelation and the Levinson recursion that stood here -- two waves busy for a fifth of the block's time, six waiting
         // -- are k_lpc's now: lane = stream, ahead of this launch; the FIR taps arrive with the window)
+        if (lpc_here) {
+            // ... except for a lone frame: one lag per wave on waves 0 .. 4, lane = stream; the window is in LDS (row r of stream s at
+            // pk_at(r, s), row 0 already the frame's special first element)
+            float *acs = &L.u.c.xc[0][0], *firs = &L.u.c.xc[8][0];   // [5][16] each, in space the coarse search takes later
+            if (wave < 5 && lane < PK_SPB) {   // wave w: lag w of the block's 16 streams (lane = stream)
+                const float *pbs = L.pb + lane;
+                float a;
+                if (wave == 0) a = pk_autocorr<0>(pbs);
+                else if (wave == 1) a = pk_autocorr<1>(pbs);
+                else if (wave == 2) a = pk_autocorr<2>(pbs);
+                else if (wave == 3) a = pk_autocorr<3>(pbs);
+                else a = pk_autocorr<4>(pbs);
+                acs[wave * PK_SPB + lane] = a;
+            }
+            __syncthreads();
+            if (dec_lane) {
+                float ac[5], taps[5];
+#pragma unroll
+                for (int i = 0; i < 5; i++) ac[i] = acs[i * PK_SPB + s];
+                lpc_finish(b, tile, sl, sp0[f].slot, ac, taps);
+#pragma unroll
+                for (int i = 0; i < 5; i++) firs[i * PK_SPB + s] = taps[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 5; i++) fir[i] = firs[i * PK_SPB + col];
+        }
         // ---- FIR5 with zero initial memory, in place (ref: src/pitch.rs:407-429): the chunk's inputs are still in the
         //      thread's registers, the five rows before it come from LDS before anyone overwrites them
         {
