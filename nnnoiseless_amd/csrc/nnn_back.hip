@@ -207,18 +207,18 @@ __device__ __forceinline__ f32x4 bk_gemm(f32x4 acc, const unsigned short *A, int
     const unsigned short *a0 = A + (size_t)(lane & 15) * row_w + g.kbase + 8 * (lane >> 4);
     uint4 cur[3], nxt[3];
 #pragma unroll
-    for (int pl = 0; pl < 3; pl++) cur[pl] = *(const uint4 *)(a0 + (size_t)pl * plane_stride);
+    for (int pl = 0; pl < GPL; pl++) cur[pl] = *(const uint4 *)(a0 + (size_t)pl * plane_stride);
 #pragma unroll
     for (int ks = 0; ks < KSMAX; ks++) {
         if (ks < g.ksteps) {
             if (ks + 1 < g.ksteps) {
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) nxt[pl] = *(const uint4 *)(a0 + (size_t)pl * plane_stride + (ks + 1) * 32);
+                for (int pl = 0; pl < GPL; pl++) nxt[pl] = *(const uint4 *)(a0 + (size_t)pl * plane_stride + (ks + 1) * 32);
             }
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) acc = mfma_16x16x32_bf16(cur[pl], fr.f[ks], acc);
+            for (int pl = 0; pl < GPL; pl++) acc = mfma_16x16x32_bf16(cur[pl], fr.f[ks], acc);
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) cur[pl] = nxt[pl];
+            for (int pl = 0; pl < GPL; pl++) cur[pl] = nxt[pl];
         }
     }
 #pragma nounroll
@@ -226,12 +226,12 @@ __device__ __forceinline__ f32x4 bk_gemm(f32x4 acc, const unsigned short *A, int
         const uint4 bf = Bg[ks * 64 + lane];
         if (ks + 1 < g.ksteps) {
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) nxt[pl] = *(const uint4 *)(a0 + (size_t)pl * plane_stride + (ks + 1) * 32);
+            for (int pl = 0; pl < GPL; pl++) nxt[pl] = *(const uint4 *)(a0 + (size_t)pl * plane_stride + (ks + 1) * 32);
         }
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) acc = mfma_16x16x32_bf16(cur[pl], bf, acc);
+        for (int pl = 0; pl < GPL; pl++) acc = mfma_16x16x32_bf16(cur[pl], bf, acc);
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) cur[pl] = nxt[pl];
+        for (int pl = 0; pl < GPL; pl++) cur[pl] = nxt[pl];
     }
     return acc;
 }

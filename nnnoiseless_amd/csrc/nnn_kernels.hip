@@ -2200,6 +2200,13 @@ __device__ __forceinline__ float load_split(const unsigned short *P, int plane_s
     return (bf16_f32(P[idx]) + bf16_f32(P[idx + plane_stride])) + bf16_f32(P[idx + 2 * plane_stride]);
 }
 
+// NNN_RNN_GEMM_PLANES = 2 (developer probe): the products use the hi and mid planes only -- activations truncated to 16
+// significand bits -- while the planes are stored and the states kept as before: what dropping a third of the MFMAs and operand reads is
+// worth, and what 16-bit activations do to gains and VAD, before anything is rebuilt around two planes.
+#ifndef NNN_RNN_GEMM_PLANES
+#define NNN_RNN_GEMM_PLANES 3
+#endif
+constexpr int GPL = NNN_RNN_GEMM_PLANES;
 // Weight fragments of one GEMM group: all k-steps (up to KSMAX) are requested together so that a layer pays
 // one trip to the Infinity Cache / HBM instead of one per k-step.
 constexpr int KSMAX = 4;
@@ -2228,7 +2235,7 @@ __device__ __forceinline__ void gemm_acc(f32x4 (&acc)[3][2], const unsigned shor
     const int steps = g.ksteps * MB;
     uint4 cur[3], nxt[3];
 #pragma unroll
-    for (int pl = 0; pl < 3; pl++) cur[pl] = *(const uint4 *)(a0 + (size_t)pl * plane_stride);
+    for (int pl = 0; pl < GPL; pl++) cur[pl] = *(const uint4 *)(a0 + (size_t)pl * plane_stride);
     for (int ks = 0; ks < g.ksteps; ks++) {
         uint4 bfr[NG];
         if (ks < KS) {
@@ -2249,16 +2256,16 @@ __device__ __forceinline__ void gemm_acc(f32x4 (&acc)[3][2], const unsigned shor
                 const int ks1 = (mb + 1 < MB) ? ks : ks + 1, mb1 = (mb + 1 < MB) ? mb + 1 : 0;
                 const unsigned short *ap = a0 + mb1 * mb_stride + ks1 * 32;
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) nxt[pl] = *(const uint4 *)(ap + (size_t)pl * plane_stride);
+                for (int pl = 0; pl < GPL; pl++) nxt[pl] = *(const uint4 *)(ap + (size_t)pl * plane_stride);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++)
+            for (int pl = 0; pl < GPL; pl++)
 #pragma unroll
                 for (int gi = 0; gi < NG; gi++) acc[G0 + gi][mb] = mfma_16x16x32_bf16(cur[pl], bfr[gi], acc[G0 + gi][mb]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) cur[pl] = nxt[pl];
+            for (int pl = 0; pl < GPL; pl++) cur[pl] = nxt[pl];
         }
     }
 }
