@@ -375,152 +375,6 @@ __device__ __forceinline__ void bk_dense(const LayerDesc &L, const BkRnn &R, con
     }
 }
 
-#if NNN_FFT_CONTRACT
-#pragma clang fp contract(fast)   // (the synthesis: downstream of the transforms, as k_synth)
-#endif
-// ---- pitch filter, band renormalisation, gains, inverse transform, overlap-add for the stream of this wave (ref: src/features.rs:223-275,
-//      src/denoise.rs:103-114): k_synth's frame body on spectra that are already in the wave's registers, in the transforms' own
-//      bin order (rfft_slot_bin).  b_* are the lane's band (lane < NB) quantities.
-__device__ __forceinline__ void bk_synth(const Buffers &b, const StepParams *sp, int f, int tile, int sl, int s, int lane, const FftLds &t, float2 *A,
-                                         float *r, float2 (&Xr)[8], const float2 (&Pk)[8], float b_ex, float b_ep, float b_xp, float b_graw,
-                                         float b_g, float vadv, bool live, float *sm)
-{
-    // the overlap memory of the stream as sample pairs (ref: src/features.rs:271-274): read and written once per frame here -- held in
-    // registers across a group's frames (k_synth's way) it costs eight of the 128 registers a wave of a 16-wave block has, on top
-    // of the two spectra, and the block's streams re-read it from the L2 of their own compute unit's XCD
-    float2 smv[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int n = lane + 64 * u;
-        smv[u] = n < FRAME / 2 ? ((const float2 *)sm)[n] : make_float2(0.0f, 0.0f);
-    }
-    float *ebuf = (float *)A, *r2 = r + NB, *gg = r + 2 * NB;
-    float *vad_out = sp->vad;
-    const int fmt = sp->fmt;
-    const int ch = sp->channels, grp = s / ch, elem = pcm_elem_bytes(fmt), sstride = ch * elem;
-    char *o = sp->out + (long long)grp * sp->group_stride + (long long)(s - grp * ch) * elem;
-    const bool store = s < b.S && !sp->discard;
-    const bool pair_ok = ch == 1 && (((size_t)o) & (size_t)(2 * elem - 1)) == 0;
-    int bmask = 1 << NB;             // lane 0: this frame's branch mask (bit 22: silent)
-    if (live) {
-        const bool up = b_xp > b_graw;   // the branch the parity tests compare (ref: src/features.rs:227)
-        const int mask = (int)(wave_ballot(up && lane < NB) & ((1ull << NB) - 1));   // bit i: band i took `exp > g`
-        if (lane < NB) {
-            float v;
-            if (up) v = 1.0f;
-            else {
-                float exp_sq = b_xp * b_xp, g_sq = b_graw * b_graw;
-                v = exp_sq * (1.0f - g_sq) / (0.001f + g_sq * (1.0f - exp_sq));
-            }
-            v = sqrtf(fminf(fmaxf(v, 0.0f), 1.0f));
-            v *= sqrtf(b_ex / (1e-8f + b_ep));
-            r[lane] = v;
-            gg[lane] = b_g;
-        }
-        wave_lds_sync();
-        if (lane == 0) {
-            NNN_TIF(b, branch, 1, f, tile, sl)[0] = mask;
-            bmask = mask;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = rfft_slot_bin(lane, u);
-            if (k >= 0) {
-                float2 X = Xr[u];
-                const float2 P = k < 400 ? Pk[u] : make_float2(0.0f, 0.0f);   // from bin 400 up the filter gain is zero
-                const float rf = interp_gain(r, k, t.frac, t.band);
-                X.x = fmaf(P.x, rf, X.x);
-                X.y = fmaf(P.y, rf, X.y);
-                Xr[u] = X;
-                if (k < 400) ebuf[bsk(k)] = fmaf(X.y, X.y, X.x * X.x);
-            }
-        }
-        wave_lds_sync();
-        {
-            const float *const v[1] = {ebuf};
-            float ne[1];
-            band_sums_par<1>(t, v, ne, lane);
-            if (lane < NB) r2[lane] = sqrtf(b_ex / (1e-8f + ne[0]));
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = rfft_slot_bin(lane, u);
-            if (k >= 0) {
-                float rf, gf;
-                interp_gain2(r2, gg, k, t.frac, t.band, rf, gf);
-                Xr[u].x *= rf; Xr[u].y *= rf;
-                Xr[u].x *= gf; Xr[u].y *= gf;
-            }
-        }
-    } else if (lane == 0) {
-        NNN_TIF(b, branch, 1, f, tile, sl)[0] = 1 << NB;
-    }
-    if (sp->log && s < b.S) {   // parity-test record of this frame: pitch index, branch mask, smoothed gains
-        unsigned *lg = sp->log + (size_t)s * FRAME_LOG_WORDS;
-        if (lane < NB) lg[2 + lane] = __float_as_uint(live ? b_g : 0.0f);
-        if (lane == 0) {
-            lg[0] = (unsigned)NNN_TIF(b, pitch, 1, f, tile, sl)[0];
-            lg[1] = (unsigned)bmask;
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const int k = rfft_slot_bin(lane, u);
-        if (k >= 0) A[k] = Xr[u];
-    }
-    wave_lds_sync();
-    // complex-to-real 960-point inverse as a 480-point complex inverse (see k_synth)
-    float2 zin[8];
-    {
-        const int j = lane < FFT_P1 ? lane : FFT_P1 - 1;
-#pragma unroll
-        for (int rr = 0; rr < 8; rr++) {
-            const int k = j + FFT_P1 * rr;
-            float2 a = A[k], c = A[NFFT - k];
-            float2 e2 = make_float2(a.x + c.x, a.y - c.y);
-            float2 d = make_float2(a.x - c.x, a.y + c.y);
-            float2 w = t.tw[k];
-            w.y = -w.y;
-            float2 o2 = cmulf(d, w);
-            zin[rr] = make_float2(e2.y + o2.x, e2.x - o2.y);
-        }
-    }
-    wave_lds_sync();   // the spectrum has been read: the transform takes its buffer
-    float2 wlo[4], whi[4];   // the two window halves, as sample pairs
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int n = lane + 64 * u;
-        const bool on = n < FRAME / 2;
-        wlo[u] = on ? ((const float2 *)b.window_s)[n] : make_float2(0.0f, 0.0f);
-        whi[u] = on ? ((const float2 *)b.window_s)[FRAME / 2 + n] : make_float2(0.0f, 0.0f);
-    }
-    fft480_regs<true>(zin, A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
-    if (lane == 0 && vad_out && s < b.S) vad_out[s] = vadv;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int n = lane + 64 * u;
-        if (n < FRAME / 2) {
-            float2 lo = A[n], hi = A[n + FRAME / 2];
-            float u0 = hi.y * whi[u].x, u1 = hi.x * whi[u].y;
-            if (store) {
-                const float y0 = fmaf(lo.y, wlo[u].x, smv[u].x), y1 = fmaf(lo.x, wlo[u].y, smv[u].y);
-                if (pair_ok && fmt == PCM_F32) ((float2 *)o)[n] = make_float2(y0, y1);
-                else if (pair_ok && fmt == PCM_I16)
-                    ((unsigned *)o)[n] = (unsigned)(unsigned short)pcm_to_i16(y0) | ((unsigned)(unsigned short)pcm_to_i16(y1) << 16);
-                else if (pair_ok) ((float2 *)o)[n] = make_float2(pcm_to_unit(y0), pcm_to_unit(y1));
-                else {
-                    pcm_store(o + (long long)(2 * n) * sstride, fmt, y0);
-                    pcm_store(o + (long long)(2 * n + 1) * sstride, fmt, y1);
-                }
-            }
-            ((float2 *)sm)[n] = make_float2(u0, u1);
-        }
-    }
-    wave_lds_sync();   // A is refilled by the next frame
-}
-#pragma clang fp contract(off)
-
 // ---------------------------------------------------------------------------------------------------------------------------------
 // k_back<true>: the fused back end.  k_back<false>: its RNN stretch alone (features in from k_fft_xp's scratch, gains out to k_synth's).
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -727,7 +581,8 @@ __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0,
         // ---------------- wave = stream: pitch filter, gains, inverse transform, overlap-add
         {
             const float b_graw = lane < NB ? gout[wave * BK_GW + lane] : 0.0f, b_g = lane < NB ? gout[wave * BK_GW + 24 + lane] : 0.0f;
-            bk_synth(b, sp, f, tile, sl, s, lane, t, Z, part, K.X, K.P, K.ex, K.ep, K.xn, b_graw, b_g, vadl[wave], !silent, sm);
+            float4 smq[2];   // (the overlap memory: read and written inside, per frame)
+            synth_frame<true>(b, sp, f, tile, sl, s, lane, t, Z, part, K.X, K.P, K.ex, K.ep, K.xn, b_graw, b_g, vadl[wave], !silent, sm, smq);
         }
         NNN_STAMP(b, 12);
     }

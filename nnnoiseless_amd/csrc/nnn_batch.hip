@@ -1326,7 +1326,13 @@ extern "C" int nnn_batch_read_tap(nnn_batch *h, int tap, void *host_dst, size_t 
     } else if (d.layout == 2) {
         std::vector<uint32_t> tmp(Sp * 2 * FSTR);
         HIPCHK(hipMemcpy(tmp.data(), p, tmp.size() * 4, hipMemcpyDeviceToHost));
-        for (int s = 0; s < h->S; s++) memcpy(dst + (size_t)s * d.len, tmp.data() + (size_t)s * 2 * FSTR, (size_t)d.len * 4);
+        // (a spectrum's row holds (bin k, bin 480 - k) pairs in the transforms' lane order: spectrum_index)
+        for (int s = 0; s < h->S; s++)
+            for (int k = 0; k < FREQ; k++) {
+                const size_t at = (size_t)s * 2 * FSTR + 2 * (size_t)spectrum_index(k);
+                dst[(size_t)s * d.len + 2 * k] = tmp[at];
+                dst[(size_t)s * d.len + 2 * k + 1] = tmp[at + 1];
+            }
     } else {  // newest frame in the history ring
         const size_t hstr = (size_t)hist_stride(h->nslot);
         std::vector<uint32_t> tmp(Sp * hstr);

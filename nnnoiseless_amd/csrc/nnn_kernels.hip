@@ -1741,6 +1741,24 @@ struct XpKeep {
     float *cnw;           // in: LDS staging of the frame's cepstrum (22) + pitch-correlation DCT (6)
     int *flag;            // in: one LDS word of the wave (the silence flag travels through it)
 };
+// a spectrum in the wave's registers (slot order, see window_rfft) <-> its row in memory: pair (slot u, slot 4 + u) = (bin k, bin 480 - k)
+// of lane j's k = j + 64 u as one 16-byte access at float4 index 64 u + j (FSTR in nnn_layout.h)
+__device__ __forceinline__ void spectrum_store(float2 *row, const float2 (&S)[8], int lane)
+{
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+        if (lane + 64 * u <= NFFT / 2) ((float4 *)row)[64 * u + lane] = make_float4(S[u].x, S[u].y, S[4 + u].x, S[4 + u].y);
+}
+__device__ __forceinline__ void spectrum_load(const float2 *row, float2 (&S)[8], int lane)
+{
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const float4 v = lane + 64 * u <= NFFT / 2 ? ((const float4 *)row)[64 * u + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        S[u] = make_float2(v.x, v.y);
+        S[4 + u] = make_float2(v.z, v.w);
+    }
+}
+
 template <bool WITH_P, bool FUSED = false>
 __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepParams *sp, int tile_in, int sub, FftLds &t, float2 *Z, float *part,
                                                  XpKeep *keep = nullptr)
@@ -1772,13 +1790,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     // region small enough to stay in the XCD's L2 -- an upper bound on what keeping X and P on chip between the transforms
     // and the synthesis (a fused back end) could gain from the removed HBM round trip.
 #ifndef NNN_PROBE_XP
-    if (!FUSED || b.taps) {   // (fused: the spectra stay in registers; memory sees them for the parity taps only)
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = rfft_slot_bin(lane, u);
-            if (k >= 0) dx[k] = X[u];
-        }
-    }
+    if (!FUSED || b.taps) spectrum_store(dx, X, lane);   // (fused: the spectra stay in registers; memory sees them for the parity taps only)
 #endif
     NNN_FUSED_RELAUNDER();
     float *vv = (float *)Z, *vc = vv + BSK_LEN;   // per-bin quantities of the band sums, skewed (bsk)
@@ -1811,15 +1823,8 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     }
     window_rfft<FUSED>(b, spw, w, t, Z, Y, lane, false);
     float2 *dp = b.P + (size_t)s * FSTR;
-    const int np = b.taps ? FREQ : 400;   // the pitch filter reads bins 0..399 only
 #ifndef NNN_PROBE_XP
-    if (!FUSED || b.taps) {
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = rfft_slot_bin(lane, u);
-            if (k >= 0 && k < np) dp[k] = Y[u];
-        }
-    }
+    if (!FUSED || b.taps) spectrum_store(dp, Y, lane);   // (whole pairs: the pitch filter reads bins 0..399, their partners come along)
 #endif
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -3108,6 +3113,153 @@ __device__ __forceinline__ void interp_gain2(const float *ga, const float *gb, i
 //     ref: src/features.rs:223-275, src/denoise.rs:103-114.  One wave per stream; the launch loops over the `g` frames of
 //     its group with the overlap memory in registers (read and written once per group, not per frame).
 // ---------------------------------------------------------------------------------------------
+// ---- pitch filter, band renormalisation, gains, inverse transform, overlap-add for the stream of this wave (ref: src/features.rs:223-275,
+//      src/denoise.rs:103-114) on spectra in the wave's registers in the transforms' own bin order (rfft_slot_bin): the frame body of
+//      k_synth (spectra from memory) and of the fused back end (spectra straight from its transforms).  b_* are the lane's band
+//      (lane < NB) quantities.  The overlap memory is `smv` (sample quads of lane j: samples 4 j + 256 u .. + 3), loaded and stored
+//      around the frame when SMV_IO (the fused kernel: eight registers it has not got across a frame) or carried by the caller.
+template <bool SMV_IO>
+__device__ __forceinline__ void synth_frame(const Buffers &b, const StepParams *sp, int f, int tile, int sl, int s, int lane, const FftLds &t, float2 *A,
+                                         float *r, float2 (&Xr)[8], const float2 (&Pk)[8], float b_ex, float b_ep, float b_xp, float b_graw,
+                                         float b_g, float vadv, bool live, float *sm, float4 (&smq)[2])
+{
+    if (SMV_IO) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) smq[u] = lane + 64 * u < FRAME / 4 ? ((const float4 *)sm)[lane + 64 * u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    float *ebuf = (float *)A, *r2 = r + NB, *gg = r + 2 * NB;
+    float *vad_out = sp->vad;
+    const int fmt = sp->fmt;
+    const int ch = sp->channels, grp = s / ch, elem = pcm_elem_bytes(fmt), sstride = ch * elem;
+    char *o = sp->out + (long long)grp * sp->group_stride + (long long)(s - grp * ch) * elem;
+    const bool store = s < b.S && !sp->discard;
+    int bmask = 1 << NB;             // lane 0: this frame's branch mask (bit 22: silent)
+    if (live) {
+        const bool up = b_xp > b_graw;   // the branch the parity tests compare (ref: src/features.rs:227)
+        const int mask = (int)(wave_ballot(up && lane < NB) & ((1ull << NB) - 1));   // bit i: band i took `exp > g`
+        if (lane < NB) {
+            float v;
+            if (up) v = 1.0f;
+            else {
+                float exp_sq = b_xp * b_xp, g_sq = b_graw * b_graw;
+                v = exp_sq * (1.0f - g_sq) / (0.001f + g_sq * (1.0f - exp_sq));
+            }
+            v = sqrtf(fminf(fmaxf(v, 0.0f), 1.0f));
+            v *= sqrtf(b_ex / (1e-8f + b_ep));
+            r[lane] = v;
+            gg[lane] = b_g;
+        }
+        wave_lds_sync();
+        if (lane == 0) {
+            NNN_TIF(b, branch, 1, f, tile, sl)[0] = mask;
+            bmask = mask;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = rfft_slot_bin(lane, u);
+            if (k >= 0) {
+                float2 X = Xr[u];
+                const float2 P = k < 400 ? Pk[u] : make_float2(0.0f, 0.0f);   // from bin 400 up the filter gain is zero
+                const float rf = interp_gain(r, k, t.frac, t.band);
+                X.x = fmaf(P.x, rf, X.x);
+                X.y = fmaf(P.y, rf, X.y);
+                Xr[u] = X;
+                if (k < 400) ebuf[bsk(k)] = fmaf(X.y, X.y, X.x * X.x);
+            }
+        }
+        wave_lds_sync();
+        {
+            const float *const v[1] = {ebuf};
+            float ne[1];
+            band_sums_par<1>(t, v, ne, lane);
+            if (lane < NB) r2[lane] = sqrtf(b_ex / (1e-8f + ne[0]));
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = rfft_slot_bin(lane, u);
+            if (k >= 0) {
+                float rf, gf;
+                interp_gain2(r2, gg, k, t.frac, t.band, rf, gf);
+                Xr[u].x *= rf; Xr[u].y *= rf;
+                Xr[u].x *= gf; Xr[u].y *= gf;
+            }
+        }
+    } else if (lane == 0) {
+        NNN_TIF(b, branch, 1, f, tile, sl)[0] = 1 << NB;
+    }
+    if (sp->log && s < b.S) {   // parity-test record of this frame: pitch index, branch mask, smoothed gains
+        unsigned *lg = sp->log + (size_t)s * FRAME_LOG_WORDS;
+        if (lane < NB) lg[2 + lane] = __float_as_uint(live ? b_g : 0.0f);
+        if (lane == 0) {
+            lg[0] = (unsigned)NNN_TIF(b, pitch, 1, f, tile, sl)[0];
+            lg[1] = (unsigned)bmask;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = rfft_slot_bin(lane, u);
+        if (k >= 0) A[k] = Xr[u];
+    }
+    wave_lds_sync();
+    // complex-to-real 960-point inverse as a 480-point complex inverse (see k_synth)
+    float2 zin[8];
+    {
+        const int j = lane < FFT_P1 ? lane : FFT_P1 - 1;
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++) {
+            const int k = j + FFT_P1 * rr;
+            float2 a = A[k], c = A[NFFT - k];
+            float2 e2 = make_float2(a.x + c.x, a.y - c.y);
+            float2 d = make_float2(a.x - c.x, a.y + c.y);
+            float2 w = t.tw[k];
+            w.y = -w.y;
+            float2 o2 = cmulf(d, w);
+            zin[rr] = make_float2(e2.y + o2.x, e2.x - o2.y);
+        }
+    }
+    wave_lds_sync();   // the spectrum has been read: the transform takes its buffer
+    // (from here on a lane owns sample quads: samples 4 j + 256 u .. + 3 of both halves, j = lane, u < 2 -- 16-byte reads of the
+    // transform, the window and the overlap memory, 16-byte stores of the audio; same arithmetic per sample as with pairs)
+    float4 wlo[2], whi[2];   // the two window halves
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int n = lane + 64 * u;
+        const bool on = n < FRAME / 4;
+        wlo[u] = on ? ((const float4 *)b.window_s)[n] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // (window / 2: the inverse transform's halving rides on it)
+        whi[u] = on ? ((const float4 *)b.window_s)[FRAME / 4 + n] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    fft480_regs<true>(zin, A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
+    if (lane == 0 && vad_out && s < b.S) vad_out[s] = vadv;
+    const bool quad_ok = ch == 1 && (((size_t)o) & (size_t)(4 * elem - 1)) == 0;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int n = lane + 64 * u;
+        if (n < FRAME / 4) {
+            const float4 lo = ((const float4 *)A)[n], hi = ((const float4 *)A)[n + FRAME / 4];   // (A[2n], A[2n + 1]) each
+            const float u0 = hi.y * whi[u].x, u1 = hi.x * whi[u].y, u2 = hi.w * whi[u].z, u3 = hi.z * whi[u].w;   // (x / 2) * w and x * (w / 2) are the same float
+            if (store) {
+                const float y0 = fmaf(lo.y, wlo[u].x, smq[u].x), y1 = fmaf(lo.x, wlo[u].y, smq[u].y), y2 = fmaf(lo.w, wlo[u].z, smq[u].z),
+                            y3 = fmaf(lo.z, wlo[u].w, smq[u].w);
+                if (quad_ok && fmt == PCM_F32) ((float4 *)o)[n] = make_float4(y0, y1, y2, y3);
+                else if (quad_ok && fmt == PCM_I16)
+                    ((uint2 *)o)[n] = make_uint2((unsigned)(unsigned short)pcm_to_i16(y0) | ((unsigned)(unsigned short)pcm_to_i16(y1) << 16),
+                                                 (unsigned)(unsigned short)pcm_to_i16(y2) | ((unsigned)(unsigned short)pcm_to_i16(y3) << 16));
+                else if (quad_ok) ((float4 *)o)[n] = make_float4(pcm_to_unit(y0), pcm_to_unit(y1), pcm_to_unit(y2), pcm_to_unit(y3));
+                else {
+                    pcm_store(o + (long long)(4 * n) * sstride, fmt, y0);
+                    pcm_store(o + (long long)(4 * n + 1) * sstride, fmt, y1);
+                    pcm_store(o + (long long)(4 * n + 2) * sstride, fmt, y2);
+                    pcm_store(o + (long long)(4 * n + 3) * sstride, fmt, y3);
+                }
+            }
+            smq[u] = make_float4(u0, u1, u2, u3);
+            if (SMV_IO) ((float4 *)sm)[n] = smq[u];
+        }
+    }
+    wave_lds_sync();   // A is refilled by the next frame
+}
+
 #ifndef NNN_SYN_MINWAVES
 #define NNN_SYN_MINWAVES 4
 #endif
@@ -3118,40 +3270,31 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
     __shared__ float r_[FFT_SPB][3 * NB];
     const int wave = threadIdx.x >> 6;
     float2 *A = A_[wave];
-    float *ebuf = (float *)A, *r = r_[wave], *r2 = r + NB, *gg = r + 2 * NB;
+    float *r = r_[wave];
     int tile, sub;
     xcd_tile_block((int)blockIdx.x, b.NT, TILE / FFT_SPB, tile, sub);
     const int lane0 = threadIdx.x & 63, sl = sub * FFT_SPB + wave, s = tile * TILE + sl;
     int lane = lane0;
     fft_tables_load(t, b);
     float *sm = b.synth_mem + (size_t)s * FRAME;
-    float2 smv[4];   // overlap memory as sample pairs, carried from frame to frame in registers
+    float4 smq[2];   // overlap memory as sample quads, carried from frame to frame in registers
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int n = lane + 64 * u;
-        smv[u] = n < FRAME / 2 ? ((const float2 *)sm)[n] : make_float2(0.0f, 0.0f);
-    }
+    for (int u = 0; u < 2; u++) smq[u] = lane + 64 * u < FRAME / 4 ? ((const float4 *)sm)[lane + 64 * u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();   // tables in place; from here on every wave is on its own (a silent stream skips the filter)
     for (int f = 0; f < g; f++) {
         lane = launder_v(lane0);   // keep the frame loop's addresses inside the loop (see launder_v)
         const size_t fo = (size_t)b.S_pad * (size_t)f;   // this frame's scratch set
-        const StepParams *sp = sp0 + f;
-        float *vad_out = sp->vad;
-        const int fmt = sp->fmt;
 #ifdef NNN_PROBE_XP
         const float2 *Xg = b.X + (size_t)(s & 255) * FSTR, *Pg = b.P + (size_t)(s & 255) * FSTR;
 #else
         const float2 *Xg = b.X + (fo + s) * FSTR, *Pg = b.P + (fo + s) * FSTR;
 #endif
-        // every global load of this frame is independent of its own results: issue them all now
+        // every global load of this frame is independent of its own results: issue them all now.  The spectra arrive as the
+        // transforms held them, (bin k, bin 480 - k) pairs in 16-byte loads (spectrum_load)
         const bool live = NNN_TIF(b, silence, 1, f, tile, sl)[0] == 0;
         float2 Xr[8], Pr[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = lane + 64 * u;
-            Xr[u] = k < FREQ ? Xg[k] : make_float2(0.0f, 0.0f);
-            Pr[u] = k < 400 ? Pg[k] : make_float2(0.0f, 0.0f);   // from bin 400 up the filter gain is zero
-        }
+        spectrum_load(Xg, Xr, lane);
+        spectrum_load(Pg, Pr, lane);
         float b_ex = 0.0f, b_ep = 0.0f, b_xp = 0.0f, b_graw = 0.0f, b_g = 0.0f;
         if (lane < NB) {
             b_ex = NNN_TIF(b, ex, NB, f, tile, sl)[(size_t)lane * TILE];
@@ -3161,137 +3304,11 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
             b_g = NNN_TIF(b, g, NB, f, tile, sl)[(size_t)lane * TILE];
         }
         const float vadv = NNN_TIF(b, vad, 1, f, tile, sl)[0];
-        // this stream's first output sample; mono streams of matching alignment take one store per sample pair
-        const int ch = sp->channels, grp = s / ch, elem = pcm_elem_bytes(fmt), sstride = ch * elem;
-        char *o = sp->out + (long long)grp * sp->group_stride + (long long)(s - grp * ch) * elem;
-        const bool store = s < b.S && !sp->discard;
-        const bool pair_ok = ch == 1 && (((size_t)o) & (size_t)(2 * elem - 1)) == 0;
-        int bmask = 1 << NB;             // lane 0: this frame's branch mask (bit 22: silent)
-        if (live) {
-            const bool up = b_xp > b_graw;   // the branch the parity tests compare (ref: src/features.rs:227)
-            const int mask = (int)(wave_ballot(up && lane < NB) & ((1ull << NB) - 1));   // bit i: band i took `exp > g`
-            if (lane < NB) {
-                float v;
-                if (up) v = 1.0f;
-                else {
-                    float exp_sq = b_xp * b_xp, g_sq = b_graw * b_graw;
-                    v = exp_sq * (1.0f - g_sq) / (0.001f + g_sq * (1.0f - exp_sq));
-                }
-                v = sqrtf(fminf(fmaxf(v, 0.0f), 1.0f));
-                v *= sqrtf(b_ex / (1e-8f + b_ep));
-                r[lane] = v;
-                gg[lane] = b_g;
-            }
-            wave_lds_sync();
-            if (lane == 0) {
-                NNN_TIF(b, branch, 1, f, tile, sl)[0] = mask;
-                bmask = mask;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int k = lane + 64 * u;
-                if (k < FREQ) {
-                    float2 X = Xr[u];
-                    const float rf = interp_gain(r, k, t.frac, t.band);
-                    X.x = fmaf(Pr[u].x, rf, X.x);
-                    X.y = fmaf(Pr[u].y, rf, X.y);
-                    Xr[u] = X;
-                    if (k < 400) ebuf[bsk(k)] = fmaf(X.y, X.y, X.x * X.x);
-                }
-            }
-            wave_lds_sync();
-            {
-                const float *const v[1] = {ebuf};
-                float ne[1];
-                band_sums_par<1>(t, v, ne, lane);
-                if (lane < NB) r2[lane] = sqrtf(b_ex / (1e-8f + ne[0]));
-            }
-            wave_lds_sync();
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int k = lane + 64 * u;
-                if (k < FREQ) {
-                    float rf, gf;
-                    interp_gain2(r2, gg, k, t.frac, t.band, rf, gf);
-                    Xr[u].x *= rf; Xr[u].y *= rf;
-                    Xr[u].x *= gf; Xr[u].y *= gf;
-                }
-            }
-        } else if (lane == 0) {
-            NNN_TIF(b, branch, 1, f, tile, sl)[0] = 1 << NB;
-        }
-        if (sp->log && s < b.S) {   // parity-test record of this frame: pitch index, branch mask, smoothed gains
-            unsigned *lg = sp->log + (size_t)s * FRAME_LOG_WORDS;
-            if (lane < NB) lg[2 + lane] = __float_as_uint(live ? b_g : 0.0f);
-            if (lane == 0) {
-                lg[0] = (unsigned)NNN_TIF(b, pitch, 1, f, tile, sl)[0];
-                lg[1] = (unsigned)bmask;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = lane + 64 * u;
-            if (k < FREQ) A[k] = Xr[u];
-        }
-        wave_lds_sync();
-        // complex-to-real 960-point inverse as a 480-point complex inverse: Zin[k] = (X[k] + conj X[480-k])
-        // + i e^{+2 pi i k/960} (X[k] - conj X[480-k]); stored re/im-swapped so the forward FFT inverts.
-        // (element k = j + 60 r on lane j: the order the transform's first pass wants its input in, see fft480_regs)
-        float2 zin[8];
-        {
-            const int j = lane < FFT_P1 ? lane : FFT_P1 - 1;
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const int k = j + FFT_P1 * r;
-                float2 a = A[k], c = A[NFFT - k];
-                float2 e2 = make_float2(a.x + c.x, a.y - c.y);
-                float2 d = make_float2(a.x - c.x, a.y + c.y);
-                float2 w = t.tw[k];
-                w.y = -w.y;
-                float2 o2 = cmulf(d, w);
-                zin[r] = make_float2(e2.y + o2.x, e2.x - o2.y);
-            }
-        }
-        wave_lds_sync();   // the spectrum has been read: the transform takes its buffer
-        // (the window is requested here, not with the frame's other loads: its 16 registers would be live across the whole frame and
-        // spill; it travels behind the transform)
-        float2 wlo[4], whi[4];   // the two window halves, as sample pairs
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int n = lane + 64 * u;
-            const bool on = n < FRAME / 2;
-            wlo[u] = on ? ((const float2 *)b.window_s)[n] : make_float2(0.0f, 0.0f);   // (window / 2: the inverse transform's halving rides on it)
-            whi[u] = on ? ((const float2 *)b.window_s)[FRAME / 2 + n] : make_float2(0.0f, 0.0f);
-        }
-        fft480_regs(zin, A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
-        if (lane == 0 && vad_out && s < b.S) vad_out[s] = vadv;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int n = lane + 64 * u;
-            if (n < FRAME / 2) {
-                float2 lo = A[n], hi = A[n + FRAME / 2];
-                float u0 = hi.y * whi[u].x, u1 = hi.x * whi[u].y;   // (x / 2) * w and x * (w / 2) are the same float
-                if (store) {
-                    const float y0 = fmaf(lo.y, wlo[u].x, smv[u].x), y1 = fmaf(lo.x, wlo[u].y, smv[u].y);
-                    if (pair_ok && fmt == PCM_F32) ((float2 *)o)[n] = make_float2(y0, y1);
-                    else if (pair_ok && fmt == PCM_I16)
-                        ((unsigned *)o)[n] = (unsigned)(unsigned short)pcm_to_i16(y0) | ((unsigned)(unsigned short)pcm_to_i16(y1) << 16);
-                    else if (pair_ok) ((float2 *)o)[n] = make_float2(pcm_to_unit(y0), pcm_to_unit(y1));
-                    else {
-                        pcm_store(o + (long long)(2 * n) * sstride, fmt, y0);
-                        pcm_store(o + (long long)(2 * n + 1) * sstride, fmt, y1);
-                    }
-                }
-                smv[u] = make_float2(u0, u1);
-            }
-        }
-        wave_lds_sync();   // A is refilled by the next frame
+        synth_frame<false>(b, sp0 + f, f, tile, sl, s, lane, t, A, r, Xr, Pr, b_ex, b_ep, b_xp, b_graw, b_g, vadv, live, sm, smq);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int n = lane + 64 * u;
-        if (n < FRAME / 2) ((float2 *)sm)[n] = smv[u];
-    }
+    for (int u = 0; u < 2; u++)
+        if (lane0 + 64 * u < FRAME / 4) ((float4 *)sm)[lane0 + 64 * u] = smq[u];
 }
 
 #pragma clang fp contract(off)

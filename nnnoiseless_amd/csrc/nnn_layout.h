@@ -51,7 +51,11 @@ constexpr int PITCH_MIN = 60, PITCH_MAX = 768;
 constexpr int NLAG1 = 147;        // coarse lags  (PITCH_MAX - 3*PITCH_MIN) / 4
 constexpr int NLAG2 = 294;        // fine lags
 constexpr int TILE = 64;
-constexpr int FSTR = 496;         // row stride of the spectra (481 bins padded to 31 lines of 128 bytes)
+constexpr int FSTR = 512;         // row stride (float2) of the spectra in memory.  A spectrum is stored as the transforms hold it: lane j of the
+                                  // stream's wave owns bins k = j + 64 u (u < 4, k <= 240) and their mirror images 480 - k, and element pair
+                                  // 2 (64 u + j), + 1 holds (bin k, bin 480 - k) -- one 16-byte store per pair in k_fft_xp, one 16-byte load in
+                                  // k_synth, lanes contiguous (until round 4: natural bin order, 8-byte accesses at 0.54-0.70 of the 16-byte rate).
+                                  // Bin 240 pairs with itself, pairs of k > 240 do not exist (slots left alone).
 constexpr int MAXN = 127;         // layer sizes are non-negative i8 (src/rnn.rs:128-134)
 
 struct ModelDims {
@@ -112,8 +116,8 @@ struct Buffers {
     int *pitch;          // TI [1]
     int *pflag;          // TI [1]      per quarter tile (its first stream's entry): number of the frame whose pitch and gain are in memory
     float *pgain;        // TI [1]
-    float2 *X, *P;       // SM [FSTR]   spectra, rows padded to whole 128-byte lines; P holds bins 0..399 unless taps are on (the
-                         //             pitch filter reads no more, ref: src/lib.rs:84-97 zero-fills from bin 400 up)
+    float2 *X, *P;       // SM [FSTR]   spectra as (bin k, bin 480 - k) pairs in the transforms' lane order (see FSTR; spectrum_index); the
+                         //             fused back end (k_back) keeps them in registers and writes them for the parity taps only
     float *ex, *ep, *exp_;  // TI [22]
     float *cn;           // TI [28]     the frame's own cepstrum (22) and pitch-correlation DCT (6), made at the end of k_fft_p
     float *feat;         // TI [42]
@@ -188,6 +192,12 @@ struct StepParams {
 };
 constexpr int FRAME_LOG_WORDS = 2 + NB;   // pitch index, branch mask, the 22 smoothed band gains (f32 bits)
 
+// where bin k (0 .. 480) of a spectrum sits in its FSTR-long row (float2 index)
+__host__ __device__ inline int spectrum_index(int k)
+{
+    const int kk = k <= 240 ? k : 480 - k;   // the pair's lower bin: lane kk % 64, slot kk / 64
+    return 2 * kk + (k <= 240 ? 0 : 1);      // (64 u + j = kk)
+}
 // ring position of logical input_mem[0] when the newest frame sits in slot `slot`
 __host__ __device__ inline int ring_base(int slot, int nslot)
 {

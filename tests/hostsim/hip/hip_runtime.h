@@ -37,6 +37,8 @@ struct uint3_ { unsigned x, y, z; };
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r = {x, y}; return r; }
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r = {x, y, z, w}; return r; }
 static inline float2 make_float2(float x, float y) { float2 r = {x, y}; return r; }
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r = {x, y, z, w}; return r; }
