@@ -512,25 +512,29 @@ __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0,
                 *(uint4 *)(IN + (size_t)plx * in_ps + row * pl.in_w + 8 * c8) = v;
             }
         }
+        // the weight fragments of a phase are requested before the barrier that opens it (see BkW); NNN_BK_PREFETCH_FUSED=0 builds the fused
+        // kernel without (measured: 61.3 against 59.2 us per one-frame launch at 4096 streams -- the registers the prefetch takes are not
+        // what makes the fused kernel spill its spectra)
+#ifndef NNN_BK_PREFETCH_FUSED
+#define NNN_BK_PREFETCH_FUSED 1
+#endif
+        constexpr bool PF = !FUSED || NNN_BK_PREFETCH_FUSED;
+#define BK_EDGE(LOAD) do { if (PF) { LOAD; lds_barrier(); } else { lds_barrier(); LOAD; } } while (0)
         BkW W;
         BkH H;
-        bk_dense_load(pl.dense, Wq, fpar, wave, lane, W);
-        lds_barrier();
+        BK_EDGE(bk_dense_load(pl.dense, Wq, fpar, wave, lane, W));
         NNN_STAMP(b, 6);
         // input dense (ref: src/rnn.rs:353-355)
         bk_dense(pl.dense, R, Wq, fpar, wave, lane, W, [&](int row, int neuron, float v, int) {
             store_split(IN, in_ps, row * pl.in_w + pl.dense.out_col + neuron, v);
         });
-        bk_gru_load_a(pl.vad, Wq, fpar, wave, lane, W);
-        lds_barrier();
+        BK_EDGE(bk_gru_load_a(pl.vad, Wq, fpar, wave, lane, W));
         NNN_STAMP(b, 7);
         // vad GRU (ref: src/rnn.rs:356-358)
         bk_gru_phase_a(pl.vad, R, SPv, o.sw_v, Wq, fpar, wave, lane, W, H);
-        bk_gru_load_b(pl.vad, Wq, lane, H, W);
-        lds_barrier();   // z and r * state complete; every wave is done reading the old state planes and the layer's inputs
+        BK_EDGE(bk_gru_load_b(pl.vad, Wq, lane, H, W));   // z and r * state complete; every wave is done reading the old state planes and the layer's inputs
         bk_gru_phase_b(pl.vad, R, SPv, o.sw_v, Wq, lane, W, H);
-        bk_gru_load_a(pl.noise, Wq, fpar, wave, lane, W);
-        lds_barrier();
+        BK_EDGE(bk_gru_load_a(pl.noise, Wq, fpar, wave, lane, W));
         NNN_STAMP(b, 8);
         // noise GRU (ref: src/rnn.rs:361-366); beside its first phase, on a wave it leaves idle, the vad output
         bk_gru_phase_a(pl.noise, R, SPn, o.sw_n, Wq, fpar, wave, lane, W, H);
@@ -541,19 +545,15 @@ __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0,
             vadl[lane] = v;
             NNN_TIF(b, vad, 1, f, tile, r0 + lane)[0] = v;
         }
-        bk_gru_load_b(pl.noise, Wq, lane, H, W);
-        lds_barrier();
+        BK_EDGE(bk_gru_load_b(pl.noise, Wq, lane, H, W));
         bk_gru_phase_b(pl.noise, R, SPn, o.sw_n, Wq, lane, W, H);
-        bk_gru_load_a(pl.dn, Wq, fpar, wave, lane, W);
-        lds_barrier();
+        BK_EDGE(bk_gru_load_a(pl.dn, Wq, fpar, wave, lane, W));
         NNN_STAMP(b, 9);
         // denoise GRU (ref: src/rnn.rs:368-377)
         bk_gru_phase_a(pl.dn, R, SPdn, o.sw_dn, Wq, fpar, wave, lane, W, H);
-        bk_gru_load_b(pl.dn, Wq, lane, H, W);
-        lds_barrier();
+        BK_EDGE(bk_gru_load_b(pl.dn, Wq, lane, H, W));
         bk_gru_phase_b(pl.dn, R, SPdn, o.sw_dn, Wq, lane, W, H);
-        bk_dense_load(pl.out, Wq, fpar, wave, lane, W);
-        lds_barrier();
+        BK_EDGE(bk_dense_load(pl.out, Wq, fpar, wave, lane, W));
         NNN_STAMP(b, 10);
         // gains (ref: src/rnn.rs:378) and smoothing g = max(g, 0.6 lastg) (ref: src/denoise.rs:106-109)
         bk_dense(pl.out, R, Wq, fpar, wave, lane, W, [&](int lrow, int band, float v, int q) {
@@ -571,6 +571,7 @@ __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0,
             gout[lrow * BK_GW + band] = gr;
             gout[lrow * BK_GW + 24 + band] = gs;
         });
+#undef BK_EDGE
         if (!FUSED) {
             lds_barrier();   // (the next frame's features may be staged)
             NNN_STAMP(b, 11);
