@@ -59,9 +59,9 @@ KERNEL_BYTES = {
                                                                    # take fewer frames per wave, up to 3456 B) + x_lp[0] in; autocorrelation and FIR taps out
     "k_pitch": 3456 + 4 + 20 + 8 + 16 // G,                         # decimated window + x_lp[0] + FIR taps in; pitch index + gain out; last pitch per group
                                                                    # (pitch_buf, coarse xcorr, the running energies and their check points never leave LDS)
-    "k_fft_xp": 3840 + 1200 + 4 + 3856 + 3856 + 264 + 112 + 4,     # 960 + (mean lag 300) history samples; X and P as 241 (bin k, bin 480 - k) pairs of 16 bytes, band energies, cepstrum head out
+    "k_fft_xp": 3840 + 1200 + 4 + 3856 + 3344 + 264 + 112 + 4,     # 960 + (mean lag 300) history samples; X as 241 (bin k, bin 480 - k) pairs of 16 bytes, P as 64 lone bins + 177 pairs; band energies, cepstrum head out
     "k_rnn": 120 + 88 + 4 + 2 * 88 + 2 * 88 + (704 + 2 * 672 + 8) // G,   # features head in; ring row, vad, gains, last gains; ring + GRU states per group
-    "k_synth": 3856 + 3856 + 440 + 8 + 1920 + 8 + 3840 // G,       # X, P (bin pairs), band quantities in; audio, vad, branch out; overlap memory per group
+    "k_synth": 3856 + 3344 + 440 + 8 + 1920 + 8 + 3840 // G,       # X (bin pairs), P (64 bins + 177 pairs), band quantities in; audio, vad, branch out; overlap memory per group
     # the fused back end (transforms + features + RNN + synthesis in one launch, the spectra in registers): history samples and pitch in; band
     # quantities (parity taps), ring row, vad, gains, last gains, branch, audio out; overlap memory in and out per frame; ring + GRU states per launch
     "k_back": 3840 + 1200 + 4 + 268 + 88 + 4 + 2 * 88 + 2 * 88 + 4 + 1920 + 3840 + (704 + 2 * 672 + 8) // 1,

@@ -1243,7 +1243,7 @@ extern "C" int nnn_batch_process_pcm_host(nnn_batch *h, const void *in, void *ou
 }
 
 // ---- taps ---------------------------------------------------------------------------------------
-struct TapDesc { int len; int is_int; int layout; /* 0 TI, 2 SM float2 rows of FSTR, 3 hist ring */ int sub_ofs; int sub_len; int needs_taps; };
+struct TapDesc { int len; int is_int; int layout; /* 0 TI, 2 / 4 SM spectrum rows of FSTR (X / P order), 3 hist ring */ int sub_ofs; int sub_len; int needs_taps; };
 static int last_slot(const nnn_batch *h) { return h ? (int)((h->frame_count + h->nslot - 1) % h->nslot) : 0; }   // ring slot of the most recent frame
 static bool tap_desc(const nnn_batch *h, int tap, TapDesc &d, const void **ptr)
 {
@@ -1261,7 +1261,7 @@ static bool tap_desc(const nnn_batch *h, int tap, TapDesc &d, const void **ptr)
     case NNN_TAP_PITCH: d = {1, 1, 0, 0, 1, 0}; *ptr = TP(pitch); return true;
     case NNN_TAP_PITCH_GAIN: d = {1, 0, 0, 0, 1, 0}; *ptr = TP(pgain); return true;
     case NNN_TAP_X: d = {2 * FREQ, 0, 2, 0, 2 * FREQ, 1}; *ptr = TP(X); return true;   // (the fused back end keeps both spectra in registers)
-    case NNN_TAP_P: d = {2 * FREQ, 0, 2, 0, 2 * FREQ, 1}; *ptr = TP(P); return true;
+    case NNN_TAP_P: d = {2 * FREQ, 0, 4, 0, 2 * FREQ, 1}; *ptr = TP(P); return true;   // (layout 4: spectrum_index_p)
     case NNN_TAP_EX: d = {NB, 0, 0, 0, NB, 0}; *ptr = TP(ex); return true;
     case NNN_TAP_EP: d = {NB, 0, 0, 0, NB, 0}; *ptr = TP(ep); return true;
     case NNN_TAP_EXP: d = {NB, 0, 0, 0, NB, 0}; *ptr = TP(exp_); return true;
@@ -1323,13 +1323,13 @@ extern "C" int nnn_batch_read_tap(nnn_batch *h, int tap, void *host_dst, size_t 
         for (int s = 0; s < h->S; s++)
             for (int i = 0; i < d.len; i++)
                 dst[(size_t)s * d.len + i] = tmp[((size_t)(s / TILE) * d.sub_len + d.sub_ofs + i) * TILE + s % TILE];
-    } else if (d.layout == 2) {
+    } else if (d.layout == 2 || d.layout == 4) {
         std::vector<uint32_t> tmp(Sp * 2 * FSTR);
         HIPCHK(hipMemcpy(tmp.data(), p, tmp.size() * 4, hipMemcpyDeviceToHost));
         // (a spectrum's row holds (bin k, bin 480 - k) pairs in the transforms' lane order: spectrum_index)
         for (int s = 0; s < h->S; s++)
             for (int k = 0; k < FREQ; k++) {
-                const size_t at = (size_t)s * 2 * FSTR + 2 * (size_t)spectrum_index(k);
+                const size_t at = (size_t)s * 2 * FSTR + 2 * (size_t)(d.layout == 4 ? spectrum_index_p(k) : spectrum_index(k));
                 dst[(size_t)s * d.len + 2 * k] = tmp[at];
                 dst[(size_t)s * d.len + 2 * k + 1] = tmp[at + 1];
             }

@@ -1759,6 +1759,30 @@ __device__ __forceinline__ void spectrum_load(const float2 *row, float2 (&S)[8],
     }
 }
 
+// The pitch-lagged spectrum P the same way, except that the partners of slot 0 -- bins 417 .. 480, which the pitch filter never reads (its
+// gain is zero from bin 400 up, ref: src/lib.rs:84-97) -- stay out of the row: 64 lone bins (8 bytes each) first, then the pairs of slots
+// 1 .. 3; with the parity taps on the 64 partners follow behind (P_TAIL).  13 % fewer bytes for P than whole pairs.
+constexpr int P_PAIRS0 = 64, P_TAIL = 64 + 2 * 177;   // float2 index of the first pair (slot 1) and of the taps-only partners of slot 0
+__device__ __forceinline__ void spectrum_store_p(float2 *row, const float2 (&S)[8], int lane, bool taps)
+{
+    row[lane] = S[0];
+    if (taps) row[P_TAIL + lane] = S[4];
+#pragma unroll
+    for (int u = 1; u < 4; u++)
+        if (lane + 64 * u <= NFFT / 2) ((float4 *)(row + P_PAIRS0))[64 * (u - 1) + lane] = make_float4(S[u].x, S[u].y, S[4 + u].x, S[4 + u].y);
+}
+__device__ __forceinline__ void spectrum_load_p(const float2 *row, float2 (&S)[8], int lane)
+{
+    S[0] = row[lane];
+    S[4] = make_float2(0.0f, 0.0f);   // (bins 417 .. 480: never read)
+#pragma unroll
+    for (int u = 1; u < 4; u++) {
+        const float4 v = lane + 64 * u <= NFFT / 2 ? ((const float4 *)(row + P_PAIRS0))[64 * (u - 1) + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        S[u] = make_float2(v.x, v.y);
+        S[4 + u] = make_float2(v.z, v.w);
+    }
+}
+
 template <bool WITH_P, bool FUSED = false>
 __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepParams *sp, int tile_in, int sub, FftLds &t, float2 *Z, float *part,
                                                  XpKeep *keep = nullptr)
@@ -1824,7 +1848,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     window_rfft<FUSED>(b, spw, w, t, Z, Y, lane, false);
     float2 *dp = b.P + (size_t)s * FSTR;
 #ifndef NNN_PROBE_XP
-    if (!FUSED || b.taps) spectrum_store(dp, Y, lane);   // (whole pairs: the pitch filter reads bins 0..399, their partners come along)
+    if (!FUSED || b.taps) spectrum_store_p(dp, Y, lane, b.taps != 0);
 #endif
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -3294,7 +3318,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
         const bool live = NNN_TIF(b, silence, 1, f, tile, sl)[0] == 0;
         float2 Xr[8], Pr[8];
         spectrum_load(Xg, Xr, lane);
-        spectrum_load(Pg, Pr, lane);
+        spectrum_load_p(Pg, Pr, lane);
         float b_ex = 0.0f, b_ep = 0.0f, b_xp = 0.0f, b_graw = 0.0f, b_g = 0.0f;
         if (lane < NB) {
             b_ex = NNN_TIF(b, ex, NB, f, tile, sl)[(size_t)lane * TILE];

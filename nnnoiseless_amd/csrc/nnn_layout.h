@@ -198,6 +198,13 @@ __host__ __device__ inline int spectrum_index(int k)
     const int kk = k <= 240 ? k : 480 - k;   // the pair's lower bin: lane kk % 64, slot kk / 64
     return 2 * kk + (k <= 240 ? 0 : 1);      // (64 u + j = kk)
 }
+// the same for the pitch-lagged spectrum P (spectrum_store_p: slot 0's bins alone, then pairs; bins 417 .. 480 behind them, taps only)
+__host__ __device__ inline int spectrum_index_p(int k)
+{
+    const int kk = k <= 240 ? k : 480 - k;
+    if (kk < 64) return k <= 240 ? kk : 64 + 2 * 177 + kk;
+    return 64 + 2 * (kk - 64) + (k <= 240 ? 0 : 1);
+}
 // ring position of logical input_mem[0] when the newest frame sits in slot `slot`
 __host__ __device__ inline int ring_base(int slot, int nslot)
 {
