@@ -84,6 +84,7 @@ struct nnn_batch {
         size_t back_lds = 0, rnn16_lds = 0;   // dynamic LDS of k_back<true> / k_back<false>; 0 = the model is outside the kernel's shape class
         BkActs acts = {};
     };
+    int hp_split = -1;             // k_hp on two waves per tile (k_hp2): -1 = for launches of up to 256 tiles, 0 / 1 = never / always (env NNN_HP_SPLIT, read at creation)
     int back_mode = -1;            // the fused back end (k_back, nnn_back.hip): 0 = never, 1 = one-frame groups (the real-time tick), 2 = every group;
                                    // 3 / 4 = its RNN stretch alone (k_back<false>) in place of k_rnn / k_rnn_wf for one-frame / all groups;
                                    // -1 = by measurement (back_choice): one-frame groups only, fused up to 8192 streams, the RNN stretch
@@ -331,6 +332,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     if (const char *e = getenv("NNN_HOST_CHUNK")) h->host_chunk = atoi(e);
     if (const char *e = getenv("NNN_RNN_WF_MIN_G")) h->wf_min_g = atoi(e);
     if (const char *e = getenv("NNN_BACK")) h->back_mode = atoi(e);
+    if (const char *e = getenv("NNN_HP_SPLIT")) h->hp_split = atoi(e);
     if (const char *e = getenv("NNN_PITCH_CHAIN")) h->pitch_chain = atoi(e);
     if (const char *e = getenv("NNN_LPC_WIDE")) h->lpc_wide = atoi(e);
     if (const char *e = getenv("NNN_LPC_FC")) h->lpc_fc = atoi(e);
@@ -701,6 +703,7 @@ extern "C" nnn_batch *nnn_batch_clone(nnn_batch *h)
     c->use_pipeline = h->use_pipeline;
     c->pitch_chain = h->pitch_chain;
     c->back_mode = h->back_mode;
+    c->hp_split = h->hp_split;
     c->lpc_wide = h->lpc_wide;
     c->lpc_fc = h->lpc_fc;
     c->inputs_ready = h->inputs_ready;
@@ -767,6 +770,12 @@ static bool lpc_in_pitch(const nnn_batch *h, int g)
     if (force >= 0) return force != 0 && g == 1;
     return g == 1 && h->S_pad <= 6144 && h->lpc_wide < 0 && h->lpc_fc == 0;   // (measured: -6 us at 4096 streams, level at 8192, +9 us at 16 384)
 }
+// k_hp on two waves per tile (recurrence | everything else): for launches that leave SIMDs empty
+static bool hp_split(const nnn_batch *h)
+{
+    if (h->hp_split >= 0) return h->hp_split != 0;
+    return h->NT <= 256;
+}
 static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams *sp0, hipStream_t st, bool prof, const StepParams *call = nullptr, int fill = 0)
 {
     if (g <= 0) return;   // (never a launch with an empty grid)
@@ -777,7 +786,8 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
     switch (s) {
     case ST_HP:
         // (`fill`: this is the first launch of a call whose parameter table is k_hp's to fill, see k_hp)
-        L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g, call ? *call : StepParams{}, call ? fill : 0);
+        if (hp_split(h)) L.go(K_HP, k_hp2, dim3(NT), dim3(128), 0, b, sp0, g, call ? *call : StepParams{}, call ? fill : 0);
+        else L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g, call ? *call : StepParams{}, call ? fill : 0);
         // the LPC analysis of the group's frames (lane = stream, frames side by side) rides on the same stream, ahead of the pitch stage
         // (launches too small to fill the GPU spread the five lags of a stream over five waves)
         if (lpc_in_pitch(h, g)) break;   // (a lone frame of a small batch: k_pitch does it on its way, see there)

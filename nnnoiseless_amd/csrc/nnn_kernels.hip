@@ -186,6 +186,23 @@ struct HpState { float m0, m1, prev; };
 // pipeline's throughput at 4096 streams, more than the kernel's share of anything.  The results of a chunk therefore cross LDS
 // (row stride 33 floats: conflict-free both ways) and leave as 8 stores of 8 streams x 128 contiguous bytes.
 constexpr int HP_LD = HP_CH + 1;
+
+// HP_CH steps of the biquad (ref: src/util.rs:95-107, coefficients :68-71): y = x + m0; m0 = f32(m1 + (b0 x - a0 y)); m1 = f32(b1 x - a1 y), in
+// f64 with the state rounded to f32 each step.  b0 = -2 and b1 = 1: their products are exact, so b0 x - a0 y is ONE rounding of
+// -2 x - fl(a0 y) -- what fma(x, -2, -fl(a0 y)) returns -- and b1 x is x.  Twelve f64 instructions per step on a chain of six.
+__device__ __forceinline__ void hp_recurrence(const float (&xs)[HP_CH], float (&ys)[HP_CH], float &m0, float &m1)
+{
+    const double a0 = (double)-1.99599f, a1 = (double)0.99600f;
+#pragma unroll
+    for (int j = 0; j < HP_CH; j++) {
+        const double x64 = (double)xs[j];
+        const double y64 = x64 + (double)m0;
+        m0 = (float)((double)m1 + fma(x64, -2.0, -(a0 * y64)));
+        m1 = (float)(x64 - a1 * y64);
+        ys[j] = (float)y64;
+    }
+}
+
 template <int FMT, bool VEC>
 __device__ __forceinline__ void hp_frame(const Buffers &b, const char *sp_in, long long sp_group_stride, int slot, int ch, int tile, int lane, HpState &st, float *Ly)
 {
@@ -212,7 +229,6 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const char *sp_in, lo
     float *dec = ring + (size_t)(240 * slot) * TILE;
     const bool mirror = slot < DEC_MIRROR;
     float4 *hw = (float4 *)(h + slot * FRAME);   // the stride * 4 and FRAME * 4 are multiples of 16
-    const double a0 = (double)-1.99599f, a1 = (double)0.99600f, b0 = (double)-2.0f, b1 = (double)1.0f;
     // Software pipeline over HP_CH-sample chunks.  Loads and stores share one in-order counter (vmcnt), so waiting for
     // chunk c's samples also waits for every store issued before: the stores of chunk c - 1 are therefore issued right
     // after that wait, and both they and the loads of chunk c + 1 travel behind the ~0.7 us recurrence of chunk c.
@@ -247,14 +263,7 @@ __device__ __forceinline__ void hp_frame(const Buffers &b, const char *sp_in, lo
         }
         if (c == FRAME / HP_CH) break;
         if (c + 1 < FRAME / HP_CH) nxt.load(in + (long long)(c + 1) * HP_CH * sstride, sstride);
-#pragma unroll
-        for (int j = 0; j < HP_CH; j++) {
-            double x64 = (double)xs[j];
-            double y64 = x64 + (double)m0;
-            m0 = (float)((double)m1 + (b0 * x64 - a0 * y64));
-            m1 = (float)(b1 * x64 - a1 * y64);
-            ys[j] = (float)y64;
-        }
+        hp_recurrence(xs, ys, m0, m1);
 #pragma unroll
         for (int t = 0; t < HP_CH / 2; t++) {
             const float a = t == 0 ? prev : ys[2 * t - 1], m = ys[2 * t], n = ys[2 * t + 1];
@@ -298,6 +307,105 @@ __device__ __forceinline__ void hp_group(const Buffers &b, const StepParams *sp,
     hp[0] = st.m0;
     hp[TILE] = st.m1;
     hl[0] = st.prev;
+}
+
+// The same frame on TWO waves (k_hp2, launches that leave most of the GPU empty: a one-frame call of 4096 streams is 64 lone waves).  The
+// recurrence issues 12 f64 instructions per step whatever else the wave does, and everything else -- the results' trip through LDS, 40
+// stores per chunk, the decimation -- used to stand between one chunk's recurrence and the next (0.5 of every 1.3 us).  Here wave 0
+// runs loads and recurrence only and leaves each chunk's results in one of two LDS buffers; wave 1 (another SIMD) takes them from there
+// behind one block barrier per chunk and does the rest while wave 0 is a chunk further.  Same arithmetic, same bits.
+template <int FMT, bool VEC>
+__device__ __forceinline__ void hp_chain_frame(const Buffers &b, const char *sp_in, long long sp_group_stride, int ch, int tile, int lane, float &m0, float &m1, float *Ly2, int &k)
+{
+    const int elem = pcm_elem_bytes(FMT), sstride = ch * elem;
+    const int s = tile * TILE + lane;
+    const int sc = s < b.S ? s : b.S - 1, grp = sc / ch;
+    const char *in = sp_in + (long long)grp * sp_group_stride + (long long)(sc - grp * ch) * elem;
+    HpChunk<FMT, VEC> nxt;
+    nxt.load(in, sstride);
+    for (int c = 0; c < FRAME / HP_CH; c++, k++) {
+        float xs[HP_CH], ys[HP_CH];
+        nxt.get(xs);
+        if (c + 1 < FRAME / HP_CH) nxt.load(in + (long long)(c + 1) * HP_CH * sstride, sstride);
+        hp_recurrence(xs, ys, m0, m1);
+        float *L = Ly2 + (k & 1) * (TILE * HP_LD) + lane * HP_LD;
+#pragma unroll
+        for (int j = 0; j < HP_CH; j++) L[j] = ys[j];
+        __syncthreads();   // chunk k is in its buffer (and wave 1 is done with chunk k - 1: this buffer's turn again at k + 2)
+    }
+}
+__device__ __forceinline__ void hp_store_frame(const Buffers &b, int slot, int tile, int lane, float &prev, const float *Ly2, int &k)
+{
+    const int s = tile * TILE + lane;
+    const int nslot = b.nslot, hstr = hist_stride(nslot);
+    float *ring = NNN_TI(b.dec, dec_len(nslot), tile, lane);
+    float *h = b.hist + (size_t)s * hstr;
+    {   // x_lp[0], as in hp_frame
+        const int rb = ring_base(slot, nslot);
+        const float x0 = h[rb], x1 = h[rb + 1];
+        NNN_TI(b.xlp0, nslot, tile, lane)[(size_t)slot * TILE] = (x1 / 2.0f + x0) / 2.0f;
+    }
+    float *dec = ring + (size_t)(240 * slot) * TILE;
+    const bool mirror = slot < DEC_MIRROR;
+    for (int c = 0; c < FRAME / HP_CH; c++, k++) {
+        __syncthreads();
+        const float *L = Ly2 + (k & 1) * (TILE * HP_LD);
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int r = 8 * it + (lane >> 3);
+            const float *y = L + r * HP_LD + 4 * (lane & 7);
+            float4 *hr = (float4 *)(b.hist + (size_t)(tile * TILE + r) * hstr + slot * FRAME + c * HP_CH) + (lane & 7);
+            *hr = make_float4(y[0], y[1], y[2], y[3]);
+        }
+        float ys[HP_CH];
+#pragma unroll
+        for (int j = 0; j < HP_CH; j++) ys[j] = L[lane * HP_LD + j];
+#pragma unroll
+        for (int t = 0; t < HP_CH / 2; t++) {
+            const float a = t == 0 ? prev : ys[2 * t - 1], m = ys[2 * t], n = ys[2 * t + 1];
+            const float dv = ((a + n) / 2.0f + m) / 2.0f;
+            dec[(size_t)(HP_CH / 2 * c + t) * TILE] = dv;
+            if (mirror) dec[(size_t)(dec_ring_len(nslot) + HP_CH / 2 * c + t) * TILE] = dv;
+        }
+        prev = ys[HP_CH - 1];
+        if (slot == 0 && c == 0) h[ring_len(nslot)] = ys[0];
+    }
+}
+template <int FMT, bool VEC>
+__device__ __forceinline__ void hp_chain_group(const Buffers &b, const StepParams *sp, int g, int tile, int lane, float *Ly2, const StepParams &v0, int fill)
+{
+    float *hp = NNN_TI(b.hp_mem, 2, tile, lane);
+    float m0 = hp[0], m1 = hp[TILE];
+    int k = 0;
+    for (int f = 0; f < g; f++) {
+        const char *in = fill > 0 ? v0.in + (long long)f * v0.frame_stride : sp[f].in;
+        hp_chain_frame<FMT, VEC>(b, in, fill > 0 ? v0.group_stride : sp[f].group_stride, fill > 0 ? v0.channels : sp[f].channels, tile, lane, m0, m1, Ly2, k);
+    }
+    hp[0] = m0;
+    hp[TILE] = m1;
+}
+__global__ void __launch_bounds__(128) k_hp2(Buffers b, const StepParams *sp, int g, StepParams v0, int fill)
+{
+    static_assert(HP_CH == 32, "");
+    const int lane = threadIdx.x & 63, role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), tile = blockIdx.x;
+    __shared__ float Ly2[2 * TILE * HP_LD];
+    if (role == 1) {
+        if (fill > 0 && tile == 0)
+            for (int t = lane; t < fill; t += 64) ((StepParams *)sp)[t] = step_params_at(v0, t, b.nslot);
+        float *hl = NNN_TI(b.hp_last, 1, tile, lane);
+        float prev = hl[0];
+        int k = 0;
+        for (int f = 0; f < g; f++) hp_store_frame(b, fill > 0 ? (v0.slot + f) % b.nslot : sp[f].slot, tile, lane, prev, Ly2, k);
+        hl[0] = prev;
+        return;
+    }
+    const int fmt = fill > 0 ? v0.fmt : sp->fmt;
+    wf_setprio_high();
+    const StepParams &lay = fill > 0 ? v0 : *sp;
+    const bool vec = lay.channels == 1 && ((((size_t)lay.in) | (size_t)lay.group_stride | (size_t)lay.frame_stride) & 15) == 0;
+    if (fmt == PCM_F32) { if (vec) hp_chain_group<PCM_F32, true>(b, sp, g, tile, lane, Ly2, v0, fill); else hp_chain_group<PCM_F32, false>(b, sp, g, tile, lane, Ly2, v0, fill); }
+    else if (fmt == PCM_I16) { if (vec) hp_chain_group<PCM_I16, true>(b, sp, g, tile, lane, Ly2, v0, fill); else hp_chain_group<PCM_I16, false>(b, sp, g, tile, lane, Ly2, v0, fill); }
+    else { if (vec) hp_chain_group<PCM_F32_UNIT, true>(b, sp, g, tile, lane, Ly2, v0, fill); else hp_chain_group<PCM_F32_UNIT, false>(b, sp, g, tile, lane, Ly2, v0, fill); }
 }
 
 __global__ void __launch_bounds__(64, HP_CH <= 16 ? 3 : 1) k_hp(Buffers b, const StepParams *sp, int g, StepParams v0, int fill)

@@ -318,3 +318,32 @@ def test_rnn_kernels_agree_bit_for_bit(hostsim_lib, monkeypatch):
     parts = [bd.process(x[:, a:b]) for a, b in ((0, 1), (1, 4), (4, 6), (6, 7))]   # k_rnn, k_rnn_wf, k_rnn, k_rnn
     assert np.array_equal(np.concatenate([p[0] for p in parts], axis=1), ref)
     assert np.array_equal(np.concatenate([p[1] for p in parts], axis=0), vref)
+
+
+def test_high_pass_on_one_wave_or_two(hostsim_lib, monkeypatch):
+    """k_hp (one wave per tile) and k_hp2 (recurrence on one wave; stores, decimation and the trip through LDS on a second: what
+    launches of up to 256 tiles take) run the same arithmetic: same bits for every boundary format, in groups and one frame per
+    call.  (Every other test of this file runs k_hp2 against the oracle: the batches here are small.)"""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd import _ffi
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T = 70, 5                                  # two tiles, the second one ragged
+    x = make_streams(77, S, T)
+    xi = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+    inter = np.ascontiguousarray(xi.reshape(S // 2, 2, T * 480).transpose(0, 2, 1))   # [group][sample][channel]
+    res = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("NNN_HP_SPLIT", split)
+        bd = nn.BatchDenoiser(S, lib=hostsim_lib, taps=True)
+        o1, v1 = bd.process(x[:, :3])
+        o2, v2 = bd.process(x[:, 3:4])
+        filt = bd.tap("filtered").copy()
+        o3, v3 = bd.process(x[:, 4:])
+        pcm = nn.BatchDenoiser(S, lib=hostsim_lib)
+        p1, w1 = pcm.process_pcm(inter[:, :960], _ffi.PCM_I16, channels=2, discard_first=True)
+        p2, w2 = pcm.process_pcm(inter[:, 960:] / np.float32(32768.0), _ffi.PCM_F32_UNIT, channels=2)
+        res[split] = (o1, o2, o3, v1, v2, v3, filt, p1, p2, w1, w2)
+        bd.close(); pcm.close()
+    for a, b in zip(res["0"], res["1"]):
+        assert np.array_equal(a, b)
+    assert np.abs(res["1"][8]).max() > 1e-3
