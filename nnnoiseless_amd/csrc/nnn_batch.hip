@@ -425,6 +425,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     HIPCHK(dalloc(h, &b.hp_last, Sp, true));
     HIPCHK(dalloc(h, &b.dec, Sp * dec_len(h->nslot), true));
     HIPCHK(dalloc(h, &b.xlp0, Sp * h->nslot, true));
+    HIPCHK(dalloc(h, &b.lpc_head, (size_t)h->NT * 5 * TILE, false));   // (made and used inside one call)
     HIPCHK(dalloc(h, &b.lpc, Sp * h->nslot * 10, false));   // (remade for every frame before it is read: not part of a snapshot)
     HIPCHK(dalloc(h, &b.ceps_mem, Sp * CEPS_MEM * NB, true));
     HIPCHK(dalloc(h, &b.mem_id, Sp, true));
@@ -776,6 +777,11 @@ static bool hp_split(const nnn_batch *h)
     if (h->hp_split >= 0) return h->hp_split != 0;
     return h->NT <= 256;
 }
+static bool lpc_head(const nnn_batch *h, int g)
+{
+    static const int force = getenv("NNN_LPC_HEAD") ? atoi(getenv("NNN_LPC_HEAD")) : -1;
+    return lpc_in_pitch(h, g) && hp_split(h) && force != 0;
+}
 static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams *sp0, hipStream_t st, bool prof, const StepParams *call = nullptr, int fill = 0)
 {
     if (g <= 0) return;   // (never a launch with an empty grid)
@@ -786,7 +792,11 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
     switch (s) {
     case ST_HP:
         // (`fill`: this is the first launch of a call whose parameter table is k_hp's to fill, see k_hp)
-        if (hp_split(h)) L.go(K_HP, k_hp2, dim3(NT), dim3(128), 0, b, sp0, g, call ? *call : StepParams{}, call ? fill : 0);
+        if (hp_split(h)) {
+            // (a lone frame whose LPC analysis runs inside k_pitch: the part of its sums that needs none of the new frame rides along here)
+            const bool head = lpc_head(h, g);
+            L.go(K_HP, k_hp2, dim3(NT + (head ? (5 * NT + 1) / 2 : 0)), dim3(128), 0, b, sp0, g, call ? *call : StepParams{}, call ? fill : 0, head ? 1 : 0);
+        }
         else L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g, call ? *call : StepParams{}, call ? fill : 0);
         // the LPC analysis of the group's frames (lane = stream, frames side by side) rides on the same stream, ahead of the pitch stage
         // (launches too small to fill the GPU spread the five lags of a stream over five waves)
@@ -806,7 +816,7 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
         // matters instead: 468 -> 515); flag values are frame numbers (> 0)
         const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
         const unsigned grid = Sp / PK_SPB * (chain ? ug : 1u);
-        L.go(K_PITCH, k_pitch, dim3(grid), dim3(PK_T), 0, b, sp0, g, chain, seq0, h->tickets, lpc_in_pitch(h, g) ? 1 : 0);
+        L.go(K_PITCH, k_pitch, dim3(grid), dim3(PK_T), 0, b, sp0, g, chain, seq0, h->tickets, lpc_in_pitch(h, g) ? (lpc_head(h, g) ? 2 : 1) : 0);
         if (chain) h->tickets += grid;   // (launches of one batch's pitch stage are ordered among themselves: a stateful stage)
         break;
     }

@@ -309,6 +309,34 @@ __device__ __forceinline__ void hp_group(const Buffers &b, const StepParams *sp,
     hl[0] = st.prev;
 }
 
+// The first 16 LPC_HEAD_BLK steps of lag K's sum -- i + K < 624: rows older than the frame being filtered -- for k_hp2's head waves
+// (lane = stream on the tile-interleaved ring, like k_lpc); k_pitch's pk_autocorr carries on from there in the same order.
+constexpr int LPC_HEAD_BLK = 38;
+static_assert(16 * LPC_HEAD_BLK + 4 <= XLP - 240, "");
+template <int K>
+__device__ __forceinline__ float lpc_head_chain(const float *base, float x0)
+{
+    constexpr int CH = 16;
+    float cur[CH + 4], nxt[CH];
+#pragma unroll
+    for (int i = 0; i < CH + 4; i++) cur[i] = base[(size_t)i * TILE];
+    cur[0] = x0;
+    float c = 0.0f;
+#pragma nounroll
+    for (int ch = 0; ch < LPC_HEAD_BLK; ch++) {
+        const float *nb = base + (size_t)((ch + 1 < LPC_HEAD_BLK ? ch + 1 : ch) * CH + 4) * TILE;
+#pragma unroll
+        for (int i = 0; i < CH; i++) nxt[i] = nb[(size_t)i * TILE];
+#pragma unroll
+        for (int j = 0; j < CH; j++) c += cur[j] * cur[j + K];
+#pragma unroll
+        for (int i = 0; i < 4; i++) cur[i] = cur[CH + i];
+#pragma unroll
+        for (int i = 0; i < CH; i++) cur[4 + i] = nxt[i];
+    }
+    return c;
+}
+
 // The same frame on TWO waves (k_hp2, launches that leave most of the GPU empty: a one-frame call of 4096 streams is 64 lone waves).  The
 // recurrence issues 12 f64 instructions per step whatever else the wave does, and everything else -- the results' trip through LDS, 40
 // stores per chunk, the decimation -- used to stand between one chunk's recurrence and the next (0.5 of every 1.3 us).  Here wave 0
@@ -384,10 +412,33 @@ __device__ __forceinline__ void hp_chain_group(const Buffers &b, const StepParam
     hp[0] = m0;
     hp[TILE] = m1;
 }
-__global__ void __launch_bounds__(128) k_hp2(Buffers b, const StepParams *sp, int g, StepParams v0, int fill)
+// `head` (a one-frame launch whose LPC analysis runs inside k_pitch): blocks NT .. are not the high-pass at all -- each of their waves takes
+// one (tile, lag) of the five autocorrelation sums through the rows of the frame's window that are older than the frame (608 of the 860
+// steps: they end before the first decimated value this launch produces), while the recurrence above runs its 20 us; k_pitch then
+// starts every sum there instead of at zero: 11 -> 3.5 us of its critical path.
+__global__ void __launch_bounds__(128) k_hp2(Buffers b, const StepParams *sp, int g, StepParams v0, int fill, int head)
 {
     static_assert(HP_CH == 32, "");
-    const int lane = threadIdx.x & 63, role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if ((int)blockIdx.x >= b.NT) {
+        const int item = 2 * ((int)blockIdx.x - b.NT) + role;
+        if (!head || item >= 5 * b.NT) return;
+        const int tile = item / 5, lag = item - 5 * tile, nslot = b.nslot;
+        const int slot = fill > 0 ? v0.slot : sp->slot;
+        const float *h = b.hist + (size_t)(tile * TILE + lane) * hist_stride(nslot);
+        const int rb = ring_base(slot, nslot);
+        const float x0 = (h[rb + 1] / 2.0f + h[rb]) / 2.0f;   // x_lp[0] is special (ref: src/pitch.rs:458); see hp_frame
+        const float *base = b.dec + ((size_t)tile * dec_len(nslot) + (size_t)dec_base(slot, nslot)) * TILE + lane;
+        float c;
+        if (lag == 0) c = lpc_head_chain<0>(base, x0);
+        else if (lag == 1) c = lpc_head_chain<1>(base, x0);
+        else if (lag == 2) c = lpc_head_chain<2>(base, x0);
+        else if (lag == 3) c = lpc_head_chain<3>(base, x0);
+        else c = lpc_head_chain<4>(base, x0);
+        b.lpc_head[(size_t)item * TILE + lane] = c;
+        return;
+    }
+    const int tile = blockIdx.x;
     __shared__ float Ly2[2 * TILE * HP_LD];
     if (role == 1) {
         if (fill > 0 && tile == 0)
@@ -841,18 +892,20 @@ __device__ __forceinline__ void pk_inner(const float *pb, int s, int q, const in
 // Lag K of the autocorrelation of a stream's 864-value window in LDS (`pbs` = L.pb + stream: row r at pk_at(r, 0)): the reference's
 // sequential sum over i = 0 .. 859 and its tail (ref: src/pitch.rs:433-446), one lag per wave so that the lag is a compile-time
 // offset into a sliding run of rows held in registers: a row is read once per lag, a step is one multiply and one dependent add.
+// `blk0`, `c0`: the sum's first 16 blk0 steps were taken elsewhere (k_hp2's head waves: they need none of the new frame) and gave c0.
 template <int K>
-__device__ __forceinline__ float pk_autocorr(const float *pbs)
+__device__ __forceinline__ float pk_autocorr(const float *pbs, int blk0 = 0, float c0 = 0.0f)
 {
-    const float *E = pbs, *O = pbs + PK_ODD;
+    const float *E = pbs + 8 * blk0 * PK_SPB, *O = E + PK_ODD;
     auto row = [&](const float *e, const float *o, int j) { return (j & 1) ? o[(j >> 1) * PK_SPB] : e[(j >> 1) * PK_SPB]; };
     float run[20];   // run[j] = x[16 blk + j]
 #pragma unroll
     for (int j = 0; j < 20; j++) run[j] = row(E, O, j);
-    float c = 0.0f;
+    E = pbs; O = pbs + PK_ODD;
+    float c = c0;
     constexpr int NBLK = 52;   // 52 blocks of 16 steps, then 28 steps on rows 832 .. 863
 #pragma nounroll
-    for (int blk = 0; blk < NBLK; blk++) {
+    for (int blk = blk0; blk < NBLK; blk++) {
         float nxt[16];   // rows 16 (blk + 1) + 4 .. + 19 travel while this block's steps are summed
         const float *En = E + (8 * (blk + 1) + 2) * PK_SPB, *On = O + (8 * (blk + 1) + 2) * PK_SPB;
 #pragma unroll
@@ -947,12 +1000,15 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             float *acs = &L.u.c.xc[0][0], *firs = &L.u.c.xc[8][0];   // [5][16] each, in space the coarse search takes later
             if (wave < 5 && lane < PK_SPB) {   // wave w: lag w of the block's 16 streams (lane = stream)
                 const float *pbs = L.pb + lane;
+                // (`lpc_here` == 2: k_hp2's head waves took the first LPC_HEAD_BLK blocks of every sum while the frame was being filtered)
+                const int blk0 = lpc_here == 2 ? LPC_HEAD_BLK : 0;
+                const float c0 = lpc_here == 2 ? b.lpc_head[((size_t)tile * 5 + wave) * TILE + q0 + lane] : 0.0f;
                 float a;
-                if (wave == 0) a = pk_autocorr<0>(pbs);
-                else if (wave == 1) a = pk_autocorr<1>(pbs);
-                else if (wave == 2) a = pk_autocorr<2>(pbs);
-                else if (wave == 3) a = pk_autocorr<3>(pbs);
-                else a = pk_autocorr<4>(pbs);
+                if (wave == 0) a = pk_autocorr<0>(pbs, blk0, c0);
+                else if (wave == 1) a = pk_autocorr<1>(pbs, blk0, c0);
+                else if (wave == 2) a = pk_autocorr<2>(pbs, blk0, c0);
+                else if (wave == 3) a = pk_autocorr<3>(pbs, blk0, c0);
+                else a = pk_autocorr<4>(pbs, blk0, c0);
                 acs[wave * PK_SPB + lane] = a;
             }
             __syncthreads();

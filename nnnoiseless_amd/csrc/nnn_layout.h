@@ -95,6 +95,7 @@ struct Buffers {
     float *hp_last;      // TI [1]      last filtered sample of the previous frame
     float *dec;          // TI [dec_len(nslot)]  2:1 decimated history: ring of nslot x 240 values whose first 960 are mirrored behind its end,
                          //             so that the 864-value window of any frame is one contiguous run (240 values are new per frame)
+    float *lpc_head;     // [NT][5][64]  one-frame calls: the five autocorrelation sums over the part of the window older than the frame (k_hp2 -> k_pitch)
     float *xlp0;         // TI [nslot]  per ring slot: pitch_downsample's special first element (x[1]/2 + x[0])/2 of that frame
     float *lpc;          // TI [nslot * 10]  per ring slot: that frame's windowed autocorrelation ac[5] and FIR taps lpc2[5], k_lpc -> k_pitch.
                          //             Kept by ring slot, not by scratch set: k_lpc rides on the high-pass stream, which runs ahead of the
