@@ -84,6 +84,7 @@ struct nnn_batch {
         size_t back_lds = 0, rnn16_lds = 0;   // dynamic LDS of k_back<true> / k_back<false>; 0 = the model is outside the kernel's shape class
         BkActs acts = {};
     };
+    int lpc_head = -1;             // one-frame calls: the LPC sums' first 608 steps in k_hp2's launch (0 = never; env NNN_LPC_HEAD, read at creation)
     int hp_split = -1;             // k_hp on two waves per tile (k_hp2): -1 = for launches of up to 256 tiles, 0 / 1 = never / always (env NNN_HP_SPLIT, read at creation)
     int back_mode = -1;            // the fused back end (k_back, nnn_back.hip): 0 = never, 1 = one-frame groups (the real-time tick), 2 = every group;
                                    // 3 / 4 = its RNN stretch alone (k_back<false>) in place of k_rnn / k_rnn_wf for one-frame / all groups;
@@ -333,6 +334,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     if (const char *e = getenv("NNN_RNN_WF_MIN_G")) h->wf_min_g = atoi(e);
     if (const char *e = getenv("NNN_BACK")) h->back_mode = atoi(e);
     if (const char *e = getenv("NNN_HP_SPLIT")) h->hp_split = atoi(e);
+    if (const char *e = getenv("NNN_LPC_HEAD")) h->lpc_head = atoi(e);
     if (const char *e = getenv("NNN_PITCH_CHAIN")) h->pitch_chain = atoi(e);
     if (const char *e = getenv("NNN_LPC_WIDE")) h->lpc_wide = atoi(e);
     if (const char *e = getenv("NNN_LPC_FC")) h->lpc_fc = atoi(e);
@@ -705,6 +707,7 @@ extern "C" nnn_batch *nnn_batch_clone(nnn_batch *h)
     c->pitch_chain = h->pitch_chain;
     c->back_mode = h->back_mode;
     c->hp_split = h->hp_split;
+    c->lpc_head = h->lpc_head;
     c->lpc_wide = h->lpc_wide;
     c->lpc_fc = h->lpc_fc;
     c->inputs_ready = h->inputs_ready;
@@ -765,22 +768,23 @@ static int back_choice(const nnn_batch *h, int g)
 }
 // one-frame groups of batches whose pitch launch is a single round of workgroups (two 8-wave blocks per compute unit)
 // run the LPC analysis inside k_pitch: one launch fewer on the critical path of a real-time tick (env NNN_LPC_IN_PITCH=0 / 1 forces)
-static bool lpc_in_pitch(const nnn_batch *h, int g)
-{
-    static const int force = getenv("NNN_LPC_IN_PITCH") ? atoi(getenv("NNN_LPC_IN_PITCH")) : -1;
-    if (force >= 0) return force != 0 && g == 1;
-    return g == 1 && h->S_pad <= 6144 && h->lpc_wide < 0 && h->lpc_fc == 0;   // (measured: -6 us at 4096 streams, level at 8192, +9 us at 16 384)
-}
 // k_hp on two waves per tile (recurrence | everything else): for launches that leave SIMDs empty
 static bool hp_split(const nnn_batch *h)
 {
     if (h->hp_split >= 0) return h->hp_split != 0;
     return h->NT <= 256;
 }
+static bool lpc_in_pitch(const nnn_batch *h, int g)
+{
+    static const int force = getenv("NNN_LPC_IN_PITCH") ? atoi(getenv("NNN_LPC_IN_PITCH")) : -1;
+    if (force >= 0) return force != 0 && g == 1;
+    // (measured per one-frame call: -6 us at 4096 streams, level at 8192, +9 us at 16 384; with the sums' head start in k_hp2's launch, see
+    // lpc_head: another -5 us at 4096, -6 at 8192, still +10 at 16 384)
+    return g == 1 && h->S_pad <= (hp_split(h) ? 8192 : 6144) && h->lpc_wide < 0 && h->lpc_fc == 0;
+}
 static bool lpc_head(const nnn_batch *h, int g)
 {
-    static const int force = getenv("NNN_LPC_HEAD") ? atoi(getenv("NNN_LPC_HEAD")) : -1;
-    return lpc_in_pitch(h, g) && hp_split(h) && force != 0;
+    return lpc_in_pitch(h, g) && hp_split(h) && h->lpc_head != 0;
 }
 static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams *sp0, hipStream_t st, bool prof, const StepParams *call = nullptr, int fill = 0)
 {

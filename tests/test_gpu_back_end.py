@@ -139,17 +139,19 @@ def test_fused_back_end_boundary_formats_and_models(nn):
 
 def test_high_pass_on_one_wave_or_two(nn, monkeypatch):
     """k_hp (one wave per 64 streams) and k_hp2 (its recurrence on one wave, everything else on a second: launches of up to 256
-    tiles) at 4096 and 20 000 streams (the latter above the automatic switch), in groups and ticks: same audio, VAD and per-frame
-    record, bit for bit."""
+    tiles) at 4096 and 20 000 streams (the latter above the automatic switch), in groups and ticks, with and without the LPC sums'
+    head start in k_hp2's launch: same audio, VAD and per-frame record, bit for bit."""
     import torch
     from nnnoiseless_amd.synthetic import make_streams
     dev = torch.device("cuda", 0)
     for S, T, calls in ((4096, 27, (1, 1, 24, 1)), (20000, 9, (8, 1))):
         x = torch.from_numpy(make_streams(5, S, T)).to(dev)
         res = []
-        for split in ("0", "1"):
+        for split, head in (("0", "1"), ("1", "0"), ("1", "1")):   # (the LPC sums' head start rides in k_hp2's launch, one-frame calls only)
             monkeypatch.setenv("NNN_HP_SPLIT", split)
+            monkeypatch.setenv("NNN_LPC_HEAD", head)
             res.append(run_device(nn, torch, S, None, x, calls, -1))
-        for a, b in zip(*res):
-            assert torch.equal(a, b), S
+        for r in res[1:]:
+            for a, b in zip(res[0], r):
+                assert torch.equal(a, b), S
         assert res[0][0].abs().max() > 1.0

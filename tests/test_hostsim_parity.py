@@ -347,3 +347,29 @@ def test_high_pass_on_one_wave_or_two(hostsim_lib, monkeypatch):
     for a, b in zip(res["0"], res["1"]):
         assert np.array_equal(a, b)
     assert np.abs(res["1"][8]).max() > 1e-3
+
+
+def test_lpc_sums_started_beside_the_high_pass(hostsim_lib, oracle_mod, weights_bytes, monkeypatch):
+    """One-frame calls on small batches: the first 608 steps of the five autocorrelation sums -- rows older than the frame -- are taken
+    by extra blocks of k_hp2's launch and k_pitch carries on from there.  Same order, same bits as without the head start and as the
+    grouped path (k_lpc); the autocorrelation and the FIR taps equal the oracle's bit for bit."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T = 70, 7
+    x = make_streams(404, S, T)
+    res = {}
+    for head in ("0", "1"):
+        monkeypatch.setenv("NNN_LPC_HEAD", head)
+        bd = nn.BatchDenoiser(S, lib=hostsim_lib, taps=True)
+        outs = [bd.process(x[:, t:t + 1]) for t in range(T)]
+        res[head] = (np.concatenate([o for o, _ in outs], axis=1), np.concatenate([v for _, v in outs], axis=0),
+                     bd.tap("ac").copy(), bd.tap("lpc2").copy(), bd.tap("pitch").copy())
+        bd.close()
+    for a, b in zip(res["0"], res["1"]):
+        assert np.array_equal(a, b)
+    monkeypatch.delenv("NNN_LPC_HEAD")
+    grouped = nn.BatchDenoiser(S, lib=hostsim_lib)
+    og, vg = grouped.process(x)
+    assert np.array_equal(og, res["1"][0]) and np.array_equal(vg, res["1"][1])
+    ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x)
+    assert np.array_equal(res["1"][4][:, 0], ref["pitch"][:, -1])
