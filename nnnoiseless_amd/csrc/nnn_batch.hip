@@ -85,6 +85,7 @@ struct nnn_batch {
         BkActs acts = {};
     };
     int lpc_head = -1;             // one-frame calls: the LPC sums' first 608 steps in k_hp2's launch (0 = never; env NNN_LPC_HEAD, read at creation)
+    int hp_tpb = 0;                // k_hp2's tiles per block: 0 = by launch (2 for groups, 1 for lone frames), 1 / 2 forced (env NNN_HP_TPB, read at creation)
     int hp_split = -1;             // k_hp on two waves per tile (k_hp2): -1 = for launches of up to 256 tiles, 0 / 1 = never / always (env NNN_HP_SPLIT, read at creation)
     int back_mode = -1;            // the fused back end (k_back, nnn_back.hip): 0 = never, 1 = one-frame groups (the real-time tick), 2 = every group;
                                    // 3 / 4 = its RNN stretch alone (k_back<false>) in place of k_rnn / k_rnn_wf for one-frame / all groups;
@@ -146,7 +147,7 @@ struct nnn_batch {
     bool have_last = false;
     uint64_t call_count = 0;
     int sched = SCHED_LANES;        // how a multi-frame call spreads over streams (env NNN_SCHED: seq | lanes | stages)
-    bool sched_auto = true;         // nobody chose a schedule (NNN_SCHED / NNN_LANES / nnn_batch_set_schedule): lanes below 16384 streams, one stream from there
+    bool sched_auto = true;         // nobody chose a schedule (NNN_SCHED / NNN_LANES / nnn_batch_set_schedule): lanes up to 16384 streams, one stream above
     int n_lanes = 1;                // SCHED_LANES: lanes (the caller's stream + internal ones) besides the high-pass stream; env NNN_LANES, 1..4.
                                     // One since the end of round 3: with the frames of a group side by side in every kernel a second group in flight
                                     // only gets in the first one's way (4096 streams: 55.5 against 54.8 M frames/s, 16 384: 63.8 / 62.3; profiles AN)
@@ -334,6 +335,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     if (const char *e = getenv("NNN_RNN_WF_MIN_G")) h->wf_min_g = atoi(e);
     if (const char *e = getenv("NNN_BACK")) h->back_mode = atoi(e);
     if (const char *e = getenv("NNN_HP_SPLIT")) h->hp_split = atoi(e);
+    if (const char *e = getenv("NNN_HP_TPB")) h->hp_tpb = atoi(e);
     if (const char *e = getenv("NNN_LPC_HEAD")) h->lpc_head = atoi(e);
     if (const char *e = getenv("NNN_PITCH_CHAIN")) h->pitch_chain = atoi(e);
     if (const char *e = getenv("NNN_LPC_WIDE")) h->lpc_wide = atoi(e);
@@ -355,6 +357,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     }
     // groups in flight behind the high-pass: what the schedule chosen at creation can use (a schedule set later works on what is there)
     h->depth = (h->n_lanes >= 2 || h->sched == SCHED_STAGES) ? DEPTH : 1;
+    if (const char *e = getenv("NNN_RING_DEPTH")) h->depth = atoi(e) >= 2 ? DEPTH : 1;   // (experiment knob)
     h->nset = h->depth * h->gmax;
     h->nslot = slots_for(h->gmax, h->depth);
     h->S = n_streams;
@@ -707,6 +710,7 @@ extern "C" nnn_batch *nnn_batch_clone(nnn_batch *h)
     c->pitch_chain = h->pitch_chain;
     c->back_mode = h->back_mode;
     c->hp_split = h->hp_split;
+    c->hp_tpb = h->hp_tpb;
     c->lpc_head = h->lpc_head;
     c->lpc_wide = h->lpc_wide;
     c->lpc_fc = h->lpc_fc;
@@ -799,7 +803,13 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
         if (hp_split(h)) {
             // (a lone frame whose LPC analysis runs inside k_pitch: the part of its sums that needs none of the new frame rides along here)
             const bool head = lpc_head(h, g);
-            L.go(K_HP, k_hp2, dim3(NT + (head ? (5 * NT + 1) / 2 : 0)), dim3(128), 0, b, sp0, g, call ? *call : StepParams{}, call ? fill : 0, head ? 1 : 0);
+            // groups: two tiles per block (see k_hp2).  NNN_HP_PAD_KB pads the block's LDS, e.g. past what leaves room for a k_pitch block
+            // beside it (48): measured, no gain
+            static const int pad_kb = getenv("NNN_HP_PAD_KB") ? atoi(getenv("NNN_HP_PAD_KB")) : 0;
+            if (h->hp_tpb ? h->hp_tpb == 2 : (g > 1 && NT >= 8))
+                L.go(K_HP, k_hp2<2>, dim3((NT + 1) / 2 + (head ? (5 * NT + 3) / 4 : 0)), dim3(256), (size_t)pad_kb * 1024, b, sp0, g, call ? *call : StepParams{}, call ? fill : 0, head ? 1 : 0);
+            else
+                L.go(K_HP, k_hp2<1>, dim3(NT + (head ? (5 * NT + 1) / 2 : 0)), dim3(128), 0, b, sp0, g, call ? *call : StepParams{}, call ? fill : 0, head ? 1 : 0);
         }
         else L.go(K_HP, k_hp, dim3(NT), dim3(64), 0, b, sp0, g, call ? *call : StepParams{}, call ? fill : 0);
         // the LPC analysis of the group's frames (lane = stream, frames side by side) rides on the same stream, ahead of the pitch stage
@@ -939,7 +949,10 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     constexpr int PIPE_MIN = 32;
     // (from 16 384 streams up every kernel fills the GPU on its own and a launch beside it only costs it cache: one stream, in order,
     // unless a schedule was asked for -- 32 768 streams: 65.9 M frames/s against 64.8 with the high-pass on a stream of its own)
-    const bool pipe = h->use_pipeline && h->sched != SCHED_SEQ && !h->profiling && n_frames >= PIPE_MIN && !(h->sched_auto && h->S_pad >= 16384);
+    // (the automatic schedule pipelines up to 16 384 streams: measured in round 4 with the high-pass held back behind the previous group's
+    // pitch kernel, see hp_after -- 16 384: 64.2-65.5 -> 66.4-66.9 M frames/s; 32 768 and 65 536 lose 1-2 % pipelined)
+    static const int pipe_max = getenv("NNN_PIPE_MAX") ? atoi(getenv("NNN_PIPE_MAX")) : 16384;
+    const bool pipe = h->use_pipeline && h->sched != SCHED_SEQ && !h->profiling && n_frames >= PIPE_MIN && !(h->sched_auto && h->S_pad > pipe_max);
     std::vector<int> sizes;
     if (pipe && h->ramp == 0) {
         int k = 2;
@@ -1005,11 +1018,18 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
         std::vector<int> first(n_groups);   // first frame (within the call) of every group
         for (int k = 0, t = 0; k < n_groups; k++) { first[k] = t; t += sizes[k]; }
         // which (stage, group) nodes have a consumer on another stream: only those record an event
+        // The high-pass of group k may start as soon as the ring slots it overwrites are free -- with the pitch kernel of group k - 1, and the
+        // two slow each other (10.8 in HISTORY.md).  From 8192 streams up a group is long enough for the chain to wait until that pitch
+        // kernel is done and still finish before group k needs it: 8192 x 48: 61.3 -> 63.9 M frames/s, 16 384: +2-3 %; at 4096 streams the
+        // window is too short (57.5 -> 56.3).  NNN_HP_AFTER = 0 | 1 | 2 | 3: never | behind pitch | fft | rnn of the previous group.
+        static const int hp_after_env = getenv("NNN_HP_AFTER") ? atoi(getenv("NNN_HP_AFTER")) : -1;
+        const int hp_after = hp_after_env >= 0 ? hp_after_env : (h->sched == SCHED_LANES && h->n_lanes == 1 && h->S_pad >= 8192 ? 1 : 0);
         auto consumers_elsewhere = [&](int s, int k) {
             const int me = stream_of(s, k);
             if (s + 1 < ST_COUNT && stream_of(s + 1, k) != me) return true;
             if ((s == ST_HP || s == ST_PITCH || s == ST_RNN || s == ST_SYN) && k + 1 < n_groups && stream_of(s, k + 1) != me) return true;
             if (s == ST_SYN) return true;   // scratch-set / ring edges and the end of the call
+            if (hp_after > 0 && s == ST_PITCH + hp_after - 1) return true;
             return false;
         };
         for (int k = 0; k < n_groups; k++) {
@@ -1029,6 +1049,12 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
                 if (s > 0) wait_for(s - 1, k);
                 if (s == ST_HP || s == ST_PITCH || s == ST_RNN || s == ST_SYN) wait_for(s, k - 1);
                 if (s == ST_PITCH) wait_for(ST_SYN, k - h->depth);
+                if (s == ST_HP && hp_after > 0) {
+                    static const int lag = getenv("NNN_HP_AFTER_LAG") ? atoi(getenv("NNN_HP_AFTER_LAG")) : 1;
+                    const int ds = ST_PITCH + hp_after - 1, pn = (int)h->prev_first.size();
+                    if (k >= lag) wait_for(ds, k - lag);
+                    else if (early_hp && pn + k - lag >= 0 && lag - k < EVR) chk(hipStreamWaitEvent(ss, h->ev[h->prev_par][ds][(pn + k - lag) % EVR], 0));
+                }
                 if (s == ST_HP) {
                     // slots written now held frames (newest of this group) - nslot and older; their last readers are the
                     // frames up to 3 later

@@ -416,12 +416,18 @@ __device__ __forceinline__ void hp_chain_group(const Buffers &b, const StepParam
 // one (tile, lag) of the five autocorrelation sums through the rows of the frame's window that are older than the frame (608 of the 860
 // steps: they end before the first decimated value this launch produces), while the recurrence above runs its 20 us; k_pitch then
 // starts every sum there instead of at zero: 11 -> 3.5 us of its critical path.
-__global__ void __launch_bounds__(128) k_hp2(Buffers b, const StepParams *sp, int g, StepParams v0, int fill, int head)
+// TPB tiles per block (waves 0 .. TPB - 1 the recurrences, waves TPB .. the helpers; TPB <= 2: every wave a SIMD of its own -- with four
+// tiles a helper shares the SIMD of a recurrence and the kernel takes twice as long).  Groups run two tiles per block: half as many
+// compute units carry a wave that takes most of its SIMD's issue slots from the pipelined call's other kernels (4096 x 48 +1 %, 8192 x 48
+// +2 %; keeping k_pitch's blocks off those units altogether by padding the block's LDS: measured, no gain).
+template <int TPB>
+__global__ void __launch_bounds__(128 * TPB) k_hp2(Buffers b, const StepParams *sp, int g, StepParams v0, int fill, int head)
 {
     static_assert(HP_CH == 32, "");
-    const int lane = threadIdx.x & 63, role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if ((int)blockIdx.x >= b.NT) {
-        const int item = 2 * ((int)blockIdx.x - b.NT) + role;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int role = wave / TPB, nblk = (b.NT + TPB - 1) / TPB;
+    if ((int)blockIdx.x >= nblk) {
+        const int item = 2 * TPB * ((int)blockIdx.x - nblk) + wave;
         if (!head || item >= 5 * b.NT) return;
         const int tile = item / 5, lag = item - 5 * tile, nslot = b.nslot;
         const int slot = fill > 0 ? v0.slot : sp->slot;
@@ -438,8 +444,13 @@ __global__ void __launch_bounds__(128) k_hp2(Buffers b, const StepParams *sp, in
         b.lpc_head[(size_t)item * TILE + lane] = c;
         return;
     }
-    const int tile = blockIdx.x;
-    __shared__ float Ly2[2 * TILE * HP_LD];
+    const int tile = (int)blockIdx.x * TPB + (wave - role * TPB);
+    __shared__ float Ly2s[TPB][2 * TILE * HP_LD];
+    float *Ly2 = Ly2s[wave - role * TPB];
+    if (tile >= b.NT) {   // (a ragged last block: its spare waves only keep the barrier count)
+        for (int i = 0; i < g * (FRAME / HP_CH); i++) __syncthreads();
+        return;
+    }
     if (role == 1) {
         if (fill > 0 && tile == 0)
             for (int t = lane; t < fill; t += 64) ((StepParams *)sp)[t] = step_params_at(v0, t, b.nslot);
@@ -973,6 +984,8 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         last_period = NNN_TI(b.last_period, 1, tile, q0 + s)[0];
         last_gain = NNN_TI(b.last_gain, 1, tile, q0 + s)[0];
     }
+    // (the head waves' sums travel with the window: asked for where they are used, their trip to memory stood on the critical path)
+    const float head_c0 = (lpc_here == 2 && wave < 5 && lane0 < PK_SPB) ? b.lpc_head[((size_t)tile * 5 + wave) * TILE + q0 + lane0] : 0.0f;
     float win[PK_CH], fir[5];
     pk_window_load(b, sp0 + f_begin, tile, q0, (int)threadIdx.x, win, fir);
     for (int f = f_begin; f < f_end; f++) {
@@ -1002,7 +1015,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 const float *pbs = L.pb + lane;
                 // (`lpc_here` == 2: k_hp2's head waves took the first LPC_HEAD_BLK blocks of every sum while the frame was being filtered)
                 const int blk0 = lpc_here == 2 ? LPC_HEAD_BLK : 0;
-                const float c0 = lpc_here == 2 ? b.lpc_head[((size_t)tile * 5 + wave) * TILE + q0 + lane] : 0.0f;
+                const float c0 = head_c0;
                 float a;
                 if (wave == 0) a = pk_autocorr<0>(pbs, blk0, c0);
                 else if (wave == 1) a = pk_autocorr<1>(pbs, blk0, c0);

@@ -332,8 +332,9 @@ def test_high_pass_on_one_wave_or_two(hostsim_lib, monkeypatch):
     xi = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
     inter = np.ascontiguousarray(xi.reshape(S // 2, 2, T * 480).transpose(0, 2, 1))   # [group][sample][channel]
     res = {}
-    for split in ("0", "1"):
+    for split, tpb in (("0", "0"), ("1", "1"), ("1", "2")):   # (two tiles per block: what groups of larger batches run; here its last block is ragged)
         monkeypatch.setenv("NNN_HP_SPLIT", split)
+        monkeypatch.setenv("NNN_HP_TPB", tpb)
         bd = nn.BatchDenoiser(S, lib=hostsim_lib, taps=True)
         o1, v1 = bd.process(x[:, :3])
         o2, v2 = bd.process(x[:, 3:4])
@@ -342,11 +343,12 @@ def test_high_pass_on_one_wave_or_two(hostsim_lib, monkeypatch):
         pcm = nn.BatchDenoiser(S, lib=hostsim_lib)
         p1, w1 = pcm.process_pcm(inter[:, :960], _ffi.PCM_I16, channels=2, discard_first=True)
         p2, w2 = pcm.process_pcm(inter[:, 960:] / np.float32(32768.0), _ffi.PCM_F32_UNIT, channels=2)
-        res[split] = (o1, o2, o3, v1, v2, v3, filt, p1, p2, w1, w2)
+        res[split + tpb] = (o1, o2, o3, v1, v2, v3, filt, p1, p2, w1, w2)
         bd.close(); pcm.close()
-    for a, b in zip(res["0"], res["1"]):
-        assert np.array_equal(a, b)
-    assert np.abs(res["1"][8]).max() > 1e-3
+    for k in ("11", "12"):
+        for a, b in zip(res["00"], res[k]):
+            assert np.array_equal(a, b), k
+    assert np.abs(res["11"][8]).max() > 1e-3
 
 
 def test_lpc_sums_started_beside_the_high_pass(hostsim_lib, oracle_mod, weights_bytes, monkeypatch):
