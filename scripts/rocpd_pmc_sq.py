@@ -19,12 +19,12 @@ for db in sys.argv[2:]:
     rows = con.execute("select k.name, e.counter_name, avg(e.counter_value) from pmc_events e join kernels k "
                        "on k.dispatch_id = e.dispatch_id group by k.name, e.counter_name").fetchall()
     for n, c, avg in rows:
-        t[n.split("(")[0].replace("nnn::", "").replace("void ", "")][c] = avg
+        t[n.split("(")[0].replace("nnn::", "").replace("void ", "").split("<")[0]][c] = avg
 out = {"streams": S, "frames_per_launch": 24, "kernels": {}, "note": __doc__.split("\n\n", 1)[1]}
 for k, v in sorted(t.items()):
     if not k.startswith("k_") or k == "k_fill_params":
         continue
-    name = "k_rnn" if k == "k_rnn_wf" else k
+    name = "k_rnn" if k == "k_rnn_wf" else ("k_hp" if k == "k_hp2" else k)
     busy = v.get("SQ_BUSY_CYCLES", 0.0)
     e = {"counters": {c: v[c] for c in sorted(v)}, "kernel_symbol": k}
     if busy:

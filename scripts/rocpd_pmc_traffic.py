@@ -33,7 +33,7 @@ for name in sorted(set(fetch) | set(write)):
     if short.startswith("k_"):
         if "k_fill_params" in short:
             continue
-        out["kernels"][short.split("<")[0].replace("k_rnn_wf", "k_rnn")] = entry
+        out["kernels"][short.split("<")[0].replace("k_rnn_wf", "k_rnn").replace("k_hp2", "k_hp")] = entry   # (k_hp2: the two-wave high-pass of small launches)
     elif "AbsFunctor" in name:
         out["calibration"]["torch_abs"] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "fetch_over_write": f / w if w else None}
 print(json.dumps(out, indent=1))
