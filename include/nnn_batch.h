@@ -221,7 +221,9 @@ int nnn_batch_set_back_end(nnn_batch *b, int mode);
 /* How a pipelined call uses the internal streams: mode 0 = not at all (as set_pipeline(0)); 1 = "lanes": the high-pass
  * chain on its own stream, the other four stages of group k on lane k mod `lanes` (1..4; default 2; lane 0 is the caller's stream);
  * 2 = "stages": one stream per stage, every stream a chain of groups.  Environment: NNN_SCHED=seq|lanes|stages,
- * NNN_LANES=n. */
+ * NNN_LANES=n.  Nobody choosing, the library does: calls of 32 frames or more are pipelined with one lane on batches of up to
+ * 16 384 streams (from 8192 streams the high-pass chain of a group waits for the previous group's pitch kernel), everything runs in
+ * order on the caller's stream above that. */
 int nnn_batch_set_schedule(nnn_batch *b, int mode, int lanes);
 
 /* Diagnostic: the device's activation functions on their own, y[i] = act(x[i]) for n host floats; act 0 = tansig_approx,
