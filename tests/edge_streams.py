@@ -17,8 +17,13 @@ def make_edge_streams(n_frames):
     s.append(9000.0 * np.sin(2 * np.pi * 63.0 * t / 48000.0))                 # period ~762: the PITCH_MAX_PERIOD end
     sweep = 6000.0 * np.sin(2 * np.pi * (100.0 + 900.0 * t / n) * t / 48000.0); s.append(sweep)  # chirp: pitch doubling logic
     s.append(np.clip(40000.0 * rng.standard_normal(n), -32768, 32767))        # clipped loud noise
+    s.append(np.zeros(n))                                                     # (replaced below: the ultrasonic tone)
+    s.append(3000.0 * np.sin(2 * np.pi * 300.0 * t / 48000.0) + 8000.0 * np.sin(2 * np.pi * 22000.0 * t / 48000.0))   # voiced, with content above bin 400 (zero gain there)
     s.append(np.zeros(n))                                                     # digital silence
     x = np.round(np.stack(s)).astype(np.float32)
+    # bin 450 alone, NOT rounded to integers (rounding noise would fill the bands): "silent" by the band energies, which end at bin
+    # 399, and therefore synthesised as it came -- the only way bins 400 .. 480 reach the output
+    x[-3] = (5000.0 * np.sin(2 * np.pi * 22500.0 * t / 48000.0)).astype(np.float32)
     return x.reshape(len(s), n_frames, 480)
 
 
