@@ -225,6 +225,12 @@ int nnn_batch_set_back_end(nnn_batch *b, int mode);
  * 16 384 streams (from 8192 streams the high-pass chain of a group waits for the previous group's pitch kernel), everything runs in
  * order on the caller's stream above that. */
 int nnn_batch_set_schedule(nnn_batch *b, int mode, int lanes);
+/* A/B knobs of the kernels' own choices, environment only, every setting the same bits (what the parity tests use them for):
+ * NNN_HP_SPLIT=0|1 (read at creation) the high-pass on one wave per 64 streams or two (k_hp2; default: two for launches of up to 256
+ * tiles), NNN_HP_TPB=1|2 its tiles per block; NNN_LPC_IN_PITCH=0|1 the LPC analysis of a one-frame call inside k_pitch (default: up to
+ * 8192 streams), NNN_LPC_HEAD=0|1 (creation) the old part of its sums in k_hp2's launch; NNN_HP_AFTER=0..3 where the high-pass chain
+ * of a pipelined call's group waits (default: behind the previous group's pitch kernel from 8192 streams), NNN_PIPE_MAX the largest
+ * batch the automatic schedule pipelines (16384). */
 
 /* Diagnostic: the device's activation functions on their own, y[i] = act(x[i]) for n host floats; act 0 = tansig_approx,
  * 1 = sigmoid_approx, 2 = relu (src/util.rs:29-53). */
