@@ -379,7 +379,8 @@ __device__ __forceinline__ void bk_dense(const LayerDesc &L, const BkRnn &R, con
 // k_back<true>: the fused back end.  k_back<false>: its RNN stretch alone (features in from k_fft_xp's scratch, gains out to k_synth's).
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct BkActs { int dense, vad, noise, dn, out, vo; };   // activation kinds of the model at hand (ref: src/rnn.rs:242-250)
-template <bool FUSED, class SH>
+// XR: the fused kernel of a one-frame call whose X transform rode in k_pitch's launch (transform_inputs, xt_rider).
+template <bool FUSED, class SH, bool XR = false>
 __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0, BkActs acts, const uint4 *__restrict__ Wq,
                                               const float *__restrict__ fpar, int tile0, int g)
 {
@@ -475,7 +476,7 @@ __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0,
             K.sl = sl;
             K.cnw = cnw;
             K.flag = flagw;
-            transform_inputs<true, true>(bf, sp, tile, 0, t, Z, part, &K);
+            transform_inputs<true, true, XR>(bf, sp, tile, 0, t, Z, part, &K);
             pitch = NNN_TI(bf.pitch, 1, tile, sl)[0];
             silent = __builtin_amdgcn_readfirstlane(K.silent) != 0;
 #ifdef NNN_PROBE_BACK_NOHOLD   // (developer probe, wrong audio, timing only: what the stretch costs when the spectra need not be kept)

@@ -84,6 +84,7 @@ struct nnn_batch {
         size_t back_lds = 0, rnn16_lds = 0;   // dynamic LDS of k_back<true> / k_back<false>; 0 = the model is outside the kernel's shape class
         BkActs acts = {};
     };
+    int x_rides = -1;              // one-frame calls: the fused back end's X transform in rider blocks of k_pitch's launch (-1 = up to 8192 streams; env NNN_X_RIDES)
     int lpc_head = -1;             // one-frame calls: the LPC sums' first 608 steps in k_hp2's launch (0 = never; env NNN_LPC_HEAD, read at creation)
     int hp_tpb = 0;                // k_hp2's tiles per block: 0 = by launch (2 for groups, 1 for lone frames), 1 / 2 forced (env NNN_HP_TPB, read at creation)
     int hp_split = -1;             // k_hp on two waves per tile (k_hp2): -1 = for launches of up to 256 tiles, 0 / 1 = never / always (env NNN_HP_SPLIT, read at creation)
@@ -337,6 +338,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     if (const char *e = getenv("NNN_HP_SPLIT")) h->hp_split = atoi(e);
     if (const char *e = getenv("NNN_HP_TPB")) h->hp_tpb = atoi(e);
     if (const char *e = getenv("NNN_LPC_HEAD")) h->lpc_head = atoi(e);
+    if (const char *e = getenv("NNN_X_RIDES")) h->x_rides = atoi(e);
     if (const char *e = getenv("NNN_PITCH_CHAIN")) h->pitch_chain = atoi(e);
     if (const char *e = getenv("NNN_LPC_WIDE")) h->lpc_wide = atoi(e);
     if (const char *e = getenv("NNN_LPC_FC")) h->lpc_fc = atoi(e);
@@ -521,6 +523,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     HIPCHK(hipFuncSetAttribute((const void *)k_rnn_wf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     HIPCHK(hipFuncSetAttribute((const void *)k_back<true, BkShapeBuiltin>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     HIPCHK(hipFuncSetAttribute((const void *)k_back<false, BkShapeBuiltin>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+    HIPCHK(hipFuncSetAttribute((const void *)k_back<true, BkShapeBuiltin, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     HIPCHK(hipDeviceSynchronize());
     h->id = g_next_batch_id.fetch_add(1) & 0xFFFFFu;
     if (!h->id) h->id = g_next_batch_id.fetch_add(1) & 0xFFFFFu;
@@ -712,6 +715,7 @@ extern "C" nnn_batch *nnn_batch_clone(nnn_batch *h)
     c->hp_split = h->hp_split;
     c->hp_tpb = h->hp_tpb;
     c->lpc_head = h->lpc_head;
+    c->x_rides = h->x_rides;
     c->lpc_wide = h->lpc_wide;
     c->lpc_fc = h->lpc_fc;
     c->inputs_ready = h->inputs_ready;
@@ -786,6 +790,12 @@ static bool lpc_in_pitch(const nnn_batch *h, int g)
     // lpc_head: another -5 us at 4096, -6 at 8192, still +10 at 16 384)
     return g == 1 && h->S_pad <= (hp_split(h) ? 8192 : 6144) && h->lpc_wide < 0 && h->lpc_fc == 0;
 }
+// one-frame calls through the fused back end on small batches: its X transform rides in k_pitch's launch (env NNN_X_RIDES=0|1, read at creation)
+static bool x_rides(const nnn_batch *h, int g, int back)
+{
+    if (g != 1 || back != 2) return false;
+    return h->x_rides >= 0 ? h->x_rides != 0 : h->S_pad <= 8192;
+}
 static bool lpc_head(const nnn_batch *h, int g)
 {
     return lpc_in_pitch(h, g) && hp_split(h) && h->lpc_head != 0;
@@ -830,14 +840,20 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
         // matters instead: 468 -> 515); flag values are frame numbers (> 0)
         const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
         const unsigned grid = Sp / PK_SPB * (chain ? ug : 1u);
-        L.go(K_PITCH, k_pitch, dim3(grid), dim3(PK_T), 0, b, sp0, g, chain, seq0, h->tickets, lpc_in_pitch(h, g) ? (lpc_head(h, g) ? 2 : 1) : 0);
+        const bool riders = x_rides(h, g, back);   // (the fused back end's X transform in rider blocks of this launch, see xt_rider)
+        L.go(K_PITCH, k_pitch, dim3(grid + (riders ? Sp / 8 : 0u)), dim3(PK_T), 0, b, sp0, g, chain, seq0, h->tickets, lpc_in_pitch(h, g) ? (lpc_head(h, g) ? 2 : 1) : 0,
+             riders ? (int)grid : 0);
         if (chain) h->tickets += grid;   // (launches of one batch's pitch stage are ordered among themselves: a stateful stage)
         break;
     }
     case ST_FFT:
         if (back == 2) {   // the fused back end takes the place of this stage and the two behind it: one launch per resident model
-            for (const nnn_batch::ModelGroup &G : h->groups)
-                L.go(K_BACK, k_back<true, BkShapeBuiltin>, dim3((unsigned)(G.ntiles * (TILE / BK_ROWS))), dim3(BK_T), G.back_lds, b, sp0, G.acts, G.wq, G.fpar, G.tile0, g);
+            for (const nnn_batch::ModelGroup &G : h->groups) {
+                if (x_rides(h, g, back))
+                    L.go(K_BACK, k_back<true, BkShapeBuiltin, true>, dim3((unsigned)(G.ntiles * (TILE / BK_ROWS))), dim3(BK_T), G.back_lds, b, sp0, G.acts, G.wq, G.fpar, G.tile0, g);
+                else
+                    L.go(K_BACK, k_back<true, BkShapeBuiltin>, dim3((unsigned)(G.ntiles * (TILE / BK_ROWS))), dim3(BK_T), G.back_lds, b, sp0, G.acts, G.wq, G.fpar, G.tile0, g);
+            }
             break;
         }
         L.go(K_FFT_XP, k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0, g);
@@ -1582,7 +1598,7 @@ static void enqueue_feature_group(nnn_batch *h, hipStream_t st, const float *in,
         }
         const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
         const unsigned grid = Sp / PK_SPB * (chain ? ug : 1u);
-        hipLaunchKernelGGL(k_pitch, dim3(grid), dim3(PK_T), 0, st, b, (const StepParams *)sp, g, chain, seq0, h->tickets, 0);
+        hipLaunchKernelGGL(k_pitch, dim3(grid), dim3(PK_T), 0, st, b, (const StepParams *)sp, g, chain, seq0, h->tickets, 0, 0);
         if (chain) h->tickets += grid;
         hipLaunchKernelGGL(k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp, g);
         hipLaunchKernelGGL(k_features, dim3(NT), dim3(64 * FEAT_WAVES), 0, st, b, g);

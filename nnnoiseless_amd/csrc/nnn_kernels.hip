@@ -915,7 +915,7 @@ __device__ __forceinline__ float pk_autocorr(const float *pbs, int blk0 = 0, flo
     E = pbs; O = pbs + PK_ODD;
     float c = c0;
     constexpr int NBLK = 52;   // 52 blocks of 16 steps, then 28 steps on rows 832 .. 863
-#pragma nounroll
+#pragma nounroll   // (two blocks per trip -- the run's hand-over a renaming instead of twenty moves -- measured: no change)
     for (int blk = blk0; blk < NBLK; blk++) {
         float nxt[16];   // rows 16 (blk + 1) + 4 .. + 19 travel while this block's steps are summed
         const float *En = E + (8 * (blk + 1) + 2) * PK_SPB, *On = O + (8 * (blk + 1) + 2) * PK_SPB;
@@ -940,6 +940,9 @@ __device__ __forceinline__ float pk_autocorr(const float *pbs, int blk0 = 0, flo
     return c + d;
 }
 
+// (defined behind the transforms, further down: the X transform of a one-frame call in rider blocks of k_pitch's launch)
+__device__ __forceinline__ void xt_rider(const Buffers &b, const StepParams *sp, int rb, void *lds);
+
 #ifndef NNN_PK_MINWAVES
 #define NNN_PK_MINWAVES 4   // waves per SIMD: two blocks of 8 waves per CU, <= 128 registers
 #endif
@@ -956,9 +959,14 @@ __device__ __forceinline__ float pk_autocorr(const float *pbs, int blk0 = 0, flo
 // waves ahead of the FIR, instead of as a launch of its own (k_lpc_wide) ahead of this one -- round 2's arrangement, which costs the
 // block 9 us with six waves waiting; for a group of frames that was the kernel's worst phase, for a lone frame it is cheaper than the
 // 14.5 us launch plus its gap on the call's critical path.  Same sums in the same order: bit-identical to k_lpc / k_lpc_wide.
-__global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, const StepParams *sp0, int g, int chain, int seq0, unsigned tbase, int lpc_here)
+__global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, const StepParams *sp0, int g, int chain, int seq0, unsigned tbase, int lpc_here,
+                                                                 int riders)
 {
     __shared__ PkLds L;
+    if (riders > 0 && (int)blockIdx.x >= riders) {   // (one-frame launches only: chain == 0, the pitch blocks are blocks 0 .. riders - 1)
+        xt_rider(b, sp0, (int)blockIdx.x - riders, &L);
+        return;
+    }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane0 = threadIdx.x & 63;
     int lane = lane0, s = lane & 15, q = lane >> 4;  // lane = (stream, chain)
     int item = (int)blockIdx.x;
@@ -1960,7 +1968,9 @@ __device__ __forceinline__ void spectrum_load_p(const float2 *row, float2 (&S)[8
     }
 }
 
-template <bool WITH_P, bool FUSED = false>
+// XR (fused, one-frame calls): X and its band energies are in memory already -- computed by rider blocks of k_pitch's launch, which needs
+// nothing of what the pitch analysis finds (xt_rider) -- and are fetched instead of computed.
+template <bool WITH_P, bool FUSED = false, bool XR = false>
 __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepParams *sp, int tile_in, int sub, FftLds &t, float2 *Z, float *part,
                                                  XpKeep *keep = nullptr)
 {
@@ -1980,29 +1990,32 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     // both windows' samples are requested now: the second transform's used to be requested when it started, a trip to memory on
     // the wave's critical path per stream-frame (these kernels move enough bytes for that to show)
     SamplePair sx[8], spw[8];
-    window_load(h, ring, rb, 0, lane, sx);
+    if (!XR) window_load(h, ring, rb, 0, lane, sx);
 #ifndef NNN_FFT_LATE_P   // (A/B knob: the second window requested where its transform starts, as before)
     if (WITH_P && !FUSED) window_load(h, ring, rb, lag, lane, spw);   // (fused: sixteen registers it has not got; requested after the first transform)
 #endif
     float2 X[8];
-    window_rfft<FUSED>(b, sx, w, t, Z, X, lane, !FUSED);
     float2 *dx = b.X + (size_t)s * FSTR;
+    if (XR) spectrum_load(dx, X, lane);
+    else window_rfft<FUSED>(b, sx, w, t, Z, X, lane, !FUSED);
     // NNN_PROBE_XP (developer probe, wrong audio, timing only): the spectra are not stored here and k_synth reads them from a
     // region small enough to stay in the XCD's L2 -- an upper bound on what keeping X and P on chip between the transforms
     // and the synthesis (a fused back end) could gain from the removed HBM round trip.
 #ifndef NNN_PROBE_XP
-    if (!FUSED || b.taps) spectrum_store(dx, X, lane);   // (fused: the spectra stay in registers; memory sees them for the parity taps only)
+    if (!XR && (!FUSED || b.taps)) spectrum_store(dx, X, lane);   // (fused: the spectra stay in registers; memory sees them for the parity taps only)
 #endif
     NNN_FUSED_RELAUNDER();
     float *vv = (float *)Z, *vc = vv + BSK_LEN;   // per-bin quantities of the band sums, skewed (bsk)
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const int k = rfft_slot_bin(lane, u);
-        if (k >= 0 && k < 400) vv[bsk(k)] = fmaf(X[u].y, X[u].y, X[u].x * X[u].x);
-    }
-    wave_lds_sync();
     float exv;
-    {
+    if (XR) {
+        exv = lane < NB ? NNN_TI(b.ex, NB, tile, sl)[(size_t)lane * TILE] : 0.0f;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = rfft_slot_bin(lane, u);
+            if (k >= 0 && k < 400) vv[bsk(k)] = fmaf(X[u].y, X[u].y, X[u].x * X[u].x);
+        }
+        wave_lds_sync();
         const float *const v[1] = {vv};
         float o[1];
         band_sums_par<1>(t, v, o, lane);
@@ -2136,6 +2149,19 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_FFT_MINWAVES) k_fft_xp(Buffe
     b = frame_view(b, frame);
     const int wave = threadIdx.x >> 6;
     transform_inputs<true>(b, sp + frame, tile, sub, t, Z[wave], part[wave]);
+}
+
+// Rider blocks of a one-frame k_pitch launch (blocks `riders` ..): the frame's lag-0 transform X and its band energies, eight streams
+// per block (wave = stream) -- the part of the back end that needs nothing from the pitch analysis, done while the pitch blocks, one per
+// compute unit and bound by their own latency chains, leave most issue slots free.  The fused back end then fetches X instead of
+// computing it (k_back<.., XR>).  The code is k_fft_x's; `lds` is the pitch kernel's own LDS block, which a rider block has to itself.
+struct XtLds { FftLds t; float2 Z[8][NFFT_BUF]; float part[8][4]; };
+__device__ __forceinline__ void xt_rider(const Buffers &b, const StepParams *sp, int rb, void *lds)
+{
+    static_assert(sizeof(XtLds) <= sizeof(PkLds) && PK_T == 512 && FFT_SPB == 4, "");
+    XtLds &x = *(XtLds *)lds;
+    const int wave = threadIdx.x >> 6;
+    transform_inputs<false>(b, sp, rb >> 3, 2 * (rb & 7), x.t, x.Z[wave], x.part[wave]);   // rows 8 (rb % 8) + wave of tile rb / 8
 }
 
 // lag-0 transform and band energies only (training rows: clean and noise states)

@@ -43,6 +43,20 @@ def test_back_ends_give_the_same_bits(hostsim_lib, mode, chunks):
     assert (ref.tap("silence")[:, 0] != 0).any() and (ref.tap("silence")[:, 0] == 0).any()
 
 
+def test_ticks_with_and_without_the_riding_transform(hostsim_lib, monkeypatch):
+    """NNN_X_RIDES=0: the fused kernel of a one-frame call computes X itself, as it does for groups; by default rider blocks of k_pitch's
+    launch do.  Same bits, and the same as three launches."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T = 70, 4
+    x = make_streams(8, S, T)
+    _, want, want_vad = _run(nn, hostsim_lib, x, 0, (T,))
+    for rides in ("0", "1"):
+        monkeypatch.setenv("NNN_X_RIDES", rides)
+        _, got, vad = _run(nn, hostsim_lib, x, 1, (1,) * T)
+        assert np.array_equal(_bits(got), _bits(want)) and np.array_equal(_bits(vad), _bits(want_vad)), rides
+
+
 def test_fused_back_end_taps_log_models_and_pcm(hostsim_lib):
     """The fused kernel with the parity taps on (both spectra and the 42 features reach memory only then), the per-frame record, a
     model of the same shape class with other activation kinds (sh.rnn), two models resident at once, and the packed int16 boundary
@@ -57,6 +71,11 @@ def test_fused_back_end_taps_log_models_and_pcm(hostsim_lib):
     assert np.array_equal(_bits(got), _bits(want))
     for tap in ("X", "P", "features", "xcorr1"):
         assert np.array_equal(_bits(bd.tap(tap)), _bits(ref.tap(tap))), tap
+    # one frame per call: X comes from the rider blocks of k_pitch's launch (xt_rider) and is fetched by the fused kernel
+    bd1, got1, _ = _run(nn, hostsim_lib, x, 1, (1,) * T, taps=True)
+    assert np.array_equal(_bits(got1), _bits(want))
+    for tap in ("X", "P", "features", "ex"):
+        assert np.array_equal(_bits(bd1.tap(tap)), _bits(ref.tap(tap))), tap
     plain = nn.BatchDenoiser(S, lib=hostsim_lib)
     with pytest.raises(RuntimeError, match="set_taps"):
         plain.tap("X")
