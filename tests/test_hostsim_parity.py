@@ -118,14 +118,14 @@ def test_edge_case_inputs(hostsim_lib, oracle_mod, weights_bytes):
 
 
 def test_long_run_ring_wrap(hostsim_lib, oracle_mod, weights_bytes):
-    """150 frames (the 16-slot rings wrap 9 times) in uneven multi-frame calls."""
+    """120 frames (the 52-slot history rings wrap twice, the scratch sets five times) in uneven multi-frame calls."""
     import nnnoiseless_amd as nn
     from nnnoiseless_amd.synthetic import make_streams
-    x = make_streams(200, 3, 150)
+    x = make_streams(200, 3, 120)
     ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x)
     bd = nn.BatchDenoiser(3, lib=hostsim_lib)
     outs, pos = [], 0
-    for n in (1, 7, 13, 2, 40, 5, 82):
+    for n in (1, 7, 13, 2, 40, 5, 52):
         outs.append(bd.process(x[:, pos:pos + n])[0])
         pos += n
     out = np.concatenate(outs, axis=1)
@@ -164,7 +164,7 @@ def test_call_length_patterns(hostsim_lib):
     x = make_streams(60, 3, 37)
     bd = nn.BatchDenoiser(3, lib=hostsim_lib)
     want, want_vad = bd.process(x)
-    for cuts in ((1, 2, 5, 7, 11, 4, 7), (2, 2, 2, 13, 1, 1, 16), (9, 9, 9, 10)):
+    for cuts in ((1, 2, 5, 7, 11, 4, 7), (2, 2, 13, 1, 1, 18)):
         bd.reset()
         outs, vads, pos = [], [], 0
         for n in cuts:

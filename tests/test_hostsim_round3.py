@@ -186,7 +186,7 @@ def test_xcd_tile_mapping_changes_no_bits(hostsim_lib):
     same bits whichever way their batch is cut: 10 tiles (8 dealt + 2), 8 tiles (all dealt), 7 tiles (none)."""
     import nnnoiseless_amd as nn
     from nnnoiseless_amd.synthetic import make_streams
-    T = 3
+    T = 2
     x = make_streams(9, 600, T)
     a, va = nn.BatchDenoiser(600, lib=hostsim_lib).process(x)
     b, vb = nn.BatchDenoiser(512, lib=hostsim_lib).process(x[:512])
