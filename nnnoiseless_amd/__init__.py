@@ -13,8 +13,14 @@ include/nnn_batch.h and include/rnnoise.h.  There is no CPU fallback: importing 
 but creating a state without the built library or without a GPU raises.
 """
 import ctypes as C
+import os
 
 import numpy as np
+
+# Several batches ticking side by side overlap only when their streams land on different hardware queues; the HIP runtime has four
+# unless told otherwise when it initialises (the library asks the same way when it is loaded, see nnn_batch.hip; the package is
+# usually imported earlier -- before the host's first GPU call, where the request still counts).  The host's own setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from . import _ffi
 from .build import LIB_PATH, build_library

@@ -1,35 +1,35 @@
 #!/usr/bin/env python3
-"""Static instruction mix per kernel from hipcc -S output (developer tool).
-usage: isa_mix.py file.s [kernel-substring]   -- with a substring, also prints the per-basic-block mix of that kernel"""
-import re, sys, collections
+"""Static instruction mix of the kernels, from device-only assembly of the product sources (no GPU needed).  The transforms, the
+synthesis and the fused back end are straight-line code per stream-frame apart from short loops, so their static count is what a wave
+issues per stream-frame.  usage: scripts/isa_mix.py [source tree (default: this repository)] [kernel name substrings ...]"""
+import collections
+import os
+import re
+import subprocess
+import sys
 
-def main():
-    txt = open(sys.argv[1]).read().split('\n')
-    want = sys.argv[2] if len(sys.argv) > 2 else None
-    cur, blocks, kernels = None, None, {}
-    for line in txt:
-        m = re.match(r'(_ZN3nnn\w+):\s', line)
-        if m:
-            cur = m.group(1); kernels[cur] = collections.OrderedDict(); blk = 'entry'; kernels[cur][blk] = collections.Counter(); continue
-        if cur is None: continue
-        if line.startswith('.Lfunc_end'):
-            cur = None; continue
-        m = re.match(r'(\.LBB\w+):', line)
-        if m:
-            blk = m.group(1); kernels[cur][blk] = collections.Counter(); continue
-        m = re.match(r'\s+([a-z_0-9]+)\s', line)
-        if m and not m.group(1).startswith('.'): kernels[cur][blk][m.group(1)] += 1
-    def summ(c):
-        tot = sum(c.values())
-        f = lambda p: sum(v for k, v in c.items() if k.startswith(p))
-        return f"total {tot:6d} valu {f('v_'):6d} pk {f('v_pk_'):5d} ds {f('ds_'):5d} vmem {f('global_')+f('buffer_')+f('scratch_'):5d} salu {f('s_'):5d} waitcnt {c['s_waitcnt']:4d} mfma {f('v_mfma'):4d}"
-    for k, bl in kernels.items():
-        c = collections.Counter()
-        for b in bl.values(): c.update(b)
-        if sum(c.values()) < 40: continue
-        short = re.sub(r'ENS.*|EPK.*', '', k)[7:]
-        print(f"{short:20s} {summ(c)}")
-        if want and want in k:
-            for name, b in bl.items():
-                if sum(b.values()) >= 30: print(f"    {name:14s} {summ(b)}  top {b.most_common(8)}")
-main()
+root = sys.argv[1] if len(sys.argv) > 1 and os.path.isdir(sys.argv[1]) else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+want = [a for a in sys.argv[1:] if not os.path.isdir(a)] or ["k_fft_xp", "k_synth", "k_pitch", "k_hp", "k_rnn_wf", "k_back"]
+src = os.path.join(root, "nnnoiseless_amd", "csrc")
+out = "/tmp/nnn_isa_mix.s"
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S", "-o", out,
+                       "-x", "hip", os.path.join(src, "nnn_batch.hip"), "-I", src, '-DNNN_WEIGHTS_PATH="x"', "-w"])
+text = open(out).read()
+GROUPS = (("valu", ("v_",)), ("lds", ("ds_",)), ("vmem", ("global_", "buffer_", "flat_", "scratch_")), ("salu", ("s_",)))
+print(f"{'kernel':44s} {'total':>6s} {'valu':>6s} {'lds':>5s} {'vmem':>5s} {'salu':>5s}   arithmetic (mul / add / fma, packed counted once) | moves | selects | integer + address")
+for m in re.finditer(r"\n(_Z\w+):\s*; @", text):
+    sym = m.group(1)
+    name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.split("(")[0].replace("void ", "").replace("nnn::", "")
+    if not any(w in name for w in want):
+        continue
+    body = text[m.end():text.index(".Lfunc_end", m.end())]
+    ins = [l.split()[0] for l in body.split("\n") if l.strip() and not l.strip().startswith((".", ";")) and not l.strip().endswith(":")]
+    c = collections.Counter(ins)
+    g = collections.Counter()
+    for k, v in c.items():
+        g[next((n for n, p in GROUPS if k.startswith(p)), "other")] += v
+    arith = sum(v for k, v in c.items() if re.match(r"v_(pk_)?(mul|add|sub|fma|fmac|mac|mad)_f(32|64)", k))
+    mov = sum(v for k, v in c.items() if k.startswith(("v_mov", "v_pk_mov", "v_accvgpr")))
+    sel = sum(v for k, v in c.items() if k.startswith("v_cndmask"))
+    integer = sum(v for k, v in c.items() if re.match(r"v_(add|sub|lshl|lshr|ashr|and|or|xor|mul_lo|mul_u|mad_u|mad_i|bfe|lshl_add|add3|lshl_or)", k) and "_f" not in k)
+    print(f"{name:44s} {len(ins):6d} {g['valu']:6d} {g['lds']:5d} {g['vmem']:5d} {g['salu']:5d}   {arith:5d} | {mov:4d} | {sel:4d} | {integer:4d}")
