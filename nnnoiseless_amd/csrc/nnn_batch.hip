@@ -57,7 +57,7 @@ int nnn_set_error(const char *msg) { return fail("%s", msg); }   // for the libr
     } while (0)
 
 // The HIP runtime maps streams onto four hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and two batches whose streams land on one
-// queue do not overlap (two 4096-stream batches ticking: 23.5 M frames/s, 33.5 M with eight queues).  The runtime reads the variable when it
+// queue do not overlap (two 4096-stream batches ticking: 31.3 M frames/s, 43.3 M with eight queues).  The runtime reads the variable when it
 // initialises -- at the host's first HIP call --, so it is asked for when this library is loaded, unless the host has a setting of its own; a
 // host that used HIP before loading the library exports it itself.
 __attribute__((constructor)) static void nnn_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
