@@ -1867,11 +1867,14 @@ __device__ __forceinline__ void window_load(const float *h, int ring, int rb, in
     int start = rb + (HIST - WINDOW) - lag;   // in (0, 2 ring)
     if (start >= ring) start -= ring;
     const int j = lane < FFT_P1 ? lane : FFT_P1 - 1;   // (lanes 60..63 shadow lane 59 and store nothing)
+    // Pair r sits 8 FFT_P1 r bytes behind pair 0, less the ring's length when that is past the ring's end: of x and x - 4 ring taken as
+    // unsigned numbers the smaller is the one in range.  Three 32-bit instructions per pair and an offset the load adds to the
+    // stream's (wave-uniform) base itself; as signed indices with a compare and a 64-bit address each, it was seven.
+    const unsigned x0 = 4u * (unsigned)(start + 2 * j), ring4 = 4u * (unsigned)ring;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        int i0 = start + 2 * (j + FFT_P1 * r);
-        if (i0 >= ring) i0 -= ring;
-        sm[r] = *(const SamplePair *)(h + i0);   // (i0 + 1 = ring reads the copy of sample 0 kept there)
+        const unsigned x = x0 + (unsigned)(8 * FFT_P1 * r), y = x - ring4;
+        sm[r] = *(const SamplePair *)((const char *)h + (x < y ? x : y));   // (the pair that starts on the ring's last sample reads the copy of sample 0 kept behind it)
     }
 }
 template <bool RL = false>
@@ -1986,7 +1989,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     for (int r = 0; r < 8; r++) w[r] = ((const float2 *)b.window_a)[(lane < FFT_P1 ? lane : FFT_P1 - 1) + FFT_P1 * r];
     const int lag = WITH_P ? NNN_TI(b.pitch, 1, tile, sl)[0] : 0;
     if (!FUSED) fft_tables_load(t, b);   // (the fused kernel loads them once per launch)
-    const float *h = b.hist + (size_t)s * hist_stride(b.nslot);
+    const float *h = b.hist + (size_t)__builtin_amdgcn_readfirstlane(s) * hist_stride(b.nslot);   // (wave = stream: a scalar base)
     // both windows' samples are requested now: the second transform's used to be requested when it started, a trip to memory on
     // the wave's critical path per stream-frame (these kernels move enough bytes for that to show)
     SamplePair sx[8], spw[8];
@@ -2029,7 +2032,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
 #ifdef NNN_FFT_LATE_P
     window_load(h, ring, rb, lag, lane, spw);
 #else
-    if (FUSED) window_load(b.hist + (size_t)s * hist_stride(b.nslot), ring, rb, lag, lane, spw);
+    if (FUSED) window_load(b.hist + (size_t)__builtin_amdgcn_readfirstlane(s) * hist_stride(b.nslot), ring, rb, lag, lane, spw);
 #endif
     if (FUSED) {   // (the window again, from the L2: sixteen registers less across the first transform and the band sums of a wave that has 128)
 #pragma unroll
