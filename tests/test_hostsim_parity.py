@@ -375,3 +375,20 @@ def test_lpc_sums_started_beside_the_high_pass(hostsim_lib, oracle_mod, weights_
     assert np.array_equal(og, res["1"][0]) and np.array_equal(vg, res["1"][1])
     ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x)
     assert np.array_equal(res["1"][4][:, 0], ref["pitch"][:, -1])
+
+
+def test_high_pass_two_tiles_per_block_with_an_odd_tile_count(hostsim_lib, monkeypatch):
+    """k_hp2<2> on three tiles: the second block's spare pair of waves only keeps the barrier count."""
+    import nnnoiseless_amd as nn
+    from nnnoiseless_amd.synthetic import make_streams
+    S, T = 130, 2
+    x = make_streams(78, S, T)
+    res = []
+    for tpb in ("1", "2"):
+        monkeypatch.setenv("NNN_HP_TPB", tpb)
+        bd = nn.BatchDenoiser(S, lib=hostsim_lib, taps=True)
+        o, v = bd.process(x)
+        res.append((o, v, bd.tap("filtered").copy()))
+        bd.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
