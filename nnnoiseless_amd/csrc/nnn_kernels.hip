@@ -1663,6 +1663,15 @@ constexpr int FFT_SPB = 4;
 // per-lane constant.  k_fft_xp 19.6 -> 18.9 us per frame at 4096 streams, 325 -> 321 at 65536 (same box).
 __device__ __forceinline__ int bsk(int k) { return k + (k >> 3); }
 constexpr int BSK_LEN = 400 + 400 / 8;
+// NNN_FFT_LANE_TW=1 (build knob, off): the second and third pass's twiddles as the lanes use them -- a lane's twiddles are constants of
+// the lane, one LDS read each instead of index, wrap and sign (five vector instructions a piece) -- in k_synth, whose blocks copy
+// the tables once per group of frames.  Measured at the end of round 4 on every transform (profiles/r4_experiments_ab.txt M: -6.6 % vector
+// instructions; k_synth -3 %, nothing for the kernels whose blocks copy the tables per stream-frame): to be switched on with its own
+// evidence pass.
+#ifndef NNN_FFT_LANE_TW
+#define NNN_FFT_LANE_TW 0
+#endif
+constexpr int FFT_TW2 = 2 * 5 * 64, FFT_TW3 = 9 * 64;
 struct alignas(16) FftLds {
     float2 tw[NFFT];           // exp(-2 pi i k / 960), k < 480; the other half of the circle is the negation
     float frac[BSK_LEN];       // triangular band weights (ref: src/lib.rs:65-82), skewed (bsk)
@@ -1672,18 +1681,29 @@ struct alignas(16) FftLds {
     float dct[NB * NB];        // DCT table (ref: src/lib.rs:118-127): the feature head's two transforms read 44 of its rows per stream-frame
                                // (from global memory they were half of k_fft_xp's vector-memory instructions; same time either way)
     float pad_[2];
+#if NNN_FFT_LANE_TW
+    float2 tw2[FFT_TW2];       // fft_pass<6, 8>: [it][r - 1][lane]; copied only by the kernels that use them (fft_tables_load)
+    float2 tw3[FFT_TW3];       // fft_pass<10, 48>: [r - 1][lane]
+#endif
 };
 static_assert(sizeof(FftLds) % 16 == 0, "copied as 16-byte pieces");
+#if NNN_FFT_LANE_TW
+constexpr int FFT_TABLES_SHORT = (int)offsetof(FftLds, tw2);
+#else
+constexpr int FFT_TABLES_SHORT = (int)sizeof(FftLds);
+#endif
+static_assert(FFT_TABLES_SHORT % 16 == 0, "");
 // Fills the block's tables from the image the host built in exactly this layout (Buffers::fft_img): a straight copy of 16-byte
 // pieces.  (Building them in the kernel from the plain tables -- skewed index, byte and short conversions, scattered narrow LDS
 // stores -- cost k_fft_xp 190 of its 1530 vector instructions per stream-frame.)  Every thread of the block calls it, the caller
 // synchronises.
-__device__ __forceinline__ void fft_tables_load(FftLds &t, const Buffers &b)
+__device__ __forceinline__ void fft_tables_load(FftLds &t, const Buffers &b, bool lane_tw = false)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     const uint4 *src = (const uint4 *)b.fft_img;
     uint4 *dst = (uint4 *)&t;
-    for (int i = tid; i < (int)(sizeof(FftLds) / 16); i += nt) dst[i] = src[i];
+    const int n = (lane_tw ? (int)sizeof(FftLds) : FFT_TABLES_SHORT) / 16;
+    for (int i = tid; i < n; i += nt) dst[i] = src[i];
 }
 // the host's side of it
 __host__ inline void fft_tables_image(FftLds &t, const float2 *tw960, const float *bin_frac, const int *bin_band, const int *seg, const float *dct)
@@ -1691,6 +1711,14 @@ __host__ inline void fft_tables_image(FftLds &t, const float2 *tw960, const floa
     memset(&t, 0, sizeof(t));
     for (int i = 0; i < NB * NB; i++) t.dct[i] = dct[i];
     for (int i = 0; i < NFFT; i++) t.tw[i] = tw960[i];
+#if NNN_FFT_LANE_TW
+    auto at = [&](int k) { const float2 w = tw960[k >= NFFT ? k - NFFT : k]; return k >= NFFT ? make_float2(-w.x, -w.y) : w; };   // tw960_at
+    for (int it = 0; it < 2; it++)       // fft_pass<6, 8>: butterfly j = lane + 64 it < 80, k = j % 8, twiddle (r k 20) % 960
+        for (int r = 1; r < 6; r++)
+            for (int l = 0; l < 64; l++) t.tw2[(it * 5 + r - 1) * 64 + l] = at((r * ((l + 64 * it) % 8) * 20) % 960);
+    for (int r = 1; r < 10; r++)         // fft_pass<10, 48>: butterfly j = lane < 48, k = j, twiddle (r k 2) % 960
+        for (int l = 0; l < 64; l++) t.tw3[(r - 1) * 64 + l] = at((r * (l % 48) * 2) % 960);
+#endif
     for (int i = 0; i < 400; i++) {
         t.frac[i + (i >> 3)] = bin_frac[i];
         t.band[i] = (unsigned char)bin_band[i];
@@ -1713,7 +1741,8 @@ __device__ __forceinline__ float2 tw960_at(const float2 *tw, int k)   // k in [0
 // -- as many LDS cycles as all other accesses of the transform together.  Its output (and the second pass's input) is
 // therefore skewed, element i at i + i / 8 (stride 9: conflict-free); the buffer holds NFFT_BUF elements for that.
 constexpr int NFFT_BUF = NFFT + NFFT / 8;
-template <int R, int NS, bool SKEW_IN, bool SKEW_OUT>
+// LT: `tw` is the pass's own per-lane twiddle table ([it][r - 1][lane], FftLds::tw2 / tw3) instead of the half circle
+template <int R, int NS, bool SKEW_IN, bool SKEW_OUT, bool LT = false>
 __device__ __forceinline__ void fft_pass(float2 *buf, const float2 *tw, int lane)
 {
     constexpr int NBF = NFFT / R, IT = (NBF + 63) / 64;
@@ -1731,7 +1760,7 @@ __device__ __forceinline__ void fft_pass(float2 *buf, const float2 *tw, int lane
             if (NS > 1) {
                 constexpr int step = 960 / (NS * R);
 #pragma unroll
-                for (int r = 1; r < R; r++) v[it][r] = cmulf(v[it][r], tw960_at(tw, (r * k * step) % 960));
+                for (int r = 1; r < R; r++) v[it][r] = cmulf(v[it][r], LT ? tw[(it * (R - 1) + r - 1) * 64 + lane] : tw960_at(tw, (r * k * step) % 960));
             }
             dftR<R>(v[it]);
         }
@@ -1761,7 +1790,7 @@ __device__ __forceinline__ void fft480(float2 *buf, const float2 *tw, int lane)
 // staging store, the first pass's reads and a synchronisation per transform.  Every earlier reader of buf must be done.
 // RL (the fused back end, a wave of 128 registers that also holds two spectra): the lane index is laundered between the passes, so that
 // each pass forms its LDS addresses and twiddle indices where it starts instead of all of them up front (see launder_v)
-template <bool RL = false>
+template <bool RL = false, bool LT = false>
 __device__ __forceinline__ void fft480_regs(float2 (&v)[8], float2 *buf, const float2 *tw, int lane)
 {
     dft8(v);
@@ -1771,6 +1800,15 @@ __device__ __forceinline__ void fft480_regs(float2 (&v)[8], float2 *buf, const f
     }
     wave_lds_sync();
     if (RL) lane = launder_v(lane);
+#if NNN_FFT_LANE_TW
+    if (LT) {   // (tw = FftLds::tw of a block that copied the whole image)
+        const float2 *tw2 = (const float2 *)((const char *)tw + (offsetof(FftLds, tw2) - offsetof(FftLds, tw)));
+        fft_pass<6, 8, true, false, true>(buf, tw2, lane);
+        if (RL) lane = launder_v(lane);
+        fft_pass<10, 48, false, false, true>(buf, tw2 + FFT_TW2, lane);
+        return;
+    }
+#endif
     fft_pass<6, 8, true, false>(buf, tw, lane);
     if (RL) lane = launder_v(lane);
     fft_pass<10, 48, false, false>(buf, tw, lane);
@@ -3459,7 +3497,7 @@ __device__ __forceinline__ void synth_frame(const Buffers &b, const StepParams *
         wlo[u] = on ? ((const float4 *)b.window_s)[n] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // (window / 2: the inverse transform's halving rides on it)
         whi[u] = on ? ((const float4 *)b.window_s)[FRAME / 4 + n] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    fft480_regs<true>(zin, A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
+    fft480_regs<true, NNN_FFT_LANE_TW && !SMV_IO>(zin, A, t.tw, lane);   // time samples: x[2n] = A[n].y, x[2n+1] = A[n].x
     if (lane == 0 && vad_out && s < b.S) vad_out[s] = vadv;
     const bool quad_ok = ch == 1 && (((size_t)o) & (size_t)(4 * elem - 1)) == 0;
 #pragma unroll
@@ -3505,7 +3543,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
     xcd_tile_block((int)blockIdx.x, b.NT, TILE / FFT_SPB, tile, sub);
     const int lane0 = threadIdx.x & 63, sl = sub * FFT_SPB + wave, s = tile * TILE + sl;
     int lane = lane0;
-    fft_tables_load(t, b);
+    fft_tables_load(t, b, NNN_FFT_LANE_TW != 0);
     float *sm = b.synth_mem + (size_t)s * FRAME;
     float4 smq[2];   // overlap memory as sample quads, carried from frame to frame in registers
 #pragma unroll

@@ -23,6 +23,7 @@ def build(force=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     weights = os.path.join(ROOT, "nnnoiseless_amd", "data", "weights.rnn")
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",
-           "-I", HERE, "-I", CSRC, f'-DNNN_WEIGHTS_PATH="{weights}"', "-x", "c++"] + srcs + ["-o", OUT]
+           "-I", HERE, "-I", CSRC, f'-DNNN_WEIGHTS_PATH="{weights}"'] + os.environ.get("NNN_HOSTSIM_DEFINES", "").split() + ["-x", "c++"] + srcs + ["-o", OUT]
+    # (NNN_HOSTSIM_DEFINES: build knobs of the product sources for a one-off check under the interpreter, e.g. -DNNN_FFT_LANE_TW=1)
     subprocess.check_call(cmd)
     return OUT
