@@ -16,6 +16,57 @@ __device__ __forceinline__ f32x4 mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// ---- the matrix-core DFT's primitives (nnn_dft_mfma.h) ----
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+// v_mfma_f32_16x16x32_f16: the same tile shapes and fragment layouts as the bf16 form, operands in IEEE half precision
+__device__ __forceinline__ f32x4 mfma_16x16x32_f16(uint4 a, uint4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+// (a, b) rounded to nearest-even half precision, a in the low half
+__device__ __forceinline__ unsigned pk_f16_rn(float a, float b)
+{
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a - (float)(low / high half of h), exact when h holds a's own rounding: one v_fma_mix_f32 each
+__device__ __forceinline__ float f16_resid_lo(float a, unsigned h)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float f16_resid_hi(float a, unsigned h)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+    return r;
+}
+// the upper halves of (a, b) as one word, a's in the low half: two floats truncated to bf16
+__device__ __forceinline__ unsigned pk_bf16_trunc(float a, float b)
+{
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+// max(|a|, |b|, m) (a NaN operand is ignored)
+__device__ __forceinline__ float amax3(float a, float b, float m)
+{
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(m));
+    return r;
+}
+// maximum over the wave's 64 lanes, wave-uniform (four DPP steps inside the rows of 16, then the four rows through scalars)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x)
+{
+    x = max(x, (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    x = max(x, (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    x = max(x, (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xf, 0xf, true));   // row_half_mirror
+    x = max(x, (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x140, 0xf, 0xf, true));   // row_mirror
+    const unsigned a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16), c = __builtin_amdgcn_readlane(x, 32),
+                   d = __builtin_amdgcn_readlane(x, 48);
+    return max(max(a, b), max(c, d));
+}
+
 // Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier, no vmcnt(0).  Unlike
 // __syncthreads() it does not drain outstanding global loads/stores, so requests issued early (weights, states)
 // keep travelling across phase boundaries.  Only for phases that exchange data through LDS.

@@ -52,6 +52,94 @@ static inline f32x4 mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c)
     return d;
 }
 
+// ---- the matrix-core DFT's primitives ----
+namespace detail {
+static inline float f16_to_f32(unsigned short h)
+{
+    const unsigned sgn = (unsigned)(h & 0x8000) << 16, e = (h >> 10) & 31, m = h & 1023;
+    if (e == 0) { float f = ldexpf((float)m, -24); return sgn ? -f : f; }
+    if (e == 31) { unsigned u = sgn | 0x7f800000u | (m << 13); float f; memcpy(&f, &u, 4); return f; }
+    unsigned u = sgn | ((e + 112) << 23) | (m << 13);
+    float f; memcpy(&f, &u, 4); return f;
+}
+static inline unsigned short f32_to_f16_rn(float f)   // round to nearest even, overflow to infinity, subnormals kept
+{
+    unsigned u; memcpy(&u, &f, 4);
+    const unsigned sgn = (u >> 16) & 0x8000;
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) return (unsigned short)(sgn | 0x7c00 | (u > 0x7f800000u ? 0x200 : 0));
+    if (u >= 0x477ff000u) return (unsigned short)(sgn | 0x7c00);   // rounds to >= 65520: infinity
+    if (u < 0x38800000u) {                                           // below the smallest normal half: a multiple of 2^-24
+        float a; memcpy(&a, &u, 4);
+        const float q = a * 16777216.0f;                            // exact
+        const float r = nearbyintf(q);                              // (default rounding mode: to nearest even)
+        return (unsigned short)(sgn | (unsigned)r);
+    }
+    const unsigned mant = u & 0x7fffffu, e = (u >> 23) - 112;
+    unsigned h = (e << 10) | (mant >> 13);
+    const unsigned rem = mant & 0x1fff;
+    if (rem > 0x1000 || (rem == 0x1000 && (h & 1))) h++;
+    return (unsigned short)(sgn | h);
+}
+static inline void mfma_tile_f16(const void *const *ins, void *const *outs, int nl)
+{
+    static float A[16][32], B[32][16], C[16][16];
+    for (int l = 0; l < nl; l++) {
+        if (!ins[l]) continue;
+        const MfmaIn *in = (const MfmaIn *)ins[l];
+        unsigned short ha[8], hb[8];
+        memcpy(ha, &in->a, 16);
+        memcpy(hb, &in->b, 16);
+        for (int e = 0; e < 8; e++) {
+            A[l & 15][8 * (l >> 4) + e] = f16_to_f32(ha[e]);
+            B[8 * (l >> 4) + e][l & 15] = f16_to_f32(hb[e]);
+        }
+        for (int q = 0; q < 4; q++) C[4 * (l >> 4) + q][l & 15] = in->c[q];
+    }
+    for (int l = 0; l < nl; l++) {
+        if (!outs[l]) continue;
+        f32x4 *d = (f32x4 *)outs[l];
+        for (int q = 0; q < 4; q++) {
+            int i = 4 * (l >> 4) + q, j = l & 15;
+            float acc = C[i][j];
+            for (int k = 0; k < 32; k++) acc = fmaf(A[i][k], B[k][j], acc);
+            (*d)[q] = acc;
+        }
+    }
+}
+static inline void umax_fn(const void *const *ins, void *const *outs, int nl)
+{
+    unsigned m = 0;
+    for (int l = 0; l < nl; l++) if (ins[l]) { unsigned v = *(const unsigned *)ins[l]; if (v > m) m = v; }
+    for (int l = 0; l < nl; l++) if (outs[l]) *(unsigned *)outs[l] = m;
+}
+}  // namespace detail
+static inline f32x4 mfma_16x16x32_f16(uint4 a, uint4 b, f32x4 c)
+{
+    detail::MfmaIn in = {a, b, c};
+    f32x4 d;
+    hostsim::wave_collective(&in, &d, detail::mfma_tile_f16);
+    return d;
+}
+static inline unsigned pk_f16_rn(float a, float b) { return (unsigned)detail::f32_to_f16_rn(a) | ((unsigned)detail::f32_to_f16_rn(b) << 16); }
+static inline float f16_resid_lo(float a, unsigned h) { return a - detail::f16_to_f32((unsigned short)(h & 0xffff)); }
+static inline float f16_resid_hi(float a, unsigned h) { return a - detail::f16_to_f32((unsigned short)(h >> 16)); }
+static inline unsigned pk_bf16_trunc(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
+static inline float amax3(float a, float b, float m)
+{
+    const float x = fabsf(a), y = fabsf(b);
+    float r = m;
+    if (x > r) r = x;   // (a NaN operand compares false: ignored)
+    if (y > r) r = y;
+    return r;
+}
+static inline unsigned wave_max_u32(unsigned x)
+{
+    unsigned m = 0;
+    hostsim::wave_collective(&x, &m, detail::umax_fn);
+    return m;
+}
+
 static inline void lds_barrier() { __syncthreads(); }
 // the interpreter's lanes are fibers, not lock-step: a wave-level rendezvous (the shuffle machinery) stands in
 static inline void wave_lds_sync() { (void)__shfl(0, 0); }
