@@ -65,3 +65,25 @@ def rel_rms(a, b):
     b = np.asarray(b, np.float64)
     den = float((b ** 2).sum())
     return (float(((a - b) ** 2).sum()) / den) ** 0.5 if den > 0 else float(np.abs(a - b).max())
+
+
+def flip_stats(gpu_branch, gpu_out, ref, ref32):
+    """The excuse for frames whose pitch-filter branch mask (`exp > g` per band, src/features.rs:227; bit 22: the silence gate) differs
+    from the oracle's, on data: the three pairings of the GPU, the oracle with its FFT in f64 (the checker) and the
+    oracle with its FFT in f32 (the arithmetic of the reference's own rustfft).  For each pairing the number of frames whose masks
+    differ and the UNMASKED relative RMS of the audio (frame 0 dropped, as the reference's callers drop it).  The reference's own
+    arithmetic against itself sets the scale: a GPU that flips about as often as f32-vs-f64 does is as close as the reference gets
+    to itself.  gpu_branch / ref[...]["branch"]: [S, T] int32, outs [S, T, 480]."""
+    def pair(b1, o1, b2, o2):
+        return int((b1 != b2).sum()), rel_rms(o1[:, 1:], o2[:, 1:])
+    fg64, rg64 = pair(gpu_branch, gpu_out, ref["branch"], ref["out"])
+    fg32, rg32 = pair(gpu_branch, gpu_out, ref32["branch"], ref32["out"])
+    f3264, r3264 = pair(ref32["branch"], ref32["out"], ref["branch"], ref["out"])
+    return {"frames": int(gpu_branch.size), "flips_gpu_vs_f64": fg64, "flips_gpu_vs_f32": fg32, "flips_f32_vs_f64": f3264,
+            "rel_rms_unmasked_gpu_vs_f64": rg64, "rel_rms_unmasked_gpu_vs_f32": rg32, "rel_rms_unmasked_f32_vs_f64": r3264}
+
+
+def assert_flips_in_line(st, tag=""):
+    """The GPU may flip a branch no more often than a few times what the reference's f32 arithmetic does against the checker."""
+    bound = max(4, 3 * st["flips_f32_vs_f64"])
+    assert st["flips_gpu_vs_f64"] <= bound, (tag, st)

@@ -16,7 +16,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ROOT, rel_rms
+from conftest import GOLDEN, ROOT, assert_flips_in_line, flip_stats, rel_rms
 
 pytestmark = pytest.mark.gpu
 
@@ -33,8 +33,9 @@ def oracle_reference(oracle_mod, blob, x):
     """The oracle on x [n, T, 480] and the per-stream gain tolerance max(1e-4, 3 x its own f32-FFT vs f64-FFT spread)."""
     nt = os.cpu_count() or 1
     ref = oracle_mod.run_streams(oracle_mod.Model(blob), x, n_threads=nt, want=("out", "pitch", "branch", "vad", "gains"))
-    ref32 = oracle_mod.run_streams(oracle_mod.Model(blob, f32_fft=True), x, n_threads=nt, want=("gains",))
+    ref32 = oracle_mod.run_streams(oracle_mod.Model(blob, f32_fft=True), x, n_threads=nt, want=("gains", "out", "branch"))
     gtol = np.maximum(1e-4, 3.0 * np.abs(ref["gains"] - ref32["gains"]).max(axis=(1, 2)))
+    ref["f32"] = ref32        # the oracle with the reference's own f32 FFT arithmetic: what flips and differs without any GPU (flip_stats)
     return ref, gtol
 
 
@@ -66,10 +67,14 @@ def check_against_oracle(out, vad, log, ref, gtol, tag):
               "gain_max_err": float(gerr.max()), "gain_tolerance_max": float(gtol.max()), "flipped": lst,
               "flipped_fraction": len(lst) / (n * T), "excused_fraction": float(excused.mean()), "rel_rms": r,
               "rel_rms_unmasked": r_all, "per_stream_rel_rms_max": float(per_stream.max())}
+    if "f32" in ref:
+        report.update(flip_stats(branch, out, ref, ref["f32"]))
     print(json.dumps(report))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(report, open(os.path.join(ROOT, "gpurun_out", f"parity_{tag}.json"), "w"), indent=1)
     assert excused.mean() < 1e-3, (tag, report["excused_fraction"])
+    if "f32" in ref:
+        assert_flips_in_line(report, tag)
     assert r <= 1e-4, (tag, r)
     assert per_stream.max() <= 1e-4, (tag, float(per_stream.max()), int(per_stream.argmax()))
     assert np.abs(d).max() <= 0.05 * max(np.abs(rr).max(), 1.0)        # flipped frames stay sane

@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ROOT, golden_metric, rel_rms
+from conftest import GOLDEN, ROOT, assert_flips_in_line, flip_stats, golden_metric, rel_rms
 
 pytestmark = pytest.mark.gpu
 
@@ -134,7 +134,8 @@ def test_parity_subset_1024x200(nn, oracle_mod, weights_bytes):
     want = ("out", "pitch", "branch", "vad", "gains")
     ref = oracle_mod.run_streams(oracle_mod.Model(weights_bytes), x, n_threads=os.cpu_count() or 1, want=want)
     # what f32 rounding in the FFT alone does to the gains, per stream: the oracle's f32-FFT build against its f64-FFT build
-    ref32 = oracle_mod.run_streams(oracle_mod.Model(weights_bytes, f32_fft=True), x, n_threads=os.cpu_count() or 1, want=("gains",))
+    ref32 = oracle_mod.run_streams(oracle_mod.Model(weights_bytes, f32_fft=True), x, n_threads=os.cpu_count() or 1,
+                                   want=("gains", "out", "branch"))
     gtol = np.maximum(1e-4, 3.0 * np.abs(ref["gains"] - ref32["gains"]).max(axis=(1, 2)))
     bd = nn.BatchDenoiser(S)
     outs, branch, pitch, gains = [], [], [], []
@@ -158,10 +159,12 @@ def test_parity_subset_1024x200(nn, oracle_mod, weights_bytes):
     r = np.sqrt((d[ok] ** 2).sum() / (rr[ok] ** 2).sum())
     report = {"streams": S, "frames": T, "flipped": lst, "flipped_fraction": len(lst) / (S * T),
               "excused_fraction": float(excused.mean()), "rel_rms_unmasked": float(r_all), "rel_rms": float(r)}
+    report.update(flip_stats(branch, out, ref, ref32))     # the excuse on data: GPU vs f64 oracle, GPU vs f32 oracle, the oracle against itself
     print(json.dumps(report))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(report, open(os.path.join(ROOT, "gpurun_out", "parity_1024x200_flipped_frames.json"), "w"), indent=1)
     assert excused.mean() < 1e-3, report["excused_fraction"]
+    assert_flips_in_line(report, "1024x200")
     assert r <= 1e-4, r                                           # measured ~1e-6
     assert np.abs(d).max() <= 0.05 * np.abs(rr).max()             # flipped frames stay sane
     per_stream = np.sqrt(((d * ok[..., None]) ** 2).sum(axis=(1, 2)) / np.maximum((rr ** 2).sum(axis=(1, 2)), 1e-9))
@@ -272,6 +275,7 @@ def test_edge_case_inputs(nn, oracle_mod, weights_bytes):
         assert (gerr <= gtol).all(), (t, gerr, gtol)
     excused, lst = flipped_frames(branch, ref["branch"])
     print("flipped (stream, frame, bands):", lst)
+    print("flips:", json.dumps(flip_stats(branch, out, ref, ref32)))      # (edge cases are ill-conditioned by design: reported, not bounded)
     scale = np.maximum(np.abs(ref["out"]).max(axis=(1, 2)), 1.0)[:, None]
     err = np.abs(out - ref["out"]).max(axis=2) / scale
     assert err[~excused].max() <= 1e-4, np.argwhere((err > 1e-4) & ~excused)
