@@ -44,6 +44,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The bench is the HOST of the library: the HIP runtime's hardware-queue count is the host's setting (the library and the
+# package no longer export it behind the host's back).  It matters for the side-by-side ticking measurements only.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3
@@ -212,7 +215,7 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
     second is a callable (or None) that runs the event-instrumented pass on this rank and returns the extra fields -- rank 0
     calls it after the ranks have parted, so that nobody idles behind it."""
     import nnnoiseless_amd as nn
-    from nnnoiseless_amd.shard import aggregate
+    from nnnoiseless_amd.shard import aggregate, gather
     from nnnoiseless_amd.synthetic import make_streams_device
     fps, K, W = args.frames_per_step, args.steps, args.warmup
     fmt = {"f32": 0, "i16": 1, "unit": 2}[args.pcm]
@@ -291,16 +294,20 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
     for i in range(W, W + K):
         run_span(i * fps, fps)
     t_enq = time.perf_counter() - t0          # host time to enqueue everything (the calls are asynchronous)
+    if not args.dry_run:
+        torch.cuda.synchronize()
+    local = time.perf_counter() - t0          # this rank's own GPU done (before it waits for the others): per-rank rates below
     barrier()
     elapsed = time.perf_counter() - t0
     if bd.fault():                            # (a caller that synchronises its own stream has to ask: nnn_batch_fault)
         raise SystemExit("bench: the library reports a frame hand-off fault (nnn_batch_fault): results invalid")
     d = dist if world > 1 else None
     frames_done, elapsed_max = aggregate(d, S * fps * K, elapsed, dev)
+    per_rank = [round(v) for v in gather(d, S * fps * K / max(local, 1e-9), dev)]   # frames/s of every rank on its own clock
     if os.environ.get("NNN_PMC_CALIB"):   # a kernel of known traffic (reads N bytes, writes N bytes) for the PMC passes' calibration
         torch.abs(x)
     res = {"value": frames_done / elapsed_max, "ms_per_step": elapsed_max * 1e3 / K, "timed_s": elapsed_max, "steps": K,
-           "host_enqueue_ms_per_step": t_enq * 1e3 / K, "pool_frames": pool,
+           "host_enqueue_ms_per_step": t_enq * 1e3 / K, "pool_frames": pool, "per_rank_frames_per_s": per_rank,
            "outputs_finite": bool(torch.isfinite(y.float()).all().item())}
 
     # the same workload at one frame per call (live 10 ms tick)
@@ -505,6 +512,13 @@ def single_process(args):
     t0 = time.perf_counter()
     for j in range(W, W + K):
         step(j)
+    # every shard's own finishing time, taken in shard order (shard i's stamp is an upper bound: it is read after shards < i have
+    # drained): a slow GPU shows as a low rate from its index on
+    lib = nn.library()
+    shard_dt = []
+    for i in range(N):
+        lib.check(lib.L.nnn_batch_synchronize(node.batch_handle(i)))
+        shard_dt.append(time.perf_counter() - t0)
     sync()
     dt = time.perf_counter() - t0
     if node.fault():
@@ -516,6 +530,8 @@ def single_process(args):
                        "streams_per_gpu": S1, "streams_total": S1 * N, "frames_per_step": fps,
                        "parallelism": f"streams sharded x{N} inside the library (nnn_node_*: one batch and one host thread per device), ONE process, "
                                       "no data-path collective", "shards": node.shards()},
+            "per_rank_frames_per_s": [round(S1 * fps * K / max(t, 1e-9)) for t in shard_dt],
+            "worker_cpus": [node.shard_cpus(i) for i in range(N)],
             "outputs_finite": all(bool(torch.isfinite(p[1]).all().item()) for p in parts), "timed_s": dt}
     print(json.dumps(line), flush=True)
     node.close()
@@ -653,11 +669,10 @@ def main():
                    # GPU alone), below that the high-pass chain on a stream of its own ahead of one lane
                    "schedule": os.environ.get("NNN_SCHED", "seq" if ((S + 63) // 64 * 64 >= 16384 and "NNN_LANES" not in os.environ) else "lanes"),
                    "lanes": int(os.environ.get("NNN_LANES", "1")),
-                   "pipeline": os.environ.get("NNN_PIPELINE", "1") != "0",
                    "inputs": "resident in HBM and final before the timed region" + ("" if args.no_overlap else "; declared to the library "
                              "(nnn_batch_set_inputs_ready): with the lanes schedule consecutive calls overlap at their boundary, outputs stay stream-ordered"),
                    "parallelism": f"streams sharded x{world}, one process per GPU, no data-path collective"},
-        "ranks_seen": ranks_seen, "timed_s": res["timed_s"], "pool_frames": res["pool_frames"],
+        "ranks_seen": ranks_seen, "per_rank_frames_per_s": res["per_rank_frames_per_s"], "timed_s": res["timed_s"], "pool_frames": res["pool_frames"],
         "tick": res.get("tick"),
         "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
         "outputs_finite": res["outputs_finite"],

@@ -244,29 +244,143 @@ impl Drop for BatchDenoiser {
     }
 }
 
-/// Same surface as `nnnoiseless::DenoiseState` (src/denoise.rs:36-116), `Clone` included.
+/// Same surface as `nnnoiseless::DenoiseState<'model>` (src/denoise.rs:36-116), lifetime and `Clone` included: host code that names
+/// `DenoiseState<'static>` or borrows a model for `'model` compiles unchanged.  The backend copies the model to the device when the
+/// state is made, so the borrow is only a marker (`PhantomData`): it keeps the reference's rule that a borrowed model outlives the
+/// states made from it, without holding a pointer to it.
 #[derive(Clone)]
-pub struct DenoiseState(BatchDenoiser);
+pub struct DenoiseState<'model> {
+    batch: BatchDenoiser,
+    _model: std::marker::PhantomData<&'model RnnModel>,
+}
 
-impl DenoiseState {
+impl DenoiseState<'static> {
+    /// A `DenoiseState` processes this many samples at a time.
     pub const FRAME_SIZE: usize = 480;
-    pub fn new() -> Box<DenoiseState> {
-        Box::new(DenoiseState(BatchDenoiser::sized(1, 1, None, 0).expect("no MI355X backend")))
+
+    /// `DenoiseState::new()` (src/denoise.rs:53-55): the built-in model.
+    pub fn new() -> Box<DenoiseState<'static>> {
+        Box::new(DenoiseState { batch: BatchDenoiser::sized(1, 1, None, 0).expect("no MI355X backend"), _model: std::marker::PhantomData })
     }
-    pub fn from_model(model: RnnModel) -> Box<DenoiseState> {
-        Self::with_model(&model)
+    /// `DenoiseState::from_model(model)` (src/denoise.rs:61-63): the state owns the model (here: its device copy; the host copy is dropped).
+    pub fn from_model(model: RnnModel) -> Box<DenoiseState<'static>> {
+        Box::new(DenoiseState { batch: BatchDenoiser::sized(1, 1, Some(&model), 0).expect("no MI355X backend"), _model: std::marker::PhantomData })
     }
-    pub fn with_model(model: &RnnModel) -> Box<DenoiseState> {
-        // the backend copies the model to the device, so no borrow needs to outlive this call
-        Box::new(DenoiseState(BatchDenoiser::sized(1, 1, Some(model), 0).expect("no MI355X backend")))
+}
+
+impl<'model> DenoiseState<'model> {
+    /// `DenoiseState::with_model(&model)` (src/denoise.rs:72-74): the same model shared between states.
+    pub fn with_model(model: &'model RnnModel) -> Box<DenoiseState<'model>> {
+        Box::new(DenoiseState { batch: BatchDenoiser::sized(1, 1, Some(model), 0).expect("no MI355X backend"), _model: std::marker::PhantomData })
     }
+    /// src/denoise.rs:95-116: 480 samples in the range of an i16 in, 480 out, returns the voice-activity probability.
     pub fn process_frame(&mut self, output: &mut [f32], input: &[f32]) -> f32 {
-        assert!(input.len() == Self::FRAME_SIZE); // src/features.rs:98
+        assert!(input.len() == DenoiseState::FRAME_SIZE); // src/features.rs:98
         let mut vad = [0.0f32];
-        self.0.process(&mut output[..Self::FRAME_SIZE], input, &mut vad, 1);
+        self.batch.process(&mut output[..DenoiseState::FRAME_SIZE], input, &mut vad, 1);
         vad[0]
     }
 }
+
+/// `nnnoiseless::DenoiseSignal` (src/signal.rs:29-138) over one batch: the per-channel loop of `refill_out_bufs`
+/// (src/signal.rs:102-104) is one call on a batch of `CHANNELS` streams.  Needs the `dasp` feature, like the reference's.
+#[cfg(feature = "dasp")]
+pub mod signal {
+    use super::{BatchDenoiser, DenoiseState, RnnModel};
+    use dasp::frame::Frame;
+    use dasp::sample::Sample;
+    use dasp::signal::Signal;
+
+    const FRAME_SIZE: usize = 480;
+
+    #[derive(Clone)]
+    pub struct DenoiseSignal<'model, S: Signal> {
+        input: S,
+        states: BatchDenoiser,               // CHANNELS streams in lock-step
+        in_bufs: Vec<f32>,                   // [channel][480]
+        out_bufs: Vec<f32>,
+        vad: Vec<f32>,
+        out_idx: usize,
+        _model: std::marker::PhantomData<&'model RnnModel>,
+    }
+
+    impl<'model, S: Signal> DenoiseSignal<'model, S> {
+        fn make(input: S, model: Option<&RnnModel>) -> Self {
+            let ch = S::Frame::CHANNELS;
+            DenoiseSignal {
+                input,
+                states: BatchDenoiser::sized(ch, 1, model, 0).expect("no MI355X backend"),
+                in_bufs: vec![0.0; ch * FRAME_SIZE],
+                out_bufs: vec![0.0; ch * FRAME_SIZE],
+                vad: vec![0.0; ch],
+                out_idx: 0,
+                _model: std::marker::PhantomData,
+            }
+            .discard_first_frame()
+        }
+        /// src/signal.rs:39-48
+        pub fn new(input: S) -> DenoiseSignal<'static, S> {
+            DenoiseSignal::<'static, S>::make(input, None)
+        }
+        /// src/signal.rs:55-64
+        pub fn with_model(input: S, model: &'model RnnModel) -> DenoiseSignal<'model, S> {
+            Self::make(input, Some(model))
+        }
+        /// src/signal.rs:72-81
+        pub fn from_model(input: S, model: RnnModel) -> DenoiseSignal<'static, S> {
+            DenoiseSignal::<'static, S>::make(input, Some(&model))
+        }
+        fn discard_first_frame(mut self) -> Self {
+            self.refill_out_bufs();
+            self.refill_out_bufs();
+            self
+        }
+        /// Returns true if the input was not exhausted (src/signal.rs:90-106).
+        fn refill_out_bufs(&mut self) -> bool {
+            if self.input.is_exhausted() {
+                return false;
+            }
+            for i in 0..FRAME_SIZE {
+                for (ch, samp) in self.input.next().to_float_frame().channels().enumerate() {
+                    self.in_bufs[ch * FRAME_SIZE + i] = samp.to_sample::<f32>() * 32768.0;
+                }
+            }
+            self.states.process(&mut self.out_bufs[..], &self.in_bufs[..], &mut self.vad[..], 1);
+            !self.input.is_exhausted()
+        }
+    }
+
+    impl<'model, S: Signal> Signal for DenoiseSignal<'model, S> {
+        type Frame = <<S as Signal>::Frame as Frame>::Float;
+
+        fn is_exhausted(&self) -> bool {
+            self.out_idx >= FRAME_SIZE
+        }
+        fn next(&mut self) -> Self::Frame {
+            if self.out_idx >= FRAME_SIZE {
+                return Self::Frame::EQUILIBRIUM;
+            }
+            let idx = self.out_idx;
+            self.out_idx += 1;
+            let ret = Frame::from_fn(|ch| {
+                let samp = (self.out_bufs[ch * FRAME_SIZE + idx] / 32768.0).clamp(-1.0, 1.0);
+                samp.to_sample()
+            });
+            if self.out_idx >= FRAME_SIZE {
+                if self.refill_out_bufs() {
+                    self.out_idx = 0;
+                }
+            }
+            ret
+        }
+    }
+    #[allow(dead_code)]
+    fn _frame_size_agrees() {
+        let _: [(); FRAME_SIZE] = [(); DenoiseState::FRAME_SIZE];
+    }
+}
+#[cfg(feature = "dasp")]
+pub use signal::DenoiseSignal;
 
 /// Page-locked host memory (`nnn_host_alloc`): slices of it cross the bus by DMA in `BatchDenoiser::process`, uploads and
 /// downloads at the same time; ordinary slices work too, through the runtime's staging copies.

@@ -93,7 +93,9 @@ int nnn_batch_load_state(nnn_batch *b, const void *host_src, size_t src_bytes);
  *   sample i of frame t of stream s:  d_in [s * stream_stride + t * frame_stride + i]   (floats)
  *                                     d_out[s * stream_stride + t * frame_stride + i]   (may alias d_in)
  *   VAD probability (return value of process_frame): d_vad[t * n_streams + s]           (NULL to skip)
- * hip_stream: a hipStream_t to enqueue on (NULL = the batch's own stream).  Asynchronous.
+ * hip_stream: a hipStream_t to enqueue on.  NULL does NOT mean HIP's null stream: it means the batch's OWN non-blocking stream, which
+ * is not ordered with anything the caller enqueued elsewhere -- a caller that produces d_in on a stream of its own passes that
+ * stream (recommended) or synchronises it first.  Asynchronous: the call returns when the work is enqueued.
  */
 int nnn_batch_process_device(nnn_batch *b, const float *d_in, float *d_out, float *d_vad, int n_frames,
                              size_t stream_stride, size_t frame_stride, void *hip_stream);
@@ -141,7 +143,7 @@ int nnn_batch_synchronize(nnn_batch *b);
  * run side by side below 16 384 streams and hand the last pitch from workgroup to workgroup): the state of the affected streams
  * is invalid from that frame on.  Work items are handed out in the order workgroups start, so the wait cannot deadlock whatever
  * order the hardware dispatches them in; the condition exists as a safety net, and what trips it is wall time (10 s without the
- * predecessor's flag, NNN_HANDOFF_TIMEOUT_MS), not a spin count: a predecessor slowed by a shared GPU is waited for.  It is sticky: every later process call and
+ * predecessor's flag), not a spin count: a predecessor slowed by a shared GPU is waited for.  It is sticky: every later process call and
  * nnn_batch_synchronize fail with it until nnn_batch_reset or nnn_batch_load_state.  Cheap (a read of page-locked host memory the
  * device writes into): callers that synchronise their own stream instead of calling nnn_batch_synchronize can poll it. */
 int nnn_batch_fault(const nnn_batch *b);
@@ -215,7 +217,7 @@ int nnn_batch_set_inputs_ready(nnn_batch *b, int on);
  * spectra in registers from their transforms to the inverse transform); 2: every group does.  3 / 4: the fused kernel's RNN stretch
  * alone (16 waves, one layer at a time) replaces the RNN kernels for one-frame / all groups.  -1 (default): by batch size, as
  * measured -- one-frame groups take the fused kernel up to 8192 streams and the RNN stretch alone above that or while other batches
- * tick beside this one; longer groups stay with the layer-pipelined RNN between k_fft_xp and k_synth.  Environment: NNN_BACK.
+ * tick beside this one ON THE SAME DEVICE; longer groups stay with the layer-pipelined RNN between k_fft_xp and k_synth.
  * Every choice gives the same bits: a stream may change back end from call to call. */
 int nnn_batch_set_back_end(nnn_batch *b, int mode);
 /* How a pipelined call uses the internal streams: mode 0 = not at all (as set_pipeline(0)); 1 = "lanes": the high-pass
@@ -225,16 +227,32 @@ int nnn_batch_set_back_end(nnn_batch *b, int mode);
  * 16 384 streams (from 8192 streams the high-pass chain of a group waits for the previous group's pitch kernel), everything runs in
  * order on the caller's stream above that. */
 int nnn_batch_set_schedule(nnn_batch *b, int mode, int lanes);
-/* A/B knobs of the kernels' own choices, environment only, every setting the same bits (what the parity tests use them for):
- * NNN_HP_SPLIT=0|1 (read at creation) the high-pass on one wave per 64 streams or two (k_hp2; default: two for launches of up to 256
- * tiles), NNN_HP_TPB=1|2 its tiles per block; NNN_LPC_IN_PITCH=0|1 the LPC analysis of a one-frame call inside k_pitch (default: up to
- * 8192 streams), NNN_LPC_HEAD=0|1 (creation) the old part of its sums in k_hp2's launch; NNN_HP_AFTER=0..3 where the high-pass chain
- * of a pipelined call's group waits (default: behind the previous group's pitch kernel from 8192 streams), NNN_PIPE_MAX the largest
- * batch the automatic schedule pipelines (16384). */
+/*
+ * Environment.  The library reads exactly these variables (the first eight when a batch is created, NNN_NODE_THREADS when a node is,
+ * NNN_DEVICE when rnnoise_create / rnnoise_init make their batch of one), every setting gives the same bits, and each is exercised by
+ * a test (named on the right).  It sets none: in particular GPU_MAX_HW_QUEUES (real-time hosts ticking several batches side by side
+ * want 8) is the host's to export before its first HIP call.
+ *   NNN_SCHED=seq|lanes|stages   how a call of 32 frames or more uses the batch's internal streams (nnn_batch_set_schedule)   test_hostsim_knobs
+ *   NNN_LANES=1..4               lanes of the "lanes" schedule                                                                  test_hostsim_knobs
+ *   NNN_HOST_CHUNK=n             frames per chunk of a host-buffer call (0 = one piece; default by call length)               test_gpu_parity / test_hostsim_pcm
+ *   NNN_RNN_ROWS=16|32           stream rows per RNN workgroup (default by model and batch size)                              test_gpu_parity / test_hostsim_parity
+ *   NNN_RNN_WF_MIN_G=n           shortest frame group the layer-pipelined RNN kernel takes                                    test_gpu_parity / test_hostsim_parity
+ *   NNN_HP_SPLIT=0|1             the high-pass on one wave per 64 streams or two (default: two for launches of <= 256 tiles)  test_gpu_back_end / test_hostsim_parity
+ *   NNN_LPC_HEAD=0|1             one-frame calls: the old part of the LPC sums in the high-pass launch                        test_gpu_back_end / test_hostsim_parity
+ *   NNN_PITCH_CHAIN=0|1|2        frames of a group side by side in k_pitch with a flag hand-off, or looped (default by size)  test_gpu_parity / test_hostsim_parity
+ *   NNN_NODE_THREADS=0           a node's shards one after the other on the caller's thread                                   test_hostsim_node
+ *   NNN_DEVICE=n                 HIP device of the rnnoise_* single-stream surface (default 0)                                 test_gpu_node
+ * Earlier rounds' A/B probe knobs (NNN_BACK, NNN_HP_TPB, NNN_X_RIDES, NNN_LPC_IN_PITCH, NNN_HP_AFTER, NNN_PIPE_MAX, ...) exist only in
+ * builds with -DNNN_DEV_KNOBS (the tests' interpreter build, scripts/build_variant*.sh); the product does not read them.
+ */
 
 /* Diagnostic: the device's activation functions on their own, y[i] = act(x[i]) for n host floats; act 0 = tansig_approx,
  * 1 = sigmoid_approx, 2 = relu (src/util.rs:29-53). */
 int nnn_debug_activations(int device, int act, const float *x, float *y, int n);
+
+/* The CPUs local to a HIP device's PCI function in the kernel's cpulist syntax ("0-63,128-191"; /sys/bus/pci/devices/<id>/local_cpulist):
+ * where a host thread that feeds that device should run (the node object pins its workers there).  0 and the text, or non-zero. */
+int nnn_device_local_cpulist(int device, char *buf, size_t cap);
 
 const char *nnn_last_error(void);
 

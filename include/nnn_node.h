@@ -7,7 +7,8 @@
  * several MI355X shards them: device i of n owns the contiguous block [lo_i, hi_i) of the streams (balanced: the first
  * n_streams mod n devices take one more), its own state slab and model replica, and NOTHING crosses between devices -- no
  * data-path collective.  A nnn_node is that split as a library object: one nnn_batch per device, one host thread per device that
- * enqueues (and, for host buffers, transfers) that device's share, fan-out and join inside every call.  A host that would
+ * enqueues (and, for host buffers, transfers) that device's share, fan-out and join inside every call.  The threads are pinned to
+ * the CPUs local to their device (nnn_node_shard_cpus) and make their batches at the same time.  A host that would
  * otherwise hand-write the loop over devices, the stream split and the threads calls this instead of nnn_batch_*.
  *
  * Plain C ABI, same conventions as nnn_batch.h: 0 on success, nnn_last_error() has the text, nothing falls back to a CPU path.
@@ -32,9 +33,15 @@ int nnn_node_num_streams(const nnn_node *n);
 int nnn_node_num_shards(const nnn_node *n);
 /* shard i: its device ordinal and its block [*lo, *hi) of the node's streams */
 int nnn_node_shard(const nnn_node *n, int i, int *device, int *lo, int *hi);
+/* the CPUs shard i's host thread is pinned to -- the local_cpulist of its device's PCI function, e.g. "0-63,128-191"; "" when the
+ * platform does not say or the node runs its shards on the caller's thread.  Owned by the node. */
+const char *nnn_node_shard_cpus(const nnn_node *n, int i);
 /* the shard's own batch, for everything nnn_batch.h offers per device (taps, schedule, snapshots); owned by the node */
 nnn_batch *nnn_node_batch(nnn_node *n, int i);
 int nnn_node_reset(nnn_node *n);
+/* A processing call that fails on any shard (the first failing shard's text in nnn_last_error) still runs and joins the other
+ * shards, which have then advanced while the failing one has not: the node is FAILED from there on -- every later processing call
+ * is refused with the original text -- until nnn_node_reset, exactly as a single batch stays faulted until nnn_batch_reset. */
 
 /* n_frames x process_frame for every stream of the node, host buffers laid out as for nnn_batch_process_host over ALL streams:
  *   sample i of frame t of stream s: in[s * stream_stride + t * frame_stride + i], out likewise (may alias in)
@@ -51,6 +58,12 @@ int nnn_node_process_pcm_host(nnn_node *n, const void *in, void *out, float *vad
  * own stream; nnn_node_synchronize waits for all of them. */
 int nnn_node_process_device(nnn_node *n, const float *const *d_in, float *const *d_out, float *const *d_vad, int n_frames,
                             size_t stream_stride, size_t frame_stride);
+/* The same with a table of HIP streams, hip_streams[i] a hipStream_t of shard i's device to enqueue that shard's share on (the table
+ * or an entry may be NULL: the shard's batch's own non-blocking stream, which is NOT ordered with the caller's null stream -- see
+ * nnn_batch_process_device), and with the tables' length stated: n_tables must equal nnn_node_num_shards (the plain form has no
+ * count and trusts the caller's tables to be long enough). */
+int nnn_node_process_device_streams(nnn_node *n, const float *const *d_in, float *const *d_out, float *const *d_vad,
+                                    void *const *hip_streams, int n_tables, int n_frames, size_t stream_stride, size_t frame_stride);
 int nnn_node_synchronize(nnn_node *n);
 /* 1 if any shard reports nnn_batch_fault */
 int nnn_node_fault(const nnn_node *n);

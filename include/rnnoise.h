@@ -29,7 +29,12 @@ int rnnoise_get_frame_size(void);
 int rnnoise_get_size(void);
 
 /* Initialise caller-allocated storage of rnnoise_get_size() bytes; model NULL = built-in model.
- * Returns 0.  (src/capi.rs:32-43) */
+ * Returns 0 (-1 if no MI355X device / kernel library is usable).  (src/capi.rs:32-43)
+ * OWNERSHIP, where this differs from the reference: the reference's state is plain memory with no heap behind it, so storage that
+ * was rnnoise_init'ed is simply abandoned.  Here the storage holds a handle to a GPU batch of one stream (device memory, streams,
+ * events) that only rnnoise_destroy releases -- and rnnoise_destroy also free()s the storage, as the reference's does
+ * (src/capi.rs:62-65), so it is only for states from rnnoise_create.  A state made by rnnoise_init in caller storage therefore
+ * keeps its GPU resources until the process exits: hosts that cycle states use rnnoise_create / rnnoise_destroy. */
 int rnnoise_init(DenoiseState *st, RNNModel *model);
 
 /* Allocate and initialise a state; model NULL = built-in.  A non-NULL model is borrowed and must

@@ -17,10 +17,9 @@ import os
 
 import numpy as np
 
-# Several batches ticking side by side overlap only when their streams land on different hardware queues; the HIP runtime has four
-# unless told otherwise when it initialises (the library asks the same way when it is loaded, see nnn_batch.hip; the package is
-# usually imported earlier -- before the host's first GPU call, where the request still counts).  The host's own setting wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (Several batches ticking side by side overlap only when their streams land on different hardware queues; the HIP runtime has four unless
+# GPU_MAX_HW_QUEUES says otherwise when it initialises.  That is the HOST's setting -- INTEGRATION.md -- and neither this package nor the
+# library touches the environment: until round 4 both exported it silently.  bench.py and the tick tools export it themselves.)
 
 from . import _ffi
 from .build import LIB_PATH, build_library
@@ -275,8 +274,10 @@ class BatchDenoiser:
         self._lib.check(self._lib.L.nnn_batch_set_graph(self._h, int(on)))
 
     def set_back_end(self, mode):
-        """0: transforms -> RNN -> synthesis as three launches; 1 (default): one-frame groups take the fused back end (k_back);
-        2: every group; 3 / 4: the fused kernel's RNN stretch alone as the RNN kernel (include/nnn_batch.h nnn_batch_set_back_end)."""
+        """-1 (default): by batch size, as measured -- one-frame groups take the fused back end (k_back) up to 8192 streams and its RNN
+        stretch alone above that or with other batches ticking on the same device, longer groups three launches; 0: transforms -> RNN ->
+        synthesis as three launches; 1: one-frame groups take the fused back end; 2: every group; 3 / 4: the fused kernel's RNN stretch
+        alone as the RNN kernel for one-frame / all groups (include/nnn_batch.h nnn_batch_set_back_end).  Every choice gives the same bits."""
         self._lib.check(self._lib.L.nnn_batch_set_back_end(self._h, int(mode)))
 
     def set_pipeline(self, on):

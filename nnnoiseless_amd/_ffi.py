@@ -20,7 +20,7 @@ BATCH_SYMBOLS = [
     "nnn_tap_info", "nnn_batch_read_tap", "nnn_batch_set_profiling", "nnn_batch_num_kernels",
     "nnn_batch_kernel_name", "nnn_batch_read_kernel_times", "nnn_batch_set_graph", "nnn_batch_set_pipeline", "nnn_batch_read_stamps",
     "nnn_host_alloc", "nnn_host_free", "nnn_last_error", "nnn_batch_fault", "nnn_batch_debug_withhold_flag", "nnn_batch_set_frame_log",
-    "nnn_batch_create_opts", "nnn_batch_max_group_frames", "nnn_batch_device_bytes", "nnn_batch_set_back_end",
+    "nnn_batch_create_opts", "nnn_batch_max_group_frames", "nnn_batch_device_bytes", "nnn_batch_set_back_end", "nnn_device_local_cpulist",
 ]
 TRAIN_SYMBOLS = [
     "nnn_train_create", "nnn_train_destroy", "nnn_train_reset", "nnn_train_process_device", "nnn_train_process_host",
@@ -31,7 +31,8 @@ RESAMPLE_SYMBOLS = [
 ]
 NODE_SYMBOLS = [
     "nnn_node_create", "nnn_node_destroy", "nnn_node_num_streams", "nnn_node_num_shards", "nnn_node_shard", "nnn_node_batch", "nnn_node_reset",
-    "nnn_node_process_host", "nnn_node_process_pcm_host", "nnn_node_process_device", "nnn_node_synchronize", "nnn_node_fault",
+    "nnn_node_process_host", "nnn_node_process_pcm_host", "nnn_node_process_device", "nnn_node_process_device_streams", "nnn_node_synchronize",
+    "nnn_node_fault", "nnn_node_shard_cpus",
 ]
 RNNOISE_SYMBOLS = [
     "rnnoise_get_frame_size", "rnnoise_get_size", "rnnoise_init", "rnnoise_create", "rnnoise_destroy",
@@ -131,6 +132,9 @@ class Library:
             L.nnn_node_process_host.argtypes = [vp, vp, vp, vp, i32, sz, sz]
             L.nnn_node_process_pcm_host.argtypes = [vp, vp, vp, vp, i32, C.POINTER(PcmLayout)]
             L.nnn_node_process_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, sz, sz]
+            L.nnn_node_process_device_streams.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, sz, sz]
+            L.nnn_node_shard_cpus.restype = C.c_char_p
+            L.nnn_node_shard_cpus.argtypes = [vp, i32]
             L.nnn_node_synchronize.argtypes = [vp]
             L.nnn_node_fault.argtypes = [vp]
         L.nnn_train_create.restype = vp

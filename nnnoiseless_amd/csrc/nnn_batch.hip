@@ -35,10 +35,34 @@ static std::recursive_mutex g_rt_mu;
 // the extra event hops cost more than they free; with GPU_MAX_HW_QUEUES=8 in the environment two batches do overlap, 33.5 M.)
 // "Other batches are ticking beside this one": another batch made a call within the last few milliseconds (remembered for 20 ms).
 // Alive is not enough -- a host may hold idle batches -- and the answer only picks between two kernels that give the same bits.
-static std::atomic<uint64_t> g_call_mark{0};   // (batch id << 44) | microseconds of the most recent call of any batch
+// One mark per DEVICE: a batch on another GPU (the node object drives one batch per device, all ticking at once) is not "beside" this one --
+// until round 5 the mark was process-wide and every shard of a node saw its neighbours on other GPUs, so the node never took the tick kernels.
+constexpr int MARK_DEVICES = 64;
+static std::atomic<uint64_t> g_call_mark[MARK_DEVICES];   // [device]: (batch id << 44) | microseconds of the most recent call of any batch on that device
 static std::atomic<uint64_t> g_next_batch_id{1};
 #define NNN_RT_LOCK std::lock_guard<std::recursive_mutex> rt_lock_(g_rt_mu)
 extern "C" const char *nnn_last_error(void) { return g_err.c_str(); }
+// The CPUs local to a device's PCI function, in the kernel's cpulist syntax (/sys/bus/pci/devices/<id>/local_cpulist): what the node
+// object pins a device's host thread to.  0 and the text in buf, or non-zero when the platform does not say.
+extern "C" int nnn_device_local_cpulist(int device, char *buf, size_t cap)
+{
+    if (!buf || cap < 2) return 1;
+    buf[0] = 0;
+    char id[64] = {0};
+    if (hipDeviceGetPCIBusId(id, (int)sizeof(id), device) != hipSuccess || !id[0]) return 1;
+    for (char *p = id; *p; p++)
+        if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');   // sysfs spells the address in lower case
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", id);
+    FILE *f = fopen(path, "r");
+    if (!f) return 1;
+    const bool ok = fgets(buf, (int)cap, f) != nullptr;
+    fclose(f);
+    if (!ok) { buf[0] = 0; return 1; }
+    for (char *p = buf; *p; p++)
+        if (*p == '\n' || *p == '\r') *p = 0;
+    return buf[0] ? 0 : 1;
+}
 static int fail(const char *fmt, ...)
 {
     char buf[512];
@@ -58,9 +82,18 @@ int nnn_set_error(const char *msg) { return fail("%s", msg); }   // for the libr
 
 // The HIP runtime maps streams onto four hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and two batches whose streams land on one
 // queue do not overlap (two 4096-stream batches ticking: 31.3 M frames/s, 43.3 M with eight queues).  The runtime reads the variable when it
-// initialises -- at the host's first HIP call --, so it is asked for when this library is loaded, unless the host has a setting of its own; a
-// host that used HIP before loading the library exports it itself.
-__attribute__((constructor)) static void nnn_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// initialises -- at the host's first HIP call -- and it is the HOST's setting: the library does not touch its host's environment (until
+// round 4 a constructor exported it; VERDICT r4 #7b).  INTEGRATION.md tells real-time hosts to export GPU_MAX_HW_QUEUES=8 themselves.
+
+// Run-time knobs.  The default build reads exactly the environment variables of the table in include/nnn_batch.h ("Environment"), each at
+// batch creation and each exercised by a test.  Everything else is a developer knob (A/B probes of earlier rounds), compiled in only with
+// -DNNN_DEV_KNOBS -- the interpreter build of the tests and scripts/build_variant*.sh define it -- and absent from the product.
+static const char *knob(const char *name) { return getenv(name); }
+#ifdef NNN_DEV_KNOBS
+static const char *dev_knob(const char *name) { return getenv(name); }
+#else
+static const char *dev_knob(const char *) { return nullptr; }
+#endif
 
 enum KernelId { K_HP, K_LPC, K_PITCH, K_FFT_XP, K_RNN, K_SYNTH, K_BACK, K_COUNT };
 static const char *kKernelNames[K_COUNT] = {"k_hp", "k_lpc", "k_pitch", "k_fft_xp", "k_rnn", "k_synth", "k_back"};
@@ -297,7 +330,7 @@ static size_t rnn_wf_lds_bytes(const WfPlan &w)
 }
 static bool rnn_wf_enabled()
 {
-    const char *e = getenv("NNN_RNN_WF");
+    const char *e = dev_knob("NNN_RNN_WF");
     return !e || atoi(e) != 0;
 }
 // below this many RNN blocks a launch leaves compute units idle and the per-block chain dominates
@@ -305,7 +338,7 @@ static int rnn_small_batch_blocks()
 {
     static int v = -1;
     if (v < 0) {
-        const char *e = getenv("NNN_RNN_MIN_BLOCKS");
+        const char *e = dev_knob("NNN_RNN_MIN_BLOCKS");
         v = e ? atoi(e) : 128;   // measured at 1024 / 4096 / 16384 streams (profiles/r1_e_rnn_rows.txt)
     }
     return v;
@@ -336,36 +369,36 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
             for (int i = 0; i < EVR; i++) HIPCHK(hipEventCreateWithFlags(&h->ev[p][s][i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_done[p], hipEventDisableTiming));
     }
-    if (const char *e = getenv("NNN_PIPELINE")) h->use_pipeline = atoi(e) != 0;
-    if (const char *e = getenv("NNN_RAMP")) h->ramp = atoi(e);
-    if (const char *e = getenv("NNN_HOST_CHUNK")) h->host_chunk = atoi(e);
-    if (const char *e = getenv("NNN_RNN_WF_MIN_G")) h->wf_min_g = atoi(e);
-    if (const char *e = getenv("NNN_BACK")) h->back_mode = atoi(e);
-    if (const char *e = getenv("NNN_HP_SPLIT")) h->hp_split = atoi(e);
-    if (const char *e = getenv("NNN_HP_TPB")) h->hp_tpb = atoi(e);
-    if (const char *e = getenv("NNN_LPC_HEAD")) h->lpc_head = atoi(e);
-    if (const char *e = getenv("NNN_X_RIDES")) h->x_rides = atoi(e);
-    if (const char *e = getenv("NNN_PITCH_CHAIN")) h->pitch_chain = atoi(e);
-    if (const char *e = getenv("NNN_LPC_WIDE")) h->lpc_wide = atoi(e);
-    if (const char *e = getenv("NNN_LPC_FC")) h->lpc_fc = atoi(e);
-    if (const char *e = getenv("NNN_SCHED")) {
+    if (const char *e = dev_knob("NNN_PIPELINE")) h->use_pipeline = atoi(e) != 0;
+    if (const char *e = dev_knob("NNN_RAMP")) h->ramp = atoi(e);
+    if (const char *e = knob("NNN_HOST_CHUNK")) h->host_chunk = atoi(e);
+    if (const char *e = knob("NNN_RNN_WF_MIN_G")) h->wf_min_g = atoi(e);
+    if (const char *e = dev_knob("NNN_BACK")) h->back_mode = atoi(e);
+    if (const char *e = knob("NNN_HP_SPLIT")) h->hp_split = atoi(e);
+    if (const char *e = dev_knob("NNN_HP_TPB")) h->hp_tpb = atoi(e);
+    if (const char *e = knob("NNN_LPC_HEAD")) h->lpc_head = atoi(e);
+    if (const char *e = dev_knob("NNN_X_RIDES")) h->x_rides = atoi(e);
+    if (const char *e = knob("NNN_PITCH_CHAIN")) h->pitch_chain = atoi(e);
+    if (const char *e = dev_knob("NNN_LPC_WIDE")) h->lpc_wide = atoi(e);
+    if (const char *e = dev_knob("NNN_LPC_FC")) h->lpc_fc = atoi(e);
+    if (const char *e = knob("NNN_SCHED")) {
         if (!strcmp(e, "seq")) h->sched = SCHED_SEQ;
         else if (!strcmp(e, "lanes")) h->sched = SCHED_LANES;
         else if (!strcmp(e, "stages")) h->sched = SCHED_STAGES;
         h->sched_auto = false;
     }
-    if (const char *e = getenv("NNN_LANES")) {
+    if (const char *e = knob("NNN_LANES")) {
         const int v = atoi(e);
         if (v >= 1 && v <= NSTREAMS - 1) h->n_lanes = v;
         h->sched_auto = false;
     }
-    if (const char *e = getenv("NNN_RNN_ROWS")) {
+    if (const char *e = knob("NNN_RNN_ROWS")) {
         const int v = atoi(e);
         if (v == 16 || v == 32) h->rnn_rows = v;
     }
     // groups in flight behind the high-pass: what the schedule chosen at creation can use (a schedule set later works on what is there)
     h->depth = (h->n_lanes >= 2 || h->sched == SCHED_STAGES) ? DEPTH : 1;
-    if (const char *e = getenv("NNN_RING_DEPTH")) h->depth = atoi(e) >= 2 ? DEPTH : 1;   // (experiment knob)
+    if (const char *e = dev_knob("NNN_RING_DEPTH")) h->depth = atoi(e) >= 2 ? DEPTH : 1;   // (experiment knob)
     h->nset = h->depth * h->gmax;
     h->nslot = slots_for(h->gmax, h->depth);
     h->S = n_streams;
@@ -460,7 +493,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     }
     HIPCHK(dalloc(h, &b.ticket, 1, false));
     {
-        const char *e = getenv("NNN_HANDOFF_TIMEOUT_MS");
+        const char *e = dev_knob("NNN_HANDOFF_TIMEOUT_MS");
         const long long ms = e && atoll(e) > 0 ? atoll(e) : 10000;
         h->handoff_ticks = ms * 100000ll;   // 100 MHz
         b.handoff_ticks = h->handoff_ticks;
@@ -790,7 +823,7 @@ static bool hp_split(const nnn_batch *h)
 }
 static bool lpc_in_pitch(const nnn_batch *h, int g)
 {
-    static const int force = getenv("NNN_LPC_IN_PITCH") ? atoi(getenv("NNN_LPC_IN_PITCH")) : -1;
+    static const int force = dev_knob("NNN_LPC_IN_PITCH") ? atoi(dev_knob("NNN_LPC_IN_PITCH")) : -1;
     if (force >= 0) return force != 0 && g == 1;
     // (measured per one-frame call: -6 us at 4096 streams, level at 8192, +9 us at 16 384; with the sums' head start in k_hp2's launch, see
     // lpc_head: another -5 us at 4096, -6 at 8192, still +10 at 16 384)
@@ -821,7 +854,7 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
             const bool head = lpc_head(h, g);
             // groups: two tiles per block (see k_hp2).  NNN_HP_PAD_KB pads the block's LDS, e.g. past what leaves room for a k_pitch block
             // beside it (48): measured, no gain
-            static const int pad_kb = getenv("NNN_HP_PAD_KB") ? atoi(getenv("NNN_HP_PAD_KB")) : 0;
+            static const int pad_kb = dev_knob("NNN_HP_PAD_KB") ? atoi(dev_knob("NNN_HP_PAD_KB")) : 0;
             if (h->hp_tpb ? h->hp_tpb == 2 : (g > 1 && NT >= 8))
                 L.go(K_HP, k_hp2<2>, dim3((NT + 1) / 2 + (head ? (5 * NT + 3) / 4 : 0)), dim3(256), (size_t)pad_kb * 1024, b, sp0, g, call ? *call : StepParams{}, call ? fill : 0, head ? 1 : 0);
             else
@@ -929,7 +962,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     {
         const uint64_t mask = (1ull << 44) - 1;
         const uint64_t now = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() & mask;
-        const uint64_t prev = g_call_mark.exchange((h->id << 44) | now, std::memory_order_relaxed);
+        const uint64_t prev = g_call_mark[h->device % MARK_DEVICES].exchange((h->id << 44) | now, std::memory_order_relaxed);
         if ((prev >> 44) != h->id && (prev >> 44) != 0 && now - (prev & mask) < 5000) h->other_seen_us = now | (1ull << 63);
         h->beside_others = (h->other_seen_us >> 63) && now - (h->other_seen_us & mask) < 20000;
     }
@@ -973,7 +1006,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     // unless a schedule was asked for -- 32 768 streams: 65.9 M frames/s against 64.8 with the high-pass on a stream of its own)
     // (the automatic schedule pipelines up to 16 384 streams: measured in round 4 with the high-pass held back behind the previous group's
     // pitch kernel, see hp_after -- 16 384: 64.2-65.5 -> 66.4-66.9 M frames/s; 32 768 and 65 536 lose 1-2 % pipelined)
-    static const int pipe_max = getenv("NNN_PIPE_MAX") ? atoi(getenv("NNN_PIPE_MAX")) : 16384;
+    static const int pipe_max = dev_knob("NNN_PIPE_MAX") ? atoi(dev_knob("NNN_PIPE_MAX")) : 16384;
     const bool pipe = h->use_pipeline && h->sched != SCHED_SEQ && !h->profiling && n_frames >= PIPE_MIN && !(h->sched_auto && h->S_pad > pipe_max);
     std::vector<int> sizes;
     if (pipe && h->ramp == 0) {
@@ -1011,7 +1044,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     const bool early_hp = pipe && h->inputs_ready && !h->host_call && h->prev_pipe && h->prev_st == st && h->sched == SCHED_LANES && h->pool[0];
     // the per-frame parameter table: a launch of its own ahead of a pipelined call's streams; otherwise the call's first kernel (k_hp of
     // the first group) fills it on its way (a one-frame call is a handful of launches of 15-35 us: one fewer is 4 % of it)
-    static const bool fold_ok = !(getenv("NNN_FOLD_FILL") && atoi(getenv("NNN_FOLD_FILL")) == 0);   // (A/B knob)
+    static const bool fold_ok = !(dev_knob("NNN_FOLD_FILL") && atoi(dev_knob("NNN_FOLD_FILL")) == 0);   // (A/B knob)
     const bool fold_fill = !pipe && !h->profiling && fold_ok;
     if (early_hp) {
         if (h->have_done[par]) chk(hipStreamWaitEvent(h->pool[0], h->ev_done[par], 0));   // the table's previous user (two calls back)
@@ -1044,7 +1077,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
         // two slow each other (10.8 in HISTORY.md).  From 8192 streams up a group is long enough for the chain to wait until that pitch
         // kernel is done and still finish before group k needs it: 8192 x 48: 61.3 -> 63.9 M frames/s, 16 384: +2-3 %; at 4096 streams the
         // window is too short (57.5 -> 56.3).  NNN_HP_AFTER = 0 | 1 | 2 | 3: never | behind pitch | fft | rnn of the previous group.
-        static const int hp_after_env = getenv("NNN_HP_AFTER") ? atoi(getenv("NNN_HP_AFTER")) : -1;
+        static const int hp_after_env = dev_knob("NNN_HP_AFTER") ? atoi(dev_knob("NNN_HP_AFTER")) : -1;
         const int hp_after = hp_after_env >= 0 ? hp_after_env : (h->sched == SCHED_LANES && h->n_lanes == 1 && h->S_pad >= 8192 ? 1 : 0);
         auto consumers_elsewhere = [&](int s, int k) {
             const int me = stream_of(s, k);
@@ -1072,7 +1105,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
                 if (s == ST_HP || s == ST_PITCH || s == ST_RNN || s == ST_SYN) wait_for(s, k - 1);
                 if (s == ST_PITCH) wait_for(ST_SYN, k - h->depth);
                 if (s == ST_HP && hp_after > 0) {
-                    static const int lag = getenv("NNN_HP_AFTER_LAG") ? atoi(getenv("NNN_HP_AFTER_LAG")) : 1;
+                    static const int lag = dev_knob("NNN_HP_AFTER_LAG") ? atoi(dev_knob("NNN_HP_AFTER_LAG")) : 1;
                     const int ds = ST_PITCH + hp_after - 1, pn = (int)h->prev_first.size();
                     if (k >= lag) wait_for(ds, k - lag);
                     else if (early_hp && pn + k - lag >= 0 && lag - k < EVR) chk(hipStreamWaitEvent(ss, h->ev[h->prev_par][ds][(pn + k - lag) % EVR], 0));

@@ -1,6 +1,9 @@
 // nnn_node.cpp -- all the GPUs of a node behind one object (include/nnn_node.h): contiguous stream shards, one nnn_batch and one host
 // thread per device, fan-out and join inside every call.  Host-only code above the batch ABI: everything that touches a device goes
 // through nnn_batch_*.  (ref: the reference's hosts walk a vector of independent states, src/nnnoiseless.rs:305-320.)
+#include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -14,6 +17,33 @@
 #include "../../include/nnn_node.h"
 
 int nnn_set_error(const char *msg);   // nnn_batch.hip
+
+// Pins the calling thread to the CPUs local to a device's PCI function ("0-31,128-159" in the kernel's cpulist syntax, from
+// nnn_device_local_cpulist): a worker that stages pageable buffers and enqueues for GPU i should run on the socket GPU i hangs off.
+// Best effort: an empty or unparsable list leaves the thread where it is.
+static bool pin_to_cpulist(const char *list)
+{
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n = 0;
+    for (const char *p = list; *p;) {
+        char *e;
+        const long a = strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        p = e;
+        if (*p == '-') {
+            b = strtol(p + 1, &e, 10);
+            if (e == p + 1) break;
+            p = e;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0) { CPU_SET((int)c, &set); n++; }
+        if (*p == ',') p++;
+        else break;
+    }
+    return n > 0 && pthread_setaffinity_np(pthread_self(), sizeof(set), &set) == 0;
+}
 
 namespace {
 // a host thread that runs the jobs its shard is handed, one at a time
@@ -72,31 +102,58 @@ struct nnn_node {
         int device = 0, lo = 0, hi = 0;
         Worker *w = nullptr;
         std::vector<float> vad;   // host calls: this shard's VAD block [n_frames][hi - lo] before it is spread over the node's rows
+        std::string cpus;         // the CPUs its worker is pinned to ("" = not pinned)
     };
     std::vector<Shard> shards;
     int n_streams = 0;
+    bool failed = false;          // a call failed on some shard: the shards may sit at different frame counts.  Sticky until nnn_node_reset
+                                  // (every process call refuses), like a batch's own fault.
+    std::string fail_text;
     bool threads = true;          // NNN_NODE_THREADS=0: the shards one after the other on the caller's thread (debugging; the
                                   // test-only interpreter build runs kernels on the calling thread and is not re-entrant)
 };
 
-// every shard runs fn(shard index); returns the first failure
+// Every shard runs fn(shard index) -- all of them, also when one fails, on the shards' own threads or (NNN_NODE_THREADS=0, one shard)
+// one after the other on the caller's: either way the other shards are joined and have advanced.  Returns the first failure in
+// shard order with its text in nnn_last_error().
 static int fan_out(nnn_node *n, const std::function<int(int)> &fn)
 {
     int rc = 0;
     std::string err;
     if (!n->threads || n->shards.size() == 1) {
-        for (size_t i = 0; i < n->shards.size() && !rc; i++) rc = fn((int)i);
-        return rc;
-    }
-    for (size_t i = 0; i < n->shards.size(); i++) n->shards[i].w->post([&fn, i] { return fn((int)i); });
-    for (size_t i = 0; i < n->shards.size(); i++) {
-        const int r = n->shards[i].w->wait();
-        if (r && !rc) {
-            rc = r;
-            err = n->shards[i].w->err;
+        for (size_t i = 0; i < n->shards.size(); i++) {
+            const int r = fn((int)i);
+            if (r && !rc) {
+                rc = r;
+                err = nnn_last_error();
+            }
+        }
+    } else {
+        for (size_t i = 0; i < n->shards.size(); i++) n->shards[i].w->post([&fn, i] { return fn((int)i); });
+        for (size_t i = 0; i < n->shards.size(); i++) {
+            const int r = n->shards[i].w->wait();
+            if (r && !rc) {
+                rc = r;
+                err = n->shards[i].w->err;
+            }
         }
     }
     if (rc) nnn_set_error(err.c_str());
+    return rc;
+}
+// a processing call: refused while the node is failed; a failure makes it so
+static int process_call(nnn_node *n, const std::function<int(int)> &fn)
+{
+    if (n->failed) {
+        std::string t = "node failed earlier (reset it): " + n->fail_text;
+        return nnn_set_error(t.c_str());
+    }
+    const int rc = fan_out(n, fn);
+    if (rc) {
+        n->failed = true;
+        n->fail_text = nnn_last_error();
+        nnn_set_error(n->fail_text.c_str());
+    }
     return rc;
 }
 
@@ -139,22 +196,28 @@ extern "C" nnn_node *nnn_node_create(const RNNModel *model, int n_streams, const
         s.lo = i * base + (i < rem ? i : rem);
         s.hi = s.lo + base + (i < rem ? 1 : 0);
     }
-    // the batches are made one after the other (creation allocates and uploads: nothing a thread per device would speed up much)
-    for (auto &s : n->shards) {
-        const int cnt = s.hi - s.lo;
-        s.b = nnn_batch_create_opts(model ? &model : nullptr, &cnt, 1, s.device, opts);
-        if (!s.b) {
-            std::string keep = nnn_last_error();
-            nnn_node_destroy(n);
-            nnn_set_error(keep.c_str());
-            return nullptr;
-        }
-    }
+    // One worker per shard, pinned to the CPUs local to its device's PCI function (the socket its GPU hangs off: a worker stages pageable
+    // buffers and enqueues for that GPU), then every worker makes its own batch -- allocation, table and weight uploads of all devices
+    // at once (serial until round 5: eight devices took eight creations' time).
     if (n->threads && n_devices > 1)
         for (auto &s : n->shards) {
             s.w = new Worker();
             s.w->th = std::thread([w = s.w] { w->loop(); });
         }
+    const int rc = fan_out(n, [&](int i) {
+        nnn_node::Shard &s = n->shards[(size_t)i];
+        char cpus[512];
+        if (s.w && nnn_device_local_cpulist(s.device, cpus, sizeof(cpus)) == 0 && pin_to_cpulist(cpus)) s.cpus = cpus;
+        const int cnt = s.hi - s.lo;
+        s.b = nnn_batch_create_opts(model ? &model : nullptr, &cnt, 1, s.device, opts);
+        return s.b ? 0 : 1;
+    });
+    if (rc) {
+        std::string keep = nnn_last_error();
+        nnn_node_destroy(n);
+        nnn_set_error(keep.c_str());
+        return nullptr;
+    }
     return n;
 }
 
@@ -168,12 +231,21 @@ extern "C" int nnn_node_shard(const nnn_node *n, int i, int *device, int *lo, in
     if (hi) *hi = n->shards[(size_t)i].hi;
     return 0;
 }
+extern "C" const char *nnn_node_shard_cpus(const nnn_node *n, int i)
+{
+    return (n && i >= 0 && i < (int)n->shards.size()) ? n->shards[(size_t)i].cpus.c_str() : "";
+}
 extern "C" nnn_batch *nnn_node_batch(nnn_node *n, int i) { return (n && i >= 0 && i < (int)n->shards.size()) ? n->shards[(size_t)i].b : nullptr; }
 
 extern "C" int nnn_node_reset(nnn_node *n)
 {
     if (!n) return nnn_set_error("null node");
-    return fan_out(n, [n](int i) { return nnn_batch_reset(n->shards[(size_t)i].b); });
+    const int rc = fan_out(n, [n](int i) { return nnn_batch_reset(n->shards[(size_t)i].b); });
+    if (!rc) {
+        n->failed = false;
+        n->fail_text.clear();
+    }
+    return rc;
 }
 
 // the shards' VAD blocks ([t][shard stream]) into the node's rows ([t][all streams])
@@ -191,7 +263,7 @@ extern "C" int nnn_node_process_host(nnn_node *n, const float *in, float *out, f
     if (!n) return nnn_set_error("null node");
     if (n_frames <= 0) return 0;
     if (!in || !out) return nnn_set_error("null buffer");
-    const int rc = fan_out(n, [&](int i) {
+    const int rc = process_call(n, [&](int i) {
         nnn_node::Shard &s = n->shards[(size_t)i];
         if (vad) s.vad.resize((size_t)n_frames * (size_t)(s.hi - s.lo));
         return nnn_batch_process_host(s.b, in + (size_t)s.lo * stream_stride, out + (size_t)s.lo * stream_stride, vad ? s.vad.data() : nullptr,
@@ -210,7 +282,7 @@ extern "C" int nnn_node_process_pcm_host(nnn_node *n, const void *in, void *out,
     for (auto &s : n->shards)
         if (s.lo % L->channels || s.hi % L->channels) return nnn_set_error("the stream split cuts a channel group: n_streams / channels must divide evenly over the shards");
     const size_t e = L->format == NNN_PCM_I16 ? 2 : 4;
-    const int rc = fan_out(n, [&](int i) {
+    const int rc = process_call(n, [&](int i) {
         nnn_node::Shard &s = n->shards[(size_t)i];
         if (vad) s.vad.resize((size_t)n_frames * (size_t)(s.hi - s.lo));
         const size_t off = (size_t)(s.lo / L->channels) * L->group_stride * e;   // the shard's first group
@@ -220,16 +292,22 @@ extern "C" int nnn_node_process_pcm_host(nnn_node *n, const void *in, void *out,
     return rc;
 }
 
+extern "C" int nnn_node_process_device_streams(nnn_node *n, const float *const *d_in, float *const *d_out, float *const *d_vad,
+                                               void *const *hip_streams, int n_tables, int n_frames, size_t stream_stride, size_t frame_stride)
+{
+    if (!n) return nnn_set_error("null node");
+    if (n_tables != (int)n->shards.size()) return nnn_set_error("the pointer tables must have one entry per shard");
+    if (n_frames <= 0) return 0;
+    if (!d_in || !d_out) return nnn_set_error("null buffer table");
+    return process_call(n, [&](int i) {
+        return nnn_batch_process_device(n->shards[(size_t)i].b, d_in[i], d_out[i], d_vad ? d_vad[i] : nullptr, n_frames, stream_stride, frame_stride,
+                                        hip_streams ? hip_streams[i] : nullptr);
+    });
+}
 extern "C" int nnn_node_process_device(nnn_node *n, const float *const *d_in, float *const *d_out, float *const *d_vad, int n_frames,
                                        size_t stream_stride, size_t frame_stride)
 {
-    if (!n) return nnn_set_error("null node");
-    if (n_frames <= 0) return 0;
-    if (!d_in || !d_out) return nnn_set_error("null buffer table");
-    return fan_out(n, [&](int i) {
-        return nnn_batch_process_device(n->shards[(size_t)i].b, d_in[i], d_out[i], d_vad ? d_vad[i] : nullptr, n_frames, stream_stride, frame_stride,
-                                        nullptr);
-    });
+    return nnn_node_process_device_streams(n, d_in, d_out, d_vad, nullptr, n ? (int)n->shards.size() : 0, n_frames, stream_stride, frame_stride);
 }
 
 extern "C" int nnn_node_synchronize(nnn_node *n)

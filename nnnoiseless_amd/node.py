@@ -64,12 +64,26 @@ class NodeDenoiser:
         self._lib.check(self._lib.L.nnn_node_process_pcm_host(self._h, _ffi.ptr(x), _ffi.ptr(out), _ffi.ptr(vad), T, C.byref(L)))
         return out, vad
 
-    def process_device(self, d_in, d_out, d_vad, n_frames, stream_stride, frame_stride):
-        """Per-shard device pointers (lists of ints, each on its shard's device); asynchronous, see synchronize()."""
-        n = len(d_in)
+    def shard_cpus(self, i):
+        """The CPUs shard i's host thread is pinned to (its device's local_cpulist), "" when not pinned."""
+        return (self._lib.L.nnn_node_shard_cpus(self._h, i) or b"").decode()
+
+    def process_device(self, d_in, d_out, d_vad, n_frames, stream_stride, frame_stride, streams=None):
+        """Per-shard device pointers (sequences of ints, one per shard, each on its shard's device) and, optionally, per-shard HIP
+        streams to enqueue on (None / 0 entries: the shard's own stream); asynchronous, see synchronize()."""
+        n = self._lib.L.nnn_node_num_shards(self._h)
+        tables = {"d_in": d_in, "d_out": d_out}
+        if d_vad is not None:
+            tables["d_vad"] = d_vad
+        if streams is not None:
+            tables["streams"] = streams
+        for name, v in tables.items():
+            if len(v) != n:   # (the C side indexes every table by shard: a short one would be read past its end)
+                raise ValueError(f"process_device: `{name}` has {len(v)} entries for {n} shards")
         arr = lambda v: (C.c_void_p * n)(*[int(p) if p else None for p in v])
-        self._lib.check(self._lib.L.nnn_node_process_device(self._h, arr(d_in), arr(d_out), arr(d_vad) if d_vad is not None else None,
-                                                            n_frames, stream_stride, frame_stride))
+        self._lib.check(self._lib.L.nnn_node_process_device_streams(self._h, arr(d_in), arr(d_out), arr(d_vad) if d_vad is not None else None,
+                                                                    arr(streams) if streams is not None else None, n, n_frames,
+                                                                    stream_stride, frame_stride))
 
     def synchronize(self):
         self._lib.check(self._lib.L.nnn_node_synchronize(self._h))

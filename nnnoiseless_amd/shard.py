@@ -20,3 +20,15 @@ def aggregate(dist, frames_done, elapsed_s, device=None):
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(f.item()), float(t.item())
+
+
+def gather(dist, value, device=None):
+    """[value of rank 0, value of rank 1, ...] on every rank (a list of one without a process group): per-rank rates beside the
+    aggregate, so that a slow GPU of a node shows in the bench line instead of hiding behind the max."""
+    if dist is None or not dist.is_initialized():
+        return [float(value)]
+    import torch
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]

@@ -2,6 +2,8 @@
 """One 10 ms frame per call, the way a real-time server is driven: H independent batches (handles) of S streams each, every batch
 on its own HIP stream, called round-robin.  Calls of different batches overlap on the GPU; a single batch called back to back
 (bench.py's `tick`) cannot overlap with itself.  usage: tick_capacity.py [streams_per_batch] [batches] [rounds] [host_threads] [max_group_frames: 0 = default batch, 1 = sized for ticks]"""
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # (the host's setting: batches ticking side by side want eight hardware queues, INTEGRATION.md)
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch

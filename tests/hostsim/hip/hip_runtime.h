@@ -123,7 +123,8 @@ static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "hostsim"; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 2; return hipSuccess; }   // (two ordinals, one interpreter: what the node tests need)
+static inline hipError_t hipDeviceGetPCIBusId(char *, int, int) { return 1; }   // (the interpreter's "device" has no PCI function)
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }

@@ -78,7 +78,17 @@ def test_rust_facade_keeps_clone_and_sync():
     (src/rnn.rs:54) and `DenoiseState: Clone + Send + Sync` (src/denoise.rs:36,125).  A text check is all this image allows."""
     src = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
     for needle in ("impl Clone for RnnModel", "fn nnn_model_clone(", "unsafe impl Sync for BatchDenoiser", "unsafe impl Send for BatchDenoiser",
-                   "#[derive(Clone)]\npub struct DenoiseState(BatchDenoiser);"):
+                   # the lifetime and the three constructors' exact signatures (src/denoise.rs:37,44-74)
+                   "#[derive(Clone)]\npub struct DenoiseState<'model> {", "_model: std::marker::PhantomData<&'model RnnModel>",
+                   "impl DenoiseState<'static> {", "pub fn new() -> Box<DenoiseState<'static>>",
+                   "pub fn from_model(model: RnnModel) -> Box<DenoiseState<'static>>", "impl<'model> DenoiseState<'model> {",
+                   "pub fn with_model(model: &'model RnnModel) -> Box<DenoiseState<'model>>",
+                   "pub fn process_frame(&mut self, output: &mut [f32], input: &[f32]) -> f32",
+                   # DenoiseSignal (src/signal.rs:29-138) behind the dasp feature, as in the reference
+                   "pub struct DenoiseSignal<'model, S: Signal> {", "pub fn new(input: S) -> DenoiseSignal<'static, S>",
+                   "pub fn with_model(input: S, model: &'model RnnModel) -> DenoiseSignal<'model, S>",
+                   "pub fn from_model(input: S, model: RnnModel) -> DenoiseSignal<'static, S>",
+                   "impl<'model, S: Signal> Signal for DenoiseSignal<'model, S> {"):
         assert needle in src, needle
 
 

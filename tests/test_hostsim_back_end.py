@@ -1,6 +1,7 @@
 """The fused back end (k_back, nnn_back.hip) under the test-only SIMT interpreter: every way of running the part of a frame behind
-the pitch analysis gives the same bits there (the interpreter build never fuses a multiply with an add, so even the transforms agree
-bit for bit; on the GPU the fused kernel's transforms agree with the unfused ones to rounding: tests/test_gpu_back_end.py)."""
+the pitch analysis gives the same bits -- here and on the GPU (tests/test_gpu_back_end.py): since round 4 a multiply fuses with an add
+only where the source says fmaf, so the transforms round the same way in every kernel they are inlined into (include/nnn_batch.h promises
+bit equality between the back ends)."""
 import os
 
 import numpy as np
