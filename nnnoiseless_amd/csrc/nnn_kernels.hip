@@ -1060,20 +1060,26 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             }
             __syncthreads();   // every chunk has its inputs
             if (ch < PK_NCH) {
-                const float n0 = fir[0], n1 = fir[1], n2 = fir[2], n3 = fir[3], n4 = fir[4];
+                // Two consecutive outputs are independent sums with the same coefficients: the halves of packed instructions (each half
+                // rounds like the single instruction; products and sums in the reference's order, left to right).  Output pair m needs
+                // the inputs as pairs in both alignments, VE[i] = (v[2i], v[2i+1]) and VO[i] = (v[2i+1], v[2i+2]): 10 packed
+                // instructions per two outputs where scalar code issued 20 (round 5; the second alignment costs a register move per pair).
+                const v2f N01 = mk2(fir[0], fir[1]), N23 = mk2(fir[2], fir[3]), N4 = mk2(fir[4], fir[4]);
                 float *tap = b.taps ? NNN_TIF(b, xlp_ti, XLP, f, tile, q0 + col) + (size_t)(ch * PK_CH) * TILE : nullptr;
 #pragma unroll
                 for (int m = 0; m < PK_CH / 2; m++) {
-                    float o[2];
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const int u = 2 * m + e;
-                        // out = x + n0 m0 + n1 m1 + n2 m2 + n3 m3 + n4 m4, left to right (m0 = previous input, ...)
-                        o[e] = v[u + 5] + n0 * v[u + 4] + n1 * v[u + 3] + n2 * v[u + 2] + n3 * v[u + 1] + n4 * v[u];
-                        if (tap) tap[(size_t)u * TILE] = o[e];
-                    }
-                    chE[m * PK_SPB] = o[0];
-                    chO[m * PK_SPB] = o[1];
+                    const v2f VE0 = mk2(v[2 * m], v[2 * m + 1]), VO0 = mk2(v[2 * m + 1], v[2 * m + 2]);
+                    const v2f VE1 = mk2(v[2 * m + 2], v[2 * m + 3]), VO1 = mk2(v[2 * m + 3], v[2 * m + 4]);
+                    const v2f VE2 = mk2(v[2 * m + 4], v[2 * m + 5]), VO2 = mk2(v[2 * m + 5], v[2 * m + 6]);
+                    // out = x + n0 m0 + n1 m1 + n2 m2 + n3 m3 + n4 m4, left to right (m0 = previous input, ...)
+                    v2f o = pk_add(VO2, pk_mul_bx(N01, VE2));
+                    o = pk_add(o, pk_mul_by(N01, VO1));
+                    o = pk_add(o, pk_mul_bx(N23, VE1));
+                    o = pk_add(o, pk_mul_by(N23, VO0));
+                    o = pk_add(o, pk_mul_bx(N4, VE0));
+                    if (tap) { tap[(size_t)(2 * m) * TILE] = o.x; tap[(size_t)(2 * m + 1) * TILE] = o.y; }
+                    chE[m * PK_SPB] = o.x;
+                    chO[m * PK_SPB] = o.y;
                 }
             }
         }
@@ -1663,13 +1669,13 @@ constexpr int FFT_SPB = 4;
 // per-lane constant.  k_fft_xp 19.6 -> 18.9 us per frame at 4096 streams, 325 -> 321 at 65536 (same box).
 __device__ __forceinline__ int bsk(int k) { return k + (k >> 3); }
 constexpr int BSK_LEN = 400 + 400 / 8;
-// NNN_FFT_LANE_TW=1 (build knob, off): the second and third pass's twiddles as the lanes use them -- a lane's twiddles are constants of
-// the lane, one LDS read each instead of index, wrap and sign (five vector instructions a piece) -- in k_synth, whose blocks copy
-// the tables once per group of frames.  Measured at the end of round 4 on every transform (profiles/r4_experiments_ab.txt M: -6.6 % vector
-// instructions; k_synth -3 %, nothing for the kernels whose blocks copy the tables per stream-frame): to be switched on with its own
-// evidence pass.
+// NNN_FFT_LANE_TW=1 (on since round 5; 0 builds the variant without): the second and third pass's twiddles as the lanes use them -- a
+// lane's twiddles are constants of the lane, one LDS read each instead of index, wrap and sign (five vector instructions a piece) -- in
+// k_synth, whose blocks copy the tables once per group of frames (-6.6 % vector instructions, -1.5 % time: profiles/r4_experiments_ab.txt M,
+// profiles/r5_experiments_ab.txt C); the kernels whose blocks copy the tables per stream-frame keep the half circle and copy the part of
+// the image before these tables only.  Same products of the same factors: bit-identical to the variant without.
 #ifndef NNN_FFT_LANE_TW
-#define NNN_FFT_LANE_TW 0
+#define NNN_FFT_LANE_TW 1
 #endif
 constexpr int FFT_TW2 = 2 * 5 * 64, FFT_TW3 = 9 * 64;
 struct alignas(16) FftLds {
@@ -1703,7 +1709,21 @@ __device__ __forceinline__ void fft_tables_load(FftLds &t, const Buffers &b, boo
     const uint4 *src = (const uint4 *)b.fft_img;
     uint4 *dst = (uint4 *)&t;
     const int n = (lane_tw ? (int)sizeof(FftLds) : FFT_TABLES_SHORT) / 16;
-    for (int i = tid; i < n; i += nt) dst[i] = src[i];
+    // every piece a thread copies is requested before the first one is stored: one trip to the L2 per block instead of one per piece
+    // (until round 5 the loop waited for each load before it asked for the next: three to five trips on the block's critical path)
+    constexpr int MAXIT = 5;   // blocks of >= 256 threads
+    static_assert(sizeof(FftLds) / 16 <= (size_t)MAXIT * 256, "");
+    uint4 r[MAXIT];
+#pragma unroll
+    for (int k = 0; k < MAXIT; k++) {
+        const int i = tid + k * nt;
+        if (i < n) r[k] = ld_global_u4(src + i);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXIT; k++) {
+        const int i = tid + k * nt;
+        if (i < n) dst[i] = r[k];
+    }
 }
 // the host's side of it
 __host__ inline void fft_tables_image(FftLds &t, const float2 *tw960, const float *bin_frac, const int *bin_band, const int *seg, const float *dct)
