@@ -444,34 +444,74 @@ def config0():
                       "golden_metric": err}), flush=True)
 
 
-def host_boundary(S, fps, calls=4):
-    """The same workload through the host-buffer entry point (the shape of the reference's own process_frame: host slices in,
-    host slices out), every call shipping its audio over PCIe and bringing the result back -- never `value`, reported beside it.
-    Page-locked buffers (nnn_host_alloc), f32 and packed int16."""
+def host_boundary_child(argv):
+    """bench.py --host-boundary-child: the host-buffer entry point in a process of its own (no torch, nothing else resident), one JSON line.
+    The workload through nnn_batch_process_pcm_host from page-locked buffers at 4096 and 65 536 streams, f32 and packed int16, and --
+    the same process, the same buffers' sizes -- what the link itself gives: hipMemcpyAsync up, down and both ways at once on two streams."""
     import ctypes as C
     import numpy as np
     import nnnoiseless_amd as nn
     from nnnoiseless_amd import _ffi
+    fps = int(argv[0]) if argv else 48
     lib = nn.library()
-    out = {"unit": "frames/s", "frames_per_call": fps, "streams": S, "calls": calls,
-           "note": "PCIe-inclusive: upload + kernels + download per call, page-locked host buffers, chunks overlapped"}
-    rng = np.random.default_rng(0)
-    for fmt, name in ((0, "f32"), (1, "i16")):
-        bd = nn.BatchDenoiser(S)
-        dt = np.float32 if fmt == 0 else np.int16
-        px, po, pv = nn.pinned_empty((S, fps * 480), dt), nn.pinned_empty((S, fps * 480), dt), nn.pinned_empty((fps, S))
-        px[:] = (rng.standard_normal((S, fps * 480), dtype=np.float32) * 3000).astype(dt)
-        L = _ffi.PcmLayout(fmt, 1, 0, 0, fps * 480, 480)
-        call = lambda: lib.check(lib.L.nnn_batch_process_pcm_host(bd._h, _ffi.ptr(px), _ffi.ptr(po), _ffi.ptr(pv), fps, C.byref(L)))
-        call()
-        t0 = time.perf_counter()
-        for _ in range(calls):
+    hip = C.CDLL("libamdhip64.so")
+    vp, sz = C.c_void_p, C.c_size_t
+    hip.hipMalloc.argtypes = [C.POINTER(vp), sz]
+    hip.hipFree.argtypes = [vp]
+    hip.hipMemcpyAsync.argtypes = [vp, vp, sz, C.c_int, vp]
+    hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(vp), C.c_uint]
+    hip.hipStreamSynchronize.argtypes = [vp]
+    s_in, s_out = vp(), vp()
+    assert hip.hipStreamCreateWithFlags(C.byref(s_in), 1) == 0 and hip.hipStreamCreateWithFlags(C.byref(s_out), 1) == 0
+    out = {"unit": "frames/s", "frames_per_call": fps,
+           "note": "PCIe-inclusive: upload + kernels + download per call, page-locked host buffers (nnn_host_alloc), chunks overlapped; "
+                   "bus = hipMemcpyAsync of the same byte counts in the same process, both directions at once on two streams; never `value`"}
+    block = (np.random.default_rng(0).standard_normal((64, fps * 480), dtype=np.float32) * 3000)
+    for S, calls in ((4096, 4), (65536, 2)):
+        for fmt, name in ((0, "f32"), (1, "i16")):
+            dt = np.float32 if fmt == 0 else np.int16
+            px, po, pv = nn.pinned_empty((S, fps * 480), dt), nn.pinned_empty((S, fps * 480), dt), nn.pinned_empty((fps, S))
+            px.reshape(S // 64, 64, -1)[:] = block.astype(dt)[None]
+            n = px.nbytes
+            # the link: both directions at once, the call's byte counts
+            d0, d1 = vp(), vp()
+            assert hip.hipMalloc(C.byref(d0), n) == 0 and hip.hipMalloc(C.byref(d1), n) == 0
+
+            def both():
+                assert hip.hipMemcpyAsync(d0, px.ctypes.data, n, 1, s_in) == 0 and hip.hipMemcpyAsync(po.ctypes.data, d1, n, 2, s_out) == 0
+            both(); hip.hipStreamSynchronize(s_in); hip.hipStreamSynchronize(s_out)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                both()
+            hip.hipStreamSynchronize(s_in); hip.hipStreamSynchronize(s_out)
+            bus = 2 * n * 3 / (time.perf_counter() - t0) / 1e9
+            hip.hipFree(d0); hip.hipFree(d1)
+            bd = nn.BatchDenoiser(S)
+            L = _ffi.PcmLayout(fmt, 1, 0, 0, fps * 480, 480)
+            call = lambda: lib.check(lib.L.nnn_batch_process_pcm_host(bd._h, _ffi.ptr(px), _ffi.ptr(po), _ffi.ptr(pv), fps, C.byref(L)))
             call()
-        dt_s = (time.perf_counter() - t0) / calls
-        out[name] = {"value": S * fps / dt_s, "ms_per_call": dt_s * 1e3, "bus_GBps_both_ways": 2 * px.nbytes / dt_s / 1e9}
-        bd.close()
-        del px, po, pv
-    return out
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                call()
+            dt_s = (time.perf_counter() - t0) / calls
+            gbs = 2 * n / dt_s / 1e9
+            out[f"{name}_{S}"] = {"streams": S, "value": S * fps / dt_s, "ms_per_call": dt_s * 1e3, "bus_GBps_both_ways": gbs,
+                                  "link_peak_GBps_both_ways": bus, "frac_of_link": gbs / bus}
+            bd.close()
+            del px, po, pv
+    out["f32"], out["i16"] = out["f32_4096"], out["i16_4096"]   # (the keys earlier rounds' lines carried)
+    print(json.dumps(out), flush=True)
+
+
+def host_boundary(fps):
+    """The host-buffer entry point (the shape of the reference's own process_frame: host slices in, host slices out) measured in a child
+    process: this one holds torch's runtime and gigabytes of resident pools, which cost the transfers a quarter of their rate (round 4's
+    line said 14.6 M f32 where a clean process measures 20)."""
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--host-boundary-child", str(fps)], capture_output=True, text=True, timeout=600)
+    for ln in reversed(r.stdout.strip().split("\n")):
+        if ln.startswith("{"):
+            return json.loads(ln)
+    return {"error": (r.stderr or r.stdout)[-400:]}
 
 
 def single_process(args):
@@ -538,6 +578,8 @@ def single_process(args):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--host-boundary-child":
+        return host_boundary_child(sys.argv[2:])
     args = parse_args()
     if args.config == 0:
         return config0()
@@ -644,7 +686,7 @@ def main():
 
     host = None
     if default_run and not args.no_host:
-        host = host_boundary(CONFIGS[1]["streams"], args.frames_per_step)
+        host = host_boundary(args.frames_per_step)
 
     cpu = None
     if not args.no_cpu_baseline and not args.dry_run:

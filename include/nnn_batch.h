@@ -101,7 +101,7 @@ int nnn_batch_process_device(nnn_batch *b, const float *d_in, float *d_out, floa
                              size_t stream_stride, size_t frame_stride, void *hip_stream);
 /* Same with host buffers (copies over PCIe, synchronous).  This is the shape of the reference's own interface -- process_frame
  * takes host slices (src/denoise.rs:95) -- and its rate is the bus's, not the kernels': a call of many gap-free frames
- * (frame_stride == 480 * channels) is cut into chunks of 4 to 16 frames, chunk i + 1 going up and chunk i - 1 coming back
+ * (frame_stride == 480 * channels) is cut into about sixteen chunks of 1 to 16 frames, chunk i + 1 going up and chunk i - 1 coming back
  * while chunk i is processed (same bits as one piece).  Buffers from nnn_host_alloc (page-locked) are transferred by DMA, both directions at once;
  * any other host memory works through the runtime's staging copies at a fraction of that rate. */
 int nnn_batch_process_host(nnn_batch *b, const float *in, float *out, float *vad, int n_frames,

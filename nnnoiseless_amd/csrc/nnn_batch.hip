@@ -1289,13 +1289,19 @@ static int process_host_span_impl(nnn_batch *h, const void *in, void *out, float
     }
     char *d = h->stage;
     float *dv = vad ? h->stage_vad : nullptr;
-    // Chunk length: the first upload and the last download are not overlapped, so short calls want short chunks (measured at
-    // 4096 streams x 48 frames, page-locked f32: 16-frame chunks 17.3, 8-frame chunks 20.2 M frames/s; one piece: 5.5) and
-    // long calls the kernels' own group length; chunks under a megabyte are not worth their launches.
+    // Chunk length.  The first upload and the last download are not overlapped, so a call wants many chunks (about sixteen); the kernels
+    // want groups of a few frames on small batches (a 4096-stream batch runs 4-frame groups at 0.8 of its 24-frame rate, a 65 536-stream
+    // batch is within 15 % of its best on one-frame groups -- and still twice as fast as the bus).  Measured with page-locked buffers
+    // against the link's own both-ways peak of 97 GB/s (profiles/r5_host_boundary.txt): 4096 streams x 48 frames f32 at 4 / 8 / 16-frame
+    // chunks 84 / 79 / 69 GB/s both ways (round 4 used 8), 65 536 x 24 at 1 / 2 / 4 / 8: 90 / 87 / 81 / 71 (int16: 81 / 84 / 77 / 66).
+    // Chunks under a megabyte are not worth their launches.
     int chunk = h->host_chunk;
     if (chunk < 0) {
-        constexpr int HC = 16;   // longest chunk (tuned on the bus, not tied to the kernels' group length)
-        chunk = n_frames >= 128 ? HC : (n_frames >= 48 ? 8 : 4);
+        constexpr int HC = 16;   // longest chunk
+        chunk = n_frames / 16;
+        if (chunk < 1) chunk = 1;
+        if (h->S_pad <= 8192 && chunk < 4) chunk = 4;
+        if (chunk > HC) chunk = HC;
         while (chunk < HC && (size_t)chunk * fr * groups < ((size_t)1 << 20)) chunk *= 2;
         if ((size_t)chunk * fr * groups < ((size_t)1 << 20)) chunk = 0;
     }
