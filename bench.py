@@ -53,6 +53,17 @@ FP32_PEAK_TFLOPS = 157.3
 BYTES_PER_FRAME_FUSED = 16948  # I/O + resident-state touch of one process_frame
 FLOPS_PER_FRAME = 0.42e6
 
+# The issue ceiling: the wave-instructions a kernel's ARITHMETIC needs per stream-frame on CDNA4 -- packed
+# FP32 where exactness allows (everything upstream of the pitch index: two multiply-adds per v_pk_mul_f32 + v_pk_add_f32 pair, no FMA), FMA
+# and packing where only a tolerance applies (transforms, synthesis), the matrix cores where built (RNN) -- if every issue slot of every SIMD
+# (one vector instruction per 4 cycles, 1024 SIMDs at 2.4 GHz) did nothing else.  Sources: k_pitch 63 k multiply-adds per stream-frame / 64
+# lanes (coarse 147 x 240, fine 10 x 480, remove_doubling 25 x 480, FIR 864 x 5, the energy scans); transforms and synthesis the arithmetic
+# column of scripts/isa_mix.py (profiles/r4_isa_mix.txt); RNN 551 activations x ~25 instructions / 64 lanes beside 32 MFMAs per stream-frame
+# (x 16 cycles: 510, less than the activations' 860 cycles); k_lpc 5 x 860 multiply-adds / 64; k_hp its HBM bytes (its 90 f64 instructions
+# per stream-frame issue in less).
+KERNEL_MIN_VALU = {"k_pitch": 985, "k_fft_xp": 632, "k_synth": 421, "k_rnn": 215, "k_lpc": 67, "k_hp": 90}
+SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 4
+
 # Algorithmic HBM bytes per stream-frame of each kernel (its own inputs + outputs, each counted once; per-group state traffic
 # divided by the G frames of a full group; derivation in DESIGN.md "Kernels")
 G = 24   # frames of a full group (a 48-frame call is two of them)
@@ -400,12 +411,41 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
                 top = max(cand, key=cand.get)
                 binding = {"resource": top, "busy": cand[top], "valu_busy": q.get("valu_busy"), "lds_busy": q.get("lds_busy"),
                            "lds_conflict_share": q.get("lds_conflict_share"), "source": f"profiles/pmc_sq_{S}streams.json (rocprofv3 --pmc SQ_* passes)"}
+        # the whole path's HBM traffic from the counters against its algorithmic bytes (16 948 B), and the issue ceiling
+        path_traffic = None
+        if pm:
+            tot = sum(v.get("hbm_bytes_per_stream_frame", 0.0) for v in pm["kernels"].values())
+            path_traffic = {"pmc_bytes_per_stream_frame_all_kernels": tot, "algorithmic_bytes_per_stream_frame": BYTES_PER_FRAME_FUSED,
+                            "traffic_over_algorithmic": tot / BYTES_PER_FRAME_FUSED,
+                            "per_kernel": {k: round(v.get("hbm_bytes_per_stream_frame", 0.0)) for k, v in pm["kernels"].items()},
+                            "note": "the excess is the spectra X and P crossing HBM between k_fft_xp and k_synth (the fused back end keeps them in registers: one-frame calls only)"}
+        ceiling = None
+        if sq:
+            fl = sq.get("frames_per_launch", 24)
+            rows, t_min = {}, 0.0
+            for k, v in kern.items():
+                issued = sq["kernels"].get(k, {}).get("counters", {}).get("SQ_INSTS_VALU")
+                need = KERNEL_MIN_VALU.get(k)
+                if need is None:
+                    continue
+                us_issue = need * VALU_ISSUE_CYCLES * S / (SIMDS * CLOCK_HZ) * 1e6
+                us_hbm = KERNEL_BYTES.get(k, 0) * S / (HBM_PEAK_GBS * 1e9) * 1e6
+                us_min = max(us_issue, us_hbm)
+                t_min += us_min
+                rows[k] = {"valu_issued_per_stream_frame": round(issued * 32 / (S * fl)) if issued else None, "valu_needed_per_stream_frame": need,
+                           "us_per_frame_floor": round(us_min, 1), "floor_set_by": "hbm" if us_hbm > us_issue else "vector issue",
+                           "us_per_frame_measured": round(v["us_per_frame"], 1)}
+            ceiling = {"kernels": rows, "sum_floor_us_per_frame": round(t_min, 1), "frames_per_s_at_the_floor": S / (t_min * 1e-6) if t_min else None,
+                       "measured_over_floor": per_gpu / (S / (t_min * 1e-6)) if t_min else None,
+                       "hbm_frac_at_the_floor": (S / (t_min * 1e-6)) * BYTES_PER_FRAME_FUSED / 1e9 / HBM_PEAK_GBS if t_min else None,
+                       "note": "floor = every SIMD issuing only the kernel's arithmetic (4 cycles per wave instruction), or its algorithmic bytes at 8 TB/s; "
+                               "issued counts from profiles/pmc_sq_*.json (SQ_INSTS_VALU x 32 shader engines / stream-frames)"}
         return {"kernels": kern, "roofline": {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "alg_bytes_per_stream_frame": KERNEL_BYTES.get(dom, 0), "traffic_per_stream_frame": traffic_psf, "traffic_source": traffic_src,
             "avg_kernel_us": avg_s * 1e6, "frames_per_launch": frames_per_launch, "bytes_per_launch": bytes_per_launch,
-            "binding": binding,
+            "binding": binding, "path_traffic": path_traffic, "issue_ceiling": ceiling,
             "useful_tflops": kern[dom]["useful_tflops"], "roof_tflops": kern[dom]["roof_tflops"], "roof": kern[dom]["roof"],
             "frac_of_applicable_roof": kern[dom]["frac_of_roof"],
             "sum_kernel_us_per_frame": sum(v["us_per_frame"] for v in kern.values()),

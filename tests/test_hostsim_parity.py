@@ -153,8 +153,10 @@ def test_nonfinite_inputs_stay_contained(hostsim_lib, oracle_mod, weights_bytes)
     assert np.array_equal(bd.tap("pitch")[:, 0], ref["pitch"][:, -1])
     assert np.array_equal(np.isnan(out), np.isnan(ref["out"]))
     ok = np.isfinite(out) & np.isfinite(ref["out"])
-    # (f32 rounding of the transforms is ~1e-6 of a stream's peak: the absolute slack follows the peak, 1e4 here, not a fixed 0.01)
-    assert np.allclose(out[ok], ref["out"][ok], rtol=1e-4, atol=5e-6 * float(np.abs(clean).max()))
+    # f32 rounding of the transforms is ~1e-6 of a stream's peak, so the absolute slack follows the peak (1.2e4 here) instead of the
+    # fixed 0.01 this test had until round 4.  Measured at round 5's HEAD: worst |error| 0.0186 on a stream peaking at 10 188 (1.8e-6 of
+    # its peak, 0.016 beyond rtol) -- the old fixed bar fails by a factor 1.6, this one (3e-6 of the peak = 0.035) holds with 2x to spare.
+    assert np.allclose(out[ok], ref["out"][ok], rtol=1e-4, atol=3e-6 * float(np.abs(clean).max()))
 
 
 def test_call_length_patterns(hostsim_lib):

@@ -41,7 +41,8 @@ def check_rows(rows, ref, ref32=None):
         # the loosest bar of the suite): within 2e-4 or FIVE times the stream's spread for all but 1 % of the streams -- one pair of
         # builds is a small sample of a chaotic quantity, and at three times 1 % of the streams fail for every build measured
         # (round 2's kernels, round 3's, the oracle's f32 build judged against a second f32 build: scripts/train_corr_probe.py) --
-        # and those few within twenty times, under the global worst-case bound above.
+        # and those few within twenty times, under the global worst-case bound above.  Said plainly: against round 3's single
+        # 10 x bar this is TIGHTER for 99 % of the streams (5 x) and LOOSER for the worst 1 % (20 x).
         e_dev, e_o32 = np.abs(rows[..., 34:40] - ref[..., 34:40]), np.abs(ref32[..., 34:40] - ref[..., 34:40])
         assert e_dev.max() <= 1.25 * e_o32.max(), (e_dev.max(), e_o32.max())
         assert np.sqrt((e_dev ** 2).mean()) <= 1.25 * np.sqrt((e_o32 ** 2).mean())
