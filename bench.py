@@ -507,6 +507,25 @@ def host_boundary_child(argv):
            "note": "PCIe-inclusive: upload + kernels + download per call, page-locked host buffers (nnn_host_alloc), chunks overlapped; "
                    "bus = hipMemcpyAsync of the same byte counts in the same process, both directions at once on two streams; never `value`"}
     block = (np.random.default_rng(0).standard_normal((64, fps * 480), dtype=np.float32) * 3000)
+    # Right after the parent bench has freed tens of gigabytes of device memory the driver is still clearing them with the copy engines, and
+    # for a second or two the two directions of the link take turns (57 GB/s both ways instead of 97; the same child started from an idle
+    # parent measures 97 from its first copy): copy both ways until the rate has settled (three rounds within 2 %, at most 5 s).
+    wn = 64 << 20
+    wh0, wh1 = nn.pinned_empty((wn,), np.uint8), nn.pinned_empty((wn,), np.uint8)
+    wd0, wd1 = vp(), vp()
+    assert hip.hipMalloc(C.byref(wd0), wn) == 0 and hip.hipMalloc(C.byref(wd1), wn) == 0
+    rates, t_start = [], time.perf_counter()
+    while time.perf_counter() - t_start < 5.0:
+        t0 = time.perf_counter()
+        for _ in range(8):
+            assert hip.hipMemcpyAsync(wd0, wh0.ctypes.data, wn, 1, s_in) == 0 and hip.hipMemcpyAsync(wh1.ctypes.data, wd1, wn, 2, s_out) == 0
+        hip.hipStreamSynchronize(s_in); hip.hipStreamSynchronize(s_out)
+        rates.append(2 * wn * 8 / (time.perf_counter() - t0) / 1e9)
+        if len(rates) >= 4 and max(rates[-3:]) - min(rates[-3:]) <= 0.02 * rates[-1] and rates[-1] >= 0.98 * max(rates):
+            break
+    out["link_settled_after_s"] = round(time.perf_counter() - t_start, 2)
+    hip.hipFree(wd0); hip.hipFree(wd1)
+    del wh0, wh1
     for S, calls in ((4096, 4), (65536, 2)):
         for fmt, name in ((0, "f32"), (1, "i16")):
             dt = np.float32 if fmt == 0 else np.int16
@@ -547,6 +566,7 @@ def host_boundary(fps):
     """The host-buffer entry point (the shape of the reference's own process_frame: host slices in, host slices out) measured in a child
     process: this one holds torch's runtime and gigabytes of resident pools, which cost the transfers a quarter of their rate (round 4's
     line said 14.6 M f32 where a clean process measures 20)."""
+    time.sleep(3.0)   # (the driver clears the tens of gigabytes this process has just freed with the copy engines: let it finish, see the child)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--host-boundary-child", str(fps)], capture_output=True, text=True, timeout=600)
     for ln in reversed(r.stdout.strip().split("\n")):
         if ln.startswith("{"):
