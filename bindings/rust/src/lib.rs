@@ -33,6 +33,20 @@ extern "C" {
         stream_stride: usize,
         frame_stride: usize,
     ) -> c_int;
+    fn nnn_node_num_shards(n: *const RawNode) -> c_int;
+    fn nnn_node_shard_cpus(n: *const RawNode, i: c_int) -> *const std::os::raw::c_char;
+    fn nnn_node_synchronize(n: *mut RawNode) -> c_int;
+    fn nnn_node_process_device_streams(
+        n: *mut RawNode,
+        d_in: *const *const c_float,
+        d_out: *const *mut c_float,
+        d_vad: *const *mut c_float,
+        hip_streams: *const *mut c_void,
+        n_tables: c_int,
+        n_frames: c_int,
+        stream_stride: usize,
+        frame_stride: usize,
+    ) -> c_int;
     fn nnn_batch_create(model: *const RawModel, n_streams: c_int, device: c_int) -> *mut RawBatch;
     fn nnn_batch_destroy(b: *mut RawBatch);
     fn nnn_batch_reset(b: *mut RawBatch) -> c_int;
@@ -459,6 +473,41 @@ impl NodeDenoiser {
         };
         assert_eq!(rc, 0, "nnnoiseless-mi355x: backend error");
     }
+    /// Buffers resident on the shards' own devices: one pointer (and optionally one `hipStream_t`) per shard; asynchronous, see `synchronize`.
+    pub unsafe fn process_device(
+        &mut self,
+        d_out: &[*mut f32],
+        d_in: &[*const f32],
+        d_vad: Option<&[*mut f32]>,
+        hip_streams: Option<&[*mut c_void]>,
+        n_frames: usize,
+        stream_stride: usize,
+        frame_stride: usize,
+    ) {
+        let n = nnn_node_num_shards(self.raw) as usize;
+        assert!(d_in.len() == n && d_out.len() == n, "one table entry per shard");
+        assert!(d_vad.map_or(true, |v| v.len() == n) && hip_streams.map_or(true, |v| v.len() == n), "one table entry per shard");
+        let rc = nnn_node_process_device_streams(
+            self.raw,
+            d_in.as_ptr(),
+            d_out.as_ptr(),
+            d_vad.map_or(std::ptr::null(), |v| v.as_ptr()),
+            hip_streams.map_or(std::ptr::null(), |v| v.as_ptr()),
+            n as c_int,
+            n_frames as c_int,
+            stream_stride,
+            frame_stride,
+        );
+        assert_eq!(rc, 0, "nnnoiseless-mi355x: backend error");
+    }
+    pub fn synchronize(&mut self) {
+        assert_eq!(unsafe { nnn_node_synchronize(self.raw) }, 0, "nnnoiseless-mi355x: backend error");
+    }
+    /// The CPUs shard `i`'s host thread is pinned to (its device's local CPUs); empty when not pinned.
+    pub fn shard_cpus(&self, i: usize) -> String {
+        unsafe { std::ffi::CStr::from_ptr(nnn_node_shard_cpus(self.raw, i as c_int)).to_string_lossy().into_owned() }
+    }
+    /// Also clears the failed state a call leaves behind when one shard fails (the others have advanced).
     pub fn reset(&mut self) {
         unsafe { nnn_node_reset(self.raw) };
     }

@@ -256,7 +256,28 @@ class NodeDenoiser {
         if (nnn_node_process_host(n_, in, out, vad, n_frames, (size_t)n_frames * NNN_FRAME_SIZE, NNN_FRAME_SIZE))
             throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
     }
-    void reset() { nnn_node_reset(n_); }
+    // buffers resident on the shards' own devices, one pointer (and optionally one hipStream_t) per shard; asynchronous: synchronize()
+    void process_device(const std::vector<const float *> &d_in, const std::vector<float *> &d_out, const std::vector<float *> &d_vad, int n_frames,
+                        size_t stream_stride, size_t frame_stride, const std::vector<void *> &hip_streams = {})
+    {
+        const int n = num_shards();
+        if ((int)d_in.size() != n || (int)d_out.size() != n || (!d_vad.empty() && (int)d_vad.size() != n) || (!hip_streams.empty() && (int)hip_streams.size() != n))
+            throw std::invalid_argument("nnnoiseless: one table entry per shard");
+        if (nnn_node_process_device_streams(n_, d_in.data(), d_out.data(), d_vad.empty() ? nullptr : d_vad.data(),
+                                            hip_streams.empty() ? nullptr : hip_streams.data(), n, n_frames, stream_stride, frame_stride))
+            throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+    }
+    void synchronize()
+    {
+        if (nnn_node_synchronize(n_)) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+    }
+    // the CPUs shard i's host thread is pinned to (its device's local CPUs), "" when not pinned
+    std::string shard_cpus(int i) const { return nnn_node_shard_cpus(n_, i); }
+    // after a call that failed on some shard the node refuses further calls until reset() (the shards sit at different frame counts)
+    void reset()
+    {
+        if (nnn_node_reset(n_)) throw std::runtime_error(std::string("nnnoiseless: ") + nnn_last_error());
+    }
     bool fault() const { return nnn_node_fault(n_) != 0; }
     nnn_node *raw() { return n_; }
 
