@@ -3406,10 +3406,16 @@ __device__ __forceinline__ void interp_gain2(const float *ga, const float *gb, i
 //      k_synth (spectra from memory) and of the fused back end (spectra straight from its transforms).  b_* are the lane's band
 //      (lane < NB) quantities.  The overlap memory is `smv` (sample quads of lane j: samples 4 j + 256 u .. + 3), loaded and stored
 //      around the frame when SMV_IO (the fused kernel: eight registers it has not got across a frame) or carried by the caller.
+// The band and the interpolation weight of a lane's eight bins are constants of the lane: k_synth, which loops over the frames of a group,
+// reads them from the tables once per launch and keeps them in registers (BinConst; round 5: two LDS reads and their index arithmetic less
+// per bin and use, three uses per frame: k_synth -2.7 %); the fused back end, which has no registers to spare, looks them up where it
+// needs them (null).  Same products of the same factors either way.  (At 128 registers the kernel now spills one 64-bit value, the address
+// of the stream's overlap memory: stored before the frame loop, reloaded once behind it -- two scratch accesses per launch, none per frame.)
+struct BinConst { int band[8]; float frac[8]; };   // band: -1 = no gain there (bins from 400 up, empty slots)
 template <bool SMV_IO>
 __device__ __forceinline__ void synth_frame(const Buffers &b, const StepParams *sp, int f, int tile, int sl, int s, int lane, const FftLds &t, float2 *A,
                                          float *r, float2 (&Xr)[8], const float2 (&Pk)[8], float b_ex, float b_ep, float b_xp, float b_graw,
-                                         float b_g, float vadv, bool live, float *sm, float4 (&smq)[2])
+                                         float b_g, float vadv, bool live, float *sm, float4 (&smq)[2], const BinConst *bc = nullptr)
 {
     if (SMV_IO) {
 #pragma unroll
@@ -3448,7 +3454,12 @@ __device__ __forceinline__ void synth_frame(const Buffers &b, const StepParams *
             if (k >= 0) {
                 float2 X = Xr[u];
                 const float2 P = k < 400 ? Pk[u] : make_float2(0.0f, 0.0f);   // from bin 400 up the filter gain is zero
-                const float rf = interp_gain(r, k, t.frac, t.band);
+                float rf;
+                if (!SMV_IO && bc) {
+                    const int i = bc->band[u] < 0 ? 0 : bc->band[u];
+                    const float fr = bc->frac[u];
+                    rf = bc->band[u] < 0 ? 0.0f : fmaf(fr, r[i + 1], (1.0f - fr) * r[i]);
+                } else rf = interp_gain(r, k, t.frac, t.band);
                 X.x = fmaf(P.x, rf, X.x);
                 X.y = fmaf(P.y, rf, X.y);
                 Xr[u] = X;
@@ -3468,7 +3479,12 @@ __device__ __forceinline__ void synth_frame(const Buffers &b, const StepParams *
             const int k = rfft_slot_bin(lane, u);
             if (k >= 0) {
                 float rf, gf;
-                interp_gain2(r2, gg, k, t.frac, t.band, rf, gf);
+                if (!SMV_IO && bc) {
+                    const int i = bc->band[u] < 0 ? 0 : bc->band[u];
+                    const float fr = bc->frac[u], om = 1.0f - fr;
+                    rf = bc->band[u] < 0 ? 0.0f : fmaf(fr, r2[i + 1], om * r2[i]);
+                    gf = bc->band[u] < 0 ? 0.0f : fmaf(fr, gg[i + 1], om * gg[i]);
+                } else interp_gain2(r2, gg, k, t.frac, t.band, rf, gf);
                 Xr[u].x *= rf; Xr[u].y *= rf;
                 Xr[u].x *= gf; Xr[u].y *= gf;
             }
@@ -3569,6 +3585,14 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
 #pragma unroll
     for (int u = 0; u < 2; u++) smq[u] = lane + 64 * u < FRAME / 4 ? ((const float4 *)sm)[lane + 64 * u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();   // tables in place; from here on every wave is on its own (a silent stream skips the filter)
+    BinConst bc;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = rfft_slot_bin(lane0, u);
+        const bool on = k >= 0 && k < 400;
+        bc.band[u] = on ? (int)t.band[on ? k : 0] : -1;
+        bc.frac[u] = on ? t.frac[bsk(on ? k : 0)] : 0.0f;
+    }
     for (int f = 0; f < g; f++) {
         lane = launder_v(lane0);   // keep the frame loop's addresses inside the loop (see launder_v)
         const size_t fo = (size_t)b.S_pad * (size_t)f;   // this frame's scratch set
@@ -3592,7 +3616,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
             b_g = NNN_TIF(b, g, NB, f, tile, sl)[(size_t)lane * TILE];
         }
         const float vadv = NNN_TIF(b, vad, 1, f, tile, sl)[0];
-        synth_frame<false>(b, sp0 + f, f, tile, sl, s, lane, t, A, r, Xr, Pr, b_ex, b_ep, b_xp, b_graw, b_g, vadv, live, sm, smq);
+        synth_frame<false>(b, sp0 + f, f, tile, sl, s, lane, t, A, r, Xr, Pr, b_ex, b_ep, b_xp, b_graw, b_g, vadv, live, sm, smq, &bc);
     }
 #pragma unroll
     for (int u = 0; u < 2; u++)
