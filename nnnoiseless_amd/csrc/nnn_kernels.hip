@@ -1760,12 +1760,18 @@ __device__ __forceinline__ float2 tw960_at(const float2 *tw, int k)   // k in [0
 // The first pass scatters with a stride of 8 elements (64 bytes): 32 lanes on 4 bank pairs, every store 8-way conflicted
 // -- as many LDS cycles as all other accesses of the transform together.  Its output (and the second pass's input) is
 // therefore skewed, element i at i + i / 8 (stride 9: conflict-free); the buffer holds NFFT_BUF elements for that.
-constexpr int NFFT_BUF = NFFT + NFFT / 8;
+// The second pass's output (the third's input) is padded the same way for the same reason (round 5): its butterflies j and j + 8 of one
+// 16-lane store group wrote elements 48 apart -- the same banks -- so every block of 48 elements now starts 8 further on (element i at
+// i + 8 (i / 48), 552 elements): the two halves of a store group sit 56 apart, 8 modulo 16, and the third pass reads with stride 56.
+constexpr int NFFT_BUF = 560;
+constexpr int FFT_P2PAD = 8;
 // LT: `tw` is the pass's own per-lane twiddle table ([it][r - 1][lane], FftLds::tw2 / tw3) instead of the half circle
 template <int R, int NS, bool SKEW_IN, bool SKEW_OUT, bool LT = false>
 __device__ __forceinline__ void fft_pass(float2 *buf, const float2 *tw, int lane)
 {
     constexpr int NBF = NFFT / R, IT = (NBF + 63) / 64;
+    constexpr bool PAD_OUT = NS == 8 && R == 6, PAD_IN = NS == 48 && R == 10;   // the second pass's padded output = the third's input
+    static_assert(!PAD_IN || NBF == 48, "");
     static_assert(!SKEW_IN || NBF % 8 == 0, "skewed reads assume r * NBF is a multiple of 8");
     static_assert(!SKEW_OUT || (NS == 1 && R == 8), "skewed writes are the first pass's");
     float2 v[IT][R];
@@ -1776,7 +1782,7 @@ __device__ __forceinline__ void fft_pass(float2 *buf, const float2 *tw, int lane
             const int k = j % NS;
             const int jj = SKEW_IN ? j + (j >> 3) : j;
 #pragma unroll
-            for (int r = 0; r < R; r++) v[it][r] = buf[jj + (SKEW_IN ? r * NBF + r * NBF / 8 : r * NBF)];
+            for (int r = 0; r < R; r++) v[it][r] = buf[jj + (SKEW_IN ? r * NBF + r * NBF / 8 : (PAD_IN ? r * (NBF + FFT_P2PAD) : r * NBF))];
             if (NS > 1) {
                 constexpr int step = 960 / (NS * R);
 #pragma unroll
@@ -1790,7 +1796,7 @@ __device__ __forceinline__ void fft_pass(float2 *buf, const float2 *tw, int lane
     for (int it = 0; it < IT; it++) {
         const int j = lane + 64 * it;
         if (j < NBF) {
-            const int base = SKEW_OUT ? 9 * j : (j / NS) * NS * R + (j % NS);   // skewed: element 8 j + r at 9 j + r
+            const int base = SKEW_OUT ? 9 * j : (j / NS) * (NS * R + (PAD_OUT ? FFT_P2PAD : 0)) + (j % NS);   // skewed: element 8 j + r at 9 j + r
 #pragma unroll
             for (int r = 0; r < R; r++) buf[base + r * NS] = v[it][r];
         }
