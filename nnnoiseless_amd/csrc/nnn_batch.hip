@@ -517,15 +517,20 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     HIPCHK(upload(h, &b.tansig, tansig));
     HIPCHK(upload(h, &b.bin_frac, bin_frac));
     HIPCHK(upload(h, &b.bin_band, bin_band));
-    {   // band-sum segmentation: every band interval cut into segments of <= 8 bins (54 segments)
+    {   // band-sum segmentation: every band interval cut into segments of <= 8 bins (54 segments), one lane slot each; the slots of an
+        // interval stay inside one row of 16 lanes (slots left idle where the next interval would straddle a row: 59 slots)
         static const int E[NB] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100};
         std::vector<int> seg(192, 0);
         int ns = 0;
         for (int i = 0; i < NB - 1; i++) {
             int k = E[i] << 2, end = E[i + 1] << 2;
+            const int need = (end - k + 7) / 8;
+            if (need > 16) return fail("band interval too long for a row of lanes");
+            if ((ns & 15) + need > 16) ns = (ns + 15) & ~15;   // (idle slots: count 0)
             seg[128 + i] = ns;
             while (k < end) {
                 int c = end - k < 8 ? end - k : 8;
+                if (ns >= 64) return fail("band segmentation overflow");
                 seg[ns] = k;
                 seg[64 + ns] = c;
                 ns++;

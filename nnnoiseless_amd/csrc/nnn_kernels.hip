@@ -1867,8 +1867,10 @@ template <int NQ>
 __device__ __forceinline__ void band_sums_par(const FftLds &t, const float *const (&v)[NQ], float (&out)[NQ], int lane)
 {
     const short *seg = t.seg;
-    const int ls = lane < 54 ? lane : 53;   // (lanes past the last segment shadow it and contribute nothing)
-    const int k0 = seg[ls], cnt = lane < 54 ? seg[64 + ls] : 0, rem = lane < 54 ? seg[192 + ls] : 0;
+    // lane = slot: k0, bin count (0: an idle slot) and the number of the interval's segments behind this one.  The slots of an interval
+    // never straddle a row of 16 lanes (the host leaves slots idle for that, 59 of 64 in use), so the suffix sum's four rounds are DPP
+    // row moves (round 5: they were wave shuffles -- an index computation and an LDS-crossbar trip each).
+    const int k0 = seg[lane], cnt = seg[64 + lane], rem = seg[192 + lane];
     const int ks0 = bsk(k0);
     float pa[NQ], pb[NQ];
 #pragma unroll
@@ -1885,15 +1887,14 @@ __device__ __forceinline__ void band_sums_par(const FftLds &t, const float *cons
         }
     }
     // segmented suffix sum: afterwards the first segment of every interval holds the interval's totals
-#pragma unroll
-    for (int d = 1; d < 16; d *= 2) {
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            const float ta = __shfl_down(pa[q], d), tb = __shfl_down(pb[q], d);
-            pa[q] += rem >= d ? ta : 0.0f;
-            pb[q] += rem >= d ? tb : 0.0f;
-        }
+#define NNN_SUFFIX_ROUND(D)                                                          \
+    _Pragma("unroll") for (int q = 0; q < NQ; q++) {                                 \
+        const float ta = dpp_row_down<D>(pa[q]), tb = dpp_row_down<D>(pb[q]);        \
+        pa[q] += rem >= D ? ta : 0.0f;                                               \
+        pb[q] += rem >= D ? tb : 0.0f;                                               \
     }
+    NNN_SUFFIX_ROUND(1) NNN_SUFFIX_ROUND(2) NNN_SUFFIX_ROUND(4) NNN_SUFFIX_ROUND(8)
+#undef NNN_SUFFIX_ROUND
     // lane = band: interval `lane - 1` from below, interval `lane` above
     const int bnd = lane < NB ? lane : 0;
     const int lo = seg[128 + (bnd >= 1 ? bnd - 1 : 0)], hi = seg[128 + (bnd < NB - 1 ? bnd : 0)];

@@ -55,6 +55,14 @@ __device__ __forceinline__ float amax3(float a, float b, float m)
     asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(m));
     return r;
 }
+// lane i of every row of 16 lanes receives lane i + D's value of the same row (a lane whose source would be past the row's end keeps its
+// own): one DPP move (row_shl) where a shuffle is an index computation and a trip through the LDS crossbar
+template <int D> __device__ __forceinline__ float dpp_row_down(float x)
+{
+    static_assert(D >= 1 && D <= 15, "");
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x100 + D, 0xf, 0xf, false));
+}
 // maximum over the wave's 64 lanes, wave-uniform (four DPP steps inside the rows of 16, then the four rows through scalars)
 __device__ __forceinline__ unsigned wave_max_u32(unsigned x)
 {
