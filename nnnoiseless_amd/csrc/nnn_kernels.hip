@@ -1900,7 +1900,7 @@ __device__ __forceinline__ void band_sums_par(const FftLds &t, const float *cons
     const int lo = seg[128 + (bnd >= 1 ? bnd - 1 : 0)], hi = seg[128 + (bnd < NB - 1 ? bnd : 0)];
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-        const float fb = __shfl(pb[q], lo), fa = __shfl(pa[q], hi);
+        const float fb = wave_read(pb[q], lo), fa = wave_read(pa[q], hi);
         float o = (bnd >= 1 ? fb : 0.0f) + (bnd < NB - 1 ? fa : 0.0f);
         if (bnd == 0 || bnd == NB - 1) o *= 2.0f;
         out[q] = lane < NB ? o : 0.0f;
@@ -2148,16 +2148,16 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
         float pm = lyv;   // inclusive prefix maximum over the bands below (lanes past the bands hold -2: never above a log energy)
 #pragma unroll
         for (int d = 1; d < 32; d *= 2) {
-            const float tt = __shfl_up(pm, d);
+            const float tt = wave_read(pm, lane - d);   // (lanes below d read some other lane and keep their own value)
             pm = lane >= d ? fmaxf(pm, tt) : pm;
         }
         float m = fmaxf(fmaxf(lyv, -2.0f - 7.0f), -2.0f - 1.5f * (float)(lane + 1));
 #pragma unroll
         for (int d = 1; d <= 4; d++) {
-            const float tt = __shfl_up(lyv, d) - 1.5f * (float)d;
+            const float tt = wave_read(lyv, lane - d) - 1.5f * (float)d;
             m = lane >= d ? fmaxf(m, tt) : m;
         }
-        const float t5 = __shfl_up(pm, 5) - 7.0f;
+        const float t5 = wave_read(pm, lane - 5) - 7.0f;
         lfl = lane >= 5 ? fmaxf(m, t5) : m;
     }
     if (lane < NB) ly[lane] = lfl;

@@ -63,6 +63,12 @@ template <int D> __device__ __forceinline__ float dpp_row_down(float x)
     const int b = __builtin_bit_cast(int, x);
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x100 + D, 0xf, 0xf, false));
 }
+// x of lane `src` (any lane of the wave, taken modulo 64): the bare ds_bpermute_b32 -- one address instruction at most where __shfl /
+// __shfl_up re-derive the lane number and clamp against a width every time (eleven vector instructions a call in k_fft_xp's feature head)
+__device__ __forceinline__ float wave_read(float x, int src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, x)));
+}
 // maximum over the wave's 64 lanes, wave-uniform (four DPP steps inside the rows of 16, then the four rows through scalars)
 __device__ __forceinline__ unsigned wave_max_u32(unsigned x)
 {

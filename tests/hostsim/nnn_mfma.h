@@ -134,6 +134,7 @@ static inline float amax3(float a, float b, float m)
     return r;
 }
 template <int D> static inline float dpp_row_down(float x) { return __shfl_down(x, D, 16); }   // (own value where the source is past the row)
+static inline float wave_read(float x, int src) { return __shfl(x, src & 63); }
 static inline unsigned wave_max_u32(unsigned x)
 {
     unsigned m = 0;
