@@ -116,6 +116,7 @@ struct nnn_batch {
         const float *fpar = nullptr;   // biases + vad output layer (device)
         size_t rnn_lds = 0;            // dynamic LDS bytes at `rows`
         bool wf = false;               // the layer-pipelined kernel (k_rnn_wf) runs this group
+        bool shape_builtin = false;    // ... in its form compiled for the built-in shape class (every plan field a constant)
         WfPlan wp;
         size_t wf_lds = 0;
         int rows = 32;                 // stream rows per RNN block: 32 or 16
@@ -312,17 +313,7 @@ static size_t rnn_lds_bytes(const RnnPlan &pl, int rows)
 }
 constexpr size_t kLdsMax = 160 * 1024;
 // the layer-pipelined kernel: strides of its per-layer matrices and its dynamic LDS (mirrors k_rnn_wf's carve-up)
-static WfPlan rnn_wf_plan(const RnnPlan &pl)
-{
-    WfPlan w;
-    w.w_v = 32 * pl.vad.in.ksteps + 8;
-    w.w_n = 32 * pl.noise.in.ksteps + 8;
-    w.w_dn = 32 * pl.dn.in.ksteps + 8;
-    w.sw_v = 32 * pl.vad.rec.ksteps + 8;
-    w.sw_n = 32 * pl.noise.rec.ksteps + 8;
-    w.sw_dn = 32 * pl.dn.rec.ksteps + 8;
-    return w;
-}
+static WfPlan rnn_wf_plan(const RnnPlan &pl) { return wf_plan_of(pl); }
 static size_t rnn_wf_lds_bytes(const WfPlan &w)
 {
     const size_t cols = (size_t)w.w_v + 2 * w.w_n + 3 * w.w_dn + 2 * ((size_t)w.sw_v + w.sw_n + w.sw_dn) + WF_FS_W;
@@ -445,6 +436,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
         // (compiled for the built-in model's shape class, nnn_back.hip; any other model takes the unfused kernels)
         {
             const bool shape_ok = bk_same_shape(G.plan, BkShapeBuiltin::plan());
+            G.shape_builtin = shape_ok;
             const size_t fb = (size_t)back_lds(G.plan, true).total, rb = (size_t)back_lds(G.plan, false).total;
             G.back_lds = shape_ok && fb <= kLdsMax ? fb : 0;
             G.rnn16_lds = shape_ok && rb <= kLdsMax ? rb : 0;
@@ -564,7 +556,8 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     }
     // the RNN kernel's dynamic LDS limit is a per-device function attribute: raise it to the hardware's 160 KB once
     HIPCHK(hipFuncSetAttribute((const void *)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
-    HIPCHK(hipFuncSetAttribute((const void *)k_rnn_wf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+    HIPCHK(hipFuncSetAttribute((const void *)k_rnn_wf<WfShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+    HIPCHK(hipFuncSetAttribute((const void *)k_rnn_wf<BkShapeBuiltin>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     HIPCHK(hipFuncSetAttribute((const void *)k_back<true, BkShapeBuiltin>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     HIPCHK(hipFuncSetAttribute((const void *)k_back<false, BkShapeBuiltin>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     HIPCHK(hipFuncSetAttribute((const void *)k_back<true, BkShapeBuiltin, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
@@ -916,8 +909,15 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
             // for its five ticks: eight 4096-stream batches ticking side by side 40.2 -> 43.4 M frames/s with k_rnn, a lone batch -8 %)
             const int min_g = h->wf_min_g > 0 ? h->wf_min_g : ((G.ntiles * (TILE / WF_ROWS) >= 1024 || h->beside_others) ? 2 : 1);
             if (G.wf && g >= min_g)
-                L.go(K_RNN, k_rnn_wf, dim3((unsigned)(G.ntiles * (TILE / WF_ROWS))), dim3(64 * WF_WAVES), G.wf_lds, b, G.plan, G.wp, G.wq,
-                     G.fpar, G.tile0, g);
+            {
+                static const bool any_shape = dev_knob("NNN_WF_ANY") && atoi(dev_knob("NNN_WF_ANY")) != 0;   // (A/B: the run-time-plan form for every model)
+                if (G.shape_builtin && !any_shape)
+                    L.go(K_RNN, k_rnn_wf<BkShapeBuiltin>, dim3((unsigned)(G.ntiles * (TILE / WF_ROWS))), dim3(64 * WF_WAVES), G.wf_lds, b, G.plan, G.wp,
+                         G.wq, G.fpar, G.tile0, g);
+                else
+                    L.go(K_RNN, k_rnn_wf<WfShapeAny>, dim3((unsigned)(G.ntiles * (TILE / WF_ROWS))), dim3(64 * WF_WAVES), G.wf_lds, b, G.plan, G.wp,
+                         G.wq, G.fpar, G.tile0, g);
+            }
             else
                 L.go(K_RNN, k_rnn, dim3((unsigned)(G.ntiles * (TILE / G.rows))), dim3(64 * RNN_WAVES), G.rnn_lds, b, G.plan, G.wq, G.fpar,
                      G.tile0, G.rows, g);

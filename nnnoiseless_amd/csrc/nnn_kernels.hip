@@ -3171,9 +3171,33 @@ struct WfPlan {   // LDS strides (bf16 elements) of the per-layer matrices, set 
     int sw_v, sw_n, sw_dn;      // state / r * state matrices
 };
 
-__global__ void __launch_bounds__(64 * WF_WAVES, NNN_WF_MINWAVES) k_rnn_wf(Buffers b, RnnPlan pl, WfPlan wp, const uint4 *__restrict__ Wq,
+__host__ __device__ constexpr WfPlan wf_plan_of(const RnnPlan &pl)
+{
+    return WfPlan{32 * pl.vad.in.ksteps + 8, 32 * pl.noise.in.ksteps + 8, 32 * pl.dn.in.ksteps + 8,
+                  32 * pl.vad.rec.ksteps + 8, 32 * pl.noise.rec.ksteps + 8, 32 * pl.dn.rec.ksteps + 8};
+}
+// SH: a shape class with a compile-time packing plan (SH::plan(), e.g. BkShapeBuiltin of nnn_back.hip: every model of the built-in
+// layer sizes) or WfShapeAny (the plan comes with the launch).  With a compile-time plan only the six activation kinds are taken from
+// the launch's plan: every stride, column and fragment offset is a constant -- the run-time form keeps some fifty of them in scalar
+// registers, more than the wave has, and pays for it in v_readlane / v_writelane spill traffic inside the tick loop (round 5: a sixth
+// of the loop's vector instructions).  Same arithmetic either way.
+struct WfShapeAny { static constexpr bool fixed = false; };
+template <class SH> struct WfFixed { static constexpr bool value = true; };
+template <> struct WfFixed<WfShapeAny> { static constexpr bool value = false; };
+template <class SH>
+__global__ void __launch_bounds__(64 * WF_WAVES, NNN_WF_MINWAVES) k_rnn_wf(Buffers b, RnnPlan pl_rt, WfPlan wp_rt, const uint4 *__restrict__ Wq,
                                                             const float *__restrict__ fpar, int tile0, int g)
 {
+    RnnPlan pl = pl_rt;
+    WfPlan wp = wp_rt;
+    if constexpr (WfFixed<SH>::value) {
+        constexpr RnnPlan p0 = SH::plan();
+        constexpr WfPlan w0 = wf_plan_of(p0);
+        pl = p0;
+        pl.dense.act = pl_rt.dense.act; pl.vad.act = pl_rt.vad.act; pl.noise.act = pl_rt.noise.act; pl.dn.act = pl_rt.dn.act;
+        pl.out.act = pl_rt.out.act; pl.act_vo = pl_rt.act_vo;
+        wp = w0;
+    }
     HIP_DYNAMIC_SHARED(float, lds_raw)
     constexpr int rm = WF_ROWS;
     const int wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
