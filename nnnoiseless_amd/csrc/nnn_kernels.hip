@@ -943,6 +943,9 @@ __device__ __forceinline__ float pk_autocorr(const float *pbs, int blk0 = 0, flo
 // (defined behind the transforms, further down: the X transform of a one-frame call in rider blocks of k_pitch's launch)
 __device__ __forceinline__ void xt_rider(const Buffers &b, const StepParams *sp, int rb, void *lds);
 
+#ifndef NNN_PK_LATE_WINDOW
+#define NNN_PK_LATE_WINDOW 1
+#endif
 #ifndef NNN_PK_MINWAVES
 #define NNN_PK_MINWAVES 4   // waves per SIMD: two blocks of 8 waves per CU, <= 128 registers
 #endif
@@ -1083,7 +1086,9 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 }
             }
         }
+#if !NNN_PK_LATE_WINDOW
         if (f + 1 < f_end) pk_window_load(b, sp0 + f + 1, tile, q0, tid, win, fir);   // the next frame's window travels behind this frame's work
+#endif
         __syncthreads();
         NNN_STAMP(b, 4);
         // ---- coarse search: the cross-correlation on waves 0..2, the running energy of the coarse lags on wave 3
@@ -1390,6 +1395,10 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         }
         __syncthreads();
         NNN_STAMP(b, 53);
+#if NNN_PK_LATE_WINDOW   // the next frame's window is requested here, two thirds into the frame (round 5; until then behind the FIR): its 32 registers are free
+                        // through the cross-correlation and the searches, and the ~8 us left of the frame still cover the trip (k_pitch -2.6 %; 0 = as before)
+        if (f + 1 < f_end) pk_window_load(b, sp0 + f + 1, tile, q0, tid, win, fir);
+#endif
         // ---- yy_lookup at the candidate periods (ref: src/pitch.rs:138-142): one candidate per lane (s, q) of waves 0..5; from the
         //      check point below T, at most four of the scan's steps.  (Read by the decision loop, behind the next barrier.)
         {
