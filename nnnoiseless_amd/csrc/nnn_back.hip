@@ -462,9 +462,10 @@ __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0,
         // (the state planes are first read behind the barrier that closes the first frame's feature stage)
     }
     NNN_STAMP(b, 1);
-    for (int f = 0; f < g; f++) {
-        lane = launder_v(lane0);   // keep the frame loop's addresses inside the loop (see launder_v)
-        wave = launder_s(wave0);
+    // (XR: a one-frame call by construction -- x_rides() -- so the frame loop is no loop: nothing is kept across it)
+    for (int f = 0; f < (XR ? 1 : g); f++) {
+        lane = XR ? lane0 : launder_v(lane0);   // keep the frame loop's addresses inside the loop (see launder_v)
+        wave = XR ? wave0 : launder_s(wave0);
         const StepParams *sp = sp0 + f;
         const Buffers bf = frame_view(b, f);
         NNN_STAMP(b, 2);
