@@ -181,6 +181,7 @@ struct nnn_batch {
     int lpc_wide = -1;              // k_lpc_wide (one lag per wave): -1 = for launches below 512 waves, 0 / 1 = never / always (env NNN_LPC_WIDE; tests)
     uint64_t id = 0, other_seen_us = 0;   // see g_call_mark
     bool beside_others = false;     // as of the current call
+    int cur_fmt = 0, cur_channels = 1;   // boundary format of the call being enqueued (k_synth's plain-format instantiation)
     bool host_call = false;         // inside a host-buffer entry point: the input is an upload enqueued by this library, final only in stream order
     hipEvent_t ev_in = nullptr;     // the caller's stream at the start of a pipelined call
     hipEvent_t ev_last = nullptr;   // end of the most recent call, on the stream it was made on
@@ -925,7 +926,8 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
         break;
     case ST_SYN:
         if (back == 2) break;
-        L.go(K_SYNTH, k_synth, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0, g);
+        if (h->cur_fmt == PCM_F32 && h->cur_channels == 1) L.go(K_SYNTH, k_synth<true>, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0, g);
+        else L.go(K_SYNTH, k_synth<false>, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0, g);
         break;
     }
 }
@@ -964,6 +966,8 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
 {
     HIPCHK(hipSetDevice(h->device));
     if (int rc = report_fault(h)) return rc;   // an earlier call's hand-off failure (seen as soon as the device has written it)
+    h->cur_fmt = fmt;
+    h->cur_channels = channels;
     {
         const uint64_t mask = (1ull << 44) - 1;
         const uint64_t now = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() & mask;

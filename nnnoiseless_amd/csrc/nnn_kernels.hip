@@ -3452,7 +3452,9 @@ __device__ __forceinline__ void interp_gain2(const float *ga, const float *gb, i
 // needs them (null).  Same products of the same factors either way.  (At 128 registers the kernel now spills one 64-bit value, the address
 // of the stream's overlap memory: stored before the frame loop, reloaded once behind it -- two scratch accesses per launch, none per frame.)
 struct BinConst { int band[8]; float frac[8]; };   // band: -1 = no gain there (bins from 400 up, empty slots)
-template <bool SMV_IO>
+// PLAIN (round 5): the call's boundary format is process_frame's own -- f32 in the range of an i16, one channel -- known when the kernel is launched:
+// the conversions, the channel arithmetic and their branches are compiled out of the instantiation the bench and most device-buffer callers run.
+template <bool SMV_IO, bool PLAIN = false>
 __device__ __forceinline__ void synth_frame(const Buffers &b, const StepParams *sp, int f, int tile, int sl, int s, int lane, const FftLds &t, float2 *A,
                                          float *r, float2 (&Xr)[8], const float2 (&Pk)[8], float b_ex, float b_ep, float b_xp, float b_graw,
                                          float b_g, float vadv, bool live, float *sm, float4 (&smq)[2], const BinConst *bc = nullptr)
@@ -3463,8 +3465,8 @@ __device__ __forceinline__ void synth_frame(const Buffers &b, const StepParams *
     }
     float *ebuf = (float *)A, *r2 = r + NB, *gg = r + 2 * NB;
     float *vad_out = sp->vad;
-    const int fmt = sp->fmt;
-    const int ch = sp->channels, grp = s / ch, elem = pcm_elem_bytes(fmt), sstride = ch * elem;
+    const int fmt = PLAIN ? (int)PCM_F32 : sp->fmt;
+    const int ch = PLAIN ? 1 : sp->channels, grp = s / ch, elem = pcm_elem_bytes(fmt), sstride = ch * elem;
     char *o = sp->out + (long long)grp * sp->group_stride + (long long)(s - grp * ch) * elem;
     const bool store = s < b.S && !sp->discard;
     int bmask = 1 << NB;             // lane 0: this frame's branch mask (bit 22: silent)
@@ -3607,6 +3609,7 @@ __device__ __forceinline__ void synth_frame(const Buffers &b, const StepParams *
 #ifndef NNN_SYN_MINWAVES
 #define NNN_SYN_MINWAVES 4
 #endif
+template <bool PLAIN>
 __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffers b, const StepParams *sp0, int g)
 {
     __shared__ FftLds t;
@@ -3656,7 +3659,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
             b_g = NNN_TIF(b, g, NB, f, tile, sl)[(size_t)lane * TILE];
         }
         const float vadv = NNN_TIF(b, vad, 1, f, tile, sl)[0];
-        synth_frame<false>(b, sp0 + f, f, tile, sl, s, lane, t, A, r, Xr, Pr, b_ex, b_ep, b_xp, b_graw, b_g, vadv, live, sm, smq, &bc);
+        synth_frame<false, PLAIN>(b, sp0 + f, f, tile, sl, s, lane, t, A, r, Xr, Pr, b_ex, b_ep, b_xp, b_graw, b_g, vadv, live, sm, smq, &bc);
     }
 #pragma unroll
     for (int u = 0; u < 2; u++)
