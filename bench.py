@@ -69,7 +69,7 @@ SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 4
 G = 24   # frames of a full group (a 48-frame call is two of them)
 KERNEL_BYTES = {
     "k_hp": 1920 + 1920 + 960 + 960 // 5 + 4 + (16 + 8) // G,     # input, history slot, 240 decimated values (+ mirrored share), x_lp[0]; biquad state per group
-    "k_lpc": (864 + 3 * 240) * 4 // 4 + 4 + 40,                     # decimated windows of four consecutive frames read once by their wave (1584 B per frame; small launches
+    "k_lpc": (864 + 7 * 240) * 4 // 8 + 4 + 40,                     # decimated windows of eight consecutive frames read once by their wave (1272 B per frame; small launches
                                                                    # take fewer frames per wave, up to 3456 B) + x_lp[0] in; autocorrelation and FIR taps out
     "k_pitch": 3456 + 4 + 20 + 8 + 16 // G,                         # decimated window + x_lp[0] + FIR taps in; pitch index + gain out; last pitch per group
                                                                    # (pitch_buf, coarse xcorr, the running energies and their check points never leave LDS)

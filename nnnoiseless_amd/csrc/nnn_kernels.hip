@@ -592,12 +592,51 @@ __device__ __forceinline__ void lpc_finish(const Buffers &b, int tile, int lane,
     }
 }
 
+// k_lpc's packed form.  One lag sum of a frame pair takes a product: MODE 1 the pair's first frame only, 2 the second only, 3 both;
+// H = the half of `p` that holds the product.
+template <int MODE, int H>
+__device__ __forceinline__ void lpc_add(v2f &a, v2f p)
+{
+    if (MODE == 3) a = H ? pk_add_by(a, p) : pk_add_bx(a, p);
+    else if (MODE == 1) a.x = sadd(a.x, H ? p.y : p.x);
+    else a.y = sadd(a.y, H ? p.y : p.x);
+}
+// the chunk's LPC_CH rows (x[i] in aligned pairs, `first` in row 0's place) against rows i .. i + 4, into the five lag sums: ac[k] +=
+// x[i] * x[i + k], i ascending (ref: src/pitch.rs:433-446)
+template <int MODE, int NP>
+__device__ __forceinline__ void lpc_rows(v2f (&acc)[5], const v2f (&rows)[NP], float first)
+{
+    v2f cur[LPC_CH / 2 + 2];
+#pragma unroll
+    for (int i = 0; i < LPC_CH / 2 + 2; i++) cur[i] = rows[i];
+    cur[0].x = first;
+#pragma unroll
+    for (int m = 0; m < LPC_CH / 2; m++) {
+        {   // row 2m: (p0, p1) (p2, p3) (p4, -)
+            const v2f a = pk_mul_bx(cur[m], cur[m]), b = pk_mul_bx(cur[m], cur[m + 1]), c = pk_mul_bx(cur[m], cur[m + 2]);
+            lpc_add<MODE, 0>(acc[0], a); lpc_add<MODE, 1>(acc[1], a); lpc_add<MODE, 0>(acc[2], b); lpc_add<MODE, 1>(acc[3], b); lpc_add<MODE, 0>(acc[4], c);
+        }
+        {   // row 2m + 1: (-, p0) (p1, p2) (p3, p4)
+            const v2f a = pk_mul_by(cur[m], cur[m]), b = pk_mul_by(cur[m], cur[m + 1]), c = pk_mul_by(cur[m], cur[m + 2]);
+            lpc_add<MODE, 1>(acc[0], a); lpc_add<MODE, 0>(acc[1], b); lpc_add<MODE, 1>(acc[2], b); lpc_add<MODE, 0>(acc[3], c); lpc_add<MODE, 1>(acc[4], c);
+        }
+    }
+}
+template <int MODE, int NP>
+__device__ __forceinline__ void lpc_rows(v2f (&acc)[5], const v2f (&rows)[NP]) { lpc_rows<MODE>(acc, rows, rows[0].x); }
+template <int NP>
+__device__ __forceinline__ float lpc_cur(const v2f (&cur)[NP], int n) { return n & 1 ? cur[n >> 1].y : cur[n >> 1].x; }
+
 // k_lpc: one wave per (tile, LPC_FC consecutive frames).  Consecutive frames' windows overlap by 624 of 864 rows, and frames of a
 // tile running as separate waves do not find each other's rows in L2 (the few hundred waves an XCD has in flight read 16 MB of
 // rows between two uses of a line: 3.4 KB per stream-frame from HBM).  Here a wave walks the union of its frames' windows once
 // -- 864 + 240 per further frame rows -- and every row serves each frame whose window holds it: the same sums in the same order
-// per frame (up to 4 x 5 independent chains in flight), 2.2x fewer rows.
-constexpr int LPC_FC = 4;
+// per frame, 2.7x fewer rows with eight frames per wave.
+#ifndef NNN_LPC_FC_MAX
+#define NNN_LPC_FC_MAX 8
+#endif
+constexpr int LPC_FC = NNN_LPC_FC_MAX;
+static_assert(LPC_FC % 2 == 0, "k_lpc sums frames in pairs");
 static_assert(240 % LPC_CH == 0, "");
 // `fc` <= LPC_FC frames per wave: the host gives small launches fewer (more, shorter waves)
 __global__ void __launch_bounds__(64) k_lpc(Buffers b, const StepParams *sp0, int g, int fc)
@@ -627,33 +666,38 @@ __global__ void __launch_bounds__(64) k_lpc(Buffers b, const StepParams *sp0, in
     };
     constexpr int NCH = (XLP - 4) / LPC_CH, STEP = 240 / LPC_CH;   // chunks of a window (43), chunks between two windows (12)
     const int J = NCH + STEP * (nf - 1);
-    float cur[LPC_CH + 4], nxt[LPC_CH];
+    // Rows in aligned register pairs, frames in pairs (acc[q][k] = lag k of frames 2q and 2q + 1): a row's five products are three packed
+    // multiplies, and while both frames of a pair hold the row -- 31 of a window's 43 chunks -- one packed add serves both (the product
+    // in both halves by operand selection).  Same products, same sums in the same order as lpc_chains above.  (The arithmetic is not what
+    // paces this kernel -- the rows are: packed or not, 22.7 us per frame at 65536 streams with four frames per wave; the packed form's
+    // registers let a wave take eight: 19.6, profiles/r5_experiments_ab.txt O.)
+    constexpr int NP = (LPC_CH + 4) / 2;
+    v2f cur[NP], nxt[LPC_CH / 2];
 #pragma unroll
-    for (int i = 0; i < LPC_CH + 4; i++) cur[i] = row(i);
-    float acc[LPC_FC][5];
+    for (int i = 0; i < NP; i++) cur[i] = v2f{row(2 * i), row(2 * i + 1)};
+    v2f acc[LPC_FC / 2][5];
 #pragma unroll
-    for (int c = 0; c < LPC_FC; c++)
+    for (int q = 0; q < LPC_FC / 2; q++)
 #pragma unroll
-        for (int k = 0; k < 5; k++) acc[c][k] = 0.0f;
+        for (int k = 0; k < 5; k++) acc[q][k] = v2f{0.0f, 0.0f};
 #pragma nounroll
     for (int j = 0; j < J; j++) {
-        // rows 20 (j + 1) + 4 .. + 23 travel while this chunk is summed (the last chunk re-reads its own rows: in range, unused)
         const int jn = j + 1 < J ? j + 1 : j;
 #pragma unroll
-        for (int i = 0; i < LPC_CH; i++) nxt[i] = row(jn * LPC_CH + 4 + i);
+        for (int i = 0; i < LPC_CH / 2; i++) nxt[i] = v2f{row(jn * LPC_CH + 4 + 2 * i), row(jn * LPC_CH + 5 + 2 * i)};
 #pragma unroll
-        for (int c = 0; c < LPC_FC; c++) {
-            const int jj = j - STEP * c;   // this chunk's place in frame c's window
-            if (c < nf && jj >= 0 && jj < NCH) {
-                // ac[k] += x[i] * x[i + k], i ascending: the reference's sequential sum per lag (ref: src/pitch.rs:433-446)
-                const float first = jj == 0 ? x0[c] : cur[0];
+        for (int q = 0; q < LPC_FC / 2; q++) {
+            const int jj0 = j - STEP * 2 * q, jj1 = jj0 - STEP;   // this chunk's place in the two frames' windows
+            const bool a0 = 2 * q < nf && jj0 >= 0 && jj0 < NCH, a1 = 2 * q + 1 < nf && jj1 >= 0 && jj1 < NCH;
+            if (a0 && a1 && jj1 != 0) lpc_rows<3>(acc[q], cur);
+            else {
+                // a window's first row is the frame's own x_lp[0] (ref: src/pitch.rs:458): that chunk on its own
+                if (a0) lpc_rows<1>(acc[q], cur, jj0 == 0 ? x0[2 * q] : cur[0].x);
+                if (a1) lpc_rows<2>(acc[q], cur, jj1 == 0 ? x0[2 * q + 1] : cur[0].x);
+            }
 #pragma unroll
-                for (int i = 0; i < LPC_CH; i++) {
-                    const float xi = i == 0 ? first : cur[i];
-#pragma unroll
-                    for (int k = 0; k < 5; k++) acc[c][k] += xi * (i + k == 0 ? first : cur[i + k]);
-                }
-                if (jj == NCH - 1) {
+            for (int h = 0; h < 2; h++)
+                if ((h ? a1 : a0) && (h ? jj1 : jj0) == NCH - 1) {
                     // tail d_k = sum_{i = k + 860}^{863} x[i] x[i - k], added after the main sum; cur[] holds rows 840 .. 863 of the window
                     float ac[5];
 #pragma unroll
@@ -661,18 +705,17 @@ __global__ void __launch_bounds__(64) k_lpc(Buffers b, const StepParams *sp0, in
                         constexpr int O = XLP - LPC_CH - 4;
                         float d = 0.0f;
 #pragma unroll
-                        for (int i = k + XLP - 4; i < XLP; i++) d += cur[i - O] * cur[i - k - O];
-                        ac[k] = acc[c][k] + d;
+                        for (int i = k + XLP - 4; i < XLP; i++) d += lpc_cur(cur, i - O) * lpc_cur(cur, i - k - O);
+                        ac[k] = (h ? acc[q][k].y : acc[q][k].x) + d;
                     }
-                    lpc_finish(b, tile, lane, slot[c], ac);
+                    lpc_finish(b, tile, lane, slot[2 * q + h], ac);
                 }
-            }
         }
         if (j + 1 < J) {
+            cur[0] = cur[LPC_CH / 2];
+            cur[1] = cur[LPC_CH / 2 + 1];
 #pragma unroll
-            for (int i = 0; i < 4; i++) cur[i] = cur[LPC_CH + i];
-#pragma unroll
-            for (int i = 0; i < LPC_CH; i++) cur[4 + i] = nxt[i];
+            for (int i = 0; i < LPC_CH / 2; i++) cur[2 + i] = nxt[i];
         }
     }
 }

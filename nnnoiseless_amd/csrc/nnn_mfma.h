@@ -174,6 +174,18 @@ __device__ __forceinline__ v2f pk_add(v2f a, v2f b)
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ v2f pk_add_bx(v2f a, v2f b)    // (a.x + b.x, a.y + b.x): b's low half onto both of a
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_add_by(v2f a, v2f b)    // (a.x + b.y, a.y + b.y)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // Frame-to-frame hand-off between workgroups of one launch (k_pitch): the producer makes its results visible device-wide
 // and then stores the flag; the consumer polls the flag and only then reads the results.

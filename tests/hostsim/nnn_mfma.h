@@ -162,6 +162,8 @@ static inline v2f pk_mul(v2f a, v2f b) { return mk2(a.x * b.x, a.y * b.y); }
 static inline v2f pk_mul_bx(v2f a, v2f b) { return mk2(a.x * b.x, a.x * b.y); }
 static inline v2f pk_mul_by(v2f a, v2f b) { return mk2(a.y * b.x, a.y * b.y); }
 static inline v2f pk_add(v2f a, v2f b) { return mk2(a.x + b.x, a.y + b.y); }
+static inline v2f pk_add_bx(v2f a, v2f b) { return mk2(a.x + b.x, a.y + b.x); }
+static inline v2f pk_add_by(v2f a, v2f b) { return mk2(a.x + b.y, a.y + b.y); }
 static inline float sadd(float a, float b) { return a + b; }
 
 // (the interpreter runs the workgroups of a launch one after the other in index order: a flag is always set when it is read)

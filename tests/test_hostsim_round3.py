@@ -98,21 +98,21 @@ def test_caller_supplied_buffers_are_validated(hostsim_lib):
 
 
 def test_lpc_kernel_variants_agree_bit_for_bit(hostsim_lib, oracle_mod, weights_bytes, monkeypatch):
-    """k_lpc (every lane carries its stream's five autocorrelation chains, a wave walking the windows of 1, 2 or 4 consecutive
-    frames at once) and k_lpc_wide (one lag per wave, what launches too small to fill the GPU use) give the same bits, and both the
+    """k_lpc (every lane carries its stream's five autocorrelation chains, a wave walking the windows of 1, 2, 4 or 8 consecutive
+    frames at once, their sums in frame pairs) and k_lpc_wide (one lag per wave, what launches too small to fill the GPU use) give the same bits, and both the
     oracle's: autocorrelation, FIR taps and everything downstream."""
     import nnnoiseless_amd as nn
     from nnnoiseless_amd.synthetic import make_streams
     S, T = 7, 7
     x = make_streams(40, S, T)
     res = {}
-    for wide, fc in (("0", "1"), ("0", "2"), ("0", "4"), ("1", "0")):
+    for wide, fc in (("0", "1"), ("0", "2"), ("0", "4"), ("0", "8"), ("1", "0")):
         monkeypatch.setenv("NNN_LPC_WIDE", wide)
         monkeypatch.setenv("NNN_LPC_FC", fc)
         bd = nn.BatchDenoiser(S, lib=hostsim_lib, taps=True)
-        out, vad = bd.process(x)                     # one group of 7 frames: with four frames per wave, a wave of 4 and a wave of 3
+        out, vad = bd.process(x)                     # one group of 7 frames: with four frames per wave, a wave of 4 and a wave of 3; with eight, one wave of 7
         res[wide + fc] = (out, vad, bd.tap("ac").copy(), bd.tap("lpc2").copy(), bd.tap("xlp").copy(), bd.tap("pitch").copy())
-    for key in ("02", "04", "10"):
+    for key in ("02", "04", "08", "10"):
         for a, b in zip(res["01"], res[key]):
             assert np.array_equal(a, b), key
     om = oracle_mod.Model(weights_bytes)
