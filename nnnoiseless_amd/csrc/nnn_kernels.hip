@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(64, HP_CH <= 16 ? 3 : 1) k_hp(Buffers b, const
 // ---------------------------------------------------------------------------------------------
 // K2  lpc: the part of pitch_downsample between the decimation and the FIR -- 5-lag autocorrelation of the 864-value window,
 //     lag window, order-4 Levinson recursion, bandwidth expansion and the extra zero (ref: src/pitch.rs:433-446, 460-480,
-//     257-292) -- lane = stream on the tile-interleaved decimated ring, one wave per (tile, up to four consecutive frames).
+//     257-292) -- lane = stream on the tile-interleaved decimated ring, one wave per (tile, up to eight consecutive frames).
 //     Each of the five sums is a serial chain of 860 steps in the reference's order; inside k_pitch (one block per 16
 //     streams) they occupied two waves for 8.7 of the block's 44 us with the other six waiting behind a barrier.  Here every lane
 //     carries its own stream's five chains (independent of each other: five-way instruction-level parallelism on full waves), the
