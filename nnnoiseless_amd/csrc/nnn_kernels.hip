@@ -2088,6 +2088,11 @@ __device__ __forceinline__ void spectrum_load_p(const float2 *row, float2 (&S)[8
     }
 }
 
+#ifndef NNN_FH_STRIDE
+#define NNN_FH_STRIDE 24
+#endif
+constexpr int FH_STRIDE = NNN_FH_STRIDE;   // floats between the feature head's three staged band arrays (22 used of each)
+static_assert(FH_STRIDE >= NB, "");
 // XR (fused, one-frame calls): X and its band energies are in memory already -- computed by rider blocks of k_pitch's launch, which needs
 // nothing of what the pitch analysis finds (xt_rider) -- and are fetched instead of computed.
 template <bool WITH_P, bool FUSED = false, bool XR = false>
@@ -2178,7 +2183,7 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
     // the silence test, and the two DCTs -- lane = band.  Same operations in the same order as when one lane did it all.
     wave_lds_sync();
     NNN_FUSED_RELAUNDER();
-    float *xc = part, *ly = part + 64, *exl = part + 128;
+    float *xc = part, *ly = part + FH_STRIDE, *exl = part + 2 * FH_STRIDE;
     float lyv = -2.0f, xnv = 0.0f;
     if (lane < NB) {
         const float xn = o[1] / sqrtf(0.001f + exv * o[0]);
@@ -2247,8 +2252,10 @@ __device__ __forceinline__ void transform_inputs(const Buffers &b, const StepPar
 #undef NNN_FUSED_RELAUNDER
 }
 
+// five waves per SIMD (96 registers, no spill) and, with LDS kept to 27.6 KB per block, five blocks per CU: k_fft_xp -3.8 % against four
+// (profiles/r5_experiments_ab.txt Q)
 #ifndef NNN_FFT_MINWAVES
-#define NNN_FFT_MINWAVES 4
+#define NNN_FFT_MINWAVES 5
 #endif
 // Block index -> (frame, tile, four streams of the tile) for the g frames of a group.  Batches of a multiple of 8 tiles: the blocks an
 // XCD receives (i mod 8, in index order) are the g frames of one quartet of streams, then the next quartet's, tile t on XCD t mod 8:
@@ -2261,9 +2268,11 @@ __device__ __forceinline__ void fft_block(const Buffers &b, int g, int &frame, i
 }
 __global__ void __launch_bounds__(64 * FFT_SPB, NNN_FFT_MINWAVES) k_fft_xp(Buffers b, const StepParams *sp, int g)
 {
-    __shared__ FftLds t;
+    // (the part of the tables this kernel copies and reads: with the staging below kept to what it holds, 27.6 KB -- a fifth of the CU's LDS)
+    __shared__ __attribute__((aligned(16))) char tbuf[FFT_TABLES_SHORT];
+    FftLds &t = *(FftLds *)tbuf;
     __shared__ float2 Z[FFT_SPB][NFFT_BUF];
-    __shared__ float part[FFT_SPB][3 * 64];   // the feature head's staging: correlation, log energies, band energies
+    __shared__ float part[FFT_SPB][3 * FH_STRIDE];   // the feature head's staging: correlation, log energies, band energies
     int frame, tile, sub;
     fft_block(b, g, frame, tile, sub);
     b = frame_view(b, frame);
