@@ -37,12 +37,12 @@ template <int MODE> __global__ void k(double *out, long long *cyc, int n)
     out[threadIdx.x] = a + b + c + d + (double)(f + g + h + e);
     if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
-template <int MODE> void run(const char *name, int per_rep, double *out, long long *cyc)
+template <int MODE> void run(const char *name, int per_rep, double *out, long long *cyc, int lanes = 64)
 {
     const int n = 64;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(64), 0, 0, out, cyc, n); hipDeviceSynchronize();
-    hipEventRecord(e0); hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(64), 0, 0, out, cyc, n * 16); hipEventRecord(e1); hipDeviceSynchronize();
+    hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(lanes), 0, 0, out, cyc, n); hipDeviceSynchronize();
+    hipEventRecord(e0); hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(lanes), 0, 0, out, cyc, n * 16); hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
     const double ops = (double)n * 16 * REP * per_rep;
@@ -63,5 +63,11 @@ int main()
     run<5>("v_cvt_f32_f64, independent", 4, out, cyc);
     run<6>("v_cvt_f64_f32, independent", 4, out, cyc);
     run<10>("recurrence chain (6 instructions)", 6, out, cyc);
+    // does a wave with fewer live lanes issue faster?  (the high-pass recurrence is one chain per stream: 32-lane waves would be twice as many)
+    run<4>("v_add_f64, 4 independent chains, 32 lanes", 4, out, cyc, 32);
+    run<4>("v_add_f64, 4 independent chains, 16 lanes", 4, out, cyc, 16);
+    run<10>("recurrence chain, 32 lanes", 6, out, cyc, 32);
+    run<10>("recurrence chain, 16 lanes", 6, out, cyc, 16);
+    run<5>("v_cvt_f32_f64, independent, 32 lanes", 4, out, cyc, 32);
     return 0;
 }
