@@ -154,7 +154,9 @@ int nnn_batch_debug_withhold_flag(nnn_batch *b, int frames_ahead);
  * [n_streams][len] (float32 or int32, see nnn_tap_info).  Test/diagnostic interface.  Everything inside the pitch kernel
  * (XLP, XCORR1, BEST1, XCORR2C, PITCH_SEARCH), X, P and FEATURES are quantities the kernels keep on
  * chip: they are stored to device memory only after nnn_batch_set_taps(batch, 1) (which also allocates their arrays), and
- * reading them without it is an error. */
+ * reading them without it is an error.  With taps at 1 the coarse pitch search computes all 147 cross-correlations exactly (the full
+ * search, so that XCORR1 is complete); nnn_batch_set_taps(batch, 2) stores the same taps from the certified search production runs take --
+ * XCORR1 then holds NaN at every lag the search ruled out and the exact sum at the lags it kept (ref: src/pitch.rs:83-84, 372-405). */
 enum nnn_tap {
     NNN_TAP_FILTERED = 0, /* [480] f32  high-passed input (features.rs:97-104)           */
     NNN_TAP_XLP,          /* [864] f32  pitch_buf after pitch_downsample (pitch.rs:448)   */

@@ -757,7 +757,7 @@ extern "C" nnn_batch *nnn_batch_clone(nnn_batch *h)
     c->lpc_wide = h->lpc_wide;
     c->lpc_fc = h->lpc_fc;
     c->inputs_ready = h->inputs_ready;
-    if (h->b[0].taps && nnn_batch_set_taps(c, 1) != 0) {
+    if (h->b[0].taps && nnn_batch_set_taps(c, h->b[0].taps) != 0) {
         nnn_batch_destroy(c);
         return nullptr;
     }
@@ -879,8 +879,10 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
         const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
         const unsigned grid = Sp / PK_SPB * (chain ? ug : 1u);
         const bool riders = x_rides(h, g, back);   // (the fused back end's X transform in rider blocks of this launch, see xt_rider)
-        L.go(K_PITCH, k_pitch, dim3(grid + (riders ? Sp / 8 : 0u)), dim3(PK_T), 0, b, sp0, g, chain, seq0, h->tickets, lpc_in_pitch(h, g) ? (lpc_head(h, g) ? 2 : 1) : 0,
-             riders ? (int)grid : 0);
+        if (lpc_in_pitch(h, g))
+            L.go(K_PITCH, k_pitch<true>, dim3(grid + (riders ? Sp / 8 : 0u)), dim3(PK_T), 0, b, sp0, g, chain, seq0, h->tickets, lpc_head(h, g) ? 2 : 1, riders ? (int)grid : 0);
+        else
+            L.go(K_PITCH, k_pitch<false>, dim3(grid + (riders ? Sp / 8 : 0u)), dim3(PK_T), 0, b, sp0, g, chain, seq0, h->tickets, 0, riders ? (int)grid : 0);
         if (chain) h->tickets += grid;   // (launches of one batch's pitch stage are ordered among themselves: a stateful stage)
         break;
     }
@@ -1420,7 +1422,9 @@ extern "C" int nnn_batch_set_taps(nnn_batch *h, int on)
         for (int set = 1; set < h->nset; set++) h->b[set] = frame_view(h->b[0], set);
         h->taps_alloc = true;
     }
-    for (int set = 0; set < h->nset; set++) h->b[set].taps = on != 0;
+    // (1: every tap, the coarse pitch search as the full search so that all 147 cross-correlations exist; 2: the same taps from the certified
+    // search -- NNN_TAP_XCORR1 then holds NaN at the lags it ruled out)
+    for (int set = 0; set < h->nset; set++) h->b[set].taps = on == 2 ? 2 : (on != 0);
     return 0;
 }
 
@@ -1652,7 +1656,7 @@ static void enqueue_feature_group(nnn_batch *h, hipStream_t st, const float *in,
         }
         const int chain = h->pitch_chain > 0 && g > 1 && (h->pitch_chain > 1 || Sp / PK_SPB < 1024u), seq0 = (int)(h->frame_count & 0x3fffffffu) + 1;
         const unsigned grid = Sp / PK_SPB * (chain ? ug : 1u);
-        hipLaunchKernelGGL(k_pitch, dim3(grid), dim3(PK_T), 0, st, b, (const StepParams *)sp, g, chain, seq0, h->tickets, 0, 0);
+        hipLaunchKernelGGL(k_pitch<false>, dim3(grid), dim3(PK_T), 0, st, b, (const StepParams *)sp, g, chain, seq0, h->tickets, 0, 0);
         if (chain) h->tickets += grid;
         hipLaunchKernelGGL(k_fft_xp, dim3(Sp * ug / FFT_SPB), dim3(64 * FFT_SPB), 0, st, b, (const StepParams *)sp, g);
         hipLaunchKernelGGL(k_features, dim3(NT), dim3(64 * FEAT_WAVES), 0, st, b, g);

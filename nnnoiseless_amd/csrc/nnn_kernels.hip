@@ -862,12 +862,33 @@ __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) { retu
 // scans were bound by the depth of a wave's store queue.)
 constexpr int PK_CKF = 8, PK_NCKF = (NLAG2 + PK_CKF - 1) / PK_CKF;    // 37
 constexpr int PK_CKY = 5, PK_NCKY = 384 / PK_CKY + 1;                  // 77
-struct PkLds {
+// The certified coarse search (round 6; see the phase in k_pitch): what it keeps in LDS.
+constexpr int PK_DP = 157;                       // a stream's row of coarse-lag energies: lag L at L + (L >> 4), an odd pitch (lane = stream and wave = stream both read it)
+constexpr int PK_RMAX = 24;                      // lags of one stream that may survive the approximate search (more: the block takes the full search)
+constexpr int PK_CAP = 384;                      // ... and of the block's 16 streams together
+constexpr int PK_PLW = XLP / 2 + 8;              // halfwords between two streams' bf16 planes (the 432 even rows of pitch_buf): 220 words, so that the
+                                                 // eight streams of a region sit on eight different banks for the FIR's word stores
+constexpr float PK_EPS = 0.0083f;                // |approximate - reference| <= PK_EPS sqrt(|x|^2 |y window|^2): two bf16 roundings 2^-7, the matrix
+                                                 // cores' f32 accumulation and the reference's own sequential f32 sum well inside the rest
+__device__ __forceinline__ int pk_den_at(int L) { return L + (L >> 4); }
+struct PkCert {
+    float den[PK_SPB][PK_DP];                    // the running energy every coarse lag sees in find_best_pitch (ref: src/pitch.rs:380-402)
+    float bsum[PK_SPB][27];                      // |.|^2 of the 27 blocks of 16 even rows (any nonzero value: at least 2^-120)
+    unsigned mask[PK_SPB][5];                    // bit L: coarse lag L of the stream survived
+    unsigned count, full, pad_[2];               // survivors of the block; != 0: the block takes the full search
+    union {
+        unsigned short plane[(PK_SPB / 2) * PK_PLW + 16];   // bf16 even rows of streams 8 .. 15 (streams 0 .. 7: over ckf / cky, idle until the scans);
+                                                            // + the 32 bytes the last fragment read of the last stream runs over (masked)
+        struct { unsigned short list[PK_CAP]; float slotv[PK_SPB][PK_RMAX]; } s;   // survivors (stream << 8 | lag); their exact sums by rank within the stream
+    } p;
+};
+struct alignas(16) PkLds {
     float pb[PK_ODD + PK_HALF];                  // the decimated window, then (in place) pitch_buf
     float ckf[PK_NCKF][PK_SPB];                  // running energy of the fine lags before lag 8 m (find_best_pitch, ref: src/pitch.rs:380-402)
     float cky[PK_NCKY][PK_SPB];                  // running energy yy of remove_doubling after step 5 m (ref: src/pitch.rs:133-142); [0] = xx
     union {
-        struct { float xc[NLAG1][PK_SPB], ysq[NLAG1][PK_SPB]; } c;   // coarse search: squared positive cross-correlation (else NaN), running energy per lag
+        struct { float xc[NLAG1][PK_SPB], ysq[NLAG1][PK_SPB]; } c;   // full coarse search: squared positive cross-correlation (else NaN), running energy per lag
+        PkCert a;                                                      // certified coarse search
         struct {                                                       // from the fine search on
             float part[PK_NC][4][PK_SPB];        // inner-product partials [slot][q][stream] (ref: src/pitch.rs:225-244)
             float yy[32][PK_SPB];                // yy_lookup at the candidate periods
@@ -883,6 +904,9 @@ struct PkLds {
         } f;
     } u;
 };
+static_assert(sizeof(PkLds) <= 80 * 1024, "two blocks per CU");
+static_assert(offsetof(PkLds, ckf) % 16 == 0 && offsetof(PkLds, u) % 16 == 0 && offsetof(PkCert, p) % 16 == 0 && (PK_PLW * 2) % 16 == 0, "16-byte fragment reads");
+static_assert(sizeof(float) * (PK_NCKF + PK_NCKY) * PK_SPB >= sizeof(unsigned short) * (PK_SPB / 2) * PK_PLW + 32, "the first eight planes fit over the check points");
 
 // Window and FIR mapping: thread = (stream col, chunk ch of 32 rows), 27 chunks (the block's last 80 threads idle here); a
 // chunk starts on an even row, so every LDS address of its 16 row pairs is the thread's base plus a constant.
@@ -895,7 +919,13 @@ __device__ __forceinline__ void pk_window_load(const Buffers &b, const StepParam
                                                float (&fir)[5])
 {
     const int col = tid & 15, ch = tid >> 4;
-    if (ch >= PK_NCH) return;
+    if (ch >= PK_NCH) {   // (defined on every path: otherwise the previous window stays live through the whole frame for the register allocator)
+#pragma unroll
+        for (int i = 0; i < PK_CH; i++) v[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 5; i++) fir[i] = 0.0f;
+        return;
+    }
     const int slot = sp->slot;
     {
         const float *lp = NNN_TI(b.lpc, b.nslot * 10, tile, q0 + col) + (size_t)(slot * 10) * TILE;
@@ -983,9 +1013,251 @@ __device__ __forceinline__ float pk_autocorr(const float *pbs, int blk0 = 0, flo
     return c + d;
 }
 
+// ---- the serial energy scans of k_pitch on quad lanes (round 6) -------------------------------------------------------------------
+// find_best_pitch and remove_doubling carry three running energies through the frame -- the energy every coarse lag sees, the one every
+// fine lag sees, yy_lookup (ref: src/pitch.rs:380-402, :133-142) -- each a chain of several hundred f32 additions whose order is the
+// reference's.  One wave issues one instruction every ~4.5 cycles whatever its lane count, and with lane = stream a step was six or seven
+// instructions (two loads, two squares, a difference, the add, the clamp) on 16 of 64 lanes: the chains, not the arithmetic of the search,
+// were the frame's critical path (round 6 stamps: 10 + 8 us of a block's 42).  Here a wave takes ONE chain for the block's 16 streams,
+// lane = (stream, q): the four lanes of a quad fetch and square the rows of four consecutive steps at once, and every lane then adds the
+// four terms in order, each add taking its operand from a quad lane through DPP -- the same additions in the same order, 2.25 to 4.25
+// instructions per step.  Rows are requested a group ahead of the adds that use them.
+constexpr int PK_FINE_K = (NLAG2 + 3) / 4;       // 74 groups of four fine lags
+constexpr int PK_YY_B = 19;                      // 19 runs of twenty steps of yy_lookup (380 steps: the last four are only ever replayed)
+// (the four terms are fetched by four independent DPP moves, then added by plain instructions: an add that takes its operand through DPP
+// waits two more states on the sum it has just written and runs at a third of the rate -- measured, 21 against 9 cycles a step)
+struct Quad4 { float t0, t1, t2, t3; };
+__device__ __forceinline__ Quad4 pk_quad4(float t)
+{
+    Quad4 r = {quad_lane<0>(t), quad_lane<1>(t), quad_lane<2>(t), quad_lane<3>(t)};
+    keep_rw(r.t0); keep_rw(r.t1); keep_rw(r.t2); keep_rw(r.t3);
+    return r;
+}
+__device__ __forceinline__ float pk_add4(float y, float t)
+{
+    const Quad4 r = pk_quad4(t);
+    y = y + r.t0;
+    y = y + r.t1;
+    y = y + r.t2;
+    return y + r.t3;
+}
+// the energy every coarse lag sees (even rows only), ref: src/pitch.rs:83 -> :380-402: its start, 1 + |y4[0 .. 239]|^2 ...
+__device__ __forceinline__ float pk_chain_coarse_start(const float *pbs, int cq)
+{
+    const float *pq = pbs + cq * PK_SPB;   // y4[4 k + cq] at pq[64 k]
+    float ysq = 1.0f;
+    float nx[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) nx[i] = pq[(4 * i) * PK_SPB];
+#pragma nounroll
+    for (int k0 = 0; k0 < 60; k0 += 4) {
+        float cur[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) cur[i] = nx[i];
+        const int kn = k0 + 4 < 60 ? k0 + 4 : k0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) nx[i] = pq[(4 * (kn + i)) * PK_SPB];
+#pragma unroll
+        for (int i = 0; i < 4; i++) ysq = pk_add4(ysq, cur[i] * cur[i]);
+    }
+    return ysq;
+}
+// ... and groups k0 .. k1 - 1 of four lags: den[pk_den_at(L)] = the energy before lag L = 4 k + cq, which drops y4[L] and takes y4[L + 240]
+constexpr int PK_COARSE_K = 38;                  // (147 lags: the 148th .. 152nd are computed and dropped)
+__device__ __forceinline__ float pk_chain_coarse(const float *pbs, int cq, float ysq, int k0, int k1, float *dn)
+{
+    float na[2], nd[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int L = 4 * (k0 + i) + cq < NLAG1 ? 4 * (k0 + i) + cq : NLAG1 - 1;
+        na[i] = pbs[(L + 240) * PK_SPB];
+        nd[i] = pbs[L * PK_SPB];
+    }
+#pragma nounroll
+    for (int k = k0; k < k1; k += 2) {
+        float ca[2], cd[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) { ca[i] = na[i]; cd[i] = nd[i]; }
+        const int kn = k + 2 < k1 ? k + 2 : k;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int L = 4 * (kn + i) + cq < NLAG1 ? 4 * (kn + i) + cq : NLAG1 - 1;
+            na[i] = pbs[(L + 240) * PK_SPB];
+            nd[i] = pbs[L * PK_SPB];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float t = ca[i] * ca[i] - cd[i] * cd[i];
+            const Quad4 r = pk_quad4(t);
+            const float y0 = ysq;
+            ysq = fmaxf(ysq + r.t0, 1.0f);
+            const float y1 = ysq;
+            ysq = fmaxf(ysq + r.t1, 1.0f);
+            const float y2 = ysq;
+            ysq = fmaxf(ysq + r.t2, 1.0f);
+            const float y3 = ysq;
+            ysq = fmaxf(ysq + r.t3, 1.0f);
+            const int L = 4 * (k + i) + cq;
+            if (L < NLAG1) dn[pk_den_at(L)] = cq == 0 ? y0 : (cq == 1 ? y1 : (cq == 2 ? y2 : y3));
+        }
+    }
+    return ysq;
+}
+// the energy every fine lag sees (ref: src/pitch.rs:97 -> :380-402): its start, 1 + |rows 0 .. 479|^2 in row order ...
+__device__ __forceinline__ float pk_chain_fine_start(const float *pbs, int cq, float ysq, int k0, int k1)   // rows 4 k0 .. 4 k1 - 1 (k0, k1 multiples of 4)
+{
+    const float *pq = pbs + ((cq & 1) ? PK_ODD : 0) + (cq >> 1) * PK_SPB;   // row 4 k + cq at pq[32 k]
+    float nx[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) nx[i] = pq[(2 * (k0 + i)) * PK_SPB];
+#pragma nounroll
+    for (int k = k0; k < k1; k += 4) {
+        float cur[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) cur[i] = nx[i];
+        const int kn = k + 4 < k1 ? k + 4 : k;
+#pragma unroll
+        for (int i = 0; i < 4; i++) nx[i] = pq[(2 * (kn + i)) * PK_SPB];
+#pragma unroll
+        for (int i = 0; i < 4; i++) ysq = pk_add4(ysq, cur[i] * cur[i]);
+    }
+    return ysq;
+}
+// ... and groups k0 .. k1 - 1 of four lags: lag 4 k + cq drops row 4 k + cq and takes row 4 k + cq + 480; check point ckf[m] = the energy
+// before lag 8 m (k even)
+__device__ __forceinline__ float pk_chain_fine(const float *pbs, int cq, int cs, float ysq, int k0, int k1, float (*ckf)[PK_SPB])
+{
+    const float *pq = pbs + ((cq & 1) ? PK_ODD : 0) + (cq >> 1) * PK_SPB;
+    float na[2], nd[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) { na[i] = pq[(2 * (k0 + i) + 240) * PK_SPB]; nd[i] = pq[(2 * (k0 + i)) * PK_SPB]; }
+#pragma nounroll
+    for (int k = k0; k < k1; k += 2) {
+        float ca[2], cd[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) { ca[i] = na[i]; cd[i] = nd[i]; }
+        const int kn = k + 2 < k1 ? k + 2 : k;
+#pragma unroll
+        for (int i = 0; i < 2; i++) { na[i] = pq[(2 * (kn + i) + 240) * PK_SPB]; nd[i] = pq[(2 * (kn + i)) * PK_SPB]; }
+        if (cq == 0) ckf[k >> 1][cs] = ysq;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float t = ca[i] * ca[i] - cd[i] * cd[i];
+            const Quad4 r = pk_quad4(t);
+            ysq = fmaxf(ysq + r.t0, 1.0f);
+            ysq = fmaxf(ysq + r.t1, 1.0f);
+            ysq = fmaxf(ysq + r.t2, 1.0f);
+            ysq = fmaxf(ysq + r.t3, 1.0f);
+        }
+    }
+    return ysq;
+}
+// xx = yy_lookup[0] = |rows 384 .. 863|^2 as inner_prod sums it: four interleaved partial sums combined ((s0 + s1) + s2) + s3
+// (ref: src/pitch.rs:133-136, :225-244) -- one partial per quad lane
+__device__ __forceinline__ float pk_chain_yy_start(const float *pbs, int cq)
+{
+    const float *pq = pbs + ((cq & 1) ? PK_ODD : 0) + (192 + (cq >> 1)) * PK_SPB;   // row 384 + 4 t + cq at pq[32 t]
+    float sq = 0.0f;
+    float nx[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) nx[i] = pq[(2 * i) * PK_SPB];
+#pragma nounroll
+    for (int t0 = 0; t0 < 120; t0 += 8) {
+        float cur[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) cur[i] = nx[i];
+        const int tn = t0 + 8 < 120 ? t0 + 8 : t0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) nx[i] = pq[(2 * (tn + i)) * PK_SPB];
+#pragma unroll
+        for (int i = 0; i < 8; i++) sq += cur[i] * cur[i];
+    }
+    return ((quad_lane<0>(sq) + quad_lane<1>(sq)) + quad_lane<2>(sq)) + quad_lane<3>(sq);
+}
+// runs b0 .. b1 - 1 of twenty steps of yy_lookup (ref: src/pitch.rs:137-142): step j takes row 384 - j and drops row 864 - j; check point
+// cky[m] = yy after step 5 m.  Lane cq of a quad prepares steps 4 k + 1 + cq.
+__device__ __forceinline__ float pk_chain_yy(const float *pbs, int cq, int cs, float yy, int b0, int b1, float (*cky)[PK_SPB])
+{
+    const float *pq = pbs + ((cq & 1) ? 0 : PK_ODD) + (191 - (cq >> 1)) * PK_SPB;   // row 383 - 4 k - cq at pq[-32 k]
+    float na[5], nc[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { na[i] = pq[-(2 * (5 * b0 + i)) * PK_SPB]; nc[i] = pq[(240 - 2 * (5 * b0 + i)) * PK_SPB]; }
+#pragma nounroll
+    for (int bk = b0; bk < b1; bk++) {
+        float ca[5], cc[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) { ca[i] = na[i]; cc[i] = nc[i]; }
+        const int bn = bk + 1 < b1 ? bk + 1 : bk;
+#pragma unroll
+        for (int i = 0; i < 5; i++) { na[i] = pq[-(2 * (5 * bn + i)) * PK_SPB]; nc[i] = pq[(240 - 2 * (5 * bn + i)) * PK_SPB]; }
+#pragma unroll
+        for (int i = 0; i < 5; i++) {   // steps 20 bk + 4 i + 1 .. + 4: the run's check points fall behind step 5, 10, 15, 20
+            const float t = ca[i] * ca[i] - cc[i] * cc[i];
+            const Quad4 r = pk_quad4(t);
+            yy = yy + r.t0;
+            if (i == 1 && cq == 0) cky[4 * bk + 1][cs] = yy;
+            yy = yy + r.t1;
+            if (i == 2 && cq == 0) cky[4 * bk + 2][cs] = yy;
+            yy = yy + r.t2;
+            if (i == 3 && cq == 0) cky[4 * bk + 3][cs] = yy;
+            yy = yy + r.t3;
+            if (i == 4 && cq == 0) cky[4 * bk + 4][cs] = yy;
+        }
+    }
+    return yy;
+}
+
+// sum_{j < 240} x[j] y[j] in order (ref: src/pitch.rs:296-363, one lag), rows PK_SPB floats apart: two register sets in turn, so that the
+// rows of the next eight taps travel while these eight are summed (the compiler rotates a one-set prefetch back into "load, wait, use")
+__device__ __forceinline__ float pk_dot240(const float *xp, const float *yp)
+{
+    float c = 0.0f;
+    v2f xa[4], ya[4], xb[4], yb[4];
+#define NNN_LD(X, Y, J) do { _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) { \
+        X[i_] = mk2(xp[((J) + 2 * i_) * PK_SPB], xp[((J) + 2 * i_ + 1) * PK_SPB]); Y[i_] = mk2(yp[((J) + 2 * i_) * PK_SPB], yp[((J) + 2 * i_ + 1) * PK_SPB]); } } while (0)
+#define NNN_ACC(X, Y) do { _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) { const v2f pr_ = pk_mul(X[i_], Y[i_]); c = sadd(c, pr_.x); c = sadd(c, pr_.y); } } while (0)
+    NNN_LD(xa, ya, 0);
+#pragma nounroll
+    for (int j = 0; j < 224; j += 16) {
+        NNN_LD(xb, yb, j + 8);
+        NNN_ACC(xa, ya);
+        NNN_LD(xa, ya, j + 16);
+        NNN_ACC(xb, yb);
+    }
+    NNN_LD(xb, yb, 232);
+    NNN_ACC(xa, ya);
+    NNN_ACC(xb, yb);
+#undef NNN_LD
+#undef NNN_ACC
+    return c;
+}
+
+// where the coarse lags' scan is cut (tuned against shader-clock stamps)
+#ifndef NNN_PK_SEG
+#define NNN_PK_SEG 16
+#endif
+constexpr int PK_SEG_D1 = NNN_PK_SEG;   // groups of coarse lags whose energies wave 7 has scanned when the search's first barrier comes
+constexpr int PK_SEG_FS = 120;
+static_assert(PK_SEG_D1 % 2 == 0 && PK_SEG_D1 <= PK_COARSE_K, "");
+
 // (defined behind the transforms, further down: the X transform of a one-frame call in rider blocks of k_pitch's launch)
 __device__ __forceinline__ void xt_rider(const Buffers &b, const StepParams *sp, int rb, void *lds);
 
+#ifndef NNN_BISECT_A
+#define NNN_BISECT_A 0
+#endif
+#ifndef NNN_BISECT_B
+#define NNN_BISECT_B 0
+#endif
+#ifndef NNN_BISECT_C
+#define NNN_BISECT_C 0
+#endif
+#ifndef NNN_BISECT_D
+#define NNN_BISECT_D 0
+#endif
+#ifndef NNN_PK_PRIO
+#define NNN_PK_PRIO 0
+#endif
 #ifndef NNN_PK_LATE_WINDOW
 #define NNN_PK_LATE_WINDOW 1
 #endif
@@ -1005,10 +1277,14 @@ __device__ __forceinline__ void xt_rider(const Buffers &b, const StepParams *sp,
 // waves ahead of the FIR, instead of as a launch of its own (k_lpc_wide) ahead of this one -- round 2's arrangement, which costs the
 // block 9 us with six waves waiting; for a group of frames that was the kernel's worst phase, for a lone frame it is cheaper than the
 // 14.5 us launch plus its gap on the call's critical path.  Same sums in the same order: bit-identical to k_lpc / k_lpc_wide.
-__global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, const StepParams *sp0, int g, int chain, int seq0, unsigned tbase, int lpc_here,
+// LPC: the instantiation that can run the LPC analysis (`lpc_here`): its autocorrelation holds 36 registers beside the prefetched window, which
+// costs the frame loop of the groups' instantiation spills at the kernel's 128-register limit (round 6).
+template <bool LPC>
+__global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, const StepParams *sp0, int g, int chain, int seq0, unsigned tbase, int lpc_here_,
                                                                  int riders)
 {
     __shared__ PkLds L;
+    const int lpc_here = LPC ? lpc_here_ : 0;
     if (riders > 0 && (int)blockIdx.x >= riders) {   // (one-frame launches only: chain == 0, the pitch blocks are blocks 0 .. riders - 1)
         xt_rider(b, sp0, (int)blockIdx.x - riders, &L);
         return;
@@ -1128,15 +1404,226 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                     chO[m * PK_SPB] = o.y;
                 }
             }
+            if (ch < PK_NCH) {
+                // for the certified coarse search: the chunk's 16 even rows -- the 4x-decimated signal -- as bf16 (to nearest) and their energy.
+                // Read back from LDS: held in registers through the FIR they cost the kernel spills (it sits at its 128-register limit there).
+                const float *ce = L.pb + launder_v((chc * (PK_CH / 2)) * PK_SPB + col);
+                unsigned *pl = (unsigned *)((col < PK_SPB / 2 ? (unsigned short *)&L.ckf[0][0] : L.u.a.p.plane) + (col & 7) * PK_PLW + (PK_CH / 2) * ch);
+                unsigned nz = 0;
+                float bs = 0.0f;
+#pragma unroll
+                for (int m = 0; m < PK_CH / 2; m += 2) {
+                    const float e0 = ce[m * PK_SPB], e1 = ce[(m + 1) * PK_SPB];
+                    pl[m >> 1] = pk_bf16_rn(e0, e1);
+                    bs += e0 * e0;
+                    bs += e1 * e1;
+                    nz |= (__float_as_uint(e0) | __float_as_uint(e1)) << 1;
+                }
+                // (a block with any nonzero value has a nonzero sum -- squares underflow; a NaN or an infinity stays what it is)
+                L.u.a.bsum[col][ch] = (nz != 0 && bs < 0x1p-120f) ? 0x1p-120f : bs;
+            }
+            if (tid < PK_SPB * 5 + 2) (&L.u.a.mask[0][0])[tid] = 0u;   // the survivors' masks, count and the full-search flag
         }
 #if !NNN_PK_LATE_WINDOW
         if (f + 1 < f_end) pk_window_load(b, sp0 + f + 1, tile, q0, tid, win, fir);   // the next frame's window travels behind this frame's work
 #endif
         __syncthreads();
         NNN_STAMP(b, 4);
-        // ---- coarse search: the cross-correlation on waves 0..2, the running energy of the coarse lags on wave 3
+        // ---- coarse search (ref: src/pitch.rs:83-84 -> :296-363, :372-405).  find_best_pitch returns the two lags with the largest
+        //      corr^2 / energy and nothing else of the 147 cross-correlations is ever used, so most of them need not be exact
+        //      (round 6).  Certified search:
+        //      (1) every correlation APPROXIMATELY, on the matrix cores: D[i][j] = sum_k A[i][k] B[k][j] with A[i][k] = x4[k - i]
+        //          (zero outside 0 .. 239), B[k][j] = y4[k + 16 j] is lag i + 16 j -- eight v_mfma_f32_16x16x32_bf16 per stream, the
+        //          operands the signal rounded to bf16 (the FIR left that plane in LDS).  Rigorous error, from the energies of the 16-value
+        //          blocks the window covers: |approx - reference| <= e = PK_EPS sqrt(|x4|^2 W_j), W_j >= |y4[16 j .. 16 j + 255]|^2.
+        //      (2) with the exact running energy den_L of every lag (the reference's own serial scan): lag L certainly scores at least
+        //          lo_L^2 = (c_L - e)^2 / den_L (if c_L - e > 0) and at most hi_L^2 = (c_L + e)^2 / den_L.  Let T be the SECOND largest lo.
+        //          A lag with hi_L < T is beaten by two lags whatever its exact value: it cannot be in the final pair, and -- being below
+        //          both of them by more than the comparisons' own rounding -- it cannot change which of the others end up there
+        //          (DESIGN.md section 4.1 has the argument).  Everything else SURVIVES: typically two to five lags per stream.
+        //      (3) the survivors' sums exactly, in the reference's order, lane = (stream, lag); find_best_pitch over them in lag order.
+        //      Blocks where that does not apply -- a stream with non-finite or extreme values, fewer than two certain lags and many
+        //      candidates, parity taps that want all 147 values -- take the full search below: round 5's code, every lag exact.
+        //      Roles: waves 0 .. 3 the search (stream sq = wave + 4 u, the four streams of a wave side by side so that one's latencies are
+        //      another's issue slots), waves 5, 6, 7 the three serial energy scans (see pk_chain_*), which run beside it in pieces cut at
+        //      the search's barriers; wave 4 joins for the exact sums.
+        //      (2) does NOT wait for the coarse lags' energy scan: it bounds den_L from both sides with the block energies and the bf16
+        //      plane (|den_L - (1 + |y4[L .. L + 239]|^2)| is the scan's own rounding, <= 2^-15 (1 + |y4|^2)); the scan's exact values are
+        //      first needed by find_best_pitch over the survivors.
         const float *pE = L.pb + s, *pO = pE + PK_ODD;   // rows 2m / 2m + 1 of this lane's stream at p?[16 m]
-        {
+        const int li = lane & 15, kg = lane >> 4;        // matrix fragments: row / column, k group
+        const int cs = lane >> 2, cq = lane & 3;         // scan waves: stream, quad lane
+        const float *pcs = L.pb + cs;
+        const int wv = launder_s(wave);                  // (keeps this phase's wave-uniform addresses inside the frame loop, see launder_v)
+        f32x4 cacc[4];                                   // approximate correlations of the wave's streams
+        float chain_y = 0.0f;                            // scan waves: the running energy
+        if (wv < 4) {
+            // x4[u] sits at halfword 192 + u of the plane; a row of A reaches 15 halfwords before x4[0] (first k-step) and 31 behind x4[239]
+            // (last k-step): masked.  Halfword e of lane (li, kg) is x4[32 t + 8 kg + e - li].
+            unsigned m0[4], m7[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int n0 = li - 8 * kg, n1 = 16 + li - 8 * kg;
+                m0[w] = (2 * w >= n0 ? 0xffffu : 0u) | (2 * w + 1 >= n0 ? 0xffff0000u : 0u);
+                m7[w] = (2 * w < n1 ? 0xffffu : 0u) | (2 * w + 1 < n1 ? 0xffff0000u : 0u);
+            }
+            const unsigned sh = (unsigned)(li & 1) * 16u;
+            const char *pl[4], *pa[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int sq = wv + 4 * u;
+                pl[u] = (const char *)((sq < PK_SPB / 2 ? (const unsigned short *)&L.ckf[0][0] : L.u.a.p.plane) + (sq & 7) * PK_PLW);
+                pa[u] = pl[u] + ((384 + 16 * kg - 2 * li) & ~3);   // A: the word that holds halfword 192 + 8 kg - li
+                pl[u] += 16 * kg + 32 * li;                        // B: halfword 8 kg + 16 li
+                cacc[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint4 bq = *(const uint4 *)(pl[u] + 64 * t);
+                    const unsigned *d = (const unsigned *)(pa[u] + 64 * t);
+                    const unsigned d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
+                    uint4 aq = make_uint4(align_bits(d1, d0, sh), align_bits(d2, d1, sh), align_bits(d3, d2, sh), align_bits(d4, d3, sh));
+                    if (t == 0) { aq.x &= m0[0]; aq.y &= m0[1]; aq.z &= m0[2]; aq.w &= m0[3]; }
+                    if (t == 7) { aq.x &= m7[0]; aq.y &= m7[1]; aq.z &= m7[2]; aq.w &= m7[3]; }
+                    cacc[u] = mfma_16x16x32_bf16(aq, bq, cacc[u]);
+                }
+            }
+            NNN_STAMPW(b, 2, wave == 0);
+            if (b.taps == 2) {   // (test mode: the cross-correlation tap keeps NaN where a lag was ruled out)
+                for (int i = 64 * wv + lane; i < NLAG1 * PK_SPB; i += 64 * 4) NNN_TIF(b, xc1, NLAG1, f, tile, q0 + (i & 15))[(size_t)(i >> 4) * TILE] = __builtin_nanf("");
+            }
+            // ---- (2) who survives.  Element r of lane (li, kg) of D is row 4 kg + r, column li: lag 16 li + 4 kg + r.
+            const int lj = li < 10 ? li : 9;   // (columns 10 .. 15 hold no lag: they follow column 9 and are masked)
+            float chp[4][4], clo[4][4], m1[4], m2[4];
+            unsigned cfl = 0;                  // bit u: stream u has nothing but zeros in x4; bit 4 + u: stream u is not ordinary
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int sq = wv + 4 * u;
+                const float *bsr = L.u.a.bsum[sq];
+                // W_j = blocks j .. j + 15 (>= the energy of the 240-value window of every lag of column j); |x4|^2 = blocks 12 .. 26 = W_12
+                float wub = 0.0f;
+#pragma unroll
+                for (int n = 0; n < 4; n++) { const int ix = li + 4 * kg + n; wub += ix < 27 ? bsr[ix] : 0.0f; }
+                wub += wave_xor16(wub, lane);
+                wub += wave_xor32(wub, lane);
+                const float xxu = lane_value(wub, 12), wtot = lane_value(wub, 0) + lane_value(wub, 11);
+                // the search is certified for ordinary values only: no NaN or infinity, no product of the comparisons in find_best_pitch
+                // near the ends of the f32 range (|corr| <= sqrt(|x4|^2 W) <= 2^41, energies <= 2^41 + 1: corr^2 * energy < 2^124)
+                const bool odd = !(wtot <= 0x1p41f) || !(xxu >= 0x1p-60f);
+                const bool xzero = xxu == 0.0f;   // every x4 is zero: every correlation is zero (or NaN), none is > 0 -- no survivor
+                cfl |= (xzero ? 1u : 0u) << u | ((odd && !xzero) ? 16u : 0u) << u;
+                const float e = PK_EPS * fast_sqrt(xxu) * fast_sqrt(wub);   // (two roots: the product of two small energies would underflow)
+                // den_L from both sides.  The window of lag 16 j + i is the tail of block j from value i on, blocks j + 1 .. j + 14 whole (their
+                // f32 energies) and the first i values of block j + 15: the two partial blocks from the bf16 plane, this lane's quarter of each
+                // as suffix / prefix sums, the other quarters' totals from the lanes that hold them.
+                const unsigned short *pv = (sq < PK_SPB / 2 ? (const unsigned short *)&L.ckf[0][0] : L.u.a.p.plane) + (sq & 7) * PK_PLW + 16 * lj + 4 * kg;
+                const uint2 av = *(const uint2 *)pv, cv = *(const uint2 *)(pv + 240);
+                const float a0 = __uint_as_float(av.x << 16), a1 = __uint_as_float(av.x & 0xffff0000u), a2 = __uint_as_float(av.y << 16), a3 = __uint_as_float(av.y & 0xffff0000u);
+                const float c0 = __uint_as_float(cv.x << 16), c1 = __uint_as_float(cv.x & 0xffff0000u), c2 = __uint_as_float(cv.y << 16), c3 = __uint_as_float(cv.y & 0xffff0000u);
+                float sfx[4], pfx[4];
+                sfx[3] = a3 * a3; sfx[2] = a2 * a2 + sfx[3]; sfx[1] = a1 * a1 + sfx[2]; sfx[0] = a0 * a0 + sfx[1];
+                pfx[0] = 0.0f; pfx[1] = c0 * c0; pfx[2] = pfx[1] + c1 * c1; pfx[3] = pfx[2] + c2 * c2;
+                const float qa = sfx[0], qc = pfx[3] + c3 * c3;
+                const float qa1 = wave_xor16(qa, lane), qa2 = wave_xor32(qa, lane), qa3 = wave_xor32(qa1, lane);   // the quarter sums of lanes kg ^ 1, kg ^ 2, kg ^ 3
+                const float qc1 = wave_xor16(qc, lane), qc2 = wave_xor32(qc, lane), qc3 = wave_xor32(qc1, lane);
+                const float sa = ((kg ^ 1) > kg ? qa1 : 0.0f) + ((kg ^ 2) > kg ? qa2 : 0.0f) + ((kg ^ 3) > kg ? qa3 : 0.0f);   // the quarters behind this one
+                const float sc = ((kg ^ 1) < kg ? qc1 : 0.0f) + ((kg ^ 2) < kg ? qc2 : 0.0f) + ((kg ^ 3) < kg ? qc3 : 0.0f);   // the quarters ahead of this one
+                const float s14 = wub - bsr[lj] - bsr[lj + 15];
+                const float slack = 0x1p-22f * wub + 0x1p-15f * (1.0f + wtot);   // the subtraction above; the serial scan's own rounding
+                m1[u] = -INFINITY;
+                m2[u] = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int Lr = 4 * kg + r + 16 * li;
+                    const bool valid = li < 10 && Lr < NLAG1;
+                    const float pr = (sfx[r] + sa) + (pfx[r] + sc);   // the partial blocks' share, within 2^-6.98 (bf16 values squared)
+                    const float dlo = fmaxf(1.0f + (s14 + pr * (1.0f - 0x1p-6f) - slack), 1.0f), dhi = 1.0f + (s14 + pr * (1.0f + 0x1p-6f) + slack);
+                    const float ch = cacc[u][r] + e;
+                    chp[u][r] = (valid && ch > 0.0f) ? ch * fast_rsq(dlo) : -1.0f;   // hi_L where the lag may be positive at all
+                    clo[u][r] = valid ? (cacc[u][r] - e) * fast_rsq(dhi) : -INFINITY;
+                    const float lo_ = fminf(m1[u], clo[u][r]);
+                    m1[u] = fmaxf(m1[u], clo[u][r]);
+                    m2[u] = fmaxf(m2[u], lo_);
+                }
+            }
+            // the second largest lo of each stream: rows of 16 lanes by DPP, the four rows through scalars
+#define NNN_TOP2(u, n1, n2) do { const float a1_ = (n1), a2_ = (n2), lo_ = fminf(m1[u], a1_); m1[u] = fmaxf(m1[u], a1_); m2[u] = fmaxf(lo_, fmaxf(m2[u], a2_)); } while (0)
+#pragma unroll
+            for (int u = 0; u < 4; u++) NNN_TOP2(u, row_partner<0>(m1[u]), row_partner<0>(m2[u]));
+#pragma unroll
+            for (int u = 0; u < 4; u++) NNN_TOP2(u, row_partner<1>(m1[u]), row_partner<1>(m2[u]));
+#pragma unroll
+            for (int u = 0; u < 4; u++) NNN_TOP2(u, row_partner<2>(m1[u]), row_partner<2>(m2[u]));
+#pragma unroll
+            for (int u = 0; u < 4; u++) NNN_TOP2(u, row_partner<3>(m1[u]), row_partner<3>(m2[u]));
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float b1 = lane_value(m1[u], 16), b2 = lane_value(m2[u], 16), c1 = lane_value(m1[u], 32), c2 = lane_value(m2[u], 32),
+                            d1 = lane_value(m1[u], 48), d2 = lane_value(m2[u], 48);
+                m1[u] = lane_value(m1[u], 0);
+                m2[u] = lane_value(m2[u], 0);
+                NNN_TOP2(u, b1, b2);
+                NNN_TOP2(u, c1, c2);
+                NNN_TOP2(u, d1, d2);
+            }
+#undef NNN_TOP2
+            bool want_full = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int sq = wv + 4 * u;
+                // two lags are certainly positive and certainly in the ordinary range: T = m2, less the rounding of this arithmetic, v_rsq_f32's
+                // ulp and the margin of (2); else every lag that may be positive survives
+                const bool two = m2[u] > 0x1p-40f;
+                const float thr = two ? m2[u] * (1.0f - 0x1p-10f) : 0.0f;
+                const bool xzero = (cfl >> u) & 1u;
+                unsigned long long bal[4];
+                unsigned tot = 0;
+                bool keep[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    keep[r] = !xzero && chp[u][r] > 0.0f && chp[u][r] >= thr;
+                    bal[r] = wave_ballot(keep[r]);
+                    tot += (unsigned)__builtin_popcountll(bal[r]);
+                }
+                if (tot != 0) {
+                    unsigned base = 0;
+                    if (lane == 0) base = lds_add_u32(&L.u.a.count, tot);
+                    base = __float_as_uint(lane_value(__uint_as_float(base), 0));
+                    want_full |= base + tot > (unsigned)PK_CAP;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int Lr = 4 * kg + r + 16 * li;
+                        const unsigned ix = base + (unsigned)__builtin_popcountll(bal[r] & ((1ull << lane) - 1ull));
+                        if (keep[r] && ix < (unsigned)PK_CAP) {
+                            L.u.a.p.s.list[ix] = (unsigned short)((sq << 8) | Lr);
+                            lds_or_u32(&L.u.a.mask[sq][Lr >> 5], 1u << (Lr & 31));
+                        }
+                        base += (unsigned)__builtin_popcountll(bal[r]);
+                    }
+                }
+                want_full |= ((cfl >> (4 + u)) & 1u) != 0 || tot > (unsigned)PK_RMAX;
+            }
+            if (lane == 0 && (want_full || b.taps == 1)) L.u.a.full = 1u;
+        } else if (wv == 7) {
+            chain_y = pk_chain_coarse_start(pcs, cq);
+            chain_y = pk_chain_coarse(pcs, cq, chain_y, 0, PK_SEG_D1, L.u.a.den[cs]);
+            NNN_STAMPW(b, 3, true);
+        } else if (wv == 5) {
+            chain_y = pk_chain_fine_start(pcs, cq, 1.0f, 0, PK_SEG_FS);
+            NNN_STAMPW(b, 28, true);
+        } else if (wv == 6) {
+            chain_y = pk_chain_yy_start(pcs, cq);
+            NNN_STAMPW(b, 29, true);
+        }
+        __syncthreads();   // (the planes are read: the scans' check points may take their place; the survivors are listed)
+        NNN_STAMP(b, 5);
+        const bool full = L.u.a.full != 0;           // block-uniform
+        const unsigned nsurv = L.u.a.count;
+        if (full) {
+            __syncthreads();   // (everyone has read the flag: the full search's arrays take the space)
+            // ---- full search: the cross-correlation of every lag on waves 0..2, the running energy of the coarse lags on wave 3
             const int grp = 4 * wave + q;
             if (grp < PK_NG) {
                 // xcorr[L] = sum_j x4[j] y4[L + j], x4[j] = p[384 + 2j], y4[m] = p[2m] (the even rows, compact): a sequential sum
@@ -1171,7 +1658,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
 #pragma unroll
                         for (int n = 0; n < PK_NP; n++) {
                             const v2f wp = (k & 1) ? PO[(k >> 1) + n] : PE[(k >> 1) + n];
-                            acc2[n] = acc2[n] + ((k & 1) ? pk_mul_by(xp2, wp) : pk_mul_bx(xp2, wp));
+                            acc2[n] = pk_add(acc2[n], (k & 1) ? pk_mul_by(xp2, wp) : pk_mul_bx(xp2, wp));
                         }
                         const float w1 = (k & 1) ? PO[(k >> 1) + PK_NP].x : PE[(k >> 1) + PK_NP].x;
                         acc1 = sadd(acc1, ((k & 1) ? xp2.y : xp2.x) * w1);
@@ -1216,116 +1703,113 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                         ysq = fmaxf(ysq, 1.0f);
                     }
                 }
-            } else if (wave == 7 && lane < PK_SPB) {
-                // the starting sums of the two long energy scans of the next phase (ref: src/pitch.rs:380-382, 133-136): these
-                // waves have nothing else to do while the cross-correlation runs, the scans are that phase's critical path
-                {
-                    float ysq = 1.0f;
-#pragma nounroll
-                    for (int m0 = 0; m0 < 240; m0 += 4) {
-                        float ve[4], vo[4];
-#pragma unroll
-                        for (int i = 0; i < 4; i++) { ve[i] = pE[(m0 + i) * PK_SPB]; vo[i] = pO[(m0 + i) * PK_SPB]; }
-#pragma unroll
-                        for (int i = 0; i < 4; i++) { ysq += ve[i] * ve[i]; ysq += vo[i] * vo[i]; }
-                    }
-                    L.ckf[0][s] = ysq;
-                }
-                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-#pragma nounroll
-                for (int m0 = 192; m0 < 432; m0 += 4) {
-                    float ve[4], vo[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { ve[i] = pE[(m0 + i) * PK_SPB]; vo[i] = pO[(m0 + i) * PK_SPB]; }
-#pragma unroll
-                    for (int i = 0; i < 4; i += 2) {
-                        s0 += ve[i] * ve[i]; s1 += vo[i] * vo[i]; s2 += ve[i + 1] * ve[i + 1]; s3 += vo[i + 1] * vo[i + 1];
-                    }
-                }
-                L.cky[0][s] = s0 + s1 + s2 + s3;   // xx = yy_lookup[0]
             }
+            __syncthreads();
         }
-        __syncthreads();
-        NNN_STAMP(b, 5);
-        // ---- find_best_pitch over the coarse lags (ref: src/pitch.rs:372-405, call site :83-84) on wave 0, a serial scan; beside it,
-        //      on waves 5 and 6 (other SIMDs), the two serial energy scans whose results are looked up later in the frame
+        NNN_STAMP(b, 63);
+        // ---- find_best_pitch over the coarse lags (ref: src/pitch.rs:372-405, call site :83-84): over the survivors' exact sums (certified
+        //      search: waves 0 .. 4 and 7 make them, wave 0 scans) or over all 147 (full search: wave 0, a serial scan); beside it, on
+        //      waves 5 and 6, the rest of the two energy scans whose results are looked up later in the frame
         int lo1 = 0, lo2 = 0;
-        if (dec_lane) {
-            BestPitch bp;
-            bp.init();
-            float c[7], e[7];
-#pragma unroll
-            for (int i = 0; i < 7; i++) { c[i] = L.u.c.xc[i][s]; e[i] = L.u.c.ysq[i][s]; }
+        if (wv == 5) chain_y = pk_chain_fine(pcs, cq, cs, chain_y, 0, PK_FINE_K, L.ckf);
+        else if (wv == 6) {
+            if (cq == 0) L.cky[0][cs] = chain_y;   // xx = yy_lookup[0]
+            chain_y = pk_chain_yy(pcs, cq, cs, chain_y, 0, PK_YY_B, L.cky);
+        } else if (wv == 7) chain_y = pk_chain_coarse(pcs, cq, chain_y, PK_SEG_D1, PK_COARSE_K, L.u.a.den[cs]);
+        else if (!full) {
+            // (3) lane = (stream, lag) of the survivor list: xcorr[L] = sum_j x4[j] y4[L + j], x4[j] = p[384 + 2j], y4[m] = p[2m], a sequential
+            //     sum (ref: src/pitch.rs:296-363), two taps per packed multiply, the adds in order
 #pragma nounroll
-            for (int i0 = 0; i0 < NLAG1; i0 += 7) {
-                float cn[7], en[7];   // the next seven lags travel while these are judged
-                const int i1 = i0 + 7 < NLAG1 ? i0 + 7 : i0;
+            for (unsigned e0 = 64u * (unsigned)wv; e0 < nsurv; e0 += 64u * 5u) {
+                const unsigned en = e0 + (unsigned)lane;
+                if (en < nsurv) {
+                    const unsigned ent = L.u.a.p.s.list[en];
+                    const int se = (int)(ent >> 8), Le = (int)(ent & 255u);
+                    const float *xp = L.pb + 192 * PK_SPB + se, *yp = L.pb + Le * PK_SPB + se;
+                    const float c = pk_dot240(xp, yp);
+                    // its place among the stream's survivors, in lag order
+                    const unsigned *mk = L.u.a.mask[se];
+                    int rk = 0;
 #pragma unroll
-                for (int i = 0; i < 7; i++) { cn[i] = L.u.c.xc[i1 + i][s]; en[i] = L.u.c.ysq[i1 + i][s]; }
-#pragma unroll
-                for (int i = 0; i < 7; i++) bp.update_sq(i0 + i, c[i], e[i]);
-#pragma unroll
-                for (int i = 0; i < 7; i++) { c[i] = cn[i]; e[i] = en[i]; }
-            }
-            if (b.taps) {
-                int *o = (int *)NNN_TIF(b, best1, 2, f, tile, sl);
-                o[0] = bp.best;
-                o[TILE] = bp.second;
-            }
-            lo1 = 2 * bp.best - 2;
-            lo2 = 2 * bp.second - 2;
-            NNN_STAMP(b, 61);
-        } else if (wave == 5 && lane < PK_SPB) {
-            // the running energy every fine lag sees (ref: src/pitch.rs:97 -> :380-402): <= 10 lags can update the best pitch there,
-            // and they are replayed below with the energy each of them saw
-            float ysq = L.ckf[0][s];   // the sum over the first 480 rows, made beside the coarse cross-correlation
-#pragma nounroll
-            for (int m = 0; m < PK_NCKF; m++) {   // lags 8 m .. 8 m + 7 (the last few past the table: computed, never looked up)
-                L.ckf[m][s] = ysq;
-                const int n0 = m * (PK_CKF / 2);
-                float ae[4], ao[4], de[4], dd[4];   // lags 2n, 2n + 1: rows (2n, 2n + 1) leave, rows (2n + 480, 2n + 481) enter
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    ae[i] = pE[(n0 + i + 240) * PK_SPB]; ao[i] = pO[(n0 + i + 240) * PK_SPB];
-                    de[i] = pE[(n0 + i) * PK_SPB]; dd[i] = pO[(n0 + i) * PK_SPB];
+                    for (int w = 0; w < 5; w++) {
+                        const unsigned mw = mk[w], below = w < (Le >> 5) ? mw : (w == (Le >> 5) ? mw & ((1u << (Le & 31)) - 1u) : 0u);
+                        rk += __builtin_popcount(below);
+                    }
+                    L.u.a.p.s.slotv[se][rk] = c;
+                    if (b.taps) NNN_TIF(b, xc1, NLAG1, f, tile, q0 + se)[(size_t)Le * TILE] = c;
                 }
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    ysq += ae[i] * ae[i] - de[i] * de[i];
-                    ysq = fmaxf(ysq, 1.0f);
-                    ysq += ao[i] * ao[i] - dd[i] * dd[i];
-                    ysq = fmaxf(ysq, 1.0f);
-                }
-            }
-        } else if (wave == 6 && lane < PK_SPB) {
-            // xx = |x|^2 over the analysis frame and the 384-step running energy yy_lookup of remove_doubling
-            // (ref: src/pitch.rs:133-142)
-            float yy = L.cky[0][s];   // xx = yy_lookup[0], made beside the coarse cross-correlation
-#pragma nounroll
-            for (int bk = 0; bk < 38; bk++) {   // steps 10 bk + 1 .. 10 bk + 10 (380 steps: the last four are only ever replayed)
-                const int n0 = 5 * bk;          // steps 2n + 1, 2n + 2: rows 383 - 2n, 382 - 2n enter, rows 863 - 2n, 862 - 2n leave
-                float ae[5], ao[5], ce[5], co[5];
-#pragma unroll
-                for (int i = 0; i < 5; i++) {
-                    ae[i] = pE[(191 - (n0 + i)) * PK_SPB]; ao[i] = pO[(191 - (n0 + i)) * PK_SPB];
-                    ce[i] = pE[(431 - (n0 + i)) * PK_SPB]; co[i] = pO[(431 - (n0 + i)) * PK_SPB];
-                }
-#pragma unroll
-                for (int i = 0; i < 5; i++) {
-                    yy += ao[i] * ao[i] - co[i] * co[i];
-                    if (i == 2) L.cky[2 * bk + 1][s] = yy;   // after step 10 bk + 5
-                    yy += ae[i] * ae[i] - ce[i] * ce[i];
-                }
-                L.cky[2 * bk + 2][s] = yy;                   // after step 10 bk + 10
             }
         }
-        __syncthreads();   // the coarse arrays are dead: their space takes the partial sums from here on
+        if (NNN_PK_PRIO && wv >= 5) wave_prio<0>();
+        if (full) {
+            if (dec_lane) {
+                BestPitch bp;
+                bp.init();
+                float c[7], e[7];
+#pragma unroll
+                for (int i = 0; i < 7; i++) { c[i] = L.u.c.xc[i][s]; e[i] = L.u.c.ysq[i][s]; }
+#pragma nounroll
+                for (int i0 = 0; i0 < NLAG1; i0 += 7) {
+                    float cn[7], en[7];   // the next seven lags travel while these are judged
+                    const int i1 = i0 + 7 < NLAG1 ? i0 + 7 : i0;
+#pragma unroll
+                    for (int i = 0; i < 7; i++) { cn[i] = L.u.c.xc[i1 + i][s]; en[i] = L.u.c.ysq[i1 + i][s]; }
+#pragma unroll
+                    for (int i = 0; i < 7; i++) bp.update_sq(i0 + i, c[i], e[i]);
+#pragma unroll
+                    for (int i = 0; i < 7; i++) { c[i] = cn[i]; e[i] = en[i]; }
+                }
+                if (b.taps) {
+                    int *o = (int *)NNN_TIF(b, best1, 2, f, tile, sl);
+                    o[0] = bp.best;
+                    o[TILE] = bp.second;
+                }
+                lo1 = 2 * bp.best - 2;
+                lo2 = 2 * bp.second - 2;
+                NNN_STAMP(b, 61);
+            }
+        } else {
+            __syncthreads();   // (the survivors' sums of waves 0 .. 4, the coarse lags' energies of wave 7)
+            NNN_STAMP(b, 27);
+            if (wave == 0) {
+                // find_best_pitch over the stream's survivors in lag order, with the energy each of them saw
+                BestPitch bp;
+                bp.init();
+                unsigned mk[5];
+#pragma unroll
+                for (int w = 0; w < 5; w++) mk[w] = lane < PK_SPB ? L.u.a.mask[s][w] : 0u;
+                for (int k = 0;; k++) {
+                    int Ln = -1;
+#pragma unroll
+                    for (int w = 4; w >= 0; w--) if (mk[w] != 0u) Ln = 32 * w + __builtin_ctz(mk[w]);
+                    if (wave_ballot(Ln >= 0) == 0ull) break;
+                    if (Ln >= 0) {
+                        bp.update(Ln, L.u.a.p.s.slotv[s][k], L.u.a.den[s][pk_den_at(Ln)]);
+#pragma unroll
+                        for (int w = 0; w < 5; w++) if (w == (Ln >> 5)) mk[w] &= mk[w] - 1u;
+                    }
+                }
+                if (dec_lane) {
+                    if (b.taps) {
+                        int *o = (int *)NNN_TIF(b, best1, 2, f, tile, sl);
+                        o[0] = bp.best;
+                        o[TILE] = bp.second;
+                    }
+                    lo1 = 2 * bp.best - 2;
+                    lo2 = 2 * bp.second - 2;
+                }
+                NNN_STAMP(b, 61);
+            }
+        }
+        // (wave 0 alone read the search's arrays in this phase; the scans' waves write their check points only: its lanes may put the fine
+        // search's windows into the space -- in the partial sums' layout -- before the barrier)
+        if (wave == 0) wave_lds_sync();
         if (dec_lane) {
             L.u.f.lo[0][s] = lo1;
             L.u.f.lo[1][s] = lo2;
             if (s == 0) L.u.f.any_refine = 0;
         }
-        __syncthreads();
+        __syncthreads();   // the coarse arrays are dead: their space takes the partial sums from here on
         NNN_STAMP(b, 6);
         // ---- fine cross-correlation at the <= 10 lags within +-2 of 2*best / 2*second (ref: src/pitch.rs:88-96): wave w
         //      takes lags lo1 + w and lo2 + w
@@ -1417,7 +1901,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             NNN_STAMP(b, 60);
             t0 = (PITCH_MAX - psr) / 2;
             if (t0 > max_period - 1) t0 = max_period - 1;
-            #pragma unroll
+        #pragma unroll
             for (int e = 0; e < PK_NSLOT; e++) {   // (unrolled: k is a constant in every copy)
                 int t;
                 if (e == 0) t = t0;
@@ -1438,10 +1922,6 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         }
         __syncthreads();
         NNN_STAMP(b, 53);
-#if NNN_PK_LATE_WINDOW   // the next frame's window is requested here, two thirds into the frame (round 5; until then behind the FIR): its 32 registers are free
-                        // through the cross-correlation and the searches, and the ~8 us left of the frame still cover the trip (k_pitch -2.6 %; 0 = as before)
-        if (f + 1 < f_end) pk_window_load(b, sp0 + f + 1, tile, q0, tid, win, fir);
-#endif
         // ---- yy_lookup at the candidate periods (ref: src/pitch.rs:138-142): one candidate per lane (s, q) of waves 0..5; from the
         //      check point below T, at most four of the scan's steps.  (Read by the decision loop, behind the next barrier.)
         {
@@ -1483,6 +1963,10 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
 #pragma unroll
             for (int c = 0; c < 3; c++) L.u.f.part[wave + 8 * c][qi][s] = acc[c];
         }
+#if NNN_PK_LATE_WINDOW   // the next frame's window is requested here, behind the candidates' inner products (round 6; round 5: ahead of them; until then behind the FIR): its 32 registers are free
+                        // through the cross-correlation and the searches, and the ~8 us left of the frame still cover the trip (k_pitch -2.6 %; 0 = as before)
+        pk_window_load(b, sp0 + f + 1, tile, q0, f + 1 < f_end ? tid : PK_T, win, fir);   // (the group's last frame: nothing to load, and no old value kept)
+#endif
         if (dec_lane) {
             if (chain && f > 0) {
                 // the previous frame of these streams is another workgroup's: wait for its flag, then take its pitch and gain

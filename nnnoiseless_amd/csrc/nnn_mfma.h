@@ -123,6 +123,7 @@ template <class T> __device__ __forceinline__ void st_global(void *p, T v)
 // from the value loop-variant for the compiler: otherwise every address of every phase is hoisted out of the frame loop as
 // loop invariant, hundreds of registers wide, and spilled (measured: 300 spills in k_rnn without it, none with it).
 __device__ __forceinline__ void wf_setprio_high() { __builtin_amdgcn_s_setprio(3); }
+template <int P> __device__ __forceinline__ void wave_prio() { __builtin_amdgcn_s_setprio(P); }   // issue priority of the calling wave (0 .. 3)
 __device__ __forceinline__ int launder_v(int x)
 {
     asm volatile("" : "+v"(x));
@@ -130,6 +131,8 @@ __device__ __forceinline__ int launder_v(int x)
 }
 // marks a value as used (an 8-byte LDS read whose second half is not needed stays an 8-byte read)
 __device__ __forceinline__ void keep_v(float x) { asm volatile("" ::"v"(x)); }
+// makes a value opaque where it stands (the compiler neither moves its producer below this point nor folds it into its consumer)
+__device__ __forceinline__ void keep_rw(float &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ int launder_s(int x)
 {
     asm volatile("" : "+s"(x));
@@ -142,6 +145,31 @@ __device__ __forceinline__ int launder_s(int x)
 // like v_mul_f32 / v_add_f32.
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f mk2(float x, float y) { v2f r = {x, y}; return r; }
+__device__ __forceinline__ float smul(float a, float b)
+{
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a single add that stays a single add (sequential sums of packed products: the compiler's pairing across accumulators
+// would cost register moves)
+__device__ __forceinline__ float sadd(float a, float b)
+{
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#ifndef NNN_NO_PK
+#define NNN_NO_PK 0
+#endif
+#if NNN_NO_PK   // experiment (round 6): every packed helper as two plain instructions -- same roundings, half-rate issue slots each
+__device__ __forceinline__ v2f pk_mul(v2f a, v2f b) { return mk2(smul(a.x, b.x), smul(a.y, b.y)); }
+__device__ __forceinline__ v2f pk_mul_bx(v2f a, v2f b) { return mk2(smul(a.x, b.x), smul(a.x, b.y)); }
+__device__ __forceinline__ v2f pk_mul_by(v2f a, v2f b) { return mk2(smul(a.y, b.x), smul(a.y, b.y)); }
+__device__ __forceinline__ v2f pk_add(v2f a, v2f b) { return mk2(sadd(a.x, b.x), sadd(a.y, b.y)); }
+__device__ __forceinline__ v2f pk_add_bx(v2f a, v2f b) { return mk2(sadd(a.x, b.x), sadd(a.y, b.x)); }
+__device__ __forceinline__ v2f pk_add_by(v2f a, v2f b) { return mk2(sadd(a.x, b.y), sadd(a.y, b.y)); }
+#else
 __device__ __forceinline__ v2f pk_mul(v2f a, v2f b)       // (a.x b.x, a.y b.y)
 {
     v2f r;
@@ -158,14 +186,6 @@ __device__ __forceinline__ v2f pk_mul_by(v2f a, v2f b)    // (a.y b.x, a.y b.y)
 {
     v2f r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// a single add that stays a single add (sequential sums of packed products: the compiler's pairing across accumulators
-// would cost register moves)
-__device__ __forceinline__ float sadd(float a, float b)
-{
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 __device__ __forceinline__ v2f pk_add(v2f a, v2f b)
@@ -186,6 +206,43 @@ __device__ __forceinline__ v2f pk_add_by(v2f a, v2f b)    // (a.x + b.y, a.y + b
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+#endif
+
+// ---- the certified coarse pitch search's primitives (k_pitch, round 6) ----
+// (a, b) rounded to nearest-even bf16, a in the low half: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pk_bf16_rn(float a, float b)
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// bits [sh + 31 : sh] of the 64-bit value hi:lo (sh in 0 .. 31): v_alignbit_b32
+__device__ __forceinline__ unsigned align_bits(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+// LDS atomics of one workgroup (relaxed: a barrier orders them against the readers)
+__device__ __forceinline__ unsigned lds_add_u32(unsigned *p, unsigned v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_or_u32(unsigned *p, unsigned v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// x of lane (lane ^ 16) / (lane ^ 32)
+__device__ __forceinline__ float wave_xor16(float x, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __builtin_bit_cast(int, x))); }
+__device__ __forceinline__ float wave_xor32(float x, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, x))); }
+// the four exchange steps of a reduction over a row of 16 lanes, as DPP moves: partner lane ^ 1, lane ^ 2, 7 - lane within its eight, 15 - lane
+// within its row (a reduction needs disjoint partners, not a butterfly)
+template <int STEP> __device__ __forceinline__ float row_partner(float x)
+{
+    const int b = __builtin_bit_cast(int, x);
+    constexpr int ctl = STEP == 0 ? 0xB1 : STEP == 1 ? 0x4E : STEP == 2 ? 0x141 : 0x140;
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(b, ctl, 0xf, 0xf, true));
+}
+// y of lane K of the caller's quad (lanes 4 i .. 4 i + 3): a DPP operand of the instruction that uses it (the serial energy scans of k_pitch:
+// the four lanes of a quad prepare four consecutive steps, every lane adds them in order)
+template <int K> __device__ __forceinline__ float quad_lane(float y)
+{
+    const int b = __builtin_bit_cast(int, y);
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(b, K * 85, 0xf, 0xf, true));
+}
+// the value lane `l` holds, wave-uniform (l a compile-time constant)
+__device__ __forceinline__ float lane_value(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32, 1 ulp
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32, 1 ulp
 
 // Frame-to-frame hand-off between workgroups of one launch (k_pitch): the producer makes its results visible device-wide
 // and then stores the flag; the consumer polls the flag and only then reads the results.

@@ -14,18 +14,19 @@ from nnnoiseless_amd import _ffi
 from nnnoiseless_amd.synthetic import make_streams_fast
 lib = _ffi.Library('/tmp/libnnn_stamps.so')
 lib.L.nnn_batch_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
-for S, T in ((4096, 4), (65536, 4)):
+for S, T in ((256, 2), (4096, 4), (65536, 24)):
     bd = nn.BatchDenoiser(S, lib=lib)
     bd.set_pipeline(False)
     x = make_streams_fast(S, 2 * T)
     bd.process(x[:, :T]); bd.process(x[:, T:])
     st = np.zeros(64, np.int64)
     lib.L.nnn_batch_read_stamps(bd._h, st.ctypes.data_as(C.c_void_p))
-    names = ["window->lds", "fir", "coarse xcorr+scans", "find_best coarse", "fine xcorr", "combine+energies", "replay", "candidates", "cand inner", "judge k", "pick", "refine", "final"]
-    idx = [0, 1, 4, 5, 6, 7, 59, 60, 53, 54, 58, 55, 56, 57]
+    names = ["window->lds", "fir", "matrix products, survivors | scan starts", "full search", "exact sums | scans", "find_best", "fine xcorr", "combine+energies", "replay", "candidates", "cand inner", "judge k", "pick", "refine", "final"]
+    idx = [0, 1, 4, 5, 63, 27, 6, 7, 59, 60, 53, 54, 58, 55, 56, 57]
     d = [(st[idx[i + 1]] - st[idx[i]]) / 2100.0 for i in range(len(names))]   # shader-clock cycles at ~2.1 GHz -> us (approximate)
     print(f"S={S} k_pitch last frame of block 0 [us, approximate]: total {sum(d):.1f}")
     print("   " + "  ".join(f"{n} {v:.2f}" for n, v in zip(names, d)))
-    print(f"   (find_best coarse: wave 0's own scan {(st[61] - st[5]) / 2100.0:.2f}, then waiting for the energy scans {(st[6] - st[61]) / 2100.0:.2f})")
+    u = lambda a, b_: (st[a] - st[b_]) / 2100.0
+    print(f"   roles, us after the FIR's barrier: matrix products done {u(2, 4):.2f}, fine-lag start sum {u(28, 4):.2f}, yy start sum {u(29, 4):.2f}, coarse-lag energies' first piece {u(3, 4):.2f}")
     bd.close()
 PY

@@ -150,9 +150,11 @@ static inline uint4 ld_global_u4(const void *p) { return ld_global<uint4>(p); }
 template <class T> static inline void st_global(void *p, T v) { memcpy(p, &v, sizeof(T)); }
 
 static inline void wf_setprio_high() {}
+template <int P> static inline void wave_prio() {}
 static inline int launder_v(int x) { return x; }
 static inline int launder_s(int x) { return x; }
 static inline void keep_v(float) {}
+static inline void keep_rw(float &) {}
 
 struct v2f { float x, y; };
 static inline v2f operator*(v2f a, v2f b) { v2f r = {a.x * b.x, a.y * b.y}; return r; }
@@ -165,6 +167,32 @@ static inline v2f pk_add(v2f a, v2f b) { return mk2(a.x + b.x, a.y + b.y); }
 static inline v2f pk_add_bx(v2f a, v2f b) { return mk2(a.x + b.x, a.y + b.x); }
 static inline v2f pk_add_by(v2f a, v2f b) { return mk2(a.x + b.y, a.y + b.y); }
 static inline float sadd(float a, float b) { return a + b; }
+static inline float smul(float a, float b) { return a * b; }
+
+// ---- the certified coarse pitch search's primitives ----
+static inline unsigned short bf16_rn_bits(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN (quiet)
+    u += 0x7fffu + ((u >> 16) & 1u);                                                   // to nearest even; overflow rounds to infinity
+    return (unsigned short)(u >> 16);
+}
+static inline unsigned pk_bf16_rn(float a, float b) { return (unsigned)bf16_rn_bits(a) | ((unsigned)bf16_rn_bits(b) << 16); }
+static inline unsigned align_bits(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)((((unsigned long long)hi << 32) | lo) >> (sh & 31)); }
+static inline unsigned lds_add_u32(unsigned *p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }   // (fibers run one at a time)
+static inline void lds_or_u32(unsigned *p, unsigned v) { *p |= v; }
+static inline float wave_xor16(float x, int) { return __shfl_xor(x, 16); }
+static inline float wave_xor32(float x, int) { return __shfl_xor(x, 32); }
+template <int STEP> static inline float row_partner(float x)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const int src = STEP == 0 ? lane ^ 1 : STEP == 1 ? lane ^ 2 : STEP == 2 ? ((lane & ~7) | (7 - (lane & 7))) : ((lane & ~15) | (15 - (lane & 15)));
+    return __shfl(x, src);
+}
+template <int K> static inline float quad_lane(float y) { return __shfl(y, (int)((threadIdx.x & 60) | K)); }
+static inline float lane_value(float x, int l) { return __shfl(x, l); }
+static inline float fast_sqrt(float x) { return sqrtf(x); }
+static inline float fast_rsq(float x) { return 1.0f / sqrtf(x); }
 
 // (the interpreter runs the workgroups of a launch one after the other in index order: a flag is always set when it is read)
 static inline void flag_publish(int *flag, int value) { *flag = value; }
