@@ -863,24 +863,24 @@ __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) { retu
 constexpr int PK_CKF = 8, PK_NCKF = (NLAG2 + PK_CKF - 1) / PK_CKF;    // 37
 constexpr int PK_CKY = 5, PK_NCKY = 384 / PK_CKY + 1;                  // 77
 // The certified coarse search (round 6; see the phase in k_pitch): what it keeps in LDS.
-constexpr int PK_DP = 157;                       // a stream's row of coarse-lag energies: lag L at L + (L >> 4), an odd pitch (lane = stream and wave = stream both read it)
+constexpr int PK_DCK = 41;                       // a stream's row of check points of the coarse lags' energy scan (one per group of four lags; an odd pitch)
 constexpr int PK_RMAX = 24;                      // lags of one stream that may survive the approximate search (more: the block takes the full search)
 constexpr int PK_CAP = 384;                      // ... and of the block's 16 streams together
 constexpr int PK_PLW = XLP / 2 + 8;              // halfwords between two streams' bf16 planes (the 432 even rows of pitch_buf): 220 words, so that the
                                                  // eight streams of a region sit on eight different banks for the FIR's word stores
 constexpr float PK_EPS = 0.0083f;                // |approximate - reference| <= PK_EPS sqrt(|x|^2 |y window|^2): two bf16 roundings 2^-7, the matrix
                                                  // cores' f32 accumulation and the reference's own sequential f32 sum well inside the rest
-__device__ __forceinline__ int pk_den_at(int L) { return L + (L >> 4); }
 struct PkCert {
-    float den[PK_SPB][PK_DP];                    // the running energy every coarse lag sees in find_best_pitch (ref: src/pitch.rs:380-402)
+    float denck[PK_SPB][PK_DCK];                 // the running energy before coarse lag 4 k (find_best_pitch, ref: src/pitch.rs:380-402): check points, as for the fine lags
     float bsum[PK_SPB][27];                      // |.|^2 of the 27 blocks of 16 even rows (any nonzero value: at least 2^-120)
     unsigned mask[PK_SPB][5];                    // bit L: coarse lag L of the stream survived
     unsigned count, full, pad_[2];               // survivors of the block; != 0: the block takes the full search
-    union {
-        unsigned short plane[(PK_SPB / 2) * PK_PLW + 16];   // bf16 even rows of streams 8 .. 15 (streams 0 .. 7: over ckf / cky, idle until the scans);
-                                                            // + the 32 bytes the last fragment read of the last stream runs over (masked)
-        struct { unsigned short list[PK_CAP]; float slotv[PK_SPB][PK_RMAX]; } s;   // survivors (stream << 8 | lag); their exact sums by rank within the stream
-    } p;
+    unsigned short list[PK_CAP];                 // survivors (stream << 8 | lag) ...
+    float slotv[PK_SPB][PK_RMAX], slotd[PK_SPB][PK_RMAX];   // ... their exact sums and the energy each of them saw, by rank within the stream
+    int slotl[PK_SPB][PK_RMAX];                  // ... and their lags
+    alignas(16) unsigned short plane[(PK_SPB / 2) * PK_PLW + 16];   // bf16 even rows of streams 8 .. 15 (streams 0 .. 7: over ckf / cky, idle until the scans);
+                                                                    // + the 32 bytes the last fragment read of the last stream runs over (masked).  Nothing
+                                                                    // shares the planes' bytes: the search reads them while its first waves list survivors
 };
 struct alignas(16) PkLds {
     float pb[PK_ODD + PK_HALF];                  // the decimated window, then (in place) pitch_buf
@@ -905,7 +905,7 @@ struct alignas(16) PkLds {
     } u;
 };
 static_assert(sizeof(PkLds) <= 80 * 1024, "two blocks per CU");
-static_assert(offsetof(PkLds, ckf) % 16 == 0 && offsetof(PkLds, u) % 16 == 0 && offsetof(PkCert, p) % 16 == 0 && (PK_PLW * 2) % 16 == 0, "16-byte fragment reads");
+static_assert(offsetof(PkLds, ckf) % 16 == 0 && offsetof(PkLds, u) % 16 == 0 && offsetof(PkCert, plane) % 16 == 0 && (PK_PLW * 2) % 16 == 0, "16-byte fragment reads");
 static_assert(sizeof(float) * (PK_NCKF + PK_NCKY) * PK_SPB >= sizeof(unsigned short) * (PK_SPB / 2) * PK_PLW + 32, "the first eight planes fit over the check points");
 
 // Window and FIR mapping: thread = (stream col, chunk ch of 32 rows), 27 chunks (the block's last 80 threads idle here); a
@@ -946,31 +946,32 @@ __device__ __forceinline__ void pk_window_load(const Buffers &b, const StepParam
 template <int NCAND>
 __device__ __forceinline__ void pk_inner(const float *pb, int s, int q, const int (&yr)[NCAND], float (&acc)[NCAND])
 {
-    constexpr int U = NCAND >= 4 ? 2 : (NCAND >= 2 ? 3 : 4);   // tap pairs per unrolled step
-    static_assert(120 % (2 * U) == 0, "");
+    constexpr int U = NCAND >= 4 ? 2 : 3;   // tap pairs per register set
+    static_assert(120 % (4 * U) == 0, "");
     const float *xp = pb + pk_at(PITCH_MAX / 2 + q, s);
     const float *yp[NCAND];
 #pragma unroll
     for (int c = 0; c < NCAND; c++) { acc[c] = 0.0f; yp[c] = pb + pk_at(yr[c] + q, s); }
+    // two register sets in turn: the rows of the next taps travel while these are summed (round 6: with one set the compiler's loop was
+    // "load, wait, use" -- every trip paid the LDS latency in full)
+    v2f xa[U], ya[NCAND][U], xb[U], yb[NCAND][U];
+#define NNN_LD(X, Y, M) do { _Pragma("unroll") for (int u_ = 0; u_ < U; u_++) { const int o_ = 32 * ((M) + 2 * u_); X[u_] = mk2(xp[o_], xp[o_ + 32]); \
+        _Pragma("unroll") for (int c_ = 0; c_ < NCAND; c_++) Y[c_][u_] = mk2(yp[c_][o_], yp[c_][o_ + 32]); } } while (0)
+#define NNN_ACC(X, Y) do { _Pragma("unroll") for (int u_ = 0; u_ < U; u_++) _Pragma("unroll") for (int c_ = 0; c_ < NCAND; c_++) { \
+        const v2f pr_ = pk_mul(X[u_], Y[c_][u_]); acc[c_] = sadd(acc[c_], pr_.x); acc[c_] = sadd(acc[c_], pr_.y); } } while (0)
+    NNN_LD(xa, ya, 0);
 #pragma nounroll
-    for (int m0 = 0; m0 < 120; m0 += 2 * U) {
-        v2f xv[U], yv[NCAND][U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int o = 32 * (m0 + 2 * u);
-            xv[u] = mk2(xp[o], xp[o + 32]);
-#pragma unroll
-            for (int c = 0; c < NCAND; c++) yv[c][u] = mk2(yp[c][o], yp[c][o + 32]);
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++)
-#pragma unroll
-            for (int c = 0; c < NCAND; c++) {
-                const v2f pr = pk_mul(xv[u], yv[c][u]);
-                acc[c] = sadd(acc[c], pr.x);
-                acc[c] = sadd(acc[c], pr.y);
-            }
+    for (int m0 = 0; m0 < 120 - 4 * U; m0 += 4 * U) {
+        NNN_LD(xb, yb, m0 + 2 * U);
+        NNN_ACC(xa, ya);
+        NNN_LD(xa, ya, m0 + 4 * U);
+        NNN_ACC(xb, yb);
     }
+    NNN_LD(xb, yb, 120 - 2 * U);
+    NNN_ACC(xa, ya);
+    NNN_ACC(xb, yb);
+#undef NNN_LD
+#undef NNN_ACC
 }
 
 // Lag K of the autocorrelation of a stream's 864-value window in LDS (`pbs` = L.pb + stream: row r at pk_at(r, 0)): the reference's
@@ -1062,7 +1063,7 @@ __device__ __forceinline__ float pk_chain_coarse_start(const float *pbs, int cq)
     }
     return ysq;
 }
-// ... and groups k0 .. k1 - 1 of four lags: den[pk_den_at(L)] = the energy before lag L = 4 k + cq, which drops y4[L] and takes y4[L + 240]
+// ... and groups k0 .. k1 - 1 of four lags (lag L drops y4[L] and takes y4[L + 240]); check point dn[k] = the energy before lag 4 k
 constexpr int PK_COARSE_K = 38;                  // (147 lags: the 148th .. 152nd are computed and dropped)
 __device__ __forceinline__ float pk_chain_coarse(const float *pbs, int cq, float ysq, int k0, int k1, float *dn)
 {
@@ -1089,16 +1090,11 @@ __device__ __forceinline__ float pk_chain_coarse(const float *pbs, int cq, float
         for (int i = 0; i < 2; i++) {
             const float t = ca[i] * ca[i] - cd[i] * cd[i];
             const Quad4 r = pk_quad4(t);
-            const float y0 = ysq;
+            if (cq == 0) dn[k + i] = ysq;
             ysq = fmaxf(ysq + r.t0, 1.0f);
-            const float y1 = ysq;
             ysq = fmaxf(ysq + r.t1, 1.0f);
-            const float y2 = ysq;
             ysq = fmaxf(ysq + r.t2, 1.0f);
-            const float y3 = ysq;
             ysq = fmaxf(ysq + r.t3, 1.0f);
-            const int L = 4 * (k + i) + cq;
-            if (L < NLAG1) dn[pk_den_at(L)] = cq == 0 ? y0 : (cq == 1 ? y1 : (cq == 2 ? y2 : y3));
         }
     }
     return ysq;
@@ -1232,13 +1228,13 @@ __device__ __forceinline__ float pk_dot240(const float *xp, const float *yp)
     return c;
 }
 
-// where the coarse lags' scan is cut (tuned against shader-clock stamps)
-#ifndef NNN_PK_SEG
-#define NNN_PK_SEG 16
-#endif
-constexpr int PK_SEG_D1 = NNN_PK_SEG;   // groups of coarse lags whose energies wave 7 has scanned when the search's first barrier comes
 constexpr int PK_SEG_FS = 120;
-static_assert(PK_SEG_D1 % 2 == 0 && PK_SEG_D1 <= PK_COARSE_K, "");
+#ifndef NNN_PK_SEG_F1
+#define NNN_PK_SEG_F1 44
+#endif
+constexpr int PK_SEG_F1 = NNN_PK_SEG_F1;   // groups of fine lags wave 5 has scanned when the survivors' exact sums are done; the rest beside find_best
+static_assert(PK_SEG_F1 % 2 == 0 && PK_SEG_F1 <= PK_FINE_K, "");
+
 
 // (defined behind the transforms, further down: the X transform of a one-frame call in rider blocks of k_pitch's launch)
 __device__ __forceinline__ void xt_rider(const Buffers &b, const StepParams *sp, int rb, void *lds);
@@ -1408,7 +1404,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 // for the certified coarse search: the chunk's 16 even rows -- the 4x-decimated signal -- as bf16 (to nearest) and their energy.
                 // Read back from LDS: held in registers through the FIR they cost the kernel spills (it sits at its 128-register limit there).
                 const float *ce = L.pb + launder_v((chc * (PK_CH / 2)) * PK_SPB + col);
-                unsigned *pl = (unsigned *)((col < PK_SPB / 2 ? (unsigned short *)&L.ckf[0][0] : L.u.a.p.plane) + (col & 7) * PK_PLW + (PK_CH / 2) * ch);
+                unsigned *pl = (unsigned *)((col < PK_SPB / 2 ? (unsigned short *)&L.ckf[0][0] : L.u.a.plane) + (col & 7) * PK_PLW + (PK_CH / 2) * ch);
                 unsigned nz = 0;
                 float bs = 0.0f;
 #pragma unroll
@@ -1444,9 +1440,9 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         //      (3) the survivors' sums exactly, in the reference's order, lane = (stream, lag); find_best_pitch over them in lag order.
         //      Blocks where that does not apply -- a stream with non-finite or extreme values, fewer than two certain lags and many
         //      candidates, parity taps that want all 147 values -- take the full search below: round 5's code, every lag exact.
-        //      Roles: waves 0 .. 3 the search (stream sq = wave + 4 u, the four streams of a wave side by side so that one's latencies are
-        //      another's issue slots), waves 5, 6, 7 the three serial energy scans (see pk_chain_*), which run beside it in pieces cut at
-        //      the search's barriers; wave 4 joins for the exact sums.
+        //      Roles: waves 0 .. 4 the search (streams wave, wave + 5, wave + 10 side by side, so that one's latencies are another's issue
+        //      slots), waves 5, 6, 7 the three serial energy scans (see pk_chain_*), which run beside it in pieces cut at the search's
+        //      barriers; wave 6, whose scan starts with the shortest sum, takes the sixteenth stream behind it.
         //      (2) does NOT wait for the coarse lags' energy scan: it bounds den_L from both sides with the block energies and the bf16
         //      plane (|den_L - (1 + |y4[L .. L + 239]|^2)| is the scan's own rounding, <= 2^-15 (1 + |y4|^2)); the scan's exact values are
         //      first needed by find_best_pitch over the survivors.
@@ -1455,9 +1451,12 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         const int cs = lane >> 2, cq = lane & 3;         // scan waves: stream, quad lane
         const float *pcs = L.pb + cs;
         const int wv = launder_s(wave);                  // (keeps this phase's wave-uniform addresses inside the frame loop, see launder_v)
-        f32x4 cacc[4];                                   // approximate correlations of the wave's streams
         float chain_y = 0.0f;                            // scan waves: the running energy
-        if (wv < 4) {
+        // the search for NS streams s0, s0 + 5, ... on the calling wave (NS a compile-time constant: waves 0 .. 4 take three streams each, wave 6 --
+        // whose scan starts with the shortest sum -- the sixteenth behind it)
+        auto search = [&](auto ns_, const int s0) {
+            constexpr int NS = decltype(ns_)::value;
+            f32x4 cacc[NS];                              // approximate correlations of the wave's streams
             // x4[u] sits at halfword 192 + u of the plane; a row of A reaches 15 halfwords before x4[0] (first k-step) and 31 behind x4[239]
             // (last k-step): masked.  Halfword e of lane (li, kg) is x4[32 t + 8 kg + e - li].
             unsigned m0[4], m7[4];
@@ -1468,11 +1467,11 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 m7[w] = (2 * w < n1 ? 0xffffu : 0u) | (2 * w + 1 < n1 ? 0xffff0000u : 0u);
             }
             const unsigned sh = (unsigned)(li & 1) * 16u;
-            const char *pl[4], *pa[4];
+            const char *pl[NS], *pa[NS];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int sq = wv + 4 * u;
-                pl[u] = (const char *)((sq < PK_SPB / 2 ? (const unsigned short *)&L.ckf[0][0] : L.u.a.p.plane) + (sq & 7) * PK_PLW);
+            for (int u = 0; u < NS; u++) {
+                const int sq = s0 + 5 * u;
+                pl[u] = (const char *)((sq < PK_SPB / 2 ? (const unsigned short *)&L.ckf[0][0] : L.u.a.plane) + (sq & 7) * PK_PLW);
                 pa[u] = pl[u] + ((384 + 16 * kg - 2 * li) & ~3);   // A: the word that holds halfword 192 + 8 kg - li
                 pl[u] += 16 * kg + 32 * li;                        // B: halfword 8 kg + 16 li
                 cacc[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -1480,7 +1479,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
 #pragma unroll
             for (int t = 0; t < 8; t++) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < NS; u++) {
                     const uint4 bq = *(const uint4 *)(pl[u] + 64 * t);
                     const unsigned *d = (const unsigned *)(pa[u] + 64 * t);
                     const unsigned d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
@@ -1492,15 +1491,16 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             }
             NNN_STAMPW(b, 2, wave == 0);
             if (b.taps == 2) {   // (test mode: the cross-correlation tap keeps NaN where a lag was ruled out)
-                for (int i = 64 * wv + lane; i < NLAG1 * PK_SPB; i += 64 * 4) NNN_TIF(b, xc1, NLAG1, f, tile, q0 + (i & 15))[(size_t)(i >> 4) * TILE] = __builtin_nanf("");
+                for (int u = 0; u < NS; u++)
+                    for (int i = lane; i < NLAG1; i += 64) NNN_TIF(b, xc1, NLAG1, f, tile, q0 + s0 + 5 * u)[(size_t)i * TILE] = __builtin_nanf("");
             }
             // ---- (2) who survives.  Element r of lane (li, kg) of D is row 4 kg + r, column li: lag 16 li + 4 kg + r.
             const int lj = li < 10 ? li : 9;   // (columns 10 .. 15 hold no lag: they follow column 9 and are masked)
-            float chp[4][4], clo[4][4], m1[4], m2[4];
+            float chp[NS][4], clo[NS][4], m1[NS], m2[NS];
             unsigned cfl = 0;                  // bit u: stream u has nothing but zeros in x4; bit 4 + u: stream u is not ordinary
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int sq = wv + 4 * u;
+            for (int u = 0; u < NS; u++) {
+                const int sq = s0 + 5 * u;
                 const float *bsr = L.u.a.bsum[sq];
                 // W_j = blocks j .. j + 15 (>= the energy of the 240-value window of every lag of column j); |x4|^2 = blocks 12 .. 26 = W_12
                 float wub = 0.0f;
@@ -1518,7 +1518,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 // den_L from both sides.  The window of lag 16 j + i is the tail of block j from value i on, blocks j + 1 .. j + 14 whole (their
                 // f32 energies) and the first i values of block j + 15: the two partial blocks from the bf16 plane, this lane's quarter of each
                 // as suffix / prefix sums, the other quarters' totals from the lanes that hold them.
-                const unsigned short *pv = (sq < PK_SPB / 2 ? (const unsigned short *)&L.ckf[0][0] : L.u.a.p.plane) + (sq & 7) * PK_PLW + 16 * lj + 4 * kg;
+                const unsigned short *pv = (sq < PK_SPB / 2 ? (const unsigned short *)&L.ckf[0][0] : L.u.a.plane) + (sq & 7) * PK_PLW + 16 * lj + 4 * kg;
                 const uint2 av = *(const uint2 *)pv, cv = *(const uint2 *)(pv + 240);
                 const float a0 = __uint_as_float(av.x << 16), a1 = __uint_as_float(av.x & 0xffff0000u), a2 = __uint_as_float(av.y << 16), a3 = __uint_as_float(av.y & 0xffff0000u);
                 const float c0 = __uint_as_float(cv.x << 16), c1 = __uint_as_float(cv.x & 0xffff0000u), c2 = __uint_as_float(cv.y << 16), c3 = __uint_as_float(cv.y & 0xffff0000u);
@@ -1551,15 +1551,15 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
             // the second largest lo of each stream: rows of 16 lanes by DPP, the four rows through scalars
 #define NNN_TOP2(u, n1, n2) do { const float a1_ = (n1), a2_ = (n2), lo_ = fminf(m1[u], a1_); m1[u] = fmaxf(m1[u], a1_); m2[u] = fmaxf(lo_, fmaxf(m2[u], a2_)); } while (0)
 #pragma unroll
-            for (int u = 0; u < 4; u++) NNN_TOP2(u, row_partner<0>(m1[u]), row_partner<0>(m2[u]));
+            for (int u = 0; u < NS; u++) NNN_TOP2(u, row_partner<0>(m1[u]), row_partner<0>(m2[u]));
 #pragma unroll
-            for (int u = 0; u < 4; u++) NNN_TOP2(u, row_partner<1>(m1[u]), row_partner<1>(m2[u]));
+            for (int u = 0; u < NS; u++) NNN_TOP2(u, row_partner<1>(m1[u]), row_partner<1>(m2[u]));
 #pragma unroll
-            for (int u = 0; u < 4; u++) NNN_TOP2(u, row_partner<2>(m1[u]), row_partner<2>(m2[u]));
+            for (int u = 0; u < NS; u++) NNN_TOP2(u, row_partner<2>(m1[u]), row_partner<2>(m2[u]));
 #pragma unroll
-            for (int u = 0; u < 4; u++) NNN_TOP2(u, row_partner<3>(m1[u]), row_partner<3>(m2[u]));
+            for (int u = 0; u < NS; u++) NNN_TOP2(u, row_partner<3>(m1[u]), row_partner<3>(m2[u]));
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < NS; u++) {
                 const float b1 = lane_value(m1[u], 16), b2 = lane_value(m2[u], 16), c1 = lane_value(m1[u], 32), c2 = lane_value(m2[u], 32),
                             d1 = lane_value(m1[u], 48), d2 = lane_value(m2[u], 48);
                 m1[u] = lane_value(m1[u], 0);
@@ -1571,8 +1571,8 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
 #undef NNN_TOP2
             bool want_full = false;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int sq = wv + 4 * u;
+            for (int u = 0; u < NS; u++) {
+                const int sq = s0 + 5 * u;
                 // two lags are certainly positive and certainly in the ordinary range: T = m2, less the rounding of this arithmetic, v_rsq_f32's
                 // ulp and the margin of (2); else every lag that may be positive survives
                 const bool two = m2[u] > 0x1p-40f;
@@ -1597,7 +1597,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                         const int Lr = 4 * kg + r + 16 * li;
                         const unsigned ix = base + (unsigned)__builtin_popcountll(bal[r] & ((1ull << lane) - 1ull));
                         if (keep[r] && ix < (unsigned)PK_CAP) {
-                            L.u.a.p.s.list[ix] = (unsigned short)((sq << 8) | Lr);
+                            L.u.a.list[ix] = (unsigned short)((sq << 8) | Lr);
                             lds_or_u32(&L.u.a.mask[sq][Lr >> 5], 1u << (Lr & 31));
                         }
                         base += (unsigned)__builtin_popcountll(bal[r]);
@@ -1606,9 +1606,11 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                 want_full |= ((cfl >> (4 + u)) & 1u) != 0 || tot > (unsigned)PK_RMAX;
             }
             if (lane == 0 && (want_full || b.taps == 1)) L.u.a.full = 1u;
-        } else if (wv == 7) {
+        };
+        if (wv < 5) search(std::integral_constant<int, 3>(), wv);
+        else if (wv == 7) {
             chain_y = pk_chain_coarse_start(pcs, cq);
-            chain_y = pk_chain_coarse(pcs, cq, chain_y, 0, PK_SEG_D1, L.u.a.den[cs]);
+            chain_y = pk_chain_coarse(pcs, cq, chain_y, 0, PK_COARSE_K, L.u.a.denck[cs]);
             NNN_STAMPW(b, 3, true);
         } else if (wv == 5) {
             chain_y = pk_chain_fine_start(pcs, cq, 1.0f, 0, PK_SEG_FS);
@@ -1616,6 +1618,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         } else if (wv == 6) {
             chain_y = pk_chain_yy_start(pcs, cq);
             NNN_STAMPW(b, 29, true);
+            search(std::integral_constant<int, 1>(), 15);
         }
         __syncthreads();   // (the planes are read: the scans' check points may take their place; the survivors are listed)
         NNN_STAMP(b, 5);
@@ -1711,19 +1714,18 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         //      search: waves 0 .. 4 and 7 make them, wave 0 scans) or over all 147 (full search: wave 0, a serial scan); beside it, on
         //      waves 5 and 6, the rest of the two energy scans whose results are looked up later in the frame
         int lo1 = 0, lo2 = 0;
-        if (wv == 5) chain_y = pk_chain_fine(pcs, cq, cs, chain_y, 0, PK_FINE_K, L.ckf);
+        if (wv == 5) chain_y = pk_chain_fine(pcs, cq, cs, chain_y, 0, PK_SEG_F1, L.ckf);   // (the rest beside find_best, below)
         else if (wv == 6) {
             if (cq == 0) L.cky[0][cs] = chain_y;   // xx = yy_lookup[0]
             chain_y = pk_chain_yy(pcs, cq, cs, chain_y, 0, PK_YY_B, L.cky);
-        } else if (wv == 7) chain_y = pk_chain_coarse(pcs, cq, chain_y, PK_SEG_D1, PK_COARSE_K, L.u.a.den[cs]);
-        else if (!full) {
+        } else if (wv != 7 && !full) {
             // (3) lane = (stream, lag) of the survivor list: xcorr[L] = sum_j x4[j] y4[L + j], x4[j] = p[384 + 2j], y4[m] = p[2m], a sequential
             //     sum (ref: src/pitch.rs:296-363), two taps per packed multiply, the adds in order
 #pragma nounroll
             for (unsigned e0 = 64u * (unsigned)wv; e0 < nsurv; e0 += 64u * 5u) {
                 const unsigned en = e0 + (unsigned)lane;
                 if (en < nsurv) {
-                    const unsigned ent = L.u.a.p.s.list[en];
+                    const unsigned ent = L.u.a.list[en];
                     const int se = (int)(ent >> 8), Le = (int)(ent & 255u);
                     const float *xp = L.pb + 192 * PK_SPB + se, *yp = L.pb + Le * PK_SPB + se;
                     const float c = pk_dot240(xp, yp);
@@ -1735,13 +1737,29 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
                         const unsigned mw = mk[w], below = w < (Le >> 5) ? mw : (w == (Le >> 5) ? mw & ((1u << (Le & 31)) - 1u) : 0u);
                         rk += __builtin_popcount(below);
                     }
-                    L.u.a.p.s.slotv[se][rk] = c;
+                    // the energy the lag saw in find_best_pitch: the scan's own steps from the check point below it (<= 3)
+                    float dy = L.u.a.denck[se][Le >> 2];
+                    {
+                        const float *yq = L.pb + (Le & ~3) * PK_SPB + se;
+                        float ra[3], rd[3];
+#pragma unroll
+                        for (int i = 0; i < 3; i++) { ra[i] = yq[(i + 240) * PK_SPB]; rd[i] = yq[i * PK_SPB]; }
+#pragma unroll
+                        for (int i = 0; i < 3; i++) {
+                            const float yn = fmaxf(dy + (ra[i] * ra[i] - rd[i] * rd[i]), 1.0f);
+                            dy = i < (Le & 3) ? yn : dy;
+                        }
+                    }
+                    L.u.a.slotv[se][rk] = c;
+                    L.u.a.slotl[se][rk] = Le;
+                    L.u.a.slotd[se][rk] = dy;
                     if (b.taps) NNN_TIF(b, xc1, NLAG1, f, tile, q0 + se)[(size_t)Le * TILE] = c;
                 }
             }
         }
         if (NNN_PK_PRIO && wv >= 5) wave_prio<0>();
         if (full) {
+            if (wv == 5) chain_y = pk_chain_fine(pcs, cq, cs, chain_y, PK_SEG_F1, PK_FINE_K, L.ckf);
             if (dec_lane) {
                 BestPitch bp;
                 bp.init();
@@ -1771,23 +1789,22 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
         } else {
             __syncthreads();   // (the survivors' sums of waves 0 .. 4, the coarse lags' energies of wave 7)
             NNN_STAMP(b, 27);
+            if (wv == 5) chain_y = pk_chain_fine(pcs, cq, cs, chain_y, PK_SEG_F1, PK_FINE_K, L.ckf);
             if (wave == 0) {
                 // find_best_pitch over the stream's survivors in lag order, with the energy each of them saw
                 BestPitch bp;
                 bp.init();
-                unsigned mk[5];
+                int ns = 0;
 #pragma unroll
-                for (int w = 0; w < 5; w++) mk[w] = lane < PK_SPB ? L.u.a.mask[s][w] : 0u;
-                for (int k = 0;; k++) {
-                    int Ln = -1;
-#pragma unroll
-                    for (int w = 4; w >= 0; w--) if (mk[w] != 0u) Ln = 32 * w + __builtin_ctz(mk[w]);
-                    if (wave_ballot(Ln >= 0) == 0ull) break;
-                    if (Ln >= 0) {
-                        bp.update(Ln, L.u.a.p.s.slotv[s][k], L.u.a.den[s][pk_den_at(Ln)]);
-#pragma unroll
-                        for (int w = 0; w < 5; w++) if (w == (Ln >> 5)) mk[w] &= mk[w] - 1u;
-                    }
+                for (int w = 0; w < 5; w++) ns += lane < PK_SPB ? __builtin_popcount(L.u.a.mask[s][w]) : 0;
+                float nc = 0.0f, nd = 1.0f;
+                int nl = 0;
+                if (ns > 0) { nl = L.u.a.slotl[s][0]; nc = L.u.a.slotv[s][0]; nd = L.u.a.slotd[s][0]; }
+                for (int k = 0; wave_ballot(k < ns) != 0ull; k++) {
+                    const int cl = nl;
+                    const float cc = nc, cd = nd;
+                    if (k + 1 < ns) { nl = L.u.a.slotl[s][k + 1]; nc = L.u.a.slotv[s][k + 1]; nd = L.u.a.slotd[s][k + 1]; }   // (the next one travels)
+                    if (k < ns) bp.update(cl, cc, cd);
                 }
                 if (dec_lane) {
                     if (b.taps) {

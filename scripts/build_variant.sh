@@ -5,7 +5,7 @@ set -eu
 R=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
 mkdir -p $R/nnnoiseless_amd/lib/variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -DNNN_DEV_KNOBS "$@" -I $R/nnnoiseless_amd/csrc \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Wno-unused-value -DNNN_DEV_KNOBS "$@" -I $R/nnnoiseless_amd/csrc \
   -DNNN_WEIGHTS_PATH="\"$R/nnnoiseless_amd/data/weights.rnn\"" -x hip $R/nnnoiseless_amd/csrc/nnn_batch.hip $R/nnnoiseless_amd/csrc/nnn_resample.hip \
   $R/nnnoiseless_amd/csrc/nnn_model.cpp $R/nnnoiseless_amd/csrc/rnnoise_capi.cpp $R/nnnoiseless_amd/csrc/nnn_node.cpp -o $R/nnnoiseless_amd/lib/variants/$name.so 2>/dev/null
 echo built $name

@@ -5,7 +5,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 W=$R/nnnoiseless_amd/data/weights.rnn
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -DNNN_STAMPS ${STAMP_FLAGS:-} -I nnnoiseless_amd/csrc -DNNN_WEIGHTS_PATH="\"$W\"" -x hip nnnoiseless_amd/csrc/nnn_batch.hip nnnoiseless_amd/csrc/nnn_resample.hip nnnoiseless_amd/csrc/nnn_model.cpp nnnoiseless_amd/csrc/rnnoise_capi.cpp nnnoiseless_amd/csrc/nnn_node.cpp -o /tmp/libnnn_stamps.so || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Wno-unused-value -DNNN_STAMPS ${STAMP_FLAGS:-} -I nnnoiseless_amd/csrc -DNNN_WEIGHTS_PATH="\"$W\"" -x hip nnnoiseless_amd/csrc/nnn_batch.hip nnnoiseless_amd/csrc/nnn_resample.hip nnnoiseless_amd/csrc/nnn_model.cpp nnnoiseless_amd/csrc/rnnoise_capi.cpp nnnoiseless_amd/csrc/nnn_node.cpp -o /tmp/libnnn_stamps.so || exit 1
 python - <<'PY'
 import ctypes as C, numpy as np, sys, os
 sys.path.insert(0, '.')

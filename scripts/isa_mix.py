@@ -12,7 +12,7 @@ root = sys.argv[1] if len(sys.argv) > 1 and os.path.isdir(sys.argv[1]) else os.p
 want = [a for a in sys.argv[1:] if not os.path.isdir(a)] or ["k_fft_xp", "k_synth", "k_pitch", "k_hp", "k_rnn_wf", "k_back"]
 src = os.path.join(root, "nnnoiseless_amd", "csrc")
 out = "/tmp/nnn_isa_mix.s"
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S", "-o", out,
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "--cuda-device-only", "-S", "-o", out,
                        "-x", "hip", os.path.join(src, "nnn_batch.hip"), "-I", src, '-DNNN_WEIGHTS_PATH="x"', "-w"])
 text = open(out).read()
 GROUPS = (("valu", ("v_",)), ("lds", ("ds_",)), ("vmem", ("global_", "buffer_", "flat_", "scratch_")), ("salu", ("s_",)))

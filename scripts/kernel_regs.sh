@@ -4,7 +4,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p /tmp/nnn_regs
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off --cuda-device-only -S -o /tmp/nnn_regs/k.s \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize --cuda-device-only -S -o /tmp/nnn_regs/k.s \
     -x hip "$R/nnnoiseless_amd/csrc/nnn_batch.hip" -I "$R/nnnoiseless_amd/csrc" '-DNNN_WEIGHTS_PATH="x"' -Wno-unused-value "$@"
 python3 - <<'P'
 import re, subprocess
