@@ -1421,6 +1421,9 @@ extern "C" int nnn_batch_set_taps(nnn_batch *h, int on)
 #undef NNN_F
         for (int set = 1; set < h->nset; set++) h->b[set] = frame_view(h->b[0], set);
         h->taps_alloc = true;
+        // (dalloc clears the arrays with hipMemset on the null stream, which the batch's own streams do not wait for: at 65 536 streams the
+        // clearing of these gigabytes ran into the first frame's tap stores -- found by round 6's certified-search test)
+        HIPCHK(hipDeviceSynchronize());
     }
     // (1: every tap, the coarse pitch search as the full search so that all 147 cross-correlations exist; 2: the same taps from the certified
     // search -- NNN_TAP_XCORR1 then holds NaN at the lags it ruled out)
