@@ -53,16 +53,26 @@ FP32_PEAK_TFLOPS = 157.3
 BYTES_PER_FRAME_FUSED = 16948  # I/O + resident-state touch of one process_frame
 FLOPS_PER_FRAME = 0.42e6
 
-# The issue ceiling: the wave-instructions a kernel's ARITHMETIC needs per stream-frame on CDNA4 -- packed
-# FP32 where exactness allows (everything upstream of the pitch index: two multiply-adds per v_pk_mul_f32 + v_pk_add_f32 pair, no FMA), FMA
-# and packing where only a tolerance applies (transforms, synthesis), the matrix cores where built (RNN) -- if every issue slot of every SIMD
-# (one vector instruction per 4 cycles, 1024 SIMDs at 2.4 GHz) did nothing else.  Sources: k_pitch 63 k multiply-adds per stream-frame / 64
-# lanes (coarse 147 x 240, fine 10 x 480, remove_doubling 25 x 480, FIR 864 x 5, the energy scans); transforms and synthesis the arithmetic
-# column of scripts/isa_mix.py (profiles/r4_isa_mix.txt); RNN 551 activations x ~25 instructions / 64 lanes beside 32 MFMAs per stream-frame
-# (x 16 cycles: 510, less than the activations' 860 cycles); k_lpc 5 x 860 multiply-adds / 64; k_hp its HBM bytes (its 90 f64 instructions
-# per stream-frame issue in less).
-KERNEL_MIN_VALU = {"k_pitch": 985, "k_fft_xp": 632, "k_synth": 421, "k_rnn": 215, "k_lpc": 67, "k_hp": 90}
-SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 4
+# The issue ceiling: the vector-ALU time a kernel's ARITHMETIC needs per stream-frame on CDNA4 if every SIMD did nothing else.
+# Issue costs measured on an MI355X (scripts/ubench/valu_issue.hip, profiles/r6_valu_issue.txt; round 5 assumed 4 cycles for every instruction): with
+# two or more waves on a SIMD a plain two-operand f32 instruction (v_add / v_mul / v_max) takes 2.27 cycles, a packed or three-operand one
+# (v_pk_*, v_fma) 4.2 -- so an exact multiply-add (no FMA upstream of the pitch index) costs 4.5 cycles per 64 lanes either way, a fused one 2.1
+# (v_pk_fma_f32).  Arithmetic per stream-frame:
+#   k_pitch   multiply-adds of the certified search (round 6): FIR 864 x 5, fine search 10 x 480, remove_doubling 25 x 480 (+ 3 x 480 when a block
+#             refines), exact coarse sums ~5 x 240, the three energy scans 240 + 2 x 147, 480 + 2 x 294, 480 + 2 x 384 -- 2.6e4, all exact (4.5 cycles / 64)
+#   k_fft_xp, k_synth   the arithmetic column of scripts/isa_mix.py (profiles/r6_isa_mix.json, written at build time: straight-line kernels, static
+#             count = issued count), at the packed / fused cost
+#   k_rnn     551 activations x ~25 plain instructions / 64 lanes beside 32 MFMAs per stream-frame (x 16 cycles, hidden under them)
+#   k_lpc     5 x 860 exact multiply-adds;  k_hp  its HBM bytes (its 90 f64 instructions per stream-frame issue in less)
+CYC_PLAIN, CYC_PACKED = 2.27, 4.2
+PITCH_MACS = 864 * 5 + 10 * 480 + 25 * 480 + 5 * 240 + (240 + 2 * 147) + (480 + 2 * 294) + (480 + 2 * 384)
+KERNEL_MIN_CYCLES = {   # SIMD cycles per stream-frame (already divided by the 64 lanes of a wave instruction)
+    "k_pitch": PITCH_MACS * 2 * CYC_PLAIN / 64,
+    "k_rnn": 215 * CYC_PLAIN,
+    "k_lpc": 5 * 860 * 2 * CYC_PLAIN / 64,
+    "k_hp": 90 * CYC_PACKED,
+}
+SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 # Algorithmic HBM bytes per stream-frame of each kernel (its own inputs + outputs, each counted once; per-group state traffic
 # divided by the G frames of a full group; derivation in DESIGN.md "Kernels")
@@ -213,12 +223,44 @@ def parse_args(argv=None):
 
 
 def pmc_profile(kind, S):
-    """A committed rocprofv3 --pmc summary for this stream count (profiles/pmc_<kind>_<S>streams.json) or None."""
+    """The newest committed rocprofv3 --pmc summary for this stream count (profiles/r<round>_pmc_<kind>_<S>streams.json) or None; the
+    summary's file name travels with it (`file`)."""
+    import glob
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{kind}_{S}streams.json")):
+        try:
+            rnd = int(os.path.basename(path).split("_")[0][1:])
+        except ValueError:
+            continue
+        if best is None or rnd > best[0]:
+            best = (rnd, path)
+    if best is None:
+        return None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", f"pmc_{kind}_{S}streams.json")))
-        return d if d.get("streams") == S else None
+        d = json.load(open(best[1]))
     except Exception:
         return None
+    if d.get("streams") != S:
+        return None
+    d["file"] = "profiles/" + os.path.basename(best[1])
+    return d
+
+
+def isa_arithmetic():
+    """Arithmetic vector instructions per stream-frame of the straight-line kernels, from the newest committed scripts/isa_mix.py --json summary
+    (static count = what a wave issues per stream-frame there; written at build time, see __graft_entry__.build / scripts/isa_mix.py)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_mix.json")), key=lambda q: int(os.path.basename(q).split("_")[0][1:]))
+    if not paths:
+        return {}, None
+    try:
+        d = json.load(open(paths[-1]))
+    except Exception:
+        return {}, None
+    out = {}
+    for k, v in d.get("kernels", {}).items():   # (k_synth<true> is the instantiation of the plain boundary format: the one the headline runs)
+        out[k.replace("<true>", "")] = v.get("arith_cycles")
+    return out, "profiles/" + os.path.basename(paths[-1])
 
 
 def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want_tick=True, want_roofline=True, min_timed_s=0.0):
@@ -399,7 +441,7 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
         if pm and dom in pm["kernels"]:
             traffic_psf = pm["kernels"][dom]["hbm_bytes_per_stream_frame"]
             traffic = traffic_psf * S * frames_per_launch
-            traffic_src = f"profiles/pmc_traffic_{S}streams.json (2*FETCH_SIZE+WRITE_SIZE, separate passes, {pm.get('frames_per_launch')}-frame launches there)"
+            traffic_src = f"{pm.get('file')} (2*FETCH_SIZE+WRITE_SIZE, separate passes, {pm.get('frames_per_launch')}-frame launches there)"
         # what binds the dominant kernel: the busiest on-chip resource of the committed SQ counter pass at this stream count
         binding = None
         sq = pmc_profile("sq", S)
@@ -410,7 +452,7 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
             if cand:
                 top = max(cand, key=cand.get)
                 binding = {"resource": top, "busy": cand[top], "valu_busy": q.get("valu_busy"), "lds_busy": q.get("lds_busy"),
-                           "lds_conflict_share": q.get("lds_conflict_share"), "source": f"profiles/pmc_sq_{S}streams.json (rocprofv3 --pmc SQ_* passes)"}
+                           "lds_conflict_share": q.get("lds_conflict_share"), "waiting_share": q.get("wait_share"), "source": f"{sq.get('file')} (rocprofv3 --pmc SQ_* passes)"}
         # the whole path's HBM traffic from the counters against its algorithmic bytes (16 948 B), and the issue ceiling
         path_traffic = None
         if pm:
@@ -422,27 +464,37 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
         ceiling = None
         if sq:
             fl = sq.get("frames_per_launch", 24)
+            arith, arith_src = isa_arithmetic()
+            min_cycles = dict(KERNEL_MIN_CYCLES)
+            for k in ("k_fft_xp", "k_synth"):   # straight-line kernels: the static arithmetic count IS the issued count, each instruction at its class's cost
+                if arith.get(k):
+                    min_cycles[k] = arith[k]
             rows, t_min = {}, 0.0
             for k, v in kern.items():
                 issued = sq["kernels"].get(k, {}).get("counters", {}).get("SQ_INSTS_VALU")
-                need = KERNEL_MIN_VALU.get(k)
+                need = min_cycles.get(k)
                 if need is None:
                     continue
-                us_issue = need * VALU_ISSUE_CYCLES * S / (SIMDS * CLOCK_HZ) * 1e6
+                us_issue = need * S / (SIMDS * CLOCK_HZ) * 1e6
                 us_hbm = KERNEL_BYTES.get(k, 0) * S / (HBM_PEAK_GBS * 1e9) * 1e6
                 us_min = max(us_issue, us_hbm)
                 t_min += us_min
-                rows[k] = {"valu_issued_per_stream_frame": round(issued * 32 / (S * fl)) if issued else None, "valu_needed_per_stream_frame": need,
+                rows[k] = {"valu_issued_per_stream_frame": round(issued * 32 / (S * fl)) if issued else None, "arithmetic_simd_cycles_per_stream_frame": round(need, 1),
                            "us_per_frame_floor": round(us_min, 1), "floor_set_by": "hbm" if us_hbm > us_issue else "vector issue",
                            "us_per_frame_measured": round(v["us_per_frame"], 1)}
             ceiling = {"kernels": rows, "sum_floor_us_per_frame": round(t_min, 1), "frames_per_s_at_the_floor": S / (t_min * 1e-6) if t_min else None,
                        "measured_over_floor": per_gpu / (S / (t_min * 1e-6)) if t_min else None,
                        "hbm_frac_at_the_floor": (S / (t_min * 1e-6)) * BYTES_PER_FRAME_FUSED / 1e9 / HBM_PEAK_GBS if t_min else None,
-                       "note": "floor = every SIMD issuing only the kernel's arithmetic (4 cycles per wave instruction), or its algorithmic bytes at 8 TB/s; "
-                               "issued counts from profiles/pmc_sq_*.json (SQ_INSTS_VALU x 32 shader engines / stream-frames)"}
+                       "issue_cycles": {"plain_f32": CYC_PLAIN, "packed_or_fused": CYC_PACKED, "source": "profiles/r6_valu_issue.txt (scripts/ubench/valu_issue.hip)"},
+                       "arithmetic_source": {"k_fft_xp, k_synth": arith_src, "others": "bench.py KERNEL_MIN_CYCLES (derivations in the comment above it)"},
+                       "note": "floor = every SIMD issuing only the kernel's arithmetic at the measured issue cost, or its algorithmic bytes at 8 TB/s; issued "
+                               f"counts from {sq.get('file')} (SQ_INSTS_VALU x 32 shader engines / stream-frames)"}
         return {"kernels": kern, "roofline": {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "frac_by_counters": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "measured_binder": (binding or {}).get("resource"),
+            "kernels_us_per_frame": {k: round(v["us_per_frame"], 1) for k, v in kern.items()},
             "alg_bytes_per_stream_frame": KERNEL_BYTES.get(dom, 0), "traffic_per_stream_frame": traffic_psf, "traffic_source": traffic_src,
             "avg_kernel_us": avg_s * 1e6, "frames_per_launch": frames_per_launch, "bytes_per_launch": bytes_per_launch,
             "binding": binding, "path_traffic": path_traffic, "issue_ceiling": ceiling,
@@ -452,9 +504,10 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
             "pipeline_fused_bytes_GBs": per_gpu * BYTES_PER_FRAME_FUSED / 1e9,
             "pipeline_hbm_frac": per_gpu * BYTES_PER_FRAME_FUSED / 1e9 / HBM_PEAK_GBS,
             "pipeline_fp32_frac": per_gpu * FLOPS_PER_FRAME / 1e12 / FP32_PEAK_TFLOPS,
-            "note": "the HBM fraction is reported because north_star asks for it; the path sits at 23-100 FLOP/B (SURVEY 8d) and its "
-                    "dominant kernel hardly touches HBM: `binding` names the on-chip resource the SQ counters show busiest and "
-                    "`frac_of_applicable_roof` the kernel's useful arithmetic against the roof that applies to it"}}
+            "note": "`bound`: the roof north_star asks the fraction of (HBM); `frac` by the kernel's algorithmic bytes, `frac_by_counters` by the bytes "
+                    "the PMC passes saw.  The path sits at 23-100 FLOP/B (SURVEY 8d) and its dominant kernel hardly touches HBM: `measured_binder` / "
+                    "`binding` name the on-chip resource the SQ counters show busiest, `frac_of_applicable_roof` the kernel's useful arithmetic "
+                    "against the roof that applies to it"}}
     return res, roofline_pass
 
 

@@ -1595,7 +1595,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int Lr = 4 * kg + r + 16 * li;
-                        const unsigned ix = base + (unsigned)__builtin_popcountll(bal[r] & ((1ull << lane) - 1ull));
+                        const unsigned ix = base + lane_rank(bal[r], lane);
                         if (keep[r] && ix < (unsigned)PK_CAP) {
                             L.u.a.list[ix] = (unsigned short)((sq << 8) | Lr);
                             lds_or_u32(&L.u.a.mask[sq][Lr >> 5], 1u << (Lr & 31));

@@ -16,7 +16,7 @@ __device__ __forceinline__ f32x4 mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
-// ---- the matrix-core DFT's primitives (nnn_dft_mfma.h) ----
+// ---- the primitives of the matrix-core DFT probe (scripts/ubench/nnn_dft_mfma.h: measured in round 5, not adopted) ----
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 // v_mfma_f32_16x16x32_f16: the same tile shapes and fragment layouts as the bf16 form, operands in IEEE half precision
 __device__ __forceinline__ f32x4 mfma_16x16x32_f16(uint4 a, uint4 b, f32x4 c)
@@ -239,6 +239,8 @@ template <int K> __device__ __forceinline__ float quad_lane(float y)
     const int b = __builtin_bit_cast(int, y);
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(b, K * 85, 0xf, 0xf, true));
 }
+// how many lanes below the caller have their bit set in a wave-wide mask (v_mbcnt_lo / _hi)
+__device__ __forceinline__ unsigned lane_rank(unsigned long long m, int) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
 // the value lane `l` holds, wave-uniform (l a compile-time constant)
 __device__ __forceinline__ float lane_value(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32, 1 ulp

@@ -190,6 +190,7 @@ template <int STEP> static inline float row_partner(float x)
     return __shfl(x, src);
 }
 template <int K> static inline float quad_lane(float y) { return __shfl(y, (int)((threadIdx.x & 60) | K)); }
+static inline unsigned lane_rank(unsigned long long m, int lane) { return (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull)); }
 static inline float lane_value(float x, int l) { return __shfl(x, l); }
 static inline float fast_sqrt(float x) { return sqrtf(x); }
 static inline float fast_rsq(float x) { return 1.0f / sqrtf(x); }

@@ -1,4 +1,4 @@
-"""The matrix-core DFT of round 5's probe (nnnoiseless_amd/csrc/nnn_dft_mfma.h; measured and NOT adopted, see
+"""The matrix-core DFT of round 5's probe (scripts/ubench/nnn_dft_mfma.h; measured and NOT adopted, see
 profiles/r5_dft_mfma_probe.txt) under the test-only SIMT interpreter: fragment layouts, index maps, plane splits and the scaling
 give a 480-point DFT that agrees with a double-precision one, for both operand schemes, next to today's fft480_regs."""
 import os
