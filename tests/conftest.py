@@ -98,6 +98,12 @@ def flip_stats(gpu_branch, gpu_out, ref, ref32):
 
 
 def assert_flips_in_line(st, tag=""):
-    """The GPU may flip a branch no more often than a few times what the reference's f32 arithmetic does against the checker."""
-    bound = max(4, 3 * st["flips_f32_vs_f64"])
-    assert st["flips_gpu_vs_f64"] <= bound, (tag, st)
+    """The GPU may flip a branch about as often as the reference's own f32 arithmetic does against the checker.  As a RATE since round 6
+    (profiles/r6_parity_flip_rates.json, 3.06 M frames: GPU vs f64 14.2 flips per million on the synthetic streams [9.5, 20.3], f32 vs
+    f64 11.2 [7.1, 16.9]; real audio 4.9 [1.6, 11.5] against 2.0 [0.2, 7.1]): the count must be inside the 99.9 % Poisson quantile of
+    TWICE the upper end of the reference arithmetic's own interval, 34 per million -- and, as before, no more than a few times what the
+    f32 oracle flipped on the same inputs when that is the larger allowance."""
+    from scipy.stats import poisson
+    by_rate = int(poisson.ppf(0.999, 34e-6 * st["frames"]))
+    bound = max(4, by_rate, 3 * st["flips_f32_vs_f64"])
+    assert st["flips_gpu_vs_f64"] <= bound, (tag, bound, st)
