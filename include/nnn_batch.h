@@ -233,7 +233,8 @@ int nnn_batch_set_schedule(nnn_batch *b, int mode, int lanes);
  * Environment.  The library reads exactly these variables (the first eight when a batch is created, NNN_NODE_THREADS when a node is,
  * NNN_DEVICE when rnnoise_create / rnnoise_init make their batch of one), every setting gives the same bits, and each is exercised by
  * a test (named on the right).  It sets none: in particular GPU_MAX_HW_QUEUES (real-time hosts ticking several batches side by side
- * want 8) is the host's to export before its first HIP call.
+ * want 8) is the host's to export before its first HIP call -- the library only LOOKS whether it is set, to print
+ * one note on stderr per process when batches are driven side by side on a device without it (they largely serialise on 4 queues).
  *   NNN_SCHED=seq|lanes|stages   how a call of 32 frames or more uses the batch's internal streams (nnn_batch_set_schedule)   test_hostsim_knobs
  *   NNN_LANES=1..4               lanes of the "lanes" schedule                                                                  test_hostsim_knobs
  *   NNN_HOST_CHUNK=n             frames per chunk of a host-buffer call (0 = one piece; default by call length)               test_gpu_parity / test_hostsim_pcm

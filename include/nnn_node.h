@@ -41,7 +41,11 @@ nnn_batch *nnn_node_batch(nnn_node *n, int i);
 int nnn_node_reset(nnn_node *n);
 /* A processing call that fails on any shard (the first failing shard's text in nnn_last_error) still runs and joins the other
  * shards, which have then advanced while the failing one has not: the node is FAILED from there on -- every later processing call
- * is refused with the original text -- until nnn_node_reset, exactly as a single batch stays faulted until nnn_batch_reset. */
+ * is refused with the original text -- until nnn_node_reset, exactly as a single batch stays faulted until nnn_batch_reset.
+ * nnn_node_reset clears the condition only if every shard resets.  While the node is failed, nnn_node_synchronize, nnn_node_fault
+ * and the per-shard handles of nnn_node_batch stay usable (for inspection and draining: the shards sit at different frame counts).
+ * A nnn_node is NOT thread-safe: one host thread drives it (its state, the failed flag included, carries no lock); the batches
+ * inside it keep their own locking. */
 
 /* n_frames x process_frame for every stream of the node, host buffers laid out as for nnn_batch_process_host over ALL streams:
  *   sample i of frame t of stream s: in[s * stream_stride + t * frame_stride + i], out likewise (may alias in)

@@ -181,7 +181,6 @@ struct nnn_batch {
     int lpc_wide = -1;              // k_lpc_wide (one lag per wave): -1 = for launches below 512 waves, 0 / 1 = never / always (env NNN_LPC_WIDE; tests)
     uint64_t id = 0, other_seen_us = 0;   // see g_call_mark
     bool beside_others = false;     // as of the current call
-    int cur_fmt = 0, cur_channels = 1;   // boundary format of the call being enqueued (k_synth's plain-format instantiation)
     bool host_call = false;         // inside a host-buffer entry point: the input is an upload enqueued by this library, final only in stream order
     hipEvent_t ev_in = nullptr;     // the caller's stream at the start of a pipelined call
     hipEvent_t ev_last = nullptr;   // end of the most recent call, on the stream it was made on
@@ -348,6 +347,7 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("no HIP device %d (found %d)", device, ndev);
+    if (device >= MARK_DEVICES) return fail("device %d: the library keeps per-device call marks for devices 0 .. %d only", device, MARK_DEVICES - 1);
     HIPCHK(hipSetDevice(device));
     h->device = device;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -838,7 +838,9 @@ static bool lpc_head(const nnn_batch *h, int g)
 {
     return lpc_in_pitch(h, g) && hp_split(h) && h->lpc_head != 0;
 }
-static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams *sp0, hipStream_t st, bool prof, const StepParams *call = nullptr, int fill = 0)
+// plain_out: the parameter table sp0 points into was filled for f32 mono audio (k_synth's plain-format instantiation ignores the table's
+// fmt / channels, so the caller states the format of the very call that fills the table, not a field of the batch)
+static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams *sp0, hipStream_t st, bool prof, bool plain_out, const StepParams *call = nullptr, int fill = 0)
 {
     if (g <= 0) return;   // (never a launch with an empty grid)
     const unsigned NT = (unsigned)h->NT, Sp = (unsigned)h->S_pad, ug = (unsigned)g;
@@ -928,7 +930,7 @@ static void launch_stage(nnn_batch *h, int s, int set0, int g, const StepParams 
         break;
     case ST_SYN:
         if (back == 2) break;
-        if (h->cur_fmt == PCM_F32 && h->cur_channels == 1) L.go(K_SYNTH, k_synth<true>, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0, g);
+        if (plain_out) L.go(K_SYNTH, k_synth<true>, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0, g);
         else L.go(K_SYNTH, k_synth<false>, dim3(Sp / FFT_SPB), dim3(64 * FFT_SPB), 0, b, sp0, g);
         break;
     }
@@ -968,14 +970,20 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
 {
     HIPCHK(hipSetDevice(h->device));
     if (int rc = report_fault(h)) return rc;   // an earlier call's hand-off failure (seen as soon as the device has written it)
-    h->cur_fmt = fmt;
-    h->cur_channels = channels;
+    const bool plain_out = fmt == PCM_F32 && channels == 1;
     {
         const uint64_t mask = (1ull << 44) - 1;
         const uint64_t now = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() & mask;
-        const uint64_t prev = g_call_mark[h->device % MARK_DEVICES].exchange((h->id << 44) | now, std::memory_order_relaxed);
+        const uint64_t prev = g_call_mark[h->device].exchange((h->id << 44) | now, std::memory_order_relaxed);
         if ((prev >> 44) != h->id && (prev >> 44) != 0 && now - (prev & mask) < 5000) h->other_seen_us = now | (1ull << 63);
         h->beside_others = (h->other_seen_us >> 63) && now - (h->other_seen_us & mask) < 20000;
+        if (h->beside_others) {   // once per process: the host's queue setting decides whether batches side by side overlap at all
+            static std::atomic<bool> told{false};
+            if (!getenv("GPU_MAX_HW_QUEUES") && !told.exchange(true))
+                fprintf(stderr, "nnnoiseless_mi355x: several batches are being driven side by side on device %d and GPU_MAX_HW_QUEUES is not set; "
+                                "the HIP runtime then maps their streams onto 4 hardware queues and they largely serialise "
+                                "(export GPU_MAX_HW_QUEUES=8 before the process starts -- INTEGRATION.md; any value of the variable silences this note)\n", h->device);
+        }
     }
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
     // calls are ordered even when consecutive ones arrive on different streams
@@ -1067,7 +1075,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     if (!pipe) {
         for (int k = 0, t = 0; k < n_groups; k++) {
             const int g = sizes[k], set0 = (int)(h->group_count % h->depth) * h->gmax;
-            for (int s = 0; s < ST_COUNT; s++) launch_stage(h, s, set0, g, tab + t, st, h->profiling, (fold_fill && k == 0) ? &v0 : nullptr, n_frames);
+            for (int s = 0; s < ST_COUNT; s++) launch_stage(h, s, set0, g, tab + t, st, h->profiling, plain_out, (fold_fill && k == 0) ? &v0 : nullptr, n_frames);
             h->group_count += 1;
             h->frame_count += g;
             h->last_set = set0 + g - 1;
@@ -1139,7 +1147,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
                         else if (h->have_done[par]) chk(hipStreamWaitEvent(ss, h->ev_done[par], 0));   // (par = the call before the previous one)
                     }
                 }
-                launch_stage(h, s, set0, g, tab + first[k], ss, false);
+                launch_stage(h, s, set0, g, tab + first[k], ss, false, plain_out);
                 if (consumers_elsewhere(s, k)) chk(hipEventRecord(h->ev[par][s][k % EVR], ss));
             }
             h->group_count += 1;

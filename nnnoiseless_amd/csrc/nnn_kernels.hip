@@ -2277,6 +2277,7 @@ __device__ __forceinline__ void fft_tables_load(FftLds &t, const Buffers &b, boo
         const int i = tid + k * nt;
         if (i < n) dst[i] = r[k];
     }
+    for (int i = tid + MAXIT * nt; i < n; i += nt) dst[i] = ld_global_u4(src + i);   // blocks of fewer than 256 threads: the rest, piece by piece
 }
 // the host's side of it
 __host__ inline void fft_tables_image(FftLds &t, const float2 *tw960, const float *bin_frac, const int *bin_band, const int *seg, const float *dct)

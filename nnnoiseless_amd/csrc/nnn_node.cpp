@@ -197,8 +197,10 @@ extern "C" nnn_node *nnn_node_create(const RNNModel *model, int n_streams, const
         s.hi = s.lo + base + (i < rem ? 1 : 0);
     }
     // One worker per shard, pinned to the CPUs local to its device's PCI function (the socket its GPU hangs off: a worker stages pageable
-    // buffers and enqueues for that GPU), then every worker makes its own batch -- allocation, table and weight uploads of all devices
-    // at once (serial until round 5: eight devices took eight creations' time).
+    // buffers and enqueues for that GPU), then every worker makes its own batch: the thread is pinned BEFORE it allocates and uploads, so the page-locked
+    // staging buffers and the tables' host copies come from its GPU's socket.  The creations themselves still run one after another:
+    // nnn_batch_create_opts holds the library's runtime lock for its whole length (allocation and legacy-stream copies must not overlap
+    // another thread's stream capture, nnn_batch.hip), so eight devices take eight creations' time.
     if (n->threads && n_devices > 1)
         for (auto &s : n->shards) {
             s.w = new Worker();

@@ -1,4 +1,5 @@
 import os, sys, numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the host's setting
 sys.path.insert(0, os.getcwd())
 import torch
 import nnnoiseless_amd as nn

@@ -9,6 +9,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "hostsi
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the host's setting for batches driven side by side: the evidence stays comparable
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 WEIGHTS = os.path.join(ROOT, "nnnoiseless_amd", "data", "weights.rnn")
 
