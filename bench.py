@@ -820,10 +820,11 @@ def main():
                                        "unit": "unit-range f32"}[args.pcm] + (f", {args.channels} interleaved channels" if args.channels > 1 else ""),
                    "streams_per_gpu": S, "streams_total": S * world, "frames_per_step": fps,
                    "inputs_ready": not args.no_overlap,
-                   # the library's own choice unless the environment asks: one stream in order from 16 384 streams up (every kernel fills the
-                   # GPU alone), below that the high-pass chain on a stream of its own ahead of one lane
-                   "schedule": os.environ.get("NNN_SCHED", "seq" if ((S + 63) // 64 * 64 >= 16384 and "NNN_LANES" not in os.environ) else "lanes"),
-                   "lanes": int(os.environ.get("NNN_LANES", "1")),
+                   # the library's own choice unless the environment asks: up to 16 384 streams the high-pass chain on a stream of its own ahead of
+                   # one lane; above that two groups in flight -- one stream per stage for calls of two groups, two lanes for longer ones (round 6)
+                   "schedule": os.environ.get("NNN_SCHED", "lanes" if ((S + 63) // 64 * 64 <= 16384 or "NNN_LANES" in os.environ)
+                                              else ("stages" if fps <= 48 else "lanes")) if fps >= 32 else "seq",
+                   "lanes": int(os.environ.get("NNN_LANES", "1" if (S + 63) // 64 * 64 <= 16384 else "2")),
                    "inputs": "resident in HBM and final before the timed region" + ("" if args.no_overlap else "; declared to the library "
                              "(nnn_batch_set_inputs_ready): with the lanes schedule consecutive calls overlap at their boundary, outputs stay stream-ordered"),
                    "parallelism": f"streams sharded x{world}, one process per GPU, no data-path collective"},

@@ -226,8 +226,10 @@ int nnn_batch_set_back_end(nnn_batch *b, int mode);
  * chain on its own stream, the other four stages of group k on lane k mod `lanes` (1..4; default 2; lane 0 is the caller's stream);
  * 2 = "stages": one stream per stage, every stream a chain of groups.  Environment: NNN_SCHED=seq|lanes|stages,
  * NNN_LANES=n.  Nobody choosing, the library does: calls of 32 frames or more are pipelined with one lane on batches of up to
- * 16 384 streams (from 8192 streams the high-pass chain of a group waits for the previous group's pitch kernel), everything runs in
- * order on the caller's stream above that. */
+ * 16 384 streams (from 8192 streams the high-pass chain of a group waits for the previous group's pitch kernel); bigger batches keep two
+ * groups in flight (650 instead of 360 KB of device memory per stream) and run such calls with one stream per stage when they are two groups
+ * long, on two lanes when longer (+2-3 % over one stream in order: every kernel of a big batch ends in a tail of half-empty compute
+ * units, which another stage's blocks fill).  Shorter calls run in order on the caller's stream. */
 int nnn_batch_set_schedule(nnn_batch *b, int mode, int lanes);
 /*
  * Environment.  The library reads exactly these variables (the first eight when a batch is created, NNN_NODE_THREADS when a node is,

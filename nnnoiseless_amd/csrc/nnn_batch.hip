@@ -105,6 +105,7 @@ enum Stage { ST_HP, ST_PITCH, ST_FFT, ST_RNN, ST_SYN, ST_COUNT };
 constexpr int NSTREAMS = 5;    // internal streams of a pipelined call
 constexpr int EVR = 16;        // event ring: groups of one call that may still be referred to
 enum SchedMode { SCHED_SEQ = 0, SCHED_LANES = 1, SCHED_STAGES = 2 };
+constexpr int AUTO_BIG = 16384;   // streams above which the automatic schedule changes (process_frames)
 
 struct nnn_batch {
     Buffers b[NSET];               // same state, NSET scratch sets (views into one allocation per scratch array: set s lies
@@ -388,8 +389,9 @@ static int create_impl(nnn_batch *h, const RNNModel *const *models, const int *g
         const int v = atoi(e);
         if (v == 16 || v == 32) h->rnn_rows = v;
     }
-    // groups in flight behind the high-pass: what the schedule chosen at creation can use (a schedule set later works on what is there)
-    h->depth = (h->n_lanes >= 2 || h->sched == SCHED_STAGES) ? DEPTH : 1;
+    // groups in flight behind the high-pass: what the schedule chosen at creation can use (a schedule set later works on what is there).
+    // Nobody choosing, batches above AUTO_BIG streams keep two groups in flight (round 6, see process_frames: their calls overlap kernels).
+    h->depth = (h->n_lanes >= 2 || h->sched == SCHED_STAGES || (h->sched_auto && (n_streams + TILE - 1) / TILE * TILE > AUTO_BIG)) ? DEPTH : 1;
     if (const char *e = dev_knob("NNN_RING_DEPTH")) h->depth = atoi(e) >= 2 ? DEPTH : 1;   // (experiment knob)
     h->nset = h->depth * h->gmax;
     h->nslot = slots_for(h->gmax, h->depth);
@@ -1025,8 +1027,15 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     // unless a schedule was asked for -- 32 768 streams: 65.9 M frames/s against 64.8 with the high-pass on a stream of its own)
     // (the automatic schedule pipelines up to 16 384 streams: measured in round 4 with the high-pass held back behind the previous group's
     // pitch kernel, see hp_after -- 16 384: 64.2-65.5 -> 66.4-66.9 M frames/s; 32 768 and 65 536 lose 1-2 % pipelined)
-    static const int pipe_max = dev_knob("NNN_PIPE_MAX") ? atoi(dev_knob("NNN_PIPE_MAX")) : 16384;
-    const bool pipe = h->use_pipeline && h->sched != SCHED_SEQ && !h->profiling && n_frames >= PIPE_MIN && !(h->sched_auto && h->S_pad > pipe_max);
+    // Round 6: above 16 384 streams the automatic schedule overlaps kernels again.  k_pitch issues a third fewer instructions than in round 5 and
+    // waits more (certified search), and every kernel of a big batch ends in a tail of half-empty compute units -- twelve tails per 48-frame
+    // call; with two groups in flight another stage's blocks fill them.  Measured on one box, interleaved (scripts/gpu_sched_r6.sh,
+    // profiles/r6_sched_sweep.txt), against one stream in order: 65 536 x 48 stages +2.6 % (lanes 2: +1.0), 65 536 x 96 lanes 2 +2.3 % (stages
+    // -0.3), 32 768 x 96 lanes 2 +1.9 % (stages +0.4), 32 768 x 48 stages +1.0 % (lanes 2: -0.4): one stream per stage for calls of two
+    // groups, two lanes for longer ones.  Costs the second block of scratch sets and the longer ring (650 against 360 KB per stream).
+    static const int pipe_max = dev_knob("NNN_PIPE_MAX") ? atoi(dev_knob("NNN_PIPE_MAX")) : AUTO_BIG;
+    const bool auto_big = h->sched_auto && h->S_pad > pipe_max;
+    const bool pipe = h->use_pipeline && h->sched != SCHED_SEQ && !h->profiling && n_frames >= PIPE_MIN && !(auto_big && h->depth < 2);
     std::vector<int> sizes;
     if (pipe && h->ramp == 0) {
         int k = 2;
@@ -1049,6 +1058,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
         rem -= g;
     }
     const int n_groups = (int)sizes.size();
+    const int call_sched = auto_big ? (n_groups <= 2 ? SCHED_STAGES : SCHED_LANES) : h->sched, call_lanes = auto_big ? 2 : h->n_lanes;
     h->call_count += 1;
     const int par = (int)(h->call_count & 1);
     StepParams *const tab = h->sp_tab + (size_t)par * h->sp_tab_cap;   // this call's parameter table
@@ -1060,7 +1070,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     // its own stream (biquad state) and the history-ring slots it overwrites (synthesis events of the groups that read them).
     // (never for the library's own host-buffer calls: their input is an upload enqueued just before on the caller's stream or on
     // a copy stream, final only in that stream's order -- the promise is about buffers the CALLER filled)
-    const bool early_hp = pipe && h->inputs_ready && !h->host_call && h->prev_pipe && h->prev_st == st && h->sched == SCHED_LANES && h->pool[0];
+    const bool early_hp = pipe && h->inputs_ready && !h->host_call && h->prev_pipe && h->prev_st == st && call_sched == SCHED_LANES && h->pool[0];
     // the per-frame parameter table: a launch of its own ahead of a pipelined call's streams; otherwise the call's first kernel (k_hp of
     // the first group) fills it on its way (a one-frame call is a handful of launches of 15-35 us: one fewer is 4 % of it)
     static const bool fold_ok = !(dev_knob("NNN_FOLD_FILL") && atoi(dev_knob("NNN_FOLD_FILL")) == 0);   // (A/B knob)
@@ -1086,8 +1096,8 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
         chk(hipEventRecord(h->ev_in, st));
         // index into h->pool; -1 = the caller's stream (lane 0 of the lanes schedule, the synthesis chain of the stages one)
         auto stream_of = [&](int s, int k) -> int {
-            if (h->sched == SCHED_STAGES) return s == ST_HP ? 0 : (s == ST_PITCH ? 1 : (s == ST_FFT ? 2 : (s == ST_RNN ? 3 : -1)));
-            return s == ST_HP ? 0 : (k % h->n_lanes) - (k % h->n_lanes == 0 ? 1 : 0);
+            if (call_sched == SCHED_STAGES) return s == ST_HP ? 0 : (s == ST_PITCH ? 1 : (s == ST_FFT ? 2 : (s == ST_RNN ? 3 : -1)));
+            return s == ST_HP ? 0 : (k % call_lanes) - (k % call_lanes == 0 ? 1 : 0);
         };
         std::vector<int> first(n_groups);   // first frame (within the call) of every group
         for (int k = 0, t = 0; k < n_groups; k++) { first[k] = t; t += sizes[k]; }
@@ -1097,7 +1107,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
         // kernel is done and still finish before group k needs it: 8192 x 48: 61.3 -> 63.9 M frames/s, 16 384: +2-3 %; at 4096 streams the
         // window is too short (57.5 -> 56.3).  NNN_HP_AFTER = 0 | 1 | 2 | 3: never | behind pitch | fft | rnn of the previous group.
         static const int hp_after_env = dev_knob("NNN_HP_AFTER") ? atoi(dev_knob("NNN_HP_AFTER")) : -1;
-        const int hp_after = hp_after_env >= 0 ? hp_after_env : (h->sched == SCHED_LANES && h->n_lanes == 1 && h->S_pad >= 8192 ? 1 : 0);
+        const int hp_after = hp_after_env >= 0 ? hp_after_env : (call_sched == SCHED_LANES && call_lanes == 1 && h->S_pad >= 8192 ? 1 : 0);
         auto consumers_elsewhere = [&](int s, int k) {
             const int me = stream_of(s, k);
             if (s + 1 < ST_COUNT && stream_of(s + 1, k) != me) return true;
