@@ -754,7 +754,7 @@ def test_pitch_frames_chained_and_looped_agree(nn, oracle_mod, weights_bytes, mo
     assert np.array_equal(first[2][:n, 0], ref["pitch"][:, -1])
 
 
-@pytest.mark.parametrize("S", [454, 4096])
+@pytest.mark.parametrize("S", [454, 4096, 20480])   # (20480: the automatic schedule of big batches -- one stream per stage / two lanes, round 6)
 def test_calls_overlapping_at_their_boundary(nn, S):
     """nnn_batch_set_inputs_ready: with the caller's promise that inputs are final at call time, the next call's high-pass chain
     starts while the previous call is still draining.  Calls made back to back on one HIP stream with no host synchronisation
