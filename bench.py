@@ -507,7 +507,12 @@ def measure(args, S, model_path, rank, world, dev, local_rank, dist, torch, want
             "note": "`bound`: the roof north_star asks the fraction of (HBM); `frac` by the kernel's algorithmic bytes, `frac_by_counters` by the bytes "
                     "the PMC passes saw.  The path sits at 23-100 FLOP/B (SURVEY 8d) and its dominant kernel hardly touches HBM: `measured_binder` / "
                     "`binding` name the on-chip resource the SQ counters show busiest, `frac_of_applicable_roof` the kernel's useful arithmetic "
-                    "against the roof that applies to it"}}
+                    "against the roof that applies to it.  `avg_kernel_us`: HIP events around every launch with the launches IN ORDER (the "
+                    "library's profiling pass; rocprofv3 --kernel-trace --stats with NNN_SCHED=seq reproduces it: profiles/r<round>_kernel_stats_*_"
+                    "sequential.md).  The timed loop of a big batch overlaps its kernels (round 6): there a kernel's wall time includes the time it "
+                    "shares the GPU with its neighbours (profiles/r<round>_kernel_stats_*streams_48fps.md), and the per-kernel times no longer sum to "
+                    "ms_per_step -- `overlap_gain` = the in-order sum / ms_per_step",
+            "overlap_gain": sum(v["us_per_frame"] for v in kern.values()) * fps / 1e3 / res["ms_per_step"]}}
     return res, roofline_pass
 
 

@@ -14,7 +14,8 @@ from nnnoiseless_amd import _ffi
 from nnnoiseless_amd.synthetic import make_streams_fast
 lib = _ffi.Library('/tmp/libnnn_stamps.so')
 lib.L.nnn_batch_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
-for S, T in ((256, 2), (4096, 4), (65536, 24)):
+for S, T in ((256, 2), (4096, 4)):   # (short launches whose frames run side by side with the flag hand-off: every stamp of block 0 is one frame's; in a launch that
+                                      # loops over 24 frames the slots written by other waves belong to other frames)
     bd = nn.BatchDenoiser(S, lib=lib)
     bd.set_pipeline(False)
     x = make_streams_fast(S, 2 * T)
