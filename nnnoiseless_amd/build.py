@@ -8,7 +8,8 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libnnnoiseless_mi355x.so")
 WEIGHTS = os.path.join(HERE, "data", "weights.rnn")
 SOURCES = ["nnn_batch.hip", "nnn_resample.hip", "nnn_model.cpp", "rnnoise_capi.cpp", "nnn_node.cpp"]
-DEPS = SOURCES + ["nnn_kernels.hip", "nnn_back.hip", "nnn_layout.h", "nnn_model.h", "nnn_mfma.h"]
+HP_SOURCE = "nnn_hp.hip"
+DEPS = SOURCES + [HP_SOURCE, "nnn_kernels.hip", "nnn_back.hip", "nnn_layout.h", "nnn_model.h", "nnn_mfma.h"]
 
 
 def _stale():
@@ -25,10 +26,16 @@ def build_library(force=False, verbose=False):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-           "-Wno-unused-value", "-I", CSRC, f'-DNNN_WEIGHTS_PATH="{WEIGHTS}"', "-x", "hip"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value", "-I", CSRC,
+              f'-DNNN_WEIGHTS_PATH="{WEIGHTS}"']
+    # the two high-pass kernels in a unit of their own, with the SLP pairing the rest of the library is built without (nnn_kernels.hip, at k_hp2)
+    hp_obj = os.path.join(LIB_DIR, "nnn_hp.o")
+    cmds = [common + ["-c", "-x", "hip", os.path.join(CSRC, HP_SOURCE), "-o", hp_obj],
+            common + ["-fno-slp-vectorize", "-DNNN_HP_EXTERN", "-shared", "-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES]
+            + ["-x", "none", hp_obj, "-o", LIB_PATH]]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    os.remove(hp_obj)
     return LIB_PATH

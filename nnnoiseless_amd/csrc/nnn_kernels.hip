@@ -87,8 +87,14 @@ __device__ __forceinline__ void xcd_tile_block_units(int blk, int ntiles, int bp
 #endif
 
 // Bark-ish band edges in units of 4 bins (ref: src/lib.rs:55-58) and SECOND_CHECK (ref: src/pitch.rs:489)
-__constant__ int kEband[NB] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100};
-__constant__ int kSecondCheck[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};
+// (internal linkage: the library is two translation units since round 6 -- nnn_hp.hip -- and each carries its own copy)
+#ifdef __HIPCC__
+#define NNN_CONSTANT static __constant__
+#else
+#define NNN_CONSTANT __constant__   // (the tests' interpreter build defines __constant__ as static)
+#endif
+NNN_CONSTANT int kEband[NB] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100};
+NNN_CONSTANT int kSecondCheck[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};
 
 // ---- PCM formats at the boundary ------------------------------------------------------------------
 // Input conversions of the reference's callers: i16 samples are used as they are (src/nnnoiseless.rs:179-228 hands
@@ -420,6 +426,19 @@ __device__ __forceinline__ void hp_chain_group(const Buffers &b, const StepParam
 // tiles a helper shares the SIMD of a recurrence and the kernel takes twice as long).  Groups run two tiles per block: half as many
 // compute units carry a wave that takes most of its SIMD's issue slots from the pipelined call's other kernels (4096 x 48 +1 %, 8192 x 48
 // +2 %; keeping k_pitch's blocks off those units altogether by padding the block's LDS: measured, no gain).
+// The two high-pass kernels are compiled in a translation unit of their own (nnn_hp.hip) WITH the compiler's SLP pairing, the rest of the
+// library without it (round 6): the recurrence is one wave's serial chain of f64 instructions, bound by that wave's own issue rate, and
+// where the loads, address arithmetic and stores land between the chain's instructions decides its pace -- with the pairing pass on the
+// same source is 14 % faster per frame on small launches (k_hp2 21.5 against 25.0 us per frame at 4096 streams, 26 against 29 us in a
+// one-frame tick), while k_pitch, the transforms and the synthesis are 2-5 % faster without it.  Same instructions on the same values either
+// way.  NNN_HP_EXTERN: this unit only declares them; NNN_ONLY_HP: this unit is nnn_hp.hip and defines nothing else.  A build that
+// defines neither (the tests' interpreter, scripts/build_variant.sh, the stamp builds) holds everything in one unit, as before.
+#ifdef NNN_HP_EXTERN
+template <int TPB> __global__ void k_hp2(Buffers b, const StepParams *sp, int g, StepParams v0, int fill, int head);
+extern template __global__ void k_hp2<1>(Buffers b, const StepParams *sp, int g, StepParams v0, int fill, int head);
+extern template __global__ void k_hp2<2>(Buffers b, const StepParams *sp, int g, StepParams v0, int fill, int head);
+__global__ void k_hp(Buffers b, const StepParams *sp, int g, StepParams v0, int fill);
+#else
 template <int TPB>
 __global__ void __launch_bounds__(128 * TPB) k_hp2(Buffers b, const StepParams *sp, int g, StepParams v0, int fill, int head)
 {
@@ -485,6 +504,13 @@ __global__ void __launch_bounds__(64, HP_CH <= 16 ? 3 : 1) k_hp(Buffers b, const
     else { if (vec) hp_group<PCM_F32_UNIT, true>(b, sp, g, tile, lane, Ly, v0, fill); else hp_group<PCM_F32_UNIT, false>(b, sp, g, tile, lane, Ly, v0, fill); }
 }
 
+#ifdef NNN_ONLY_HP
+template __global__ void k_hp2<1>(Buffers b, const StepParams *sp, int g, StepParams v0, int fill, int head);
+template __global__ void k_hp2<2>(Buffers b, const StepParams *sp, int g, StepParams v0, int fill, int head);
+#endif
+#endif   // NNN_HP_EXTERN
+
+#ifndef NNN_ONLY_HP   // (everything from here to the end of the file)
 // ---------------------------------------------------------------------------------------------
 // K2  lpc: the part of pitch_downsample between the decimation and the FIR -- 5-lag autocorrelation of the 864-value window,
 //     lag window, order-4 Levinson recursion, bandwidth expansion and the extra zero (ref: src/pitch.rs:433-446, 460-480,
@@ -4238,5 +4264,7 @@ __global__ void k_fill_params(StepParams *tab, StepParams v, int n, int nslot)
     if (t >= n) return;
     tab[t] = step_params_at(v, t, nslot);
 }
+
+#endif   // NNN_ONLY_HP
 
 }  // namespace nnn
