@@ -1027,7 +1027,7 @@ static int process_frames(nnn_batch *h, const void *d_in, void *d_out, float *d_
     // unless a schedule was asked for -- 32 768 streams: 65.9 M frames/s against 64.8 with the high-pass on a stream of its own)
     // (the automatic schedule pipelines up to 16 384 streams: measured in round 4 with the high-pass held back behind the previous group's
     // pitch kernel, see hp_after -- 16 384: 64.2-65.5 -> 66.4-66.9 M frames/s; 32 768 and 65 536 lose 1-2 % pipelined)
-    // Round 6: above 16 384 streams the automatic schedule overlaps kernels again.  k_pitch issues a third fewer instructions than in round 5 and
+    // Round 6: above 16 384 streams the automatic schedule overlaps kernels again.  k_pitch issues a fifth fewer instructions than in round 5 and
     // waits more (certified search), and every kernel of a big batch ends in a tail of half-empty compute units -- twelve tails per 48-frame
     // call; with two groups in flight another stage's blocks fill them.  Measured on one box, interleaved (scripts/gpu_sched_r6.sh,
     // profiles/r6_sched_sweep.txt), against one stream in order: 65 536 x 48 stages +2.6 % (lanes 2: +1.0), 65 536 x 96 lanes 2 +2.3 % (stages
