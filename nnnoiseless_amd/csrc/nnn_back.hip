@@ -397,6 +397,7 @@ __global__ void __launch_bounds__(BK_T) k_back(Buffers b, const StepParams *sp0,
     xcd_tile_block((int)blockIdx.x, (tile0 & 7) ? 1 : (int)gridDim.x / per, per, tile, sub);
     tile += tile0;                                 // tile0: first tile of this model's run
     const int r0 = sub * BK_ROWS;                  // first row of the tile handled here
+    if (tile * TILE + r0 >= b.S) return;   // (a block whose streams are all padding -- the last tile of a batch that is not a multiple of 64 -- has nothing to do)
     const int sl = r0 + wave0, s = tile * TILE + sl;   // this wave's stream: its row in the tile, its index in the batch
     // ---- LDS
     float *tab = (float *)(lds + o.tab);

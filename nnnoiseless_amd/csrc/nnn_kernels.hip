@@ -1053,10 +1053,9 @@ constexpr int PK_FINE_K = (NLAG2 + 3) / 4;       // 74 groups of four fine lags
 constexpr int PK_YY_B = 19;                      // 19 runs of twenty steps of yy_lookup (380 steps: the last four are only ever replayed)
 // (the four terms are fetched by four independent DPP moves, then added by plain instructions: an add that takes its operand through DPP
 // waits two more states on the sum it has just written and runs at a third of the rate -- measured, 21 against 9 cycles a step)
-struct Quad4 { float t0, t1, t2, t3; };
 __device__ __forceinline__ Quad4 pk_quad4(float t)
 {
-    Quad4 r = {quad_lane<0>(t), quad_lane<1>(t), quad_lane<2>(t), quad_lane<3>(t)};
+    Quad4 r = quad_all(t);   // (nnn_mfma.h: four DPP moves; the tests' interpreter: one rendezvous of the wave's lanes)
     keep_rw(r.t0); keep_rw(r.t1); keep_rw(r.t2); keep_rw(r.t3);
     return r;
 }
@@ -1328,6 +1327,7 @@ __global__ void __launch_bounds__(PK_T, NNN_PK_MINWAVES) k_pitch(Buffers b, cons
     int tile, sub_;
     xcd_tile_block(item - f_begin * per, b.NT, TILE / PK_SPB, tile, sub_);
     const int q0 = sub_ * PK_SPB;   // first stream of this block within its tile
+    if (tile * TILE + q0 >= b.S) return;   // (a block whose streams are all padding -- the last tile of a batch that is not a multiple of 64 -- has nothing to do)
     const int min_period = PITCH_MIN / 2, max_period = PITCH_MAX / 2;
     const bool dec_lane = wave == 0 && lane0 < PK_SPB;                // lane = stream decisions
     int last_period = 0;
@@ -2803,6 +2803,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_FFT_MINWAVES) k_fft_xp(Buffe
     __shared__ float part[FFT_SPB][3 * FH_STRIDE];   // the feature head's staging: correlation, log energies, band energies
     int frame, tile, sub;
     fft_block(b, g, frame, tile, sub);
+    if (tile * TILE + sub * FFT_SPB >= b.S) return;   // (a block whose streams are all padding -- the last tile of a batch that is not a multiple of 64 -- has nothing to do)
     b = frame_view(b, frame);
     const int wave = threadIdx.x >> 6;
     transform_inputs<true>(b, sp + frame, tile, sub, t, Z[wave], part[wave]);
@@ -2818,6 +2819,7 @@ __device__ __forceinline__ void xt_rider(const Buffers &b, const StepParams *sp,
     static_assert(sizeof(XtLds) <= sizeof(PkLds) && PK_T == 512 && FFT_SPB == 4, "");
     XtLds &x = *(XtLds *)lds;
     const int wave = threadIdx.x >> 6;
+    if ((rb >> 3) * TILE + 8 * (rb & 7) >= b.S) return;
     transform_inputs<false>(b, sp, rb >> 3, 2 * (rb & 7), x.t, x.Z[wave], x.part[wave]);   // rows 8 (rb % 8) + wave of tile rb / 8
 }
 
@@ -2829,6 +2831,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB) k_fft_x(Buffers b, const StepPar
     __shared__ float part[FFT_SPB][4];   // (the feature head's staging: unused without the second transform)
     int frame, tile, sub;
     fft_block(b, g, frame, tile, sub);
+    if (tile * TILE + sub * FFT_SPB >= b.S) return;
     b = frame_view(b, frame);
     const int wave = threadIdx.x >> 6;
     transform_inputs<false>(b, sp + frame, tile, sub, t, Z[wave], part[wave]);
@@ -3376,6 +3379,7 @@ __global__ void __launch_bounds__(64 * RNN_WAVES) k_rnn(Buffers b, RnnPlan pl, c
     xcd_tile_block((int)blockIdx.x, (tile0 & 7) ? 1 : (int)gridDim.x / per, per, tile, sub);
     tile += tile0;                                         // tile0: first tile of this model's run
     const int r0 = sub * rm;                               // first row of the tile handled here
+    if (tile * TILE + r0 >= b.S) return;   // (a block whose streams are all padding -- the last tile of a batch that is not a multiple of 64 -- has nothing to do)
     const bool rowl = lane < rm;                           // lane = stream phases: this lane has a row
     const int trow = r0 + (rowl ? lane : 0);               // its row in the tile
     // ---- LDS carve-up (rnn_lds_bytes on the host mirrors it)
@@ -3796,6 +3800,7 @@ __global__ void __launch_bounds__(64 * WF_WAVES, NNN_WF_MINWAVES) k_rnn_wf(Buffe
     xcd_tile_block((int)blockIdx.x, (tile0 & 7) ? 1 : (int)gridDim.x / (TILE / rm), TILE / rm, tile, sub);
     tile += tile0;
     const int r0 = sub * rm;                                 // first row of the tile handled here
+    if (tile * TILE + r0 >= b.S) return;   // (a block whose streams are all padding -- the last tile of a batch that is not a multiple of 64 -- has nothing to do)
     const bool rowl = lane0 < rm;
     const int trow = r0 + (rowl ? lane0 : 0);
     NNN_STAMP(b, 50);
@@ -4200,6 +4205,7 @@ __global__ void __launch_bounds__(64 * FFT_SPB, NNN_SYN_MINWAVES) k_synth(Buffer
     float *r = r_[wave];
     int tile, sub;
     xcd_tile_block((int)blockIdx.x, b.NT, TILE / FFT_SPB, tile, sub);
+    if (tile * TILE + sub * FFT_SPB >= b.S) return;   // (a block whose streams are all padding -- the last tile of a batch that is not a multiple of 64 -- has nothing to do)
     const int lane0 = threadIdx.x & 63, sl = sub * FFT_SPB + wave, s = tile * TILE + sl;
     int lane = lane0;
     fft_tables_load(t, b, NNN_FFT_LANE_TW != 0);

@@ -239,6 +239,9 @@ template <int K> __device__ __forceinline__ float quad_lane(float y)
     const int b = __builtin_bit_cast(int, y);
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(b, K * 85, 0xf, 0xf, true));
 }
+// y of all four lanes of the caller's quad
+struct Quad4 { float t0, t1, t2, t3; };
+__device__ __forceinline__ Quad4 quad_all(float y) { Quad4 r = {quad_lane<0>(y), quad_lane<1>(y), quad_lane<2>(y), quad_lane<3>(y)}; return r; }
 // how many lanes below the caller have their bit set in a wave-wide mask (v_mbcnt_lo / _hi)
 __device__ __forceinline__ unsigned lane_rank(unsigned long long m, int) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
 // the value lane `l` holds, wave-uniform (l a compile-time constant)

@@ -190,6 +190,27 @@ template <int STEP> static inline float row_partner(float x)
     return __shfl(x, src);
 }
 template <int K> static inline float quad_lane(float y) { return __shfl(y, (int)((threadIdx.x & 60) | K)); }
+// the four values of the caller's quad in ONE rendezvous of the wave's fibers (k_pitch's serial scans call this once per four steps: as four
+// shuffles it was most of the interpreter's time)
+struct Quad4 { float t0, t1, t2, t3; };
+namespace detail {
+static inline void quad_all_fn(const void *const *ins, void *const *outs, int nl)
+{
+    for (int l = 0; l < nl; l++) {
+        if (!outs[l]) continue;
+        float q[4];
+        for (int k = 0; k < 4; k++) { const void *p = ins[(l & ~3) | k]; q[k] = p ? *(const float *)p : 0.0f; }
+        Quad4 r = {q[0], q[1], q[2], q[3]};
+        *(Quad4 *)outs[l] = r;
+    }
+}
+}  // namespace detail
+static inline Quad4 quad_all(float y)
+{
+    Quad4 r;
+    hostsim::wave_collective(&y, &r, detail::quad_all_fn);
+    return r;
+}
 static inline unsigned lane_rank(unsigned long long m, int lane) { return (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull)); }
 static inline float lane_value(float x, int l) { return __shfl(x, l); }
 static inline float fast_sqrt(float x) { return sqrtf(x); }
