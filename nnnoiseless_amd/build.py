@@ -29,13 +29,21 @@ def build_library(force=False, verbose=False):
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value", "-I", CSRC,
               f'-DNNN_WEIGHTS_PATH="{WEIGHTS}"']
     # the two high-pass kernels in a unit of their own, with the SLP pairing the rest of the library is built without (nnn_kernels.hip, at k_hp2)
-    hp_obj = os.path.join(LIB_DIR, "nnn_hp.o")
+    # (per-process temporaries, the library moved into place at the end: two builds at once -- a test run beside a manual build -- do not
+    # see each other's half-written files)
+    hp_obj = os.path.join(LIB_DIR, f"nnn_hp.{os.getpid()}.o")
+    tmp_lib = os.path.join(LIB_DIR, f"libnnnoiseless_mi355x.{os.getpid()}.so")
     cmds = [common + ["-c", "-x", "hip", os.path.join(CSRC, HP_SOURCE), "-o", hp_obj],
             common + ["-fno-slp-vectorize", "-DNNN_HP_EXTERN", "-shared", "-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES]
-            + ["-x", "none", hp_obj, "-o", LIB_PATH]]
-    for cmd in cmds:
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-    os.remove(hp_obj)
+            + ["-x", "none", hp_obj, "-o", tmp_lib]]
+    try:
+        for cmd in cmds:
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        os.replace(tmp_lib, LIB_PATH)
+    finally:
+        for f in (hp_obj, tmp_lib):
+            if os.path.exists(f):
+                os.remove(f)
     return LIB_PATH

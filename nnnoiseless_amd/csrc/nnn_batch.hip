@@ -152,6 +152,10 @@ struct nnn_batch {
     float *stage_vad = nullptr;
     size_t stage_cap = 0, stage_vad_cap = 0;
     std::vector<char> stage_host;   // host side of the copy back
+    // small host-buffer calls (the drop-in single-stream surface: a batch of one, a frame per call) skip both copies: the kernels read the
+    // input from, and write the audio and the VAD into, page-locked host memory mapped into the device's address space (round 6)
+    char *zc_host = nullptr, *zc_dev = nullptr;
+    size_t zc_cap = 0;
     hipStream_t copy_in = nullptr, copy_out = nullptr;   // host-buffer calls in chunks: uploads, downloads (created on first use)
     std::vector<hipEvent_t> ev_up, ev_run;               // per chunk: uploaded, processed
     int wf_min_g = 0;               // groups shorter than this run k_rnn instead of the layer-pipelined kernel (env NNN_RNN_WF_MIN_G; 0 = by batch size)
@@ -297,6 +301,7 @@ extern "C" void nnn_batch_destroy(nnn_batch *h)
     if (h->copy_out) hipStreamDestroy(h->copy_out);
     if (h->stage) hipFree(h->stage);
     if (h->stage_vad) hipFree(h->stage_vad);
+    if (h->zc_host) hipHostFree(h->zc_host);
     for (int i = 0; i < NSTREAMS; i++)
         if (h->pool[i]) hipStreamDestroy(h->pool[i]);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1295,8 +1300,40 @@ static int process_host_span_impl(nnn_batch *h, const void *in, void *out, float
     const size_t e = (size_t)pcm_elem_bytes(L->format), groups = (size_t)(h->S / L->channels), fr = (size_t)FRAME * L->channels * e;
     const size_t span = (groups - 1) * L->group_stride * e + (size_t)(n_frames - 1) * L->frame_stride * e + fr;
     const int drop = (L->discard_first && h->frame_count == 0) ? 1 : 0;
-    // device staging grows as needed and is kept for the next call (per-call hipMalloc / hipFree cost more than a frame)
     const size_t vbytes = vad ? (size_t)n_frames * h->S * sizeof(float) : 0;
+    // Small calls -- the RNNoise C ABI's state is a batch of one, a frame per call -- have nothing to overlap and pay for every runtime call they
+    // make: two or three staged copies of a few kilobytes cost more than the three kernels between them.  Up to ZC_MAX bytes the kernels work on
+    // page-locked host memory directly (the input read over the link by the first kernel, audio and VAD written over it by the last): one
+    // memcpy in, one wait, one memcpy out.  Same kernels, same bits.
+    constexpr size_t ZC_MAX = (size_t)1 << 20;
+    static const bool zc_on = !(dev_knob("NNN_ZERO_COPY") && atoi(dev_knob("NNN_ZERO_COPY")) == 0);   // (A/B knob)
+    if (zc_on && span + vbytes + 16 <= ZC_MAX) {
+        const size_t vofs = (span + 15) / 16 * 16;
+        if (!h->zc_host) {
+            NNN_RT_LOCK;
+            if (int rc = quiesce(h)) return rc;
+            void *hp = nullptr, *dp = nullptr;
+            HIPCHK(hipHostMalloc(&hp, ZC_MAX, hipHostMallocMapped));
+            HIPCHK(hipHostGetDevicePointer(&dp, hp, 0));
+            h->zc_host = (char *)hp;
+            h->zc_dev = (char *)dp;
+            h->zc_cap = ZC_MAX;
+        }
+        memcpy(h->zc_host, in, span);
+        int rc = nnn_batch_process_pcm_device(h, h->zc_dev, h->zc_dev, vad ? (float *)(h->zc_dev + vofs) : nullptr, n_frames, L, h->stream);
+        if (!rc) rc = nnn_batch_synchronize(h);   // (also reports a frame hand-off that never arrived)
+        else hipStreamSynchronize(h->stream);
+        if (!rc) {
+            for (size_t g = 0; g < groups; g++)
+                for (int t = 0; t < n_frames - drop; t++) {
+                    size_t o = g * L->group_stride * e + (size_t)t * L->frame_stride * e;
+                    memcpy((char *)out + o, h->zc_host + o, fr);
+                }
+            if (vad) memcpy(vad, h->zc_host + vofs, vbytes);
+        }
+        return rc;
+    }
+    // device staging grows as needed and is kept for the next call (per-call hipMalloc / hipFree cost more than a frame)
     if (span > h->stage_cap || vbytes > h->stage_vad_cap) {
         NNN_RT_LOCK;
         if (int rc = quiesce(h)) return rc;
